@@ -1,0 +1,184 @@
+/*
+ * safeopt_hip.h -- C ABI of libsafeopt_hip.so (MI355X / gfx950, HIP + RCCL).
+ *
+ * The drop-in boundary for SafeOpt's GP-posterior + safe-set hot path.  The
+ * reference (befelix/SafeOpt, pure Python) has no FFI; its seam is the
+ * duck-typed "GPy model" handle plus the NumPy sweep in safeopt/gp_opt.py.
+ * Every entry point below names the reference call site(s) it replaces
+ * (paths relative to /root/reference).  INTEGRATION.md shows the ctypes stub
+ * a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, no C++ / torch types.
+ *   - every function returns 0 on success; <0 = HIP/RCCL/runtime error,
+ *     >0 = numerical failure (e.g. Cholesky info).  sgp_last_error() gives
+ *     the message.  No exception crosses the ABI.
+ *   - all host buffers are borrowed for the duration of the call only;
+ *     outputs go to caller-allocated buffers.  All real data is float64,
+ *     masks are uint8 (NumPy bool), indices int64.
+ *   - one sgp_ctx per (process, device); calls on one ctx are serialised by
+ *     the caller (the reference is single-threaded too).
+ */
+#ifndef SAFEOPT_HIP_H
+#define SAFEOPT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGP_MAX_D 8        /* input dimension incl. context columns            */
+#define SGP_MAX_PARTS 4    /* factors of a product kernel                      */
+#define SGP_MAX_GPS 8      /* objective + constraints                          */
+#define SGP_TOPK 16        /* expander candidates examined per pass            */
+
+/* kernel kinds: GPy.kern.RBF / Matern32 / Matern52 (Stationary.K_of_r)        */
+enum { SGP_RBF = 0, SGP_MATERN32 = 1, SGP_MATERN52 = 2 };
+/* sgp_grid_download selectors                                                 */
+enum { SGP_Q = 0, SGP_S = 1, SGP_M = 2, SGP_G = 3, SGP_MEAN = 4, SGP_VAR = 5 };
+/* sgp_grid_argmax modes                                                       */
+enum { SGP_ARGMAX_MG_WIDTH = 0, SGP_ARGMAX_UCB = 1, SGP_ARGMAX_LCB = 2 };
+/* sgp_swarm_fitness swarm types (gp_opt.py:901-1013)                          */
+enum { SGP_SWARM_GREEDY = 0, SGP_SWARM_MAXIMIZERS = 1, SGP_SWARM_EXPANDERS = 2,
+       SGP_SWARM_SAFE_SET = 3 };
+
+typedef struct sgp_ctx sgp_ctx;   /* device, stream, scratch, RCCL communicator */
+typedef struct sgp_gp sgp_gp;     /* one GP: data, L^-1 (packed), alpha         */
+typedef struct sgp_grid sgp_grid; /* resident candidate rows + Q/S/M/G          */
+
+/* ---- context ---------------------------------------------------------------*/
+int sgp_device_count(int* n);
+int sgp_create(int device, sgp_ctx** out);
+void sgp_destroy(sgp_ctx* ctx);
+/* message of the last failing call on ctx (ctx may be NULL: process-global)   */
+const char* sgp_last_error(sgp_ctx* ctx);
+int sgp_sync(sgp_ctx* ctx);
+
+/* ---- GP handle: replaces GPy.models.GPRegression as SafeOpt uses it --------
+ * kernel = product over n_parts of  variance_p * k_kind_p(r_p),
+ * r_p^2 = sum_k ((x_k - x'_k) * inv_ls[p*d + k])^2   (inv_ls = 0 on columns
+ * outside the part's active_dims; = 1/lengthscale otherwise).               */
+int sgp_gp_create(sgp_ctx* ctx, int d, int n_parts, const int* kinds,
+                  const double* variances, const double* inv_ls,
+                  double noise_var, sgp_gp** out);
+void sgp_gp_destroy(sgp_gp* gp);
+/* gp.set_XY (gp_opt.py:227, 267, 275): K = k(X,X), Ky = K + (noise+1e-8) I,
+ * L = jitchol(Ky), L^-1, alpha = Ky^-1 Y -- all on the device.  X is (n,d)
+ * row-major, Y is (n).  chol_info: 0 ok, k>0 = pivot k not positive even
+ * after 5 jitter escalations (GPy jitchol); jitter_used: diagonal jitter.    */
+int sgp_gp_set_data(sgp_gp* gp, const double* X, const double* Y, int64_t n,
+                    int* chol_info, double* jitter_used);
+/* gp.predict_noiseless / gp._raw_predict (gp_opt.py:469, 591, 929, 973, 1117,
+ * 1132; utilities.py:203, 282, 355).  Xnew element (r,c) at
+ * Xnew[r*stride_row + c*stride_col] (strides in elements: C or F order).
+ * var is clipped to [1e-15, inf) like GPy.                                   */
+int sgp_gp_predict(sgp_gp* gp, const double* Xnew, int64_t N,
+                   int64_t stride_row, int64_t stride_col, double* mean,
+                   double* var);
+/* test hook: dense L^-1 (n x n, row-major) and alpha (n)                     */
+int sgp_gp_get_factor(sgp_gp* gp, double* Linv, double* alpha);
+/* gp.kern.K(X, X2) (gp_opt.py:847, 1093; utilities.py:89, 135): out is
+ * (n1,n2) row-major; X1 (n1,d), X2 (n2,d) row-major.                         */
+int sgp_kern_K(sgp_ctx* ctx, int d, int n_parts, const int* kinds,
+               const double* variances, const double* inv_ls, const double* X1,
+               int64_t n1, const double* X2, int64_t n2, double* out);
+
+/* ---- resident candidate grid: SafeOpt.inputs / Q / S / M / G ----------------
+ * (gp_opt.py:358-390).  `base` element (r,c) at byte offset
+ * r*stride_row_B + c*stride_col_B (the stock grid is F-ordered); rows are
+ * this rank's shard, global index = global_offset + local row.               */
+int sgp_grid_create(sgp_ctx* ctx, const double* base, int64_t N, int d,
+                    int64_t stride_row_B, int64_t stride_col_B, int G,
+                    int64_t global_offset, sgp_grid** out);
+void sgp_grid_destroy(sgp_grid* grid);
+/* SafeOpt.context setter (gp_opt.py:439-451): fill the last nc columns       */
+int sgp_grid_set_context(sgp_grid* grid, const double* c, int nc);
+/* update_confidence_intervals + compute_safe_set (gp_opt.py:453-481), fused:
+ * for every GP mean/var over all rows, Q[:,2i] = mean - beta*std,
+ * Q[:,2i+1] = mean + beta*std, S = all(Q[:, ::2] > fmin).
+ * out2 = { max(l0[S]) or -inf, any(S) }  (local rows).                       */
+int sgp_grid_confidence(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
+                        const double* fmin, double* out2);
+/* replace Q by host values (N x 2G row-major) and recompute S (tests, and
+ * users who edit opt.Q by hand).                                             */
+int sgp_grid_upload_Q(sgp_grid* grid, const double* Q, const double* fmin,
+                      double* out2);
+/* gp_opt.py:511-513: M = S & (u0 >= max_l); out = max(u0[M]-l0[M]) or -inf   */
+int sgp_grid_maximizers(sgp_grid* grid, double max_l, double* out);
+/* gp_opt.py:527-540: candidate mask.  full_sets=0: s = S & ~M &
+ * (max_i (u_i-l_i)/scaling_i > max_var) & any_i(u_i-l_i > thr_beta_i);
+ * full_sets=1: s = S.  Also clears G.  counts = {#candidates, #unsafe}.      */
+int sgp_grid_candidates(sgp_grid* grid, double max_var, const double* scaling,
+                        const double* thr_beta, int full_sets, int64_t* counts);
+/* gp_opt.py:542-552: next <=k candidates in visiting order after the cut
+ * (cut_w, cut_idx), i.e. descending w = max_i(u_i - l_i), ties: higher global
+ * index first.  mode 1 (full_sets): ascending global index after cut_idx.
+ * Start with cut_w = +inf, cut_idx = INT64_MAX (mode 1: cut_idx = -1).       */
+int sgp_grid_topk(sgp_grid* grid, int mode, double cut_w, int64_t cut_idx,
+                  int k, double* w_out, int64_t* gidx_out, int* n_out);
+/* rows of the resident arrays for m GLOBAL indices owned by this rank:
+ * x (m,d), mean (m,G), var (m,G), Q (m,2G)                                   */
+int sgp_grid_gather_rows(sgp_grid* grid, const int64_t* gidx, int m, double* x,
+                         double* mean, double* var, double* Q);
+/* expander test of gp_opt.py:579-606 for m<=SGP_TOPK candidates at once, as a
+ * rank-1 posterior update instead of two re-factorisations: for every GP i
+ * with finite fmin_i, flags[c*G+i] = any over UNSAFE local rows x of
+ *   mu2 - beta*sqrt(var2) >= fmin_i,
+ *   mu2 = mu_i(x) + c(x) (u_i(x_c) - mu_i(x_c)) / s2,
+ *   var2 = max(var_i(x) - c(x)^2 / s2, 1e-15),
+ *   c(x) = k(x,x_c) - k(X,x)^T Ky^-1 k(X,x_c),  s2 = var_i(x_c)+noise+1e-8.
+ * xc (m,d), mu_c/u_c (m,G) come from sgp_grid_gather_rows on the owner.      */
+int sgp_grid_expander_check(sgp_grid* grid, sgp_gp* const* gps, int G,
+                            double beta, const double* fmin, int m,
+                            const double* xc, const double* mu_c,
+                            const double* u_c, int32_t* flags);
+/* Lipschitz variant, gp_opt.py:558-576: flags[c*G+i] = any over unsafe rows
+ * of u_i(x_c) - L_i * ||x_c - x||_2 >= fmin_i                                */
+int sgp_grid_lipschitz_check(sgp_grid* grid, int G, const double* fmin,
+                             const double* lipschitz, int m, const double* xc,
+                             const double* u_c, int32_t* flags);
+/* gp_opt.py:615: G[idx] = True for owned global indices                      */
+int sgp_grid_mark_expanders(sgp_grid* grid, const int64_t* gidx, int m);
+/* get_new_query_point / get_maximum arg-max (gp_opt.py:635, 642-644,
+ * 708-710), first (lowest) global index wins among equal values.
+ * value = -inf and gidx = -1 when the masked set is empty.                   */
+int sgp_grid_argmax(sgp_grid* grid, int mode, const double* scaling,
+                    double* value, int64_t* gidx);
+/* copy a resident array to the host: Q (N,2G) f64 | S/M/G (N) u8 |
+ * mean/var (G,N) f64                                                         */
+int sgp_grid_download(sgp_grid* grid, int what, void* out);
+
+/* ---- SafeOptSwarm._compute_particle_fitness (gp_opt.py:901-1013) -----------
+ * particles (P,d) row-major; values (P) f64; safe (P) u8.                    */
+int sgp_swarm_fitness(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
+                      const double* particles, int64_t P, double beta,
+                      const double* fmin, const double* scaling,
+                      double best_lower_bound, double* values, uint8_t* safe);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI -------------------------
+ * The only cross-rank traffic of the path is a handful of scalars per
+ * iteration (max / any / arg-max / top-k merge).                             */
+int sgp_comm_unique_id(void* id128);              /* rank 0: ncclGetUniqueId  */
+int sgp_comm_init(sgp_ctx* ctx, const void* id128, int rank, int world);
+int sgp_comm_allreduce_max(sgp_ctx* ctx, double* buf, int n);   /* in place   */
+int sgp_comm_allgather(sgp_ctx* ctx, const void* send, void* recv,
+                       int64_t nbytes);           /* recv = world*nbytes      */
+int sgp_comm_barrier(sgp_ctx* ctx);
+
+/* ---- measurement -----------------------------------------------------------*/
+/* hipEvent pair on the ctx stream around a region of calls                   */
+int sgp_timer_start(sgp_ctx* ctx);
+int sgp_timer_stop(sgp_ctx* ctx, float* ms);
+/* per-launch hipEvent timing of the posterior sweep kernel (the dominant
+ * kernel): enable, run, then read {total ms, launches, algorithmic flops}    */
+int sgp_profile_enable(sgp_ctx* ctx, int on);
+int sgp_profile_read(sgp_ctx* ctx, double* total_ms, int64_t* launches,
+                     double* flops);
+/* fp64 MFMA issue-rate microbenchmark (v_mfma_f64_16x16x4_f64), TFLOP/s      */
+int sgp_microbench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAFEOPT_HIP_H */

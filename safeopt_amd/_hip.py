@@ -1,0 +1,452 @@
+"""ctypes binding of libsafeopt_hip.so (include/safeopt_hip.h).
+
+There is NO CPU fallback: every numerical entry point of the package goes
+through this module, and a missing library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsafeopt_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_i32_p = C.POINTER(C.c_int32)
+c_i64_p = C.POINTER(C.c_int64)
+c_u8_p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+vpp = C.POINTER(C.c_void_p)
+
+RBF, MATERN32, MATERN52 = 0, 1, 2
+Q, S, M, G, MEAN, VAR = 0, 1, 2, 3, 4, 5
+ARGMAX_MG_WIDTH, ARGMAX_UCB, ARGMAX_LCB = 0, 1, 2
+SWARM_TYPES = {"greedy": 0, "maximizers": 1, "expanders": 2, "safe_set": 3}
+MAX_D, MAX_PARTS, MAX_GPS, TOPK = 8, 4, 8, 16
+
+# name -> (restype, argtypes); mirrors include/safeopt_hip.h one to one
+PROTOTYPES = {
+    "sgp_device_count": (C.c_int, [c_int_p]),
+    "sgp_create": (C.c_int, [C.c_int, vpp]),
+    "sgp_destroy": (None, [vp]),
+    "sgp_last_error": (C.c_char_p, [vp]),
+    "sgp_sync": (C.c_int, [vp]),
+    "sgp_gp_create": (C.c_int, [vp, C.c_int, C.c_int, c_int_p, c_double_p,
+                                c_double_p, C.c_double, vpp]),
+    "sgp_gp_destroy": (None, [vp]),
+    "sgp_gp_set_data": (C.c_int, [vp, c_double_p, c_double_p, C.c_int64,
+                                  c_int_p, c_double_p]),
+    "sgp_gp_predict": (C.c_int, [vp, c_double_p, C.c_int64, C.c_int64,
+                                 C.c_int64, c_double_p, c_double_p]),
+    "sgp_gp_get_factor": (C.c_int, [vp, c_double_p, c_double_p]),
+    "sgp_kern_K": (C.c_int, [vp, C.c_int, C.c_int, c_int_p, c_double_p,
+                             c_double_p, c_double_p, C.c_int64, c_double_p,
+                             C.c_int64, c_double_p]),
+    "sgp_grid_create": (C.c_int, [vp, c_double_p, C.c_int64, C.c_int,
+                                  C.c_int64, C.c_int64, C.c_int, C.c_int64,
+                                  vpp]),
+    "sgp_grid_destroy": (None, [vp]),
+    "sgp_grid_set_context": (C.c_int, [vp, c_double_p, C.c_int]),
+    "sgp_grid_confidence": (C.c_int, [vp, vpp, C.c_int, C.c_double,
+                                      c_double_p, c_double_p]),
+    "sgp_grid_upload_Q": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
+    "sgp_grid_maximizers": (C.c_int, [vp, C.c_double, c_double_p]),
+    "sgp_grid_candidates": (C.c_int, [vp, C.c_double, c_double_p, c_double_p,
+                                      C.c_int, c_i64_p]),
+    "sgp_grid_topk": (C.c_int, [vp, C.c_int, C.c_double, C.c_int64, C.c_int,
+                                c_double_p, c_i64_p, c_int_p]),
+    "sgp_grid_gather_rows": (C.c_int, [vp, c_i64_p, C.c_int, c_double_p,
+                                       c_double_p, c_double_p, c_double_p]),
+    "sgp_grid_expander_check": (C.c_int, [vp, vpp, C.c_int, C.c_double,
+                                          c_double_p, C.c_int, c_double_p,
+                                          c_double_p, c_double_p, c_i32_p]),
+    "sgp_grid_lipschitz_check": (C.c_int, [vp, C.c_int, c_double_p,
+                                           c_double_p, C.c_int, c_double_p,
+                                           c_double_p, c_i32_p]),
+    "sgp_grid_mark_expanders": (C.c_int, [vp, c_i64_p, C.c_int]),
+    "sgp_grid_argmax": (C.c_int, [vp, C.c_int, c_double_p, c_double_p,
+                                  c_i64_p]),
+    "sgp_grid_download": (C.c_int, [vp, C.c_int, vp]),
+    "sgp_swarm_fitness": (C.c_int, [vp, vpp, C.c_int, C.c_int, c_double_p,
+                                    C.c_int64, C.c_double, c_double_p,
+                                    c_double_p, C.c_double, c_double_p,
+                                    c_u8_p]),
+    "sgp_comm_unique_id": (C.c_int, [vp]),
+    "sgp_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "sgp_comm_allreduce_max": (C.c_int, [vp, c_double_p, C.c_int]),
+    "sgp_comm_allgather": (C.c_int, [vp, vp, vp, C.c_int64]),
+    "sgp_comm_barrier": (C.c_int, [vp]),
+    "sgp_timer_start": (C.c_int, [vp]),
+    "sgp_timer_stop": (C.c_int, [vp, C.POINTER(C.c_float)]),
+    "sgp_profile_enable": (C.c_int, [vp, C.c_int]),
+    "sgp_profile_read": (C.c_int, [vp, c_double_p, c_i64_p, c_double_p]),
+    "sgp_microbench_mfma_f64": (C.c_int, [vp, C.c_int, c_double_p]),
+}
+
+_lib = None
+
+
+class HipError(RuntimeError):
+    """A call into libsafeopt_hip.so failed (HIP / RCCL / argument error)."""
+
+
+def lib():
+    """Load the shared library once; fail loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(
+                "libsafeopt_hip.so is not built (%s). Run "
+                "`python -m safeopt_amd.build`; there is no CPU fallback."
+                % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().sgp_device_count(C.byref(n))
+    return n.value
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class Context(object):
+    """One device context (stream, scratch, optional RCCL communicator)."""
+
+    _default = {}
+
+    def __init__(self, device=0):
+        L = lib()
+        if device_count() <= device:
+            raise HipError("no HIP device %d visible: %s -- the HIP path is "
+                           "the only path" % (device, L.sgp_last_error(None).decode()))
+        h = vp()
+        rc = L.sgp_create(device, C.byref(h))
+        if rc != 0:
+            raise HipError(L.sgp_last_error(None).decode())
+        self.h = h
+        self.device = device
+        self.rank, self.world = 0, 1
+
+    @classmethod
+    def default(cls, device=None):
+        if device is None:
+            device = int(os.environ.get("SAFEOPT_HIP_DEVICE",
+                                        os.environ.get("LOCAL_RANK", "0")))
+            n = device_count()
+            if n > 0:
+                device %= n
+        if device not in cls._default:
+            cls._default[device] = Context(device)
+        return cls._default[device]
+
+    def check(self, rc):
+        if rc != 0:
+            raise HipError("libsafeopt_hip (rc=%d): %s"
+                           % (rc, lib().sgp_last_error(self.h).decode()))
+
+    def sync(self):
+        self.check(lib().sgp_sync(self.h))
+
+    # -- measurement
+    def timer_start(self):
+        self.check(lib().sgp_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        self.check(lib().sgp_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        self.check(lib().sgp_profile_enable(self.h, int(bool(on))))
+
+    def profile_read(self):
+        ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
+        self.check(lib().sgp_profile_read(self.h, C.byref(ms), C.byref(n),
+                                          C.byref(fl)))
+        return ms.value, n.value, fl.value
+
+    def microbench_mfma_f64(self, iters=20000):
+        t = C.c_double(0)
+        self.check(lib().sgp_microbench_mfma_f64(self.h, iters, C.byref(t)))
+        return t.value
+
+    # -- RCCL
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        rc = lib().sgp_comm_unique_id(buf)
+        if rc != 0:
+            raise HipError(lib().sgp_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, uid, rank, world):
+        buf = C.create_string_buffer(uid, 128)
+        self.check(lib().sgp_comm_init(self.h, buf, rank, world))
+        self.rank, self.world = rank, world
+
+    def allreduce_max(self, a):
+        a = f64(a).copy()
+        self.check(lib().sgp_comm_allreduce_max(self.h, dptr(a), a.size))
+        return a
+
+    def allgather_bytes(self, b):
+        out = C.create_string_buffer(len(b) * self.world)
+        src = C.create_string_buffer(bytes(b), len(b))
+        self.check(lib().sgp_comm_allgather(self.h, src, out, len(b)))
+        return out.raw
+
+    def barrier(self):
+        self.check(lib().sgp_comm_barrier(self.h))
+
+    def kern_K(self, kdesc, X1, X2):
+        d, kinds, variances, inv_ls = kdesc
+        X1 = f64(X1).reshape(-1, d)
+        X2 = f64(X2).reshape(-1, d)
+        out = np.empty((X1.shape[0], X2.shape[0]))
+        if out.size:
+            self.check(lib().sgp_kern_K(
+                self.h, d, len(kinds), kinds.ctypes.data_as(c_int_p),
+                dptr(variances), dptr(inv_ls), dptr(X1), X1.shape[0],
+                dptr(X2), X2.shape[0], dptr(out)))
+        return out
+
+
+def _gp_array(gps):
+    arr = (vp * len(gps))(*[g.h for g in gps])
+    return C.cast(arr, vpp)
+
+
+class DeviceGP(object):
+    """Device-resident GP state (training data, packed L^-1, alpha)."""
+
+    def __init__(self, ctx, kdesc, noise_var):
+        d, kinds, variances, inv_ls = kdesc
+        self.ctx = ctx
+        self.d = d
+        h = vp()
+        ctx.check(lib().sgp_gp_create(
+            ctx.h, d, len(kinds), kinds.ctypes.data_as(c_int_p),
+            dptr(variances), dptr(inv_ls), float(noise_var), C.byref(h)))
+        self.h = h
+        self.n = 0
+        self.jitter = 0.0
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().sgp_gp_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_data(self, X, Y):
+        X = f64(X).reshape(-1, self.d)
+        Y = f64(Y).reshape(-1)
+        info, jit = C.c_int(0), C.c_double(0)
+        rc = lib().sgp_gp_set_data(self.h, dptr(X), dptr(Y), X.shape[0],
+                                   C.byref(info), C.byref(jit))
+        if rc > 0 or info.value != 0:
+            raise np.linalg.LinAlgError(
+                lib().sgp_last_error(self.ctx.h).decode())
+        self.ctx.check(rc)
+        self.n = X.shape[0]
+        self.jitter = jit.value
+
+    def predict(self, Xnew):
+        Xnew = np.asarray(Xnew, dtype=np.float64)
+        if Xnew.ndim != 2 or Xnew.shape[1] != self.d:
+            Xnew = np.atleast_2d(Xnew).reshape(-1, self.d)
+        N = Xnew.shape[0]
+        it = Xnew.itemsize
+        if Xnew.strides[0] % it or Xnew.strides[1] % it or \
+                min(Xnew.strides) < 0:
+            Xnew = np.ascontiguousarray(Xnew)
+        mean = np.empty((N, 1))
+        var = np.empty((N, 1))
+        if N:
+            self.ctx.check(lib().sgp_gp_predict(
+                self.h, dptr(Xnew), N, Xnew.strides[0] // it,
+                Xnew.strides[1] // it, dptr(mean), dptr(var)))
+        return mean, var
+
+    def factor(self):
+        Linv = np.empty((self.n, self.n))
+        alpha = np.empty(self.n)
+        self.ctx.check(lib().sgp_gp_get_factor(self.h, dptr(Linv), dptr(alpha)))
+        return Linv, alpha
+
+
+class DeviceGrid(object):
+    """This rank's shard of SafeOpt.inputs resident in HBM, with Q/S/M/G."""
+
+    def __init__(self, ctx, inputs, G, global_offset=0):
+        inputs = np.asarray(inputs, dtype=np.float64)
+        assert inputs.ndim == 2
+        if min(inputs.strides) < 0:
+            inputs = np.ascontiguousarray(inputs)
+        self.ctx = ctx
+        self.N, self.d = inputs.shape
+        self.G = G
+        self.goff = int(global_offset)
+        h = vp()
+        ctx.check(lib().sgp_grid_create(
+            ctx.h, dptr(inputs), self.N, self.d, inputs.strides[0],
+            inputs.strides[1], G, self.goff, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().sgp_grid_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_context(self, c):
+        c = f64(c).reshape(-1)
+        self.ctx.check(lib().sgp_grid_set_context(self.h, dptr(c), c.size))
+
+    def confidence(self, gps, beta, fmin):
+        fmin = f64(fmin)
+        out = np.empty(2)
+        self.ctx.check(lib().sgp_grid_confidence(
+            self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin),
+            dptr(out)))
+        return out[0], bool(out[1])
+
+    def upload_Q(self, Qh, fmin):
+        Qh = f64(Qh).reshape(self.N, 2 * self.G)
+        fmin = f64(fmin)
+        out = np.empty(2)
+        self.ctx.check(lib().sgp_grid_upload_Q(self.h, dptr(Qh), dptr(fmin),
+                                               dptr(out)))
+        return out[0], bool(out[1])
+
+    def maximizers(self, max_l):
+        out = C.c_double(0)
+        self.ctx.check(lib().sgp_grid_maximizers(self.h, float(max_l),
+                                                 C.byref(out)))
+        return out.value
+
+    def candidates(self, max_var, scaling, thr_beta, full_sets=False):
+        scaling = f64(scaling)
+        thr_beta = f64(thr_beta)
+        counts = np.zeros(2, dtype=np.int64)
+        self.ctx.check(lib().sgp_grid_candidates(
+            self.h, float(max_var), dptr(scaling), dptr(thr_beta),
+            int(bool(full_sets)), counts.ctypes.data_as(c_i64_p)))
+        return int(counts[0]), int(counts[1])
+
+    def topk(self, mode, cut_w, cut_idx, k=TOPK):
+        w = np.empty(k)
+        idx = np.empty(k, dtype=np.int64)
+        n = C.c_int(0)
+        self.ctx.check(lib().sgp_grid_topk(
+            self.h, int(mode), float(cut_w), int(cut_idx), k, dptr(w),
+            idx.ctypes.data_as(c_i64_p), C.byref(n)))
+        return w[:n.value], idx[:n.value]
+
+    def gather_rows(self, gidx):
+        gidx = np.ascontiguousarray(gidx, dtype=np.int64)
+        m = gidx.size
+        x = np.empty((m, self.d))
+        mean = np.empty((m, self.G))
+        var = np.empty((m, self.G))
+        Qr = np.empty((m, 2 * self.G))
+        if m:
+            self.ctx.check(lib().sgp_grid_gather_rows(
+                self.h, gidx.ctypes.data_as(c_i64_p), m, dptr(x), dptr(mean),
+                dptr(var), dptr(Qr)))
+        return x, mean, var, Qr
+
+    def expander_check(self, gps, beta, fmin, xc, mu_c, u_c):
+        fmin = f64(fmin)
+        xc = f64(xc).reshape(-1, self.d)
+        m = xc.shape[0]
+        mu_c = f64(mu_c).reshape(m, self.G)
+        u_c = f64(u_c).reshape(m, self.G)
+        flags = np.zeros((m, self.G), dtype=np.int32)
+        self.ctx.check(lib().sgp_grid_expander_check(
+            self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin), m,
+            dptr(xc), dptr(mu_c), dptr(u_c), flags.ctypes.data_as(c_i32_p)))
+        return flags
+
+    def lipschitz_check(self, fmin, lipschitz, xc, u_c):
+        fmin = f64(fmin)
+        lipschitz = f64(lipschitz)
+        xc = f64(xc).reshape(-1, self.d)
+        m = xc.shape[0]
+        u_c = f64(u_c).reshape(m, self.G)
+        flags = np.zeros((m, self.G), dtype=np.int32)
+        self.ctx.check(lib().sgp_grid_lipschitz_check(
+            self.h, self.G, dptr(fmin), dptr(lipschitz), m, dptr(xc),
+            dptr(u_c), flags.ctypes.data_as(c_i32_p)))
+        return flags
+
+    def mark_expanders(self, gidx):
+        gidx = np.ascontiguousarray(gidx, dtype=np.int64)
+        if gidx.size:
+            self.ctx.check(lib().sgp_grid_mark_expanders(
+                self.h, gidx.ctypes.data_as(c_i64_p), gidx.size))
+
+    def argmax(self, mode, scaling):
+        scaling = f64(scaling)
+        v = C.c_double(0)
+        i = C.c_int64(0)
+        self.ctx.check(lib().sgp_grid_argmax(self.h, int(mode), dptr(scaling),
+                                             C.byref(v), C.byref(i)))
+        return v.value, i.value
+
+    def download(self, what, out=None):
+        if what == Q:
+            shape, dt = (self.N, 2 * self.G), np.float64
+        elif what in (S, M, G):
+            shape, dt = (self.N,), np.uint8
+        else:
+            shape, dt = (self.G, self.N), np.float64
+        buf = np.empty(shape, dtype=dt)
+        self.ctx.check(lib().sgp_grid_download(self.h, what,
+                                               buf.ctypes.data_as(vp)))
+        if dt == np.uint8:
+            buf = buf.view(np.bool_)
+        if out is not None:
+            np.copyto(out, buf)
+            return out
+        return buf
+
+
+def swarm_fitness(ctx, gps, swarm_type, particles, beta, fmin, scaling,
+                  best_lower_bound):
+    d = gps[0].d
+    particles = f64(particles).reshape(-1, d)
+    P = particles.shape[0]
+    fmin = f64(fmin)
+    scaling = f64(scaling)
+    values = np.empty(P)
+    safe = np.empty(P, dtype=np.uint8)
+    if P:
+        ctx.check(lib().sgp_swarm_fitness(
+            ctx.h, _gp_array(gps), len(gps), SWARM_TYPES[swarm_type],
+            dptr(particles), P, float(beta), dptr(fmin), dptr(scaling),
+            float(best_lower_bound), dptr(values),
+            safe.ctypes.data_as(c_u8_p)))
+    return values, safe.view(np.bool_)

@@ -1,0 +1,70 @@
+"""Build libsafeopt_hip.so (hipcc, gfx950 only) in-tree.
+
+    python -m safeopt_amd.build [--force] [--verbose]
+
+The library is the whole device side of the product: hand-written HIP kernels
+plus the C ABI declared in include/safeopt_hip.h.  hipcc cross-compiles for
+gfx950 without a GPU, so this also is the "does it build" check.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+OUT = os.path.join(PKG, "libsafeopt_hip.so")
+SOURCES = ["api.hip", "sweep.hip", "factor.hip", "sets.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kern_eval.h"),
+           os.path.join(REPO, "include", "safeopt_hip.h")]
+BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+        "-I", os.path.join(REPO, "include"), "-I", CSRC, "-Wall",
+        "-Wno-unused-function"]
+EXTRA = {"sets.hip": ["-ffp-contract=off"]}
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = _hipcc()
+    objs, jobs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + HEADERS):
+            jobs.append([hipcc] + BASE + EXTRA.get(src, []) + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or _stale(OUT, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

@@ -1,0 +1,860 @@
+// C ABI of libsafeopt_hip.so -- see include/safeopt_hip.h for the contract and
+// the reference call site each entry point replaces.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <cmath>
+#include <limits>
+#include <new>
+
+#include "common.h"
+
+namespace {
+std::string g_err;  // errors raised without a context
+
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t,
+                            ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t,
+                            ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+// RCCL is loaded lazily: single-GPU runs never touch it.
+int load_rccl(sgp_ctx* ctx) {
+  if (g_rccl.lib) return 0;
+  const char* names[] = {"librccl.so.1", "librccl.so",
+                         "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* nm : names) {
+    g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.lib) break;
+  }
+  if (!g_rccl.lib) {
+    sgp_set_error(ctx, "cannot dlopen librccl.so: %s", dlerror());
+    return -3;
+  }
+#define SYM(field, name)                                                       \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(                     \
+      dlsym(g_rccl.lib, name));                                                \
+  if (!g_rccl.field) {                                                         \
+    sgp_set_error(ctx, "librccl.so lacks %s", name);                           \
+    return -3;                                                                 \
+  }
+  SYM(GetUniqueId, "ncclGetUniqueId")
+  SYM(CommInitRank, "ncclCommInitRank")
+  SYM(CommDestroy, "ncclCommDestroy")
+  SYM(AllReduce, "ncclAllReduce")
+  SYM(AllGather, "ncclAllGather")
+  SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+  return 0;
+}
+
+#define SGP_NCCL(ctx, call)                                                    \
+  do {                                                                         \
+    ncclResult_t r_ = (call);                                                  \
+    if (r_ != ncclSuccess) {                                                   \
+      sgp_set_error((ctx), "%s:%d %s -> %s", __FILE__, __LINE__, #call,        \
+                    g_rccl.GetErrorString(r_));                                \
+      return -4;                                                               \
+    }                                                                          \
+  } while (0)
+
+int fill_kern(sgp_ctx* ctx, KernDesc* kd, int d, int n_parts, const int* kinds,
+              const double* variances, const double* inv_ls) {
+  SGP_CHECK(ctx, d >= 1 && d <= SGP_MAX_D, "input dimension %d not in 1..%d", d,
+            SGP_MAX_D);
+  SGP_CHECK(ctx, n_parts >= 1 && n_parts <= SGP_MAX_PARTS,
+            "kernel has %d parts, supported 1..%d", n_parts, SGP_MAX_PARTS);
+  memset(kd, 0, sizeof(*kd));
+  kd->d = d;
+  kd->n_parts = n_parts;
+  kd->kdiag = 1.0;
+  for (int p = 0; p < n_parts; ++p) {
+    SGP_CHECK(ctx, kinds[p] >= SGP_RBF && kinds[p] <= SGP_MATERN52,
+              "unknown kernel kind %d", kinds[p]);
+    kd->kind[p] = kinds[p];
+    kd->variance[p] = variances[p];
+    kd->kdiag *= variances[p];
+    for (int k = 0; k < d; ++k) kd->inv_ls[p][k] = inv_ls[p * d + k];
+  }
+  return 0;
+}
+
+int collect_gps(sgp_ctx* ctx, sgp_gp* const* gps, int G, int d, GpDev* host) {
+  SGP_CHECK(ctx, G >= 1 && G <= SGP_MAX_GPS, "%d GPs, supported 1..%d", G,
+            SGP_MAX_GPS);
+  for (int g = 0; g < G; ++g) {
+    SGP_CHECK(ctx, gps[g] && gps[g]->n > 0, "GP %d has no data", g);
+    SGP_CHECK(ctx, gps[g]->kern.d == d, "GP %d input_dim %d != %d", g,
+              gps[g]->kern.d, d);
+    host[g] = gps[g]->dev;
+  }
+  return 0;
+}
+}  // namespace
+
+void sgp_set_error(sgp_ctx* ctx, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  g_err = buf;
+}
+
+int sgp_reserve(sgp_ctx* ctx, DevBuf* b, size_t bytes) {
+  if (bytes <= b->cap && b->p) return 0;
+  if (b->p) {
+    SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SGP_HIP(ctx, hipFree(b->p));
+    b->p = nullptr;
+    b->cap = 0;
+  }
+  size_t cap = bytes < 256 ? 256 : bytes;
+  SGP_HIP(ctx, hipMalloc(&b->p, cap));
+  b->cap = cap;
+  return 0;
+}
+
+void* sgp_scratch(sgp_ctx* ctx, int slot, size_t bytes) {
+  if (sgp_reserve(ctx, &ctx->scratch[slot], bytes) != 0) return nullptr;
+  return ctx->scratch[slot].p;
+}
+
+// Host <-> device copies.  Small transfers go through the pinned staging
+// buffer so the async copy really is asynchronous w.r.t. pageable memory.
+int sgp_h2d(sgp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  SGP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice,
+                              ctx->stream));
+  // the source is a borrowed (pageable) host buffer: complete before return
+  SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int sgp_d2h(sgp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  if (bytes <= ctx->pinned_cap) {
+    SGP_HIP(ctx, hipMemcpyAsync(ctx->pinned, src, bytes, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(dst, ctx->pinned, bytes);
+  } else {
+    SGP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return 0;
+}
+
+extern "C" {
+
+// ---- context ------------------------------------------------------------------
+int sgp_device_count(int* n) {
+  *n = 0;
+  hipError_t e = hipGetDeviceCount(n);
+  if (e != hipSuccess) {
+    *n = 0;
+    sgp_set_error(nullptr, "hipGetDeviceCount -> %s", hipGetErrorString(e));
+    (void)hipGetLastError();
+    return -1;
+  }
+  return 0;
+}
+
+int sgp_create(int device, sgp_ctx** out) {
+  *out = nullptr;
+  sgp_ctx* ctx = new (std::nothrow) sgp_ctx();
+  if (!ctx) return -1;
+  ctx->device = device;
+#define CREATE_HIP(call)                                                       \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      sgp_set_error(nullptr, "%s -> %s", #call, hipGetErrorString(e_));        \
+      delete ctx;                                                              \
+      return -1;                                                               \
+    }                                                                          \
+  } while (0)
+  CREATE_HIP(hipSetDevice(device));
+  CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  ctx->pinned_cap = 1 << 16;
+  CREATE_HIP(hipHostMalloc(&ctx->pinned, ctx->pinned_cap, hipHostMallocDefault));
+  CREATE_HIP(hipEventCreate(&ctx->ev0));
+  CREATE_HIP(hipEventCreate(&ctx->ev1));
+  hipDeviceProp_t prop;
+  CREATE_HIP(hipGetDeviceProperties(&prop, device));
+  ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+#undef CREATE_HIP
+  *out = ctx;
+  return 0;
+}
+
+void sgp_destroy(sgp_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm && g_rccl.CommDestroy)
+    g_rccl.CommDestroy(static_cast<ncclComm_t>(ctx->comm));
+  for (auto& b : ctx->scratch)
+    if (b.p) (void)hipFree(b.p);
+  for (auto e : ctx->prof_events) (void)hipEventDestroy(e);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* sgp_last_error(sgp_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_err.c_str();
+}
+
+int sgp_sync(sgp_ctx* ctx) {
+  SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// ---- GP -----------------------------------------------------------------------
+int sgp_gp_create(sgp_ctx* ctx, int d, int n_parts, const int* kinds,
+                  const double* variances, const double* inv_ls,
+                  double noise_var, sgp_gp** out) {
+  *out = nullptr;
+  KernDesc kd;
+  SGP_TRY(fill_kern(ctx, &kd, d, n_parts, kinds, variances, inv_ls));
+  sgp_gp* gp = new (std::nothrow) sgp_gp();
+  SGP_CHECK(ctx, gp != nullptr, "out of host memory");
+  gp->ctx = ctx;
+  gp->kern = kd;
+  gp->noise_var = noise_var;
+  *out = gp;
+  return 0;
+}
+
+void sgp_gp_destroy(sgp_gp* gp) {
+  if (!gp) return;
+  sgp_ctx* ctx = gp->ctx;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  DevBuf* bufs[] = {&gp->X, &gp->Y, &gp->Xpad, &gp->alpha, &gp->Apack,
+                    &gp->Linv, &gp->Kmat, &gp->work, &gp->tvec};
+  for (DevBuf* b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  delete gp;
+}
+
+int sgp_gp_set_data(sgp_gp* gp, const double* X, const double* Y, int64_t n,
+                    int* chol_info, double* jitter_used) {
+  sgp_ctx* ctx = gp->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, n >= 1 && n <= 16384, "n = %lld training points unsupported",
+            (long long)n);
+  const int d = gp->kern.d;
+  gp->n = n;
+  gp->n_pad = int((n + 15) / 16) * 16;
+  gp->n_f = int((n + 31) / 32) * 32;
+  SGP_TRY(sgp_reserve(ctx, &gp->X, size_t(n) * d * sizeof(double)));
+  SGP_TRY(sgp_reserve(ctx, &gp->Y, size_t(n) * sizeof(double)));
+  SGP_TRY(sgp_h2d(ctx, gp->X.p, X, size_t(n) * d * sizeof(double)));
+  SGP_TRY(sgp_h2d(ctx, gp->Y.p, Y, size_t(n) * sizeof(double)));
+  // GPy util.linalg.jitchol: plain attempt, then jitter = mean(diag)*1e-6,
+  // *10 per retry, at most 5 retries.
+  gp->jitter = 0.0;
+  int info = 0;
+  SGP_TRY(factor_gp(gp, &info));
+  if (info != 0) {
+    const double diag_mean = gp->kern.kdiag + gp->noise_var + 1e-8;
+    double jitter = diag_mean * 1e-6;
+    for (int t = 0; t < 5 && info != 0 && std::isfinite(jitter); ++t) {
+      gp->jitter = jitter;
+      SGP_TRY(factor_gp(gp, &info));
+      jitter *= 10.0;
+    }
+  }
+  if (chol_info) *chol_info = info;
+  if (jitter_used) *jitter_used = gp->jitter;
+  if (info != 0) {
+    gp->n = 0;
+    sgp_set_error(ctx, "not positive definite, even with jitter (pivot %d)",
+                  info);
+    return info > 0 ? info : -2;
+  }
+  return 0;
+}
+
+int sgp_gp_predict(sgp_gp* gp, const double* Xnew, int64_t N,
+                   int64_t stride_row, int64_t stride_col, double* mean,
+                   double* var) {
+  sgp_ctx* ctx = gp->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, gp->n > 0, "GP has no data");
+  if (N <= 0) return 0;
+  const int d = gp->kern.d;
+  // stage the rows through a dense row-major device copy
+  double* stage = static_cast<double*>(
+      sgp_scratch(ctx, 3, size_t(N) * d * sizeof(double)));
+  double* pts = static_cast<double*>(
+      sgp_scratch(ctx, 4, size_t(N) * (d + 2) * sizeof(double)));
+  GpDev* gdev = static_cast<GpDev*>(sgp_scratch(ctx, 5, sizeof(GpDev)));
+  SGP_CHECK(ctx, stage && pts && gdev, "device allocation failed: %s",
+            ctx->err.c_str());
+  if (stride_col == 1 && stride_row == d) {
+    SGP_TRY(sgp_h2d(ctx, stage, Xnew, size_t(N) * d * sizeof(double)));
+    SGP_TRY(launch_import_points(ctx, stage, N, d, d, 1, pts));
+  } else if (stride_row == 1 && stride_col == N) {
+    SGP_TRY(sgp_h2d(ctx, pts, Xnew, size_t(N) * d * sizeof(double)));
+  } else {
+    // generic strides: gather on the host into pinned-free scratch
+    std::vector<double> tmp(size_t(N) * d);
+    for (int64_t r = 0; r < N; ++r)
+      for (int k = 0; k < d; ++k)
+        tmp[size_t(k) * N + r] = Xnew[r * stride_row + k * stride_col];
+    SGP_TRY(sgp_h2d(ctx, pts, tmp.data(), tmp.size() * sizeof(double)));
+  }
+  SGP_TRY(sgp_h2d(ctx, gdev, &gp->dev, sizeof(GpDev)));
+  double* mv = pts + size_t(N) * d;
+  SweepPoints sp{pts, N, 1, N};
+  ConfOut co{};
+  co.Q = nullptr;
+  co.mean = mv;
+  co.var = mv + N;
+  co.S = nullptr;
+  co.partial = nullptr;
+  co.beta = 0.0;
+  SGP_TRY(launch_sweep_conf(ctx, gdev, &gp->dev, 1, d, sp, co));
+  SGP_TRY(sgp_d2h(ctx, mean, mv, size_t(N) * sizeof(double)));
+  SGP_TRY(sgp_d2h(ctx, var, mv + N, size_t(N) * sizeof(double)));
+  return 0;
+}
+
+int sgp_gp_get_factor(sgp_gp* gp, double* Linv, double* alpha) {
+  sgp_ctx* ctx = gp->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, gp->n > 0, "GP has no data");
+  const int64_t n = gp->n;
+  if (Linv) {
+    SGP_HIP(ctx, hipMemcpy2DAsync(Linv, n * sizeof(double), gp->Linv.p,
+                                  size_t(gp->n_f) * sizeof(double),
+                                  n * sizeof(double), n, hipMemcpyDeviceToHost,
+                                  ctx->stream));
+    SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (alpha) SGP_TRY(sgp_d2h(ctx, alpha, gp->alpha.p, n * sizeof(double)));
+  return 0;
+}
+
+int sgp_kern_K(sgp_ctx* ctx, int d, int n_parts, const int* kinds,
+               const double* variances, const double* inv_ls, const double* X1,
+               int64_t n1, const double* X2, int64_t n2, double* out) {
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  KernDesc kd;
+  SGP_TRY(fill_kern(ctx, &kd, d, n_parts, kinds, variances, inv_ls));
+  if (n1 <= 0 || n2 <= 0) return 0;
+  const size_t b1 = size_t(n1) * d * sizeof(double);
+  const size_t b2 = size_t(n2) * d * sizeof(double);
+  const size_t bo = size_t(n1) * n2 * sizeof(double);
+  double* x1 = static_cast<double*>(sgp_scratch(ctx, 3, b1 + b2));
+  double* o = static_cast<double*>(sgp_scratch(ctx, 4, bo));
+  SGP_CHECK(ctx, x1 && o, "device allocation failed: %s", ctx->err.c_str());
+  double* x2 = x1 + size_t(n1) * d;
+  SGP_TRY(sgp_h2d(ctx, x1, X1, b1));
+  SGP_TRY(sgp_h2d(ctx, x2, X2, b2));
+  SGP_TRY(launch_kernel_matrix(ctx, kd, x1, n1, x2, n2, o, n2, 0, 0.0,
+                               std::numeric_limits<int64_t>::max()));
+  SGP_TRY(sgp_d2h(ctx, out, o, bo));
+  return 0;
+}
+
+// ---- grid ---------------------------------------------------------------------
+int sgp_grid_create(sgp_ctx* ctx, const double* base, int64_t N, int d,
+                    int64_t stride_row_B, int64_t stride_col_B, int G,
+                    int64_t global_offset, sgp_grid** out) {
+  *out = nullptr;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, N >= 1, "empty grid");
+  SGP_CHECK(ctx, d >= 1 && d <= SGP_MAX_D, "input dimension %d not in 1..%d", d,
+            SGP_MAX_D);
+  SGP_CHECK(ctx, G >= 1 && G <= SGP_MAX_GPS, "%d GPs, supported 1..%d", G,
+            SGP_MAX_GPS);
+  SGP_CHECK(ctx, stride_row_B % 8 == 0 && stride_col_B % 8 == 0,
+            "grid strides must be multiples of 8 bytes");
+  sgp_grid* g = new (std::nothrow) sgp_grid();
+  SGP_CHECK(ctx, g != nullptr, "out of host memory");
+  g->ctx = ctx;
+  g->N = N;
+  g->d = d;
+  g->G = G;
+  g->goff = global_offset;
+  const size_t nd = size_t(N) * sizeof(double);
+  g->partial_cap = N / 128 + 2;
+  struct {
+    void** p;
+    size_t bytes;
+  } allocs[] = {{(void**)&g->pts, nd * d},      {(void**)&g->Q, nd * 2 * G},
+                {(void**)&g->mean, nd * G},     {(void**)&g->var, nd * G},
+                {(void**)&g->S, size_t(N)},     {(void**)&g->M, size_t(N)},
+                {(void**)&g->Gm, size_t(N)},    {(void**)&g->cand, size_t(N)},
+                {(void**)&g->w, nd},
+                {(void**)&g->partial, size_t(g->partial_cap) * sizeof(double)},
+                {(void**)&g->gpdev, sizeof(GpDev) * SGP_MAX_GPS}};
+  for (auto& a : allocs) {
+    hipError_t e = hipMalloc(a.p, a.bytes);
+    if (e != hipSuccess) {
+      sgp_set_error(ctx, "hipMalloc(%zu) -> %s", a.bytes, hipGetErrorString(e));
+      sgp_grid_destroy(g);
+      return -1;
+    }
+  }
+  SGP_HIP(ctx, hipMemsetAsync(g->S, 0, N, ctx->stream));
+  SGP_HIP(ctx, hipMemsetAsync(g->M, 0, N, ctx->stream));
+  SGP_HIP(ctx, hipMemsetAsync(g->Gm, 0, N, ctx->stream));
+  SGP_HIP(ctx, hipMemsetAsync(g->cand, 0, N, ctx->stream));
+  // upload the rows; the resident layout is SoA [d][N] (= the F-ordered array
+  // linearly_spaced_combinations returns, so the common case is one memcpy)
+  const int64_t sr = stride_row_B / 8, sc = stride_col_B / 8;
+  if (sr == 1 && sc == N) {
+    SGP_TRY(sgp_h2d(ctx, g->pts, base, nd * d));
+  } else if (sc == 1 && sr == d) {
+    double* stage = static_cast<double*>(sgp_scratch(ctx, 3, nd * d));
+    SGP_CHECK(ctx, stage, "device allocation failed: %s", ctx->err.c_str());
+    SGP_TRY(sgp_h2d(ctx, stage, base, nd * d));
+    SGP_TRY(launch_import_points(ctx, stage, N, d, d, 1, g->pts));
+    SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  } else {
+    std::vector<double> tmp(size_t(N) * d);
+    for (int64_t r = 0; r < N; ++r)
+      for (int k = 0; k < d; ++k) tmp[size_t(k) * N + r] = base[r * sr + k * sc];
+    SGP_TRY(sgp_h2d(ctx, g->pts, tmp.data(), nd * d));
+  }
+  *out = g;
+  return 0;
+}
+
+void sgp_grid_destroy(sgp_grid* g) {
+  if (!g) return;
+  sgp_ctx* ctx = g->ctx;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  void* ptrs[] = {g->pts, g->Q,    g->mean, g->var,     g->S,    g->M,
+                  g->Gm,  g->cand, g->w,    g->partial, g->gpdev};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete g;
+}
+
+int sgp_grid_set_context(sgp_grid* g, const double* c, int nc) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, nc >= 0 && nc <= g->d && nc <= SGP_MAX_GPS,
+            "bad number of context columns %d", nc);
+  if (nc == 0) return 0;
+  return launch_fill_cols(g, c, nc);
+}
+
+static int finish_safe_partials(sgp_grid* g, int nblocks, double* out2) {
+  sgp_ctx* ctx = g->ctx;
+  double* red = static_cast<double*>(sgp_scratch(ctx, 1, 64));
+  SGP_CHECK(ctx, red, "device allocation failed: %s", ctx->err.c_str());
+  SGP_TRY(launch_reduce_max(ctx, g->partial, nblocks, red));
+  double m = 0.0;
+  SGP_TRY(sgp_d2h(ctx, &m, red, sizeof(double)));
+  out2[0] = m;
+  out2[1] = (m > -INFINITY) ? 1.0 : 0.0;
+  return 0;
+}
+
+int sgp_grid_confidence(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
+                        const double* fmin, double* out2) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  GpDev host[SGP_MAX_GPS];
+  SGP_TRY(collect_gps(ctx, gps, G, g->d, host));
+  SGP_HIP(ctx, hipMemcpyAsync(g->gpdev, host, sizeof(GpDev) * G,
+                              hipMemcpyHostToDevice, ctx->stream));
+  SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host[] is on the stack
+  SweepPoints sp{g->pts, g->N, 1, g->N};
+  ConfOut co{};
+  co.Q = g->Q;
+  co.mean = g->mean;
+  co.var = g->var;
+  co.S = g->S;
+  co.partial = g->partial;
+  co.beta = beta;
+  for (int i = 0; i < SGP_MAX_GPS; ++i) co.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
+  SGP_TRY(launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co));
+  return finish_safe_partials(g, sweep_num_blocks(g->N), out2);
+}
+
+int sgp_grid_upload_Q(sgp_grid* g, const double* Q, const double* fmin,
+                      double* out2) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_TRY(sgp_h2d(ctx, g->Q, Q, size_t(g->N) * 2 * g->G * sizeof(double)));
+  SGP_TRY(launch_safe_set(g, fmin));
+  return finish_safe_partials(g, int((g->N + 255) / 256), out2);
+}
+
+int sgp_grid_maximizers(sgp_grid* g, double max_l, double* out) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_TRY(launch_maximizers(g, max_l));
+  double* red = static_cast<double*>(sgp_scratch(ctx, 1, 64));
+  SGP_CHECK(ctx, red, "device allocation failed: %s", ctx->err.c_str());
+  SGP_TRY(launch_reduce_max(ctx, g->partial, (g->N + 255) / 256, red));
+  return sgp_d2h(ctx, out, red, sizeof(double));
+}
+
+int sgp_grid_candidates(sgp_grid* g, double max_var, const double* scaling,
+                        const double* thr_beta, int full_sets,
+                        int64_t* counts) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_TRY(launch_candidates(g, max_var, scaling, thr_beta, full_sets));
+  return sgp_d2h(ctx, counts, ctx->scratch[1].p, 2 * sizeof(int64_t));
+}
+
+int sgp_grid_topk(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, int k,
+                  double* w_out, int64_t* gidx_out, int* n_out) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, k >= 1 && k <= 64, "k = %d not in 1..64", k);
+  char* res = static_cast<char*>(sgp_scratch(ctx, 1, 2048));
+  SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
+  double* wd = reinterpret_cast<double*>(res);
+  int64_t* id = reinterpret_cast<int64_t*>(res + 512);
+  int* nd = reinterpret_cast<int*>(res + 1024);
+  if (mode == 1) cut_w = (cut_idx < 0) ? INFINITY : -double(cut_idx);
+  SGP_TRY(launch_topk(g, mode, cut_w, cut_idx, k, wd, id, nd));
+  char host[1024 + 8];
+  SGP_TRY(sgp_d2h(ctx, host, res, 1024 + 8));
+  memcpy(w_out, host, size_t(k) * sizeof(double));
+  memcpy(gidx_out, host + 512, size_t(k) * sizeof(int64_t));
+  memcpy(n_out, host + 1024, sizeof(int));
+  return 0;
+}
+
+static int upload_local_idx(sgp_grid* g, const int64_t* gidx, int m,
+                            int64_t** dev) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_CHECK(ctx, m >= 1 && m <= 4096, "m = %d rows out of range", m);
+  std::vector<int64_t> li(m);
+  for (int j = 0; j < m; ++j) {
+    li[j] = gidx[j] - g->goff;
+    SGP_CHECK(ctx, li[j] >= 0 && li[j] < g->N,
+              "global index %lld is not owned by this shard",
+              (long long)gidx[j]);
+  }
+  int64_t* d = static_cast<int64_t*>(sgp_scratch(ctx, 6, size_t(m) * 8));
+  SGP_CHECK(ctx, d, "device allocation failed: %s", ctx->err.c_str());
+  SGP_TRY(sgp_h2d(ctx, d, li.data(), size_t(m) * 8));
+  *dev = d;
+  return 0;
+}
+
+int sgp_grid_gather_rows(sgp_grid* g, const int64_t* gidx, int m, double* x,
+                         double* mean, double* var, double* Q) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  int64_t* li = nullptr;
+  SGP_TRY(upload_local_idx(g, gidx, m, &li));
+  const int d = g->d, G = g->G;
+  const size_t per = size_t(d) + 4 * size_t(G);
+  double* o = static_cast<double*>(sgp_scratch(ctx, 7, size_t(m) * per * 8));
+  SGP_CHECK(ctx, o, "device allocation failed: %s", ctx->err.c_str());
+  double* ox = o;
+  double* om = ox + size_t(m) * d;
+  double* ov = om + size_t(m) * G;
+  double* oq = ov + size_t(m) * G;
+  SGP_TRY(launch_gather_rows(g, li, m, ox, om, ov, oq));
+  std::vector<double> host(size_t(m) * per);
+  SGP_TRY(sgp_d2h(ctx, host.data(), o, host.size() * 8));
+  memcpy(x, host.data(), size_t(m) * d * 8);
+  memcpy(mean, host.data() + size_t(m) * d, size_t(m) * G * 8);
+  memcpy(var, host.data() + size_t(m) * (d + G), size_t(m) * G * 8);
+  memcpy(Q, host.data() + size_t(m) * (d + 2 * G), size_t(m) * 2 * G * 8);
+  return 0;
+}
+
+int sgp_grid_mark_expanders(sgp_grid* g, const int64_t* gidx, int m) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  if (m <= 0) return 0;
+  int64_t* li = nullptr;
+  SGP_TRY(upload_local_idx(g, gidx, m, &li));
+  return launch_mark(g, li, m);
+}
+
+int sgp_grid_lipschitz_check(sgp_grid* g, int G, const double* fmin,
+                             const double* lipschitz, int m, const double* xc,
+                             const double* u_c, int32_t* flags) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  SGP_CHECK(ctx, m >= 1 && m <= SGP_TOPK, "m = %d not in 1..%d", m, SGP_TOPK);
+  const int d = g->d;
+  const size_t bx = size_t(m) * d * 8, bu = size_t(m) * G * 8,
+               bf = size_t(m) * G * 4;
+  char* buf = static_cast<char*>(sgp_scratch(ctx, 7, bx + bu + bf + 64));
+  SGP_CHECK(ctx, buf, "device allocation failed: %s", ctx->err.c_str());
+  double* dx = reinterpret_cast<double*>(buf);
+  double* du = reinterpret_cast<double*>(buf + bx);
+  int32_t* df = reinterpret_cast<int32_t*>(buf + bx + bu);
+  SGP_TRY(sgp_h2d(ctx, dx, xc, bx));
+  SGP_TRY(sgp_h2d(ctx, du, u_c, bu));
+  SGP_HIP(ctx, hipMemsetAsync(df, 0, bf, ctx->stream));
+  SGP_TRY(launch_lipschitz(g, G, fmin, lipschitz, m, dx, du, df));
+  return sgp_d2h(ctx, flags, df, bf);
+}
+
+int sgp_grid_argmax(sgp_grid* g, int mode, const double* scaling, double* value,
+                    int64_t* gidx) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  char* res = static_cast<char*>(sgp_scratch(ctx, 1, 64));
+  SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
+  SGP_TRY(launch_argmax(g, mode, scaling, reinterpret_cast<double*>(res),
+                        reinterpret_cast<int64_t*>(res + 8)));
+  char host[16];
+  SGP_TRY(sgp_d2h(ctx, host, res, 16));
+  memcpy(value, host, 8);
+  memcpy(gidx, host + 8, 8);
+  return 0;
+}
+
+int sgp_grid_download(sgp_grid* g, int what, void* out) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t N = size_t(g->N), G = size_t(g->G);
+  switch (what) {
+    case SGP_Q: return sgp_d2h(ctx, out, g->Q, N * 2 * G * 8);
+    case SGP_S: return sgp_d2h(ctx, out, g->S, N);
+    case SGP_M: return sgp_d2h(ctx, out, g->M, N);
+    case SGP_G: return sgp_d2h(ctx, out, g->Gm, N);
+    case SGP_MEAN: return sgp_d2h(ctx, out, g->mean, N * G * 8);
+    case SGP_VAR: return sgp_d2h(ctx, out, g->var, N * G * 8);
+  }
+  sgp_set_error(ctx, "unknown array selector %d", what);
+  return -2;
+}
+
+int sgp_grid_expander_check(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
+                            const double* fmin, int m, const double* xc,
+                            const double* mu_c, const double* u_c,
+                            int32_t* flags) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  SGP_CHECK(ctx, m >= 1 && m <= SGP_TOPK, "m = %d not in 1..%d", m, SGP_TOPK);
+  GpDev host[SGP_MAX_GPS];
+  SGP_TRY(collect_gps(ctx, gps, G, g->d, host));
+  const int d = g->d;
+  int np_max = 0;
+  for (int i = 0; i < G; ++i) np_max = host[i].n_pad > np_max ? host[i].n_pad : np_max;
+  const int64_t wstride = int64_t(np_max / 4) * 64;
+  // device layout: xc | resid[G][16] | delta[G][16] | inv_s2[G][16] | flags | W
+  const size_t bx = size_t(SGP_TOPK) * d * 8, bv = size_t(G) * 16 * 8,
+               bf = size_t(SGP_TOPK) * G * 4 + 64;
+  const size_t total = bx + 3 * bv + bf + size_t(G) * wstride * 8;
+  char* buf = static_cast<char*>(sgp_scratch(ctx, 7, total));
+  SGP_CHECK(ctx, buf, "device allocation failed: %s", ctx->err.c_str());
+  double* dxc = reinterpret_cast<double*>(buf);
+  double* dres = reinterpret_cast<double*>(buf + bx);
+  double* ddel = reinterpret_cast<double*>(buf + bx + bv);
+  double* dis2 = reinterpret_cast<double*>(buf + bx + 2 * bv);
+  int32_t* dfl = reinterpret_cast<int32_t*>(buf + bx + 3 * bv);
+  double* dW = reinterpret_cast<double*>(buf + bx + 3 * bv + bf);
+  std::vector<double> resid(size_t(G) * 16, 0.0);
+  for (int c = 0; c < m; ++c)
+    for (int i = 0; i < G; ++i) resid[size_t(i) * 16 + c] = u_c[c * G + i] - mu_c[c * G + i];
+  SGP_TRY(sgp_h2d(ctx, dxc, xc, size_t(m) * d * 8));
+  SGP_TRY(sgp_h2d(ctx, dres, resid.data(), bv));
+  SGP_HIP(ctx, hipMemsetAsync(dfl, 0, bf, ctx->stream));
+  SGP_HIP(ctx, hipMemcpyAsync(g->gpdev, host, sizeof(GpDev) * G,
+                              hipMemcpyHostToDevice, ctx->stream));
+  ExpanderArgs ea{};
+  for (int i = 0; i < SGP_MAX_GPS; ++i) {
+    ea.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
+    ea.active[i] = (i < G) && (fmin[i] != -INFINITY);
+  }
+  for (int i = 0; i < G; ++i) {
+    if (!ea.active[i]) continue;
+    SGP_TRY(expander_operands(gps[i], dxc, m, dres + i * 16, dW + i * wstride,
+                              ddel + i * 16, dis2 + i * 16));
+  }
+  ea.Wpack = dW;
+  ea.xc = dxc;
+  ea.delta = ddel;
+  ea.inv_s2 = dis2;
+  ea.m = m;
+  ea.beta = beta;
+  ea.S = g->S;
+  ea.mean = g->mean;
+  ea.var = g->var;
+  ea.flags = dfl;
+  ea.wstride = wstride;
+  SweepPoints sp{g->pts, g->N, 1, g->N};
+  SGP_TRY(launch_expander_check(ctx, g->gpdev, host, G, d, sp, ea));
+  std::vector<int32_t> fl(size_t(SGP_TOPK) * G);
+  SGP_TRY(sgp_d2h(ctx, fl.data(), dfl, fl.size() * 4));
+  memcpy(flags, fl.data(), size_t(m) * G * 4);
+  return 0;
+}
+
+// ---- swarm ----------------------------------------------------------------------
+int sgp_swarm_fitness(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
+                      const double* particles, int64_t P, double beta,
+                      const double* fmin, const double* scaling,
+                      double best_lower_bound, double* values, uint8_t* safe) {
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, swarm_type >= SGP_SWARM_GREEDY && swarm_type <= SGP_SWARM_SAFE_SET,
+            "Invalid swarm type %d", swarm_type);
+  SGP_CHECK(ctx, G >= 1 && gps[0], "no GP");
+  if (P <= 0) return 0;
+  const int d = gps[0]->kern.d;
+  GpDev host[SGP_MAX_GPS];
+  SGP_TRY(collect_gps(ctx, gps, G, d, host));
+  const size_t nd = size_t(P) * 8;
+  double* stage = static_cast<double*>(sgp_scratch(ctx, 3, nd * d));
+  char* work = static_cast<char*>(
+      sgp_scratch(ctx, 4, nd * d + nd + size_t(P) + sizeof(GpDev) * SGP_MAX_GPS + 64));
+  SGP_CHECK(ctx, stage && work, "device allocation failed: %s", ctx->err.c_str());
+  double* pts = reinterpret_cast<double*>(work);
+  double* dval = reinterpret_cast<double*>(work + nd * d);
+  GpDev* gdev = reinterpret_cast<GpDev*>(work + nd * d + nd);
+  uint8_t* dsafe = reinterpret_cast<uint8_t*>(work + nd * d + nd + sizeof(GpDev) * SGP_MAX_GPS);
+  SGP_TRY(sgp_h2d(ctx, stage, particles, nd * d));
+  SGP_TRY(launch_import_points(ctx, stage, P, d, d, 1, pts));
+  SGP_TRY(sgp_h2d(ctx, gdev, host, sizeof(GpDev) * G));
+  FitnessArgs fa{};
+  fa.swarm_type = swarm_type;
+  fa.beta = beta;
+  fa.best_lower_bound = best_lower_bound;
+  for (int i = 0; i < SGP_MAX_GPS; ++i) {
+    fa.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
+    fa.scaling[i] = (i < G) ? scaling[i] : 1.0;
+  }
+  fa.values = dval;
+  fa.safe = dsafe;
+  SweepPoints sp{pts, P, 1, P};
+  SGP_TRY(launch_sweep_fitness(ctx, gdev, host, G, d, sp, fa));
+  SGP_TRY(sgp_d2h(ctx, values, dval, nd));
+  SGP_TRY(sgp_d2h(ctx, safe, dsafe, size_t(P)));
+  return 0;
+}
+
+// ---- timing ---------------------------------------------------------------------
+int sgp_timer_start(sgp_ctx* ctx) {
+  SGP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return 0;
+}
+
+int sgp_timer_stop(sgp_ctx* ctx, float* ms) {
+  SGP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  SGP_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  SGP_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return 0;
+}
+
+int sgp_profile_enable(sgp_ctx* ctx, int on) {
+  ctx->profiling = on != 0;
+  ctx->prof_used = 0;
+  ctx->prof_flops = 0.0;
+  return 0;
+}
+
+int sgp_profile_read(sgp_ctx* ctx, double* total_ms, int64_t* launches,
+                     double* flops) {
+  SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+    float ms = 0.f;
+    SGP_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_events[i],
+                                     ctx->prof_events[i + 1]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = int64_t(ctx->prof_used / 2);
+  *flops = ctx->prof_flops;
+  return 0;
+}
+
+int sgp_microbench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops) {
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_microbench(ctx, iters, tflops);
+}
+
+// ---- RCCL -----------------------------------------------------------------------
+int sgp_comm_unique_id(void* id128) {
+  SGP_TRY(load_rccl(nullptr));
+  ncclUniqueId id;
+  SGP_NCCL(nullptr, g_rccl.GetUniqueId(&id));
+  memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+int sgp_comm_init(sgp_ctx* ctx, const void* id128, int rank, int world) {
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_TRY(load_rccl(ctx));
+  SGP_CHECK(ctx, world >= 1 && rank >= 0 && rank < world,
+            "bad rank %d / world %d", rank, world);
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  ncclComm_t comm;
+  SGP_NCCL(ctx, g_rccl.CommInitRank(&comm, world, id, rank));
+  ctx->comm = comm;
+  ctx->rank = rank;
+  ctx->world = world;
+  return 0;
+}
+
+int sgp_comm_allreduce_max(sgp_ctx* ctx, double* buf, int n) {
+  if (ctx->world <= 1 || n <= 0) return 0;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, ctx->comm, "sgp_comm_init was not called");
+  double* d = static_cast<double*>(sgp_scratch(ctx, 6, size_t(n) * 8));
+  SGP_CHECK(ctx, d, "device allocation failed: %s", ctx->err.c_str());
+  SGP_TRY(sgp_h2d(ctx, d, buf, size_t(n) * 8));
+  SGP_NCCL(ctx, g_rccl.AllReduce(d, d, size_t(n), ncclFloat64, ncclMax,
+                                 static_cast<ncclComm_t>(ctx->comm),
+                                 ctx->stream));
+  return sgp_d2h(ctx, buf, d, size_t(n) * 8);
+}
+
+int sgp_comm_allgather(sgp_ctx* ctx, const void* send, void* recv,
+                       int64_t nbytes) {
+  if (nbytes <= 0) return 0;
+  if (ctx->world <= 1) {
+    memcpy(recv, send, size_t(nbytes));
+    return 0;
+  }
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, ctx->comm, "sgp_comm_init was not called");
+  char* d = static_cast<char*>(
+      sgp_scratch(ctx, 6, size_t(nbytes) * (size_t(ctx->world) + 1)));
+  SGP_CHECK(ctx, d, "device allocation failed: %s", ctx->err.c_str());
+  char* r = d + nbytes;
+  SGP_TRY(sgp_h2d(ctx, d, send, size_t(nbytes)));
+  SGP_NCCL(ctx, g_rccl.AllGather(d, r, size_t(nbytes), ncclInt8,
+                                 static_cast<ncclComm_t>(ctx->comm),
+                                 ctx->stream));
+  return sgp_d2h(ctx, recv, r, size_t(nbytes) * size_t(ctx->world));
+}
+
+int sgp_comm_barrier(sgp_ctx* ctx) {
+  double z = 0.0;
+  SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return sgp_comm_allreduce_max(ctx, &z, 1);
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+// Internal declarations shared by the translation units of libsafeopt_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "safeopt_hip.h"
+
+// ---- error plumbing ---------------------------------------------------------
+void sgp_set_error(sgp_ctx* ctx, const char* fmt, ...);
+
+#define SGP_HIP(ctx, call)                                                     \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      sgp_set_error((ctx), "%s:%d %s -> %s", __FILE__, __LINE__, #call,        \
+                    hipGetErrorString(e_));                                    \
+      return -1;                                                               \
+    }                                                                          \
+  } while (0)
+
+#define SGP_CHECK(ctx, cond, ...)                                              \
+  do {                                                                         \
+    if (!(cond)) {                                                             \
+      sgp_set_error((ctx), __VA_ARGS__);                                       \
+      return -2;                                                               \
+    }                                                                          \
+  } while (0)
+
+#define SGP_TRY(expr)                                                          \
+  do {                                                                         \
+    int r_ = (expr);                                                           \
+    if (r_ != 0) return r_;                                                    \
+  } while (0)
+
+// ---- device-side descriptors ------------------------------------------------
+struct KernDesc {
+  int d;
+  int n_parts;
+  int kind[SGP_MAX_PARTS];
+  double variance[SGP_MAX_PARTS];
+  double inv_ls[SGP_MAX_PARTS][SGP_MAX_D];
+  double kdiag;  // product of the variances = k(x, x)
+};
+
+// One GP as the sweep kernels see it.  All pointers are device pointers.
+struct GpDev {
+  const double* Apack;  // L^-1 in MFMA A-operand order: [nblk][n_pad/4][64]
+  const double* Xpad;   // training inputs, [n_pad][d], zero padded
+  const double* alpha;  // Ky^-1 y, [n_pad], zero padded
+  int n;                // training points
+  int n_pad;            // n rounded up to 16
+  int nblk;             // n_pad / 16
+  int pad_;
+  KernDesc kern;
+};
+
+// ---- host-side objects ------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct sgp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // small pinned staging area for scalar H2D / D2H traffic
+  void* pinned = nullptr;
+  size_t pinned_cap = 0;
+  // device scratch (grown on demand)
+  DevBuf scratch[8];
+  // timing
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool profiling = false;
+  std::vector<hipEvent_t> prof_events;  // start/stop pairs of sweep launches
+  size_t prof_used = 0;
+  double prof_flops = 0.0;
+  // RCCL
+  void* comm = nullptr;  // ncclComm_t
+  int rank = 0, world = 1;
+  int num_cu = 256;
+};
+
+struct sgp_gp {
+  sgp_ctx* ctx = nullptr;
+  KernDesc kern;
+  double noise_var = 0.0;
+  double jitter = 0.0;
+  int64_t n = 0;
+  int n_pad = 0;  // multiple of 16 (sweep blocks)
+  int n_f = 0;    // multiple of 32 (factorisation leaves)
+  DevBuf X, Y, Xpad, alpha, Apack, Linv, Kmat, work, tvec;
+  GpDev dev;      // filled by set_data
+};
+
+struct sgp_grid {
+  sgp_ctx* ctx = nullptr;
+  int64_t N = 0;
+  int d = 0;
+  int G = 0;
+  int64_t goff = 0;
+  double* pts = nullptr;     // SoA [d][N]
+  double* Q = nullptr;       // [N][2G]
+  double* mean = nullptr;    // [G][N]
+  double* var = nullptr;     // [G][N]
+  uint8_t* S = nullptr;      // [N]
+  uint8_t* M = nullptr;
+  uint8_t* Gm = nullptr;
+  uint8_t* cand = nullptr;   // candidate mask s
+  double* w = nullptr;       // [N] max_i(u_i - l_i) of candidates
+  double* partial = nullptr; // block partials
+  int64_t partial_cap = 0;
+  GpDev* gpdev = nullptr;    // [SGP_MAX_GPS] device copy of descriptors
+};
+
+// ---- helpers (api.hip) ------------------------------------------------------
+int sgp_reserve(sgp_ctx* ctx, DevBuf* b, size_t bytes);
+void* sgp_scratch(sgp_ctx* ctx, int slot, size_t bytes);  // nullptr on failure
+int sgp_h2d(sgp_ctx* ctx, void* dst, const void* src, size_t bytes);
+int sgp_d2h(sgp_ctx* ctx, void* dst, const void* src, size_t bytes);  // syncs
+
+// ---- kernel launchers (implemented in the .hip files) -----------------------
+// factor.hip
+int launch_kernel_matrix(sgp_ctx* ctx, const KernDesc& kd, const double* X1,
+                         int64_t n1, const double* X2, int64_t n2, double* out,
+                         int64_t ld, int symmetric_diag, double diag_add,
+                         int64_t n_valid);
+int factor_gp(sgp_gp* gp, int* info);  // Kmat -> Linv, Apack, alpha
+int expander_operands(sgp_gp* gp, const double* xc_dev, int m,
+                      const double* resid_dev, double* Wpack, double* delta,
+                      double* inv_s2);
+
+// sweep.hip
+struct SweepPoints {
+  const double* base;
+  int64_t N;
+  int64_t stride_row;  // elements
+  int64_t stride_col;
+};
+struct ConfOut {
+  double* Q;        // [N][2G] or null
+  double* mean;     // [G][N]
+  double* var;      // [G][N]
+  uint8_t* S;       // [N] or null
+  double* partial;  // [nblocks] max l0 over safe rows of the block, or null
+  double beta;
+  double fmin[SGP_MAX_GPS];
+};
+struct FitnessArgs {
+  int swarm_type;
+  double beta;
+  double fmin[SGP_MAX_GPS];
+  double scaling[SGP_MAX_GPS];
+  double best_lower_bound;
+  double* values;
+  uint8_t* safe;
+};
+int sweep_num_blocks(int64_t N);
+int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
+                      int G, int d, SweepPoints pts, ConfOut out);
+int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,
+                         const GpDev* gps_host, int G, int d, SweepPoints pts,
+                         FitnessArgs fa);
+struct ExpanderArgs {
+  const double* Wpack;   // [G][n_pad_max/4][64] MFMA A-operand (cand x j)
+  const double* xc;      // [m][d]
+  const double* delta;   // [G][16]  (u_c - mu_c) / s2
+  const double* inv_s2;  // [G][16]
+  int m;
+  double beta;
+  double fmin[SGP_MAX_GPS];
+  int active[SGP_MAX_GPS];
+  const uint8_t* S;
+  const double* mean;    // [G][N]
+  const double* var;
+  int32_t* flags;        // [16][G] device
+  int64_t wstride;       // doubles between consecutive GPs in Wpack
+};
+int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
+                          const GpDev* gps_host, int G, int d, SweepPoints pts,
+                          ExpanderArgs ea);
+int launch_microbench(sgp_ctx* ctx, int iters, double* tflops);
+
+// sets.hip
+int launch_reduce_max(sgp_ctx* ctx, const double* in, int64_t n, double* out);
+int launch_safe_set(sgp_grid* g, const double* fmin);  // from Q -> S, partial
+int launch_maximizers(sgp_grid* g, double max_l);
+int launch_candidates(sgp_grid* g, double max_var, const double* scaling,
+                      const double* thr_beta, int full_sets);
+int launch_topk(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, int k,
+                double* w_out_dev, int64_t* idx_out_dev, int* n_out_dev);
+int launch_lipschitz(sgp_grid* g, int G, const double* fmin,
+                     const double* lipschitz, int m, const double* xc_dev,
+                     const double* uc_dev, int32_t* flags_dev);
+int launch_argmax(sgp_grid* g, int mode, const double* scaling,
+                  double* value_dev, int64_t* idx_dev);
+int launch_fill_cols(sgp_grid* g, const double* c, int nc);
+int launch_gather_rows(sgp_grid* g, const int64_t* lidx_dev, int m, double* x,
+                       double* mean, double* var, double* Q);
+int launch_mark(sgp_grid* g, const int64_t* lidx_dev, int m);
+int launch_import_points(sgp_ctx* ctx, const double* src, int64_t N, int d,
+                         int64_t stride_row, int64_t stride_col, double* dst);

@@ -1,0 +1,418 @@
+// GP "set_XY" on the device: kernel matrix, Cholesky, L^-1, alpha.
+//
+// Replaces what GPy's ExactGaussianInference does behind gp.set_XY
+// (safeopt/gp_opt.py:227, 267, 275):  Ky = k(X,X) + (noise + 1e-8) I,
+// L = jitchol(Ky), Ky^-1 via the triangular inverse, alpha = Ky^-1 y.
+// n <= a few thousand, so n^3/3 <= ~3 GFLOP: a recursive blocked algorithm
+// (32x32 leaves in LDS + one tiled fp64 GEMM kernel) is launch-bound, not
+// flop-bound, and runs replicated on every GPU (no communication).
+//
+//   factor(A[0:s]):  s == 32 -> leaf (potf2 + triangular inverse in LDS)
+//     else split h:  factor(A11); L21 = A21 Linv11^T; A22 -= L21 L21^T;
+//                    factor(A22); Linv21 = -Linv22 (L21 Linv11)
+#include "kern_eval.h"
+
+namespace {
+
+constexpr int NB = 32;  // leaf size
+
+// ---- covariance matrix --------------------------------------------------------
+// out[i*ld + j] = k(X1_i, X2_j) (+ diag_add on i == j when symmetric_diag).
+// Rows/cols >= n_valid (padding of a square factorisation matrix) become the
+// identity so the padded Cholesky stays well defined.
+template <int D>
+__global__ void k_kernel_matrix(KernDesc kd, const double* X1, int64_t n1,
+                                const double* X2, int64_t n2, double* out,
+                                int64_t ld, int symmetric_diag, double diag_add,
+                                int64_t n_valid) {
+  const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t i = int64_t(blockIdx.y) * blockDim.y + threadIdx.y;
+  if (i >= n1 || j >= n2) return;
+  double v;
+  if (i >= n_valid || j >= n_valid) {
+    v = (i == j) ? 1.0 : 0.0;
+  } else {
+    double a[D], b[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      a[k] = X1[i * D + k];
+      b[k] = X2[j * D + k];
+    }
+    v = kern_eval<D>(kd, a, b);
+    if (symmetric_diag && i == j) v += diag_add;
+  }
+  out[i * ld + j] = v;
+}
+
+// ---- leaf: 32x32 Cholesky + inverse of the factor, one workgroup --------------
+// A (ld) holds the symmetric block (lower part used); on exit A's lower part is
+// L, and Linv (ldi) receives L^-1 (lower).  info[0] = first bad pivot (1-based,
+// offset by `row0`) if a pivot is not positive / not finite.
+__global__ __launch_bounds__(256) void k_leaf(double* A, int64_t ld,
+                                              double* Linv, int64_t ldi,
+                                              int row0, int* info) {
+  __shared__ double a[NB][NB + 1];
+  __shared__ double inv[NB][NB + 1];
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) bad = 0;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e / NB, j = e % NB;
+    a[i][j] = (j <= i) ? A[i * ld + j] : 0.0;
+    inv[i][j] = 0.0;
+  }
+  __syncthreads();
+  for (int k = 0; k < NB; ++k) {
+    const double piv = a[k][k];
+    if (!(piv > 0.0) || !isfinite(piv)) {
+      if (tid == 0 && bad == 0) bad = row0 + k + 1;
+      __syncthreads();
+      break;
+    }
+    const double dk = sqrt(piv);
+    __syncthreads();
+    if (tid == 0) a[k][k] = dk;
+    if (tid > k && tid < NB) a[tid][k] /= dk;
+    __syncthreads();
+    // trailing update: a[i][j] -= a[i][k] a[j][k], k < j <= i
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int i = e / NB, j = e % NB;
+      if (j > k && j <= i) a[i][j] -= a[i][k] * a[j][k];
+    }
+    __syncthreads();
+  }
+  if (bad != 0) {
+    if (tid == 0) atomicCAS(info, 0, bad);
+    return;
+  }
+  // inverse by forward substitution, one column per thread
+  if (tid < NB) {
+    const int j = tid;
+    for (int i = j; i < NB; ++i) {
+      double s = (i == j) ? 1.0 : 0.0;
+      for (int k = j; k < i; ++k) s -= a[i][k] * inv[k][j];
+      inv[i][j] = s / a[i][i];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e / NB, j = e % NB;
+    if (j <= i) {
+      A[i * ld + j] = a[i][j];
+      Linv[i * ldi + j] = inv[i][j];
+    }
+  }
+}
+
+// ---- tiled fp64 GEMM: C = alpha * A * op(B) + beta * C ------------------------
+// Row-major, 64x64 tile per workgroup, 4x4 micro-tile per thread, K step 16.
+// transB: op(B) = B^T with B given as (n x k).  lowerB: B (k x n) is lower
+// triangular (entries with row < col are skipped = treated as 0); lowerA: same
+// for A (m x k).
+template <bool TRANSB>
+__global__ __launch_bounds__(256) void k_gemm(int m, int n, int k, double alpha,
+                                              const double* A, int64_t lda,
+                                              const double* B, int64_t ldb,
+                                              double beta, double* C,
+                                              int64_t ldc) {
+  __shared__ double As[16][64 + 1];  // As[kk][i]
+  __shared__ double Bs[16][64 + 1];  // Bs[kk][j]
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  double acc[4][4] = {};
+  for (int k0 = 0; k0 < k; k0 += 16) {
+    for (int e = tid; e < 64 * 16; e += 256) {
+      {  // A tile: rows i0..i0+63, cols k0..k0+15
+        const int i = e >> 4, kk = e & 15;
+        const int gi = i0 + i, gk = k0 + kk;
+        As[kk][i] = (gi < m && gk < k) ? A[int64_t(gi) * lda + gk] : 0.0;
+      }
+      if (TRANSB) {  // B is (n x k): Bs[kk][j] = B[j0+j][k0+kk]
+        const int j = e >> 4, kk = e & 15;
+        const int gj = j0 + j, gk = k0 + kk;
+        Bs[kk][j] = (gj < n && gk < k) ? B[int64_t(gj) * ldb + gk] : 0.0;
+      } else {  // B is (k x n)
+        const int kk = e >> 6, j = e & 63;
+        const int gj = j0 + j, gk = k0 + kk;
+        Bs[kk][j] = (gj < n && gk < k) ? B[int64_t(gk) * ldb + gj] : 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = As[kk][ty + 16 * r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[c] = Bs[kk][tx + 16 * c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = fma(a[r], b[c], acc[r][c]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gi = i0 + ty + 16 * r;
+    if (gi >= m) continue;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int gj = j0 + tx + 16 * c;
+      if (gj >= n) continue;
+      double* p = C + int64_t(gi) * ldc + gj;
+      const double old = (beta == 0.0) ? 0.0 : beta * (*p);
+      *p = alpha * acc[r][c] + old;
+    }
+  }
+}
+
+int gemm(sgp_ctx* ctx, bool transB, int m, int n, int k, double alpha,
+         const double* A, int64_t lda, const double* B, int64_t ldb,
+         double beta, double* C, int64_t ldc) {
+  if (m <= 0 || n <= 0) return 0;
+  dim3 grid((n + 63) / 64, (m + 63) / 64);
+  if (transB)
+    hipLaunchKernelGGL(k_gemm<true>, grid, dim3(256), 0, ctx->stream, m, n, k,
+                       alpha, A, lda, B, ldb, beta, C, ldc);
+  else
+    hipLaunchKernelGGL(k_gemm<false>, grid, dim3(256), 0, ctx->stream, m, n, k,
+                       alpha, A, lda, B, ldb, beta, C, ldc);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// Recursive Cholesky + inverse on the n_f x n_f device matrices A (-> L) and
+// Li (-> L^-1, must be zero-initialised); T is an n_f x n_f workspace.
+int factor_rec(sgp_ctx* ctx, double* A, double* Li, double* T, int64_t ld,
+               int off, int s, int* info_dev) {
+  double* Ad = A + int64_t(off) * ld + off;
+  double* Ld = Li + int64_t(off) * ld + off;
+  if (s <= NB) {
+    hipLaunchKernelGGL(k_leaf, dim3(1), dim3(256), 0, ctx->stream, Ad, ld, Ld,
+                       ld, off, info_dev);
+    SGP_HIP(ctx, hipGetLastError());
+    return 0;
+  }
+  const int h = ((s / NB + 1) / 2) * NB;  // split at a leaf boundary
+  const int r = s - h;
+  SGP_TRY(factor_rec(ctx, A, Li, T, ld, off, h, info_dev));
+  double* A21 = Ad + int64_t(h) * ld;
+  double* A22 = Ad + int64_t(h) * ld + h;
+  double* Li21 = Ld + int64_t(h) * ld;
+  double* Li22 = Ld + int64_t(h) * ld + h;
+  double* T21 = T + int64_t(off + h) * ld + off;
+  // T21 = A21 * Linv11^T ; A21 <- T21  (L21)
+  SGP_TRY(gemm(ctx, true, r, h, h, 1.0, A21, ld, Ld, ld, 0.0, T21, ld));
+  SGP_HIP(ctx, hipMemcpy2DAsync(A21, ld * sizeof(double), T21,
+                                ld * sizeof(double), h * sizeof(double), r,
+                                hipMemcpyDeviceToDevice, ctx->stream));
+  // A22 -= L21 L21^T
+  SGP_TRY(gemm(ctx, true, r, r, h, -1.0, A21, ld, A21, ld, 1.0, A22, ld));
+  SGP_TRY(factor_rec(ctx, A, Li, T, ld, off + h, r, info_dev));
+  // Linv21 = -Linv22 * (L21 * Linv11)
+  SGP_TRY(gemm(ctx, false, r, h, h, 1.0, A21, ld, Ld, ld, 0.0, T21, ld));
+  SGP_TRY(gemm(ctx, false, r, h, r, -1.0, Li22, ld, T21, ld, 0.0, Li21, ld));
+  return 0;
+}
+
+// ---- pack L^-1 into MFMA A-operand order ----------------------------------------
+// Apack[(b * nsteps + s) * 64 + lane] = Linv[16 b + (lane & 15)][4 s + (lane >> 4)]
+// (zero outside the n x n lower triangle).
+__global__ void k_pack(const double* Li, int64_t ld, int n, int nblk,
+                       int nsteps, double* Apack) {
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t total = int64_t(nblk) * nsteps * 64;
+  if (e >= total) return;
+  const int lane = int(e & 63);
+  const int64_t bs = e >> 6;
+  const int s = int(bs % nsteps);
+  const int b = int(bs / nsteps);
+  const int i = 16 * b + (lane & 15);
+  const int j = 4 * s + (lane >> 4);
+  double v = 0.0;
+  if (i < n && j <= i) v = Li[int64_t(i) * ld + j];
+  Apack[e] = v;
+}
+
+// t = Linv * y (lower-triangular matvec), one thread per row
+__global__ void k_trmv_lower(const double* Li, int64_t ld, int n,
+                             const double* y, double* t) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int j = 0; j <= i; ++j) s = fma(Li[int64_t(i) * ld + j], y[j], s);
+  t[i] = s;
+}
+
+// out = Linv^T * t, one thread per column; out has n_out >= n entries (zero pad)
+__global__ void k_trmv_lower_t(const double* Li, int64_t ld, int n,
+                               const double* t, double* out, int n_out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_out) return;
+  double s = 0.0;
+  if (j < n)
+    for (int i = j; i < n; ++i) s = fma(Li[int64_t(i) * ld + j], t[i], s);
+  out[j] = s;
+}
+
+__global__ void k_pad_rows(const double* X, int n, int n_pad, int d,
+                           double* Xpad) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_pad * d) return;
+  Xpad[e] = (e < n * d) ? X[e] : 0.0;
+}
+
+
+// ---- operands of the rank-1 expander test ---------------------------------------
+// s2_c = k(x_c,x_c) + noise + 1e-8 + jitter - |t_c|^2 ; delta = resid / s2
+__global__ void k_s2(const double* Tt, int64_t ld, int n, int m, double prior,
+                     const double* resid, double* delta, double* inv_s2) {
+  __shared__ double sh[256 / 64];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double t = Tt[int64_t(c) * ld + i];
+    s = fma(t, t, s);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < int(blockDim.x >> 6); ++w) tot += sh[w];
+    const double s2 = prior - tot;
+    inv_s2[c] = 1.0 / s2;
+    delta[c] = resid[c] / s2;
+  }
+  (void)m;
+}
+
+// Wpack[s*64 + lane] = Wt[lane & 15][4 s + (lane >> 4)]  (A operand: cand x j)
+__global__ void k_pack_w(const double* Wt, int64_t ld, int n, int m, int nsteps,
+                         double* Wpack) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nsteps * 64) return;
+  const int lane = e & 63, s = e >> 6;
+  const int c = lane & 15, j = 4 * s + (lane >> 4);
+  Wpack[e] = (c < m && j < n) ? Wt[int64_t(c) * ld + j] : 0.0;
+}
+
+}  // namespace
+
+int launch_kernel_matrix(sgp_ctx* ctx, const KernDesc& kd, const double* X1,
+                         int64_t n1, const double* X2, int64_t n2, double* out,
+                         int64_t ld, int symmetric_diag, double diag_add,
+                         int64_t n_valid) {
+  if (n1 <= 0 || n2 <= 0) return 0;
+  dim3 block(64, 4);
+  dim3 grid(unsigned((n2 + 63) / 64), unsigned((n1 + 3) / 4));
+#define KM_CASE(DD)                                                            \
+  case DD:                                                                     \
+    hipLaunchKernelGGL(k_kernel_matrix<DD>, grid, block, 0, ctx->stream, kd,   \
+                       X1, n1, X2, n2, out, ld, symmetric_diag, diag_add,      \
+                       n_valid);                                               \
+    break;
+  switch (kd.d) {
+    KM_CASE(1) KM_CASE(2) KM_CASE(3) KM_CASE(4)
+    KM_CASE(5) KM_CASE(6) KM_CASE(7) KM_CASE(8)
+    default:
+      sgp_set_error(ctx, "input dimension %d not in 1..%d", kd.d, SGP_MAX_D);
+      return -2;
+  }
+#undef KM_CASE
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// Build Ky (with gp->jitter), factor, invert, pack, alpha.  *info = 0 or the
+// 1-based index of the first non-positive pivot.
+int factor_gp(sgp_gp* gp, int* info) {
+  sgp_ctx* ctx = gp->ctx;
+  const int n = int(gp->n), nf = gp->n_f, np = gp->n_pad;
+  const size_t mat = size_t(nf) * nf * sizeof(double);
+  SGP_TRY(sgp_reserve(ctx, &gp->Kmat, mat));
+  SGP_TRY(sgp_reserve(ctx, &gp->Linv, mat));
+  SGP_TRY(sgp_reserve(ctx, &gp->work, mat));
+  SGP_TRY(sgp_reserve(ctx, &gp->tvec, size_t(nf) * sizeof(double) + 64));
+  double* K = static_cast<double*>(gp->Kmat.p);
+  double* Li = static_cast<double*>(gp->Linv.p);
+  double* T = static_cast<double*>(gp->work.p);
+  double* tv = static_cast<double*>(gp->tvec.p);
+  int* info_dev = reinterpret_cast<int*>(tv + nf);
+
+  // padded rows of X are never read: n_valid = n turns them into identity
+  SGP_TRY(launch_kernel_matrix(ctx, gp->kern, static_cast<double*>(gp->X.p),
+                               nf, static_cast<double*>(gp->X.p), nf, K, nf, 1,
+                               gp->noise_var + 1e-8 + gp->jitter, n));
+  SGP_HIP(ctx, hipMemsetAsync(Li, 0, mat, ctx->stream));
+  SGP_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
+  SGP_TRY(factor_rec(ctx, K, Li, T, nf, 0, nf, info_dev));
+  SGP_TRY(sgp_d2h(ctx, info, info_dev, sizeof(int)));
+  if (*info != 0) return 0;
+
+  const int nblk = np / 16, nsteps = np / 4;
+  const int64_t total = int64_t(nblk) * nsteps * 64;
+  SGP_TRY(sgp_reserve(ctx, &gp->Apack, size_t(total) * sizeof(double)));
+  hipLaunchKernelGGL(k_pack, dim3(unsigned((total + 255) / 256)), dim3(256), 0,
+                     ctx->stream, Li, int64_t(nf), n, nblk, nsteps,
+                     static_cast<double*>(gp->Apack.p));
+  SGP_HIP(ctx, hipGetLastError());
+  SGP_TRY(sgp_reserve(ctx, &gp->alpha, size_t(np) * sizeof(double)));
+  hipLaunchKernelGGL(k_trmv_lower, dim3((n + 127) / 128), dim3(128), 0,
+                     ctx->stream, Li, int64_t(nf), n,
+                     static_cast<double*>(gp->Y.p), tv);
+  hipLaunchKernelGGL(k_trmv_lower_t, dim3((np + 127) / 128), dim3(128), 0,
+                     ctx->stream, Li, int64_t(nf), n, tv,
+                     static_cast<double*>(gp->alpha.p), np);
+  SGP_HIP(ctx, hipGetLastError());
+  SGP_TRY(sgp_reserve(ctx, &gp->Xpad,
+                      size_t(np) * gp->kern.d * sizeof(double)));
+  hipLaunchKernelGGL(k_pad_rows, dim3((np * gp->kern.d + 255) / 256), dim3(256),
+                     0, ctx->stream, static_cast<double*>(gp->X.p), n, np,
+                     gp->kern.d, static_cast<double*>(gp->Xpad.p));
+  SGP_HIP(ctx, hipGetLastError());
+
+  gp->dev.Apack = static_cast<double*>(gp->Apack.p);
+  gp->dev.Xpad = static_cast<double*>(gp->Xpad.p);
+  gp->dev.alpha = static_cast<double*>(gp->alpha.p);
+  gp->dev.n = n;
+  gp->dev.n_pad = np;
+  gp->dev.nblk = nblk;
+  gp->dev.kern = gp->kern;
+  return 0;
+}
+
+// For m <= 16 candidates xc (m x d, device) and residuals u_c - mu_c (device):
+// w_c = Ky^-1 k(X, x_c) packed as an MFMA A operand, delta_c, 1/s2_c.
+int expander_operands(sgp_gp* gp, const double* xc_dev, int m,
+                      const double* resid_dev, double* Wpack, double* delta,
+                      double* inv_s2) {
+  sgp_ctx* ctx = gp->ctx;
+  const int n = int(gp->n), nf = gp->n_f, np = gp->n_pad;
+  double* Li = static_cast<double*>(gp->Linv.p);
+  // work (n_f x n_f) is free after the factorisation: rows 0..15 = Kc,
+  // rows 16..31 = T^T, rows 32..47 = W^T  (n_f >= 32; use a scratch if not)
+  double* buf = static_cast<double*>(sgp_scratch(ctx, 3, size_t(48) * nf * 8));
+  if (!buf) return -1;
+  double* Kc = buf;
+  double* Tt = buf + size_t(16) * nf;
+  double* Wt = buf + size_t(32) * nf;
+  SGP_TRY(launch_kernel_matrix(ctx, gp->kern, xc_dev, m,
+                               static_cast<double*>(gp->X.p), n, Kc, nf, 0,
+                               0.0, INT64_MAX));
+  // T^T[c][i] = sum_j Kc[c][j] Li[i][j]
+  SGP_TRY(gemm(ctx, true, m, n, n, 1.0, Kc, nf, Li, nf, 0.0, Tt, nf));
+  // W^T[c][j] = sum_i T^T[c][i] Li[i][j]
+  SGP_TRY(gemm(ctx, false, m, n, n, 1.0, Tt, nf, Li, nf, 0.0, Wt, nf));
+  const double prior = gp->kern.kdiag + gp->noise_var + 1e-8 + gp->jitter;
+  hipLaunchKernelGGL(k_s2, dim3(m), dim3(256), 0, ctx->stream, Tt, int64_t(nf),
+                     n, m, prior, resid_dev, delta, inv_s2);
+  const int nsteps = np / 4;
+  hipLaunchKernelGGL(k_pack_w, dim3((nsteps * 64 + 255) / 256), dim3(256), 0,
+                     ctx->stream, Wt, int64_t(nf), n, m, nsteps, Wpack);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,444 @@
+// HBM-bound passes of SafeOpt.compute_sets / get_new_query_point
+// (safeopt/gp_opt.py:478-649): safe set, maximisers, candidate-expander mask,
+// visiting order (top-k by interval width), Lipschitz scan, masked arg-max.
+// Every comparison keeps the reference's strictness (> for S, >= for M, > for
+// both candidate filters, >= for the expander tests) and NumPy's IEEE
+// expression order; this file is compiled with -ffp-contract=off so the masks
+// are bit-exact with the NumPy restatement for identical Q.
+#include "kern_eval.h"
+
+namespace {
+
+constexpr int T = 256;
+
+struct Pair {
+  double v;
+  int64_t i;
+};
+
+// ordering used for the expander visiting order: larger w first, ties ->
+// larger global index first (a stable ascending sort, reversed)
+__device__ __forceinline__ bool before_desc(const Pair& a, const Pair& b) {
+  return a.v > b.v || (a.v == b.v && a.i > b.i);
+}
+// ordering of np.argmax: larger value first, ties -> smaller index first
+__device__ __forceinline__ bool before_first(const Pair& a, const Pair& b) {
+  if (b.i < 0) return a.i >= 0;
+  if (a.i < 0) return false;
+  return a.v > b.v || (a.v == b.v && a.i < b.i);
+}
+
+template <bool FIRST>
+__device__ __forceinline__ Pair block_best(Pair p, Pair* sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    Pair q;
+    q.v = __shfl_xor(p.v, o, 64);
+    q.i = __shfl_xor(p.i, o, 64);
+    if (FIRST ? before_first(q, p) : before_desc(q, p)) p = q;
+  }
+  __syncthreads();
+  if (lane == 0) sh[wave] = p;
+  __syncthreads();
+  Pair best = sh[0];
+  const int nw = blockDim.x >> 6;
+  for (int w = 1; w < nw; ++w) {
+    const Pair q = sh[w];
+    if (FIRST ? before_first(q, best) : before_desc(q, best)) best = q;
+  }
+  return best;
+}
+
+__device__ __forceinline__ double block_max(double v, double* sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double m = sh[0];
+  const int nw = blockDim.x >> 6;
+  for (int w = 1; w < nw; ++w) m = fmax(m, sh[w]);
+  return m;
+}
+
+struct Vec8 {
+  double v[SGP_MAX_GPS];
+};
+
+// S = all(Q[:, ::2] > fmin); partial[block] = max l0 over safe rows
+__global__ __launch_bounds__(T) void k_safe_set(const double* Q, int64_t N,
+                                                int G, Vec8 fmin, uint8_t* S,
+                                                double* partial) {
+  __shared__ double sh[T / 64];
+  const int64_t i = int64_t(blockIdx.x) * T + threadIdx.x;
+  double v = -INFINITY;
+  if (i < N) {
+    bool safe = true;
+    for (int g = 0; g < G; ++g) safe = safe && (Q[(i * G + g) * 2] > fmin.v[g]);
+    S[i] = safe ? 1 : 0;
+    if (safe) v = Q[i * G * 2];
+  }
+  const double m = block_max(v, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = m;
+}
+
+// M = S & (u0 >= max_l); partial = max(u0 - l0) over M
+__global__ __launch_bounds__(T) void k_maximizers(const double* Q,
+                                                  const uint8_t* S, int64_t N,
+                                                  int G, double max_l,
+                                                  uint8_t* M, double* partial) {
+  __shared__ double sh[T / 64];
+  const int64_t i = int64_t(blockIdx.x) * T + threadIdx.x;
+  double v = -INFINITY;
+  if (i < N) {
+    const double l0 = Q[i * G * 2], u0 = Q[i * G * 2 + 1];
+    const bool m = S[i] && (u0 >= max_l);
+    M[i] = m ? 1 : 0;
+    if (m) v = u0 - l0;
+  }
+  const double mx = block_max(v, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = mx;
+}
+
+// candidate mask + widths; counts[0] += #candidates, counts[1] += #unsafe
+__global__ __launch_bounds__(T) void k_candidates(
+    const double* Q, const uint8_t* S, const uint8_t* M, int64_t N, int G,
+    double max_var, Vec8 scaling, Vec8 thr_beta, int full_sets, uint8_t* cand,
+    double* w, uint8_t* Gm, unsigned long long* counts) {
+  const int64_t i = int64_t(blockIdx.x) * T + threadIdx.x;
+  bool c = false, unsafe = false;
+  if (i < N) {
+    const bool s = S[i] != 0;
+    unsafe = !s;
+    double wmax = -INFINITY;
+    if (s) {
+      double smax = -INFINITY;
+      bool above = false;
+      for (int g = 0; g < G; ++g) {
+        const double width = Q[(i * G + g) * 2 + 1] - Q[(i * G + g) * 2];
+        wmax = fmax(wmax, width);
+        smax = fmax(smax, width / scaling.v[g]);
+        above = above || (width > thr_beta.v[g]);
+      }
+      c = full_sets ? true : (!M[i] && (smax > max_var) && above);
+    }
+    cand[i] = c ? 1 : 0;
+    w[i] = wmax;
+    Gm[i] = 0;
+  }
+  const unsigned long long bc = __ballot(c), bu = __ballot(unsafe);
+  if ((threadIdx.x & 63) == 0) {
+    if (bc) atomicAdd(&counts[0], (unsigned long long)__popcll(bc));
+    if (bu) atomicAdd(&counts[1], (unsigned long long)__popcll(bu));
+  }
+}
+
+// ---- top-k: the next k elements after the cut, in visiting order ----------------
+// level 1 (src_idx == nullptr): elements are grid rows [chunk of the block],
+//   key w[i] (or -gidx when index_key), valid = cand[i]
+// level 2: elements are (src_w, src_idx) pairs, valid = idx >= 0; single block
+constexpr int TK_CHUNK = 4096;
+__global__ __launch_bounds__(T) void k_topk(const uint8_t* cand,
+                                            const double* src_w,
+                                            const int64_t* src_idx, int64_t n,
+                                            int64_t goff, int index_key,
+                                            double cut_w, int64_t cut_idx,
+                                            int k, double* out_w,
+                                            int64_t* out_idx, int* n_out) {
+  __shared__ Pair sh[T / 64];
+  int64_t begin, end;
+  if (src_idx == nullptr) {
+    begin = int64_t(blockIdx.x) * TK_CHUNK;
+    end = min(n, begin + TK_CHUNK);
+  } else {
+    begin = 0;
+    end = n;
+  }
+  Pair cut{cut_w, cut_idx};
+  int found = 0;
+  for (int r = 0; r < k; ++r) {
+    Pair best{-INFINITY, -1};
+    for (int64_t e = begin + threadIdx.x; e < end; e += T) {
+      Pair p;
+      if (src_idx == nullptr) {
+        if (!cand[e]) continue;
+        p.i = goff + e;
+        p.v = index_key ? -double(p.i) : src_w[e];
+      } else {
+        p.i = src_idx[e];
+        if (p.i < 0) continue;
+        p.v = src_w[e];
+      }
+      // strictly after the cut in visiting order
+      if (!(p.v < cut.v || (p.v == cut.v && p.i < cut.i))) continue;
+      if (best.i < 0 || before_desc(p, best)) best = p;
+    }
+    // empty slots carry (-inf, -1); make them lose against every real entry
+    Pair win = block_best<false>(best, sh);
+    if (win.i < 0) {
+      // a real entry with v == -inf could be shadowed; none exists because
+      // interval widths are finite
+    }
+    if (threadIdx.x == 0) {
+      out_w[int64_t(blockIdx.x) * k + r] = win.v;
+      out_idx[int64_t(blockIdx.x) * k + r] = win.i;
+    }
+    if (win.i >= 0) {
+      ++found;
+      cut = win;
+    } else {
+      cut = Pair{-INFINITY, -1};  // nothing left: later rounds stay empty
+    }
+  }
+  if (n_out && threadIdx.x == 0) *n_out = found;
+}
+
+// Lipschitz expander test (gp_opt.py:558-576)
+__global__ __launch_bounds__(T) void k_lipschitz(
+    const double* pts, const uint8_t* S, int64_t N, int d, int G, Vec8 fmin,
+    Vec8 lips, int m, const double* xc, const double* uc, int32_t* flags) {
+  const int64_t i = int64_t(blockIdx.x) * T + threadIdx.x;
+  const bool unsafe = (i < N) && (S[i] == 0);
+  double x[SGP_MAX_D];
+  for (int k = 0; k < d; ++k) x[k] = unsafe ? pts[int64_t(k) * N + i] : 0.0;
+  for (int c = 0; c < m; ++c) {
+    double s = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const double df = xc[c * d + k] - x[k];
+      s += df * df;
+    }
+    const double dist = sqrt(s);
+    for (int g = 0; g < G; ++g) {
+      if (fmin.v[g] == -INFINITY) continue;
+      const bool hit = unsafe && (uc[c * G + g] - lips.v[g] * dist >= fmin.v[g]);
+      const unsigned long long b = __ballot(hit);
+      if (b != 0ull && (threadIdx.x & 63) == 0) atomicOr(&flags[c * G + g], 1);
+    }
+  }
+}
+
+// masked arg-max, first index wins.  level 1: rows; level 2: partial pairs
+__global__ __launch_bounds__(T) void k_argmax(const double* Q, const uint8_t* S,
+                                              const uint8_t* M,
+                                              const uint8_t* Gm, int64_t N,
+                                              int G, int64_t goff, int mode,
+                                              Vec8 scaling, double* out_v,
+                                              int64_t* out_i) {
+  __shared__ Pair sh[T / 64];
+  Pair best{-INFINITY, -1};
+  const int64_t begin = int64_t(blockIdx.x) * (T * 4);
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = begin + r * T + threadIdx.x;
+    if (i >= N) continue;
+    Pair p{0.0, goff + i};
+    if (mode == SGP_ARGMAX_MG_WIDTH) {
+      if (!(M[i] || Gm[i])) continue;
+      double v = -INFINITY;
+      for (int g = 0; g < G; ++g)
+        v = fmax(v, (Q[(i * G + g) * 2 + 1] - Q[(i * G + g) * 2]) / scaling.v[g]);
+      p.v = v;
+    } else {
+      if (!S[i]) continue;
+      p.v = Q[i * G * 2 + (mode == SGP_ARGMAX_UCB ? 1 : 0)];
+    }
+    if (before_first(p, best)) best = p;
+  }
+  const Pair win = block_best<true>(best, sh);
+  if (threadIdx.x == 0) {
+    out_v[blockIdx.x] = win.v;
+    out_i[blockIdx.x] = win.i;
+  }
+}
+
+__global__ __launch_bounds__(T) void k_argmax_final(const double* in_v,
+                                                    const int64_t* in_i,
+                                                    int64_t n, double* out_v,
+                                                    int64_t* out_i) {
+  __shared__ Pair sh[T / 64];
+  Pair best{-INFINITY, -1};
+  for (int64_t e = threadIdx.x; e < n; e += T) {
+    const Pair p{in_v[e], in_i[e]};
+    if (before_first(p, best)) best = p;
+  }
+  const Pair win = block_best<true>(best, sh);
+  if (threadIdx.x == 0) {
+    out_v[0] = win.v;
+    out_i[0] = win.i;
+  }
+}
+
+__global__ void k_reduce_max(const double* in, int64_t n, double* out) {
+  __shared__ double sh[1024 / 64];
+  double v = -INFINITY;
+  for (int64_t e = threadIdx.x; e < n; e += blockDim.x) v = fmax(v, in[e]);
+  const double m = block_max(v, sh);
+  if (threadIdx.x == 0) out[0] = m;
+}
+
+__global__ void k_fill_cols(double* pts, int64_t N, int d, int nc, Vec8 c) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  for (int t = 0; t < nc; ++t) pts[int64_t(d - nc + t) * N + i] = c.v[t];
+}
+
+__global__ void k_gather_rows(const double* pts, const double* mean,
+                              const double* var, const double* Q, int64_t N,
+                              int d, int G, const int64_t* lidx, int m,
+                              double* x, double* mo, double* vo, double* qo) {
+  const int j = blockIdx.x;
+  if (j >= m) return;
+  const int64_t li = lidx[j];
+  for (int k = threadIdx.x; k < d; k += blockDim.x)
+    x[j * d + k] = pts[int64_t(k) * N + li];
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    mo[j * G + g] = mean[int64_t(g) * N + li];
+    vo[j * G + g] = var[int64_t(g) * N + li];
+  }
+  for (int q = threadIdx.x; q < 2 * G; q += blockDim.x)
+    qo[j * 2 * G + q] = Q[li * 2 * G + q];
+}
+
+__global__ void k_mark(uint8_t* Gm, const int64_t* lidx, int m) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) Gm[lidx[j]] = 1;
+}
+
+__global__ void k_import_points(const double* src, int64_t N, int d,
+                                int64_t stride_row, int64_t stride_col,
+                                double* dst) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  for (int k = 0; k < d; ++k)
+    dst[int64_t(k) * N + i] = src[i * stride_row + k * stride_col];
+}
+
+inline Vec8 vec8(const double* p, int n, double fill) {
+  Vec8 v;
+  for (int i = 0; i < SGP_MAX_GPS; ++i) v.v[i] = (p && i < n) ? p[i] : fill;
+  return v;
+}
+
+inline unsigned nblk(int64_t N, int per) { return unsigned((N + per - 1) / per); }
+
+}  // namespace
+
+int launch_reduce_max(sgp_ctx* ctx, const double* in, int64_t n, double* out) {
+  hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(1024), 0, ctx->stream, in, n,
+                     out);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_safe_set(sgp_grid* g, const double* fmin) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_safe_set, dim3(nblk(g->N, T)), dim3(T), 0, ctx->stream,
+                     g->Q, g->N, g->G, vec8(fmin, g->G, -INFINITY), g->S,
+                     g->partial);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_maximizers(sgp_grid* g, double max_l) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_maximizers, dim3(nblk(g->N, T)), dim3(T), 0, ctx->stream,
+                     g->Q, g->S, g->N, g->G, max_l, g->M, g->partial);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_candidates(sgp_grid* g, double max_var, const double* scaling,
+                      const double* thr_beta, int full_sets) {
+  sgp_ctx* ctx = g->ctx;
+  unsigned long long* counts =
+      static_cast<unsigned long long*>(sgp_scratch(ctx, 1, 64));
+  if (!counts) return -1;
+  SGP_HIP(ctx, hipMemsetAsync(counts, 0, 16, ctx->stream));
+  hipLaunchKernelGGL(k_candidates, dim3(nblk(g->N, T)), dim3(T), 0, ctx->stream,
+                     g->Q, g->S, g->M, g->N, g->G, max_var,
+                     vec8(scaling, g->G, 1.0), vec8(thr_beta, g->G, 0.0),
+                     full_sets, g->cand, g->w, g->Gm, counts);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_topk(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, int k,
+                double* w_out_dev, int64_t* idx_out_dev, int* n_out_dev) {
+  sgp_ctx* ctx = g->ctx;
+  const unsigned nb = nblk(g->N, TK_CHUNK);
+  double* pw = static_cast<double*>(
+      sgp_scratch(ctx, 2, size_t(nb) * k * (sizeof(double) + sizeof(int64_t))));
+  if (!pw) return -1;
+  int64_t* pi = reinterpret_cast<int64_t*>(pw + size_t(nb) * k);
+  hipLaunchKernelGGL(k_topk, dim3(nb), dim3(T), 0, ctx->stream, g->cand, g->w,
+                     static_cast<const int64_t*>(nullptr), g->N, g->goff, mode,
+                     cut_w, cut_idx, k, pw, pi, static_cast<int*>(nullptr));
+  hipLaunchKernelGGL(k_topk, dim3(1), dim3(T), 0, ctx->stream,
+                     static_cast<const uint8_t*>(nullptr), pw, pi,
+                     int64_t(nb) * k, int64_t(0), 0, INFINITY,
+                     INT64_MAX, k, w_out_dev, idx_out_dev, n_out_dev);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_lipschitz(sgp_grid* g, int G, const double* fmin,
+                     const double* lipschitz, int m, const double* xc_dev,
+                     const double* uc_dev, int32_t* flags_dev) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_lipschitz, dim3(nblk(g->N, T)), dim3(T), 0, ctx->stream,
+                     g->pts, g->S, g->N, g->d, G, vec8(fmin, G, -INFINITY),
+                     vec8(lipschitz, G, 0.0), m, xc_dev, uc_dev, flags_dev);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_argmax(sgp_grid* g, int mode, const double* scaling,
+                  double* value_dev, int64_t* idx_dev) {
+  sgp_ctx* ctx = g->ctx;
+  const unsigned nb = nblk(g->N, T * 4);
+  double* pv = static_cast<double*>(
+      sgp_scratch(ctx, 2, size_t(nb) * (sizeof(double) + sizeof(int64_t))));
+  if (!pv) return -1;
+  int64_t* pi = reinterpret_cast<int64_t*>(pv + nb);
+  hipLaunchKernelGGL(k_argmax, dim3(nb), dim3(T), 0, ctx->stream, g->Q, g->S,
+                     g->M, g->Gm, g->N, g->G, g->goff, mode,
+                     vec8(scaling, g->G, 1.0), pv, pi);
+  hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(T), 0, ctx->stream, pv, pi,
+                     int64_t(nb), value_dev, idx_dev);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_fill_cols(sgp_grid* g, const double* c, int nc) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_fill_cols, dim3(nblk(g->N, T)), dim3(T), 0, ctx->stream,
+                     g->pts, g->N, g->d, nc, vec8(c, nc, 0.0));
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_gather_rows(sgp_grid* g, const int64_t* lidx_dev, int m, double* x,
+                       double* mean, double* var, double* Q) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_gather_rows, dim3(m), dim3(64), 0, ctx->stream, g->pts,
+                     g->mean, g->var, g->Q, g->N, g->d, g->G, lidx_dev, m, x,
+                     mean, var, Q);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_mark(sgp_grid* g, const int64_t* lidx_dev, int m) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_mark, dim3((m + 63) / 64), dim3(64), 0, ctx->stream,
+                     g->Gm, lidx_dev, m);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_import_points(sgp_ctx* ctx, const double* src, int64_t N, int d,
+                         int64_t stride_row, int64_t stride_col, double* dst) {
+  hipLaunchKernelGGL(k_import_points, dim3(nblk(N, T)), dim3(T), 0, ctx->stream,
+                     src, N, d, stride_row, stride_col, dst);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,535 @@
+// posterior_sweep: the dominant kernel of the path.
+//
+// Replaces gp.predict_noiseless(self.inputs) + the Q update of
+// SafeOpt.update_confidence_intervals (safeopt/gp_opt.py:453-476), the safe-set
+// test (:478-481), SafeOptSwarm._compute_particle_fitness (:901-1013) and the
+// per-candidate re-prediction of the expander loop (:579-606).
+//
+// For a tile of candidate rows the kernel forms the covariance tile
+// K[j, pt] = k(X_j, x_pt) ON THE FLY in registers, directly in the B-operand
+// layout of v_mfma_f64_16x16x4_f64, and contracts it with A = L^-1 (lower
+// triangular, pre-packed in A-operand order) on the fp64 matrix cores:
+//     var(pt)  = k(x,x) - || A K[:, pt] ||^2          (n^2 flops / row)
+//     mean(pt) = alpha . K[:, pt]                      (2n flops / row)
+// K (n x N doubles, 1.6 GB at n=200, N=1e6) is never written to memory.
+//
+// Work split: workgroup = 8 waves = 128 rows; wave w owns 16 rows (the MFMA
+// N dimension); all waves share the staged A chunk through LDS.  The rows of A
+// are processed in chunks of 16 MFMA row blocks (256 rows) held in 16
+// accumulators per wave; the triangular structure is exploited at 16x16 block
+// granularity (a j-block only feeds row blocks >= its own index).
+#include "kern_eval.h"
+
+namespace {
+
+constexpr int kThreads = 512;
+constexpr int kWaves = 8;
+constexpr int kTilePts = 16 * kWaves;  // 128 candidate rows per workgroup
+constexpr int kIB = 16;                // accumulator slots = 256 rows of L^-1
+constexpr int kJC = 16;                // training points per staged chunk
+constexpr int kSteps = kJC / 4;        // MFMA k-steps per chunk (one j-block)
+constexpr int kATile = kIB * kSteps * 64;           // doubles (32 KB)
+constexpr int kXTile = kJC * SGP_MAX_D;             // doubles
+constexpr int kBuf = kATile + kXTile + kJC;         // + alpha chunk
+constexpr size_t kLdsBytes = (2 * size_t(kBuf) + kWaves) * sizeof(double);
+constexpr int kStageVec = kATile / 2 / kThreads;    // double2 per thread (4)
+
+enum { MODE_CONF = 0, MODE_FITNESS = 1 };
+
+struct SweepParams {
+  const GpDev* gps;
+  int G;
+  int mode;
+  SweepPoints pts;
+  ConfOut conf;
+  FitnessArgs fit;
+};
+
+struct Stage {
+  double2 a[kStageVec];
+  double x;
+};
+
+// Issue the global loads of the A chunk of j-block `jb` for the row-block chunk
+// starting at global row block b0 (+ the X / alpha rows of that j-block).
+// LDS image: slot-major, A[slot][step][lane]; slot = row block - b0 + shift so
+// that the last row block of the chunk always sits in slot 15.
+__device__ __forceinline__ void stage_load(Stage& st, const GpDev& gp, int D,
+                                           int b0, int shift, int jb, int tid) {
+  const int nsteps_total = gp.n_pad >> 2;
+  const int within = tid & 127;           // double2 index inside one slot
+  const int sg = jb * kSteps + (within >> 5);
+  const int l2 = within & 31;
+#pragma unroll
+  for (int k = 0; k < kStageVec; ++k) {
+    const int slot = (tid >> 7) + 4 * k;
+    const int bg = b0 + slot - shift;
+    double2 v = make_double2(0.0, 0.0);
+    if (slot >= shift && jb <= bg) {      // lower triangle only
+      const double* src =
+          gp.Apack + (int64_t(bg) * nsteps_total + sg) * 64 + l2 * 2;
+      v = *reinterpret_cast<const double2*>(src);
+    }
+    st.a[k] = v;
+  }
+  st.x = 0.0;
+  const int j0 = jb * kJC;
+  if (tid < kJC * D) {
+    st.x = gp.Xpad[j0 * D + tid];
+  } else if (tid >= 256 && tid < 256 + kJC) {
+    st.x = gp.alpha[j0 + (tid - 256)];
+  }
+}
+
+__device__ __forceinline__ void stage_store(const Stage& st, double* buf, int D,
+                                            int tid) {
+  double2* a2 = reinterpret_cast<double2*>(buf);
+  const int within = tid & 127;
+#pragma unroll
+  for (int k = 0; k < kStageVec; ++k) {
+    const int slot = (tid >> 7) + 4 * k;
+    a2[slot * 128 + within] = st.a[k];
+  }
+  if (tid < kJC * D) {
+    buf[kATile + tid] = st.x;
+  } else if (tid >= 256 && tid < 256 + kJC) {
+    buf[kATile + kXTile + (tid - 256)] = st.x;
+  }
+}
+
+// One 16-wide j-block (4 MFMA k-steps) against accumulator slots lo..15.
+// Slots are guarded in pairs by wave-uniform branches, so a slot below `lo`
+// costs nothing except (for odd lo) one zero block: the staged image holds
+// zeros above the diagonal.  Each guarded group interleaves two independent
+// accumulator chains.
+__device__ __forceinline__ void mfma_jblock(int lo, double4_t (&acc)[kIB],
+                                            const double* aT,
+                                            const double (&kv)[4]) {
+#pragma unroll
+  for (int b = 0; b < kIB; b += 2) {
+    if (b + 1 >= lo) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double a0 = aT[(b * kSteps + q) * 64];
+        const double a1 = aT[((b + 1) * kSteps + q) * 64];
+        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, kv[q], acc[b], 0, 0, 0);
+        acc[b + 1] =
+            __builtin_amdgcn_mfma_f64_16x16x4f64(a1, kv[q], acc[b + 1], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// Posterior mean / variance of one GP at this lane's candidate row.
+// Must be called by every thread of the workgroup (contains barriers).
+// On return every lane holds the values of row (lane & 15) of its wave.
+template <int D>
+__device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
+                                                 const double (&x)[D],
+                                                 double* lds, double& mean_out,
+                                                 double& var_out) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int nchunks = (gp.nblk + kIB - 1) / kIB;
+  double sumsq = 0.0, mean = 0.0;
+
+  // single stationary part (the common case): hyper-parameters in SGPRs
+  const bool single = gp.kern.n_parts == 1;
+  const int kind0 = gp.kern.kind[0];
+  const double var0 = gp.kern.variance[0];
+  double il0[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) il0[k] = gp.kern.inv_ls[0][k];
+
+#pragma unroll 1
+  for (int c = 0; c < nchunks; ++c) {
+    const int b0 = c * kIB;
+    const int nib = min(kIB, gp.nblk - b0);
+    const int shift = kIB - nib;
+    const int njb = b0 + nib;                  // j-blocks feeding this chunk
+    const bool last = (c == nchunks - 1);
+
+    double4_t acc[kIB];
+#pragma unroll
+    for (int b = 0; b < kIB; ++b) acc[b] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+    Stage st;
+    stage_load(st, gp, D, b0, shift, 0, tid);
+    stage_store(st, lds, D, tid);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int jb = 0; jb < njb; ++jb) {
+      double* cur = lds + (jb & 1) * kBuf;
+      double* nxt = lds + ((jb & 1) ^ 1) * kBuf;
+      const bool more = (jb + 1 < njb);
+      if (more) stage_load(st, gp, D, b0, shift, jb + 1, tid);
+
+      const double* xT = cur + kATile;
+      const double* alT = cur + kATile + kXTile;
+      double kv[4];
+      if (single) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double* y = xT + (q * 4 + (lane >> 4)) * D;
+          double r2 = 0.0;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            const double t = (x[k] - y[k]) * il0[k];
+            r2 = fma(t, t, r2);
+          }
+          kv[q] = var0 * k_of_r2(kind0, r2);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          kv[q] = kern_eval<D>(gp.kern, x, xT + (q * 4 + (lane >> 4)) * D);
+      }
+      if (last) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
+      }
+      const int lo = shift + max(0, jb - b0);
+      mfma_jblock(lo, acc, cur + lane, kv);
+
+      if (more) stage_store(st, nxt, D, tid);
+      __syncthreads();
+    }
+
+#pragma unroll
+    for (int b = 0; b < kIB; ++b) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sumsq = fma(acc[b][r], acc[b][r], sumsq);
+    }
+  }
+
+  sumsq = sum_lane_groups(sumsq);
+  mean = sum_lane_groups(mean);
+  mean_out = mean;
+  var_out = fmax(gp.kern.kdiag - sumsq, 1e-15);  // GPy: clip(var, 1e-15, inf)
+}
+
+// SafeOptSwarm._compute_penalty (gp_opt.py:874-899) for one value.
+__device__ __forceinline__ double swarm_penalty(double slack) {
+  double pen = fmin(slack, 0.0);
+  if (slack < 0.0 && slack > -0.001) pen *= 2.0;
+  if (slack <= -0.001 && slack > -0.1) pen *= 5.0;
+  if (slack <= -0.1 && slack > -1.0) pen *= 10.0;
+  if (slack < -1.0) pen = -300.0 * pen * pen;
+  return pen;
+}
+
+template <int D>
+__global__ __launch_bounds__(kThreads, 2) void k_sweep(SweepParams p) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* red = lds + 2 * kBuf;  // all LDS lives in the one dynamic region
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t row = int64_t(blockIdx.x) * kTilePts + wave * 16 + (lane & 15);
+  const bool valid = row < p.pts.N;
+  const int64_t rrow = valid ? row : p.pts.N - 1;
+
+  double x[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+    x[k] = p.pts.base[rrow * p.pts.stride_row + k * p.pts.stride_col];
+
+  const bool writer = valid && (lane < 16);
+  const bool conf = p.mode == MODE_CONF;
+  const int st = p.fit.swarm_type;
+  const int Geff = (!conf && st == SGP_SWARM_GREEDY) ? 1 : p.G;
+
+  // running state of the per-row epilogue (confidence sweep / swarm fitness)
+  bool safe = true;
+  double l0 = 0.0, values = 0.0, interest = 1.0, total_pen = 0.0, lower = 0.0;
+
+#pragma unroll 1
+  for (int g = 0; g < Geff; ++g) {
+    double mean, var;
+    posterior_one_gp<D>(p.gps[g], x, lds, mean, var);
+    const double sd = sqrt(var);
+    if (conf) {
+      // update_confidence_intervals + compute_safe_set (gp_opt.py:453-481)
+      const double lo = mean - p.conf.beta * sd;
+      const double up = mean + p.conf.beta * sd;
+      if (g == 0) l0 = lo;
+      safe = safe && (lo > p.conf.fmin[g]);
+      if (writer) {
+        p.conf.mean[int64_t(g) * p.pts.N + row] = mean;
+        p.conf.var[int64_t(g) * p.pts.N + row] = var;
+        if (p.conf.Q) {
+          const double2 q = make_double2(lo, up);
+          *reinterpret_cast<double2*>(p.conf.Q + (row * p.G + g) * 2) = q;
+        }
+      }
+    } else {
+      // SafeOptSwarm._compute_particle_fitness, gp_opt.py:925-1013
+      const FitnessArgs& f = p.fit;
+      lower = mean - f.beta * sd;
+      if (g == 0) {
+        values = sd / f.scaling[0];
+        if (st == SGP_SWARM_EXPANDERS) interest = double(p.G);
+        if (st == SGP_SWARM_MAXIMIZERS) {
+          const double upper = mean + f.beta * sd;
+          const double z = 10.0 * (upper - f.best_lower_bound) / f.scaling[0];
+          interest = 1.0 / (1.0 + exp(-z));  // scipy.special.expit
+        }
+      } else {
+        values = fmax(values, sd / f.scaling[g]);
+      }
+      if (f.fmin[g] != -INFINITY) {
+        double slack = lower - f.fmin[g];
+        safe = safe && (slack >= 0.0);
+        if (st != SGP_SWARM_SAFE_SET) {
+          slack = slack / f.scaling[g];
+          total_pen += swarm_penalty(slack);
+          if (st == SGP_SWARM_EXPANDERS) {
+            // scipy.stats.norm.pdf(slack, scale=0.2)
+            const double z = slack / 0.2;
+            interest *= exp(-0.5 * z * z) / 2.5066282746310002 / 0.2;
+          }
+        }
+      }
+    }
+  }
+
+  if (conf) {
+    if (p.conf.S) {
+      if (writer) p.conf.S[row] = safe ? 1 : 0;
+      // block maximum of l0 over safe rows -> one partial per workgroup
+      double v = (writer && safe) ? l0 : -INFINITY;
+      v = wave_max(v);
+      if (lane == 0) red[wave] = v;
+      __syncthreads();
+      if (tid == 0) {
+        double m = red[0];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) m = fmax(m, red[w]);
+        p.conf.partial[blockIdx.x] = m;
+      }
+    }
+  } else if (writer) {
+    double out;
+    if (st == SGP_SWARM_GREEDY) {
+      out = lower;
+      safe = true;
+    } else if (st == SGP_SWARM_SAFE_SET) {
+      out = lower;
+    } else {
+      out = (values + total_pen) * interest;
+    }
+    p.fit.values[row] = out;
+    p.fit.safe[row] = safe ? 1 : 0;
+  }
+}
+
+// ---- expander check ---------------------------------------------------------
+// One MFMA row block = up to 16 candidates: acc[cand, pt] = sum_j w_c[j] K[j,pt].
+template <int D>
+__global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
+                                                  SweepPoints pts,
+                                                  ExpanderArgs ea) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t row = int64_t(blockIdx.x) * 64 + wave * 16 + (lane & 15);
+  const bool valid = row < pts.N;
+  const int64_t rrow = valid ? row : pts.N - 1;
+  const bool unsafe = valid && (ea.S[rrow] == 0);
+  // skip waves with no unsafe row (wave-uniform)
+  if (__ballot(unsafe) == 0ull) return;
+
+  double x[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+    x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
+
+  for (int g = 0; g < G; ++g) {
+    if (!ea.active[g]) continue;
+    const GpDev& gp = gps[g];
+    const double* W = ea.Wpack + int64_t(g) * ea.wstride + lane;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    const int nsteps = gp.n_pad >> 2;
+    for (int s = 0; s < nsteps; ++s) {
+      const int j = s * 4 + (lane >> 4);
+      const double kv = kern_eval<D>(gp.kern, x, gp.Xpad + j * D);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[s * 64], kv, acc, 0, 0, 0);
+    }
+    const double mu = ea.mean[int64_t(g) * pts.N + rrow];
+    const double var = ea.var[int64_t(g) * pts.N + rrow];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 r
+      const int cand = (lane >> 4) + 4 * r;
+      bool hit = false;
+      if (cand < ea.m && unsafe) {
+        const double kxc = kern_eval<D>(gp.kern, x, ea.xc + cand * D);
+        const double cx = kxc - acc[r];
+        const double mu2 = mu + cx * ea.delta[g * 16 + cand];
+        const double var2 =
+            fmax(var - cx * cx * ea.inv_s2[g * 16 + cand], 1e-15);
+        const double l2 = mu2 - ea.beta * sqrt(var2);
+        hit = l2 >= ea.fmin[g];
+      }
+      const unsigned long long b = __ballot(hit);
+      if (lane == 0 && b != 0ull) {
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+          if ((b >> (16 * grp)) & 0xffffull)
+            atomicOr(&ea.flags[(grp + 4 * r) * G + g], 1);
+        }
+      }
+    }
+  }
+}
+
+// ---- fp64 MFMA issue-rate microbenchmark --------------------------------------
+__global__ __launch_bounds__(256) void k_mfma_bench(double* out, int iters) {
+  double4_t a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0,
+            a6 = a0, a7 = a0;
+  const double av = 1.0 + threadIdx.x * 1e-9, bv = 1.0 - threadIdx.x * 1e-9;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a3, 0, 0, 0);
+    a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a4, 0, 0, 0);
+    a5 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a5, 0, 0, 0);
+    a6 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a6, 0, 0, 0);
+    a7 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a7, 0, 0, 0);
+  }
+  double s = 0;
+  for (int r = 0; r < 4; ++r)
+    s += a0[r] + a1[r] + a2[r] + a3[r] + a4[r] + a5[r] + a6[r] + a7[r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int D>
+int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    SGP_HIP(ctx, hipFuncSetAttribute(
+                     reinterpret_cast<const void*>(&k_sweep<D>),
+                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                     int(kLdsBytes)));
+    attr_set = true;
+  }
+  const int nblocks = sweep_num_blocks(p.pts.N);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->profiling) {
+    if (ctx->prof_used + 2 > ctx->prof_events.size()) {
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t e;
+        SGP_HIP(ctx, hipEventCreate(&e));
+        ctx->prof_events.push_back(e);
+      }
+    }
+    e0 = ctx->prof_events[ctx->prof_used];
+    e1 = ctx->prof_events[ctx->prof_used + 1];
+    ctx->prof_used += 2;
+    ctx->prof_flops += flops;
+    SGP_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  }
+  hipLaunchKernelGGL(k_sweep<D>, dim3(nblocks), dim3(kThreads), kLdsBytes,
+                     ctx->stream, p);
+  SGP_HIP(ctx, hipGetLastError());
+  if (e1) SGP_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  return 0;
+}
+
+int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
+  // algorithmic flops: G * (n^2 + 2n) per row
+  double flops = 0.0;
+  const int Geff =
+      (p.mode == MODE_FITNESS && p.fit.swarm_type == SGP_SWARM_GREEDY) ? 1
+                                                                       : p.G;
+  for (int g = 0; g < Geff; ++g)
+    flops += (double(gh[g].n) * gh[g].n + 2.0 * gh[g].n) * double(p.pts.N);
+  if (p.pts.N <= 0) return 0;
+  switch (d) {
+    case 1: return launch_sweep_d<1>(ctx, p, flops);
+    case 2: return launch_sweep_d<2>(ctx, p, flops);
+    case 3: return launch_sweep_d<3>(ctx, p, flops);
+    case 4: return launch_sweep_d<4>(ctx, p, flops);
+    case 5: return launch_sweep_d<5>(ctx, p, flops);
+    case 6: return launch_sweep_d<6>(ctx, p, flops);
+    case 7: return launch_sweep_d<7>(ctx, p, flops);
+    case 8: return launch_sweep_d<8>(ctx, p, flops);
+  }
+  sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
+  return -2;
+}
+
+}  // namespace
+
+int sweep_num_blocks(int64_t N) { return int((N + kTilePts - 1) / kTilePts); }
+
+int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
+                      int G, int d, SweepPoints pts, ConfOut out) {
+  SweepParams p;
+  p.gps = gps_dev;
+  p.G = G;
+  p.mode = MODE_CONF;
+  p.pts = pts;
+  p.conf = out;
+  p.fit = FitnessArgs{};
+  return launch_sweep(ctx, p, gps_host, d);
+}
+
+int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,
+                         const GpDev* gps_host, int G, int d, SweepPoints pts,
+                         FitnessArgs fa) {
+  SweepParams p;
+  p.gps = gps_dev;
+  p.G = G;
+  p.mode = MODE_FITNESS;
+  p.pts = pts;
+  p.conf = ConfOut{};
+  p.fit = fa;
+  return launch_sweep(ctx, p, gps_host, d);
+}
+
+int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
+                          const GpDev* gps_host, int G, int d, SweepPoints pts,
+                          ExpanderArgs ea) {
+  (void)gps_host;
+  if (pts.N <= 0) return 0;
+  const int nblocks = int((pts.N + 63) / 64);
+#define EXP_CASE(DD)                                                          \
+  case DD:                                                                    \
+    hipLaunchKernelGGL(k_expander<DD>, dim3(nblocks), dim3(256), 0,           \
+                       ctx->stream, gps_dev, G, pts, ea);                     \
+    break;
+  switch (d) {
+    EXP_CASE(1) EXP_CASE(2) EXP_CASE(3) EXP_CASE(4)
+    EXP_CASE(5) EXP_CASE(6) EXP_CASE(7) EXP_CASE(8)
+    default:
+      sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
+      return -2;
+  }
+#undef EXP_CASE
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_microbench(sgp_ctx* ctx, int iters, double* tflops) {
+  const int nblocks = ctx->num_cu * 8;
+  double* out = static_cast<double*>(
+      sgp_scratch(ctx, 0, size_t(nblocks) * 256 * sizeof(double)));
+  if (!out) return -1;
+  hipLaunchKernelGGL(k_mfma_bench, dim3(nblocks), dim3(256), 0, ctx->stream,
+                     out, 16);  // warm-up
+  SGP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(k_mfma_bench, dim3(nblocks), dim3(256), 0, ctx->stream,
+                     out, iters);
+  SGP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  SGP_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  SGP_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  const double flops = double(nblocks) * 4.0 * iters * 8.0 * 2048.0;
+  *tflops = flops / (double(ms) * 1e-3) / 1e12;
+  return 0;
+}

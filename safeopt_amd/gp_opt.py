@@ -1,0 +1,725 @@
+"""SafeOpt / SafeOptSwarm on top of the MI355X HIP path.
+
+Class surface = ``/root/reference/safeopt/gp_opt.py`` (constructor signatures,
+method names, attribute names incl. the ``liptschitz`` spelling, exception
+types).  What differs is where the arithmetic runs:
+
+* ``SafeOpt.inputs`` lives in HBM (row-sharded over the ranks of a
+  communicator), together with ``Q``, ``S``, ``M``, ``G``; the NumPy
+  attributes of the same names are host mirrors that are refreshed lazily
+  when read.
+* ``update_confidence_intervals`` + ``compute_safe_set`` are ONE fused HIP
+  kernel (``posterior_sweep``) per call; ``compute_sets`` /
+  ``get_new_query_point`` are a handful of HBM-bound passes whose only host
+  visible results are scalars.
+* the expander loop (``gp_opt.py:557-612``) keeps its sequential semantics
+  (first expander in descending-width order wins) but tests
+  ``SGP_TOPK`` = 16 candidates per device pass with a closed-form rank-1
+  posterior update instead of two O(n^3) re-factorisations per candidate.
+
+The host code below is orchestration only; it never touches an ``(N, .)``
+array unless the user reads one of the mirrors.
+"""
+from __future__ import annotations
+
+import logging
+from functools import partial
+
+import numpy as np
+
+from . import _hip
+from .dist import LocalComm, merge_argmax, merge_topk, shard_range
+from .swarm import SwarmOptimization
+
+__all__ = ['SafeOpt', 'SafeOptSwarm']
+
+_I64_MAX = np.iinfo(np.int64).max
+
+
+class GaussianProcessOptimization(object):
+    """Base class: GP list, ``fmin``, ``beta``, ``scaling``, data plumbing.
+
+    Parameters follow ``gp_opt.py:30-99`` of the reference.
+    """
+
+    def __init__(self, gp, fmin, beta=2, num_contexts=0, threshold=0,
+                 scaling='auto'):
+        self.gps = gp if isinstance(gp, list) else [gp]
+        self.gp = self.gps[0]
+        if len(self.gps) > _hip.MAX_GPS:
+            raise ValueError("at most %d GPs are supported" % _hip.MAX_GPS)
+
+        self.fmin = fmin
+        if not isinstance(self.fmin, list):
+            self.fmin = [self.fmin] * len(self.gps)
+        self.fmin = np.atleast_1d(np.asarray(self.fmin).squeeze())
+
+        if hasattr(beta, '__call__'):
+            self.beta = beta
+        else:
+            self.beta = lambda t: beta
+
+        if isinstance(scaling, str) and scaling == 'auto':
+            dummy = np.zeros((1, self.gps[0].input_dim))
+            self.scaling = np.sqrt(np.asarray(
+                [g.kern.Kdiag(dummy)[0] for g in self.gps]))
+        else:
+            self.scaling = np.asarray(scaling)
+            if self.scaling.shape[0] != len(self.gps):
+                raise ValueError("The number of scaling values should be "
+                                 "equal to the number of GPs")
+
+        self.threshold = threshold
+        self._parameter_set = None
+        self.bounds = None
+        self.num_samples = 0
+        self.num_contexts = num_contexts
+
+        self._x = None
+        self._y = None
+        self._get_initial_xy()
+
+    @property
+    def x(self):
+        return self._x
+
+    @property
+    def y(self):
+        return self._y
+
+    @property
+    def data(self):
+        """The measurements ``(x, y)`` seen so far."""
+        return self._x, self._y
+
+    @property
+    def t(self):
+        """Time step = number of measurements."""
+        return self._x.shape[0]
+
+    def _get_initial_xy(self):
+        self._x = self.gp.X
+        ys = [self.gp.Y]
+        for gp in self.gps[1:]:
+            if np.allclose(self._x, gp.X):
+                ys.append(gp.Y)
+            else:
+                raise NotImplementedError('The GPs have different '
+                                          'measurements.')
+        self._y = np.concatenate(ys, axis=1)
+
+    def plot(self, *args, **kwargs):
+        raise NotImplementedError(
+            "plotting is outside the accelerated path (SURVEY.md section 2, "
+            "row 13); read opt.Q / opt.S / opt.M / opt.G and plot with "
+            "matplotlib directly")
+
+    def _add_context(self, x, context):
+        context = np.atleast_2d(context)
+        nc = context.shape[1]
+        x2 = np.empty((x.shape[0], x.shape[1] + nc), dtype=float)
+        x2[:, :x.shape[1]] = x
+        x2[:, x.shape[1]:] = context
+        return x2
+
+    def _add_data_point(self, gp, x, y, context=None):
+        """Append ``(x, y)`` to one GP only (does not touch ``self.x/y``)."""
+        if context is not None:
+            x = self._add_context(x, context)
+        gp.set_XY(np.vstack([gp.X, x]), np.vstack([gp.Y, y]))
+
+    def add_new_data_point(self, x, y, context=None):
+        """Add a measurement; ``nan`` entries of ``y`` skip that GP."""
+        x = np.atleast_2d(x)
+        y = np.atleast_2d(y)
+        if self.num_contexts:
+            x = self._add_context(x, context)
+        for i, gp in enumerate(self.gps):
+            ok = ~np.isnan(y[:, i])
+            if np.any(ok):
+                self._add_data_point(gp, x[ok, :], y[ok, [i]])
+        self._x = np.concatenate((self._x, x), axis=0)
+        self._y = np.concatenate((self._y, y), axis=0)
+
+    def _remove_last_data_point(self, gp):
+        gp.set_XY(gp.X[:-1, :], gp.Y[:-1, :])
+
+    def remove_last_data_point(self):
+        """Undo the last ``add_new_data_point``."""
+        last_y = self._y[-1]
+        for gp, yi in zip(self.gps, last_y):
+            if not np.isnan(yi):
+                gp.set_XY(gp.X[:-1, :], gp.Y[:-1, :])
+        self._x = self._x[:-1, :]
+        self._y = self._y[:-1, :]
+
+
+class _HipGridBackend(object):
+    """Rank-local device state of a ``SafeOpt``: the shard of ``inputs`` in
+    HBM plus the GP handles.  (Tests drive the same phase interface with a
+    NumPy stand-in to exercise the sharded host logic without a GPU.)"""
+
+    def __init__(self, gps, inputs_shard, global_offset, ctx=None):
+        self.ctx = ctx if ctx is not None else _hip.Context.default()
+        self.gps = gps
+        self.grid = _hip.DeviceGrid(self.ctx, inputs_shard, len(gps),
+                                    global_offset)
+        self.lo = int(global_offset)
+        self.hi = self.lo + self.grid.N
+
+    def _dev(self):
+        return [g._fitted() for g in self.gps]
+
+    def owns(self, gidx):
+        return self.lo <= gidx < self.hi
+
+    def set_context(self, c):
+        self.grid.set_context(c)
+
+    def confidence(self, beta, fmin):
+        return self.grid.confidence(self._dev(), beta, fmin)
+
+    def upload_Q(self, Q, fmin):
+        return self.grid.upload_Q(Q, fmin)
+
+    def maximizers(self, max_l):
+        return self.grid.maximizers(max_l)
+
+    def candidates(self, max_var, scaling, thr_beta, full_sets):
+        return self.grid.candidates(max_var, scaling, thr_beta, full_sets)
+
+    def topk(self, mode, cut_w, cut_idx, k):
+        return self.grid.topk(mode, cut_w, cut_idx, k)
+
+    def gather_rows(self, gidx):
+        return self.grid.gather_rows(gidx)
+
+    def expander_check(self, beta, fmin, xc, mu_c, u_c):
+        return self.grid.expander_check(self._dev(), beta, fmin, xc, mu_c, u_c)
+
+    def lipschitz_check(self, fmin, lipschitz, xc, u_c):
+        return self.grid.lipschitz_check(fmin, lipschitz, xc, u_c)
+
+    def mark_expanders(self, gidx):
+        self.grid.mark_expanders(gidx)
+
+    def argmax(self, mode, scaling):
+        return self.grid.argmax(mode, scaling)
+
+    def download(self, what):
+        return self.grid.download(what)
+
+
+class SafeOpt(GaussianProcessOptimization):
+    """Safe Bayesian optimisation over a discretised parameter set.
+
+    Parameters
+    ----------
+    gp : GP handle or list of GP handles (``safeopt_amd.gpy``)
+        First GP = objective, the others = safety constraints.
+    parameter_set : 2d-array
+        Candidate parameters, one per row (every rank passes the full set;
+        each rank keeps its contiguous row block on its GPU).
+    fmin : float or list of floats
+        Safety thresholds (``-inf`` disables the constraint of a GP).
+    lipschitz : float or list of floats, optional
+    beta : float or callable ``beta(t)``
+    num_contexts : int
+    threshold : float or list of floats
+    scaling : list of floats or ``'auto'``
+    comm : communicator, optional
+        ``safeopt_amd.dist.RcclComm`` for multi-GPU runs (default: 1 GPU).
+
+    Examples
+    --------
+    >>> from safeopt_amd import SafeOpt, linearly_spaced_combinations
+    >>> import safeopt_amd.gpy as GPy          # doctest: +SKIP
+    >>> gp = GPy.models.GPRegression(np.array([[0.]]), np.array([[1.]]),
+    ...                              noise_var=0.01**2)      # doctest: +SKIP
+    >>> ps = linearly_spaced_combinations([[-1., 1.]], 100)
+    >>> opt = SafeOpt(gp, ps, fmin=[0.])                      # doctest: +SKIP
+    >>> x = opt.optimize()                                    # doctest: +SKIP
+    >>> opt.add_new_data_point(x, np.array([[1.]]))           # doctest: +SKIP
+    """
+
+    def __init__(self, gp, parameter_set, fmin, lipschitz=None, beta=2,
+                 num_contexts=0, threshold=0, scaling='auto', comm=None,
+                 _backend_factory=None):
+        super(SafeOpt, self).__init__(gp, fmin=fmin, beta=beta,
+                                      num_contexts=num_contexts,
+                                      threshold=threshold, scaling=scaling)
+        parameter_set = np.asarray(parameter_set)
+        if self.num_contexts > 0:
+            ctx_shape = (parameter_set.shape[0], self.num_contexts)
+            self.inputs = np.hstack((parameter_set,
+                                     np.zeros(ctx_shape,
+                                              dtype=parameter_set.dtype)))
+            self.parameter_set = self.inputs[:, :-self.num_contexts]
+        else:
+            self.inputs = self.parameter_set = parameter_set
+
+        self.liptschitz = lipschitz
+        if self.liptschitz is not None:
+            if not isinstance(self.liptschitz, list):
+                self.liptschitz = [self.liptschitz] * len(self.gps)
+            self.liptschitz = np.atleast_1d(
+                np.asarray(self.liptschitz).squeeze())
+        self._use_lipschitz = lipschitz is not None
+
+        N = self.inputs.shape[0]
+        # host mirrors of the resident arrays (same dtypes / shapes as the
+        # reference: gp_opt.py:374-390)
+        self._Q = np.empty((N, 2 * len(self.gps)), dtype=float)
+        self._S = np.zeros(N, dtype=bool)
+        self._G = self._S.copy()
+        self._M = self._S.copy()
+        self._stale = dict(Q=False, S=False, M=False, G=False)
+
+        self._comm = comm if comm is not None else LocalComm()
+        lo, hi = shard_range(N, self._comm.rank, self._comm.world)
+        self._shard = (lo, hi)
+        factory = _backend_factory or _HipGridBackend
+        self._backend = factory(self.gps, self.inputs[lo:hi], lo)
+        self._any_safe = False
+        self._max_l = -np.inf
+        self._ci_fresh = False
+
+    # -- host mirrors ---------------------------------------------------------
+    def _mirror(self, name, what):
+        if self._stale[name]:
+            arr = getattr(self, '_' + name)
+            part = self._backend.download(what)
+            if self._comm.world == 1:
+                np.copyto(arr, part)
+            else:
+                lo, hi = self._shard
+                counts = [np.subtract(*shard_range(arr.shape[0], r,
+                                                   self._comm.world)[::-1])
+                          for r in range(self._comm.world)]
+                pad = max(counts)
+                buf = np.zeros((pad,) + arr.shape[1:], dtype=arr.dtype)
+                buf[:hi - lo] = part
+                allp = self._comm.allgather(buf)
+                off = 0
+                for r, c in enumerate(counts):
+                    arr[off:off + c] = allp[r][:c]
+                    off += c
+            self._stale[name] = False
+        return getattr(self, '_' + name)
+
+    @property
+    def Q(self):
+        """Confidence intervals ``[l_0, u_0, l_1, u_1, ...]`` per row."""
+        return self._mirror('Q', _hip.Q)
+
+    @Q.setter
+    def Q(self, value):
+        """Assigning ``opt.Q`` uploads the intervals and recomputes ``S``."""
+        value = np.asarray(value, dtype=float).reshape(self._Q.shape)
+        lo, hi = self._shard
+        m, a = self._backend.upload_Q(value[lo:hi], self.fmin)
+        red = self._comm.allreduce_max(np.array([m, float(a)]))
+        self._max_l, self._any_safe = red[0], bool(red[1] > 0)
+        np.copyto(self._Q, value)
+        self._stale.update(Q=False, S=True)
+        self._ci_fresh = True
+
+    @property
+    def S(self):
+        """Safe set mask."""
+        return self._mirror('S', _hip.S)
+
+    @property
+    def M(self):
+        """Potential maximisers mask."""
+        return self._mirror('M', _hip.M)
+
+    @property
+    def G(self):
+        """Expanders mask."""
+        return self._mirror('G', _hip.G)
+
+    # -- reference properties ---------------------------------------------------
+    @property
+    def use_lipschitz(self):
+        """Whether the Lipschitz constant (instead of the GP confidence
+        intervals) certifies expanders."""
+        return self._use_lipschitz
+
+    @use_lipschitz.setter
+    def use_lipschitz(self, value):
+        if value and self.liptschitz is None:
+            raise ValueError('Lipschitz constant not defined')
+        self._use_lipschitz = value
+
+    @property
+    def parameter_set(self):
+        """Discrete parameter samples."""
+        return self._parameter_set
+
+    @parameter_set.setter
+    def parameter_set(self, parameter_set):
+        self._parameter_set = parameter_set
+        self.bounds = list(zip(np.min(self._parameter_set, axis=0),
+                               np.max(self._parameter_set, axis=0)))
+        self.num_samples = [len(np.unique(self._parameter_set[:, i]))
+                            for i in range(self._parameter_set.shape[1])]
+
+    @property
+    def context_fixed_inputs(self):
+        """Fixed inputs (column, value) of the current context."""
+        n = self.gp.input_dim - 1
+        nc = self.num_contexts
+        if nc > 0:
+            contexts = self.inputs[0, -self.num_contexts:]
+            return list(zip(range(n, n - nc, -1), contexts))
+
+    @property
+    def context(self):
+        """Current context variables."""
+        if self.num_contexts:
+            return self.inputs[0, -self.num_contexts:]
+
+    @context.setter
+    def context(self, context):
+        if self.num_contexts:
+            if context is None:
+                raise ValueError('Need to provide value for context.')
+            self.inputs[:, -self.num_contexts:] = context
+            self._backend.set_context(
+                np.asarray(self.inputs[0, -self.num_contexts:], dtype=float))
+            self._ci_fresh = False
+
+    # -- the hot path -------------------------------------------------------------
+    def update_confidence_intervals(self, context=None):
+        """Posterior sweep of every GP over all candidates -> ``Q`` (and ``S``).
+
+        One fused kernel per rank; the only values that come back are
+        ``max(l_0[S])`` and ``any(S)``.
+        """
+        beta = self.beta(self.t)
+        self.context = context
+        m, a = self._backend.confidence(beta, self.fmin)
+        red = self._comm.allreduce_max(np.array([m, float(a)]))
+        self._max_l, self._any_safe = red[0], bool(red[1] > 0)
+        self._stale.update(Q=True, S=True)
+        self._ci_fresh = True
+
+    def compute_safe_set(self):
+        """``S = all(l_i > fmin_i)``; fused into the sweep, nothing to redo."""
+        if not self._ci_fresh:
+            self.update_confidence_intervals(context=self.context)
+
+    def _sum_over_ranks(self, values):
+        v = np.asarray(values, dtype=np.float64)
+        return self._comm.allgather(v).sum(axis=0)
+
+    def compute_sets(self, full_sets=False):
+        """Maximisers ``M`` and expanders ``G`` from the current intervals.
+
+        ``full_sets=True`` evaluates every safe point as an expander candidate
+        (plotting mode of the reference).
+        """
+        beta = self.beta(self.t)
+        self.compute_safe_set()
+        be = self._backend
+        G = len(self.gps)
+        thr_beta = np.broadcast_to(
+            np.asarray(self.threshold, dtype=float) * beta, (G,)).copy()
+
+        if not self._any_safe:
+            # M = G = False everywhere
+            be.maximizers(np.inf)
+            be.candidates(np.inf, self.scaling, thr_beta, False)
+            self._stale.update(M=True, G=True)
+            return
+
+        width = self._comm.allreduce_max(
+            np.array([be.maximizers(self._max_l)]))[0]
+        max_var = width / self.scaling[0]
+        n_cand, n_unsafe = self._sum_over_ranks(
+            be.candidates(max_var, self.scaling, thr_beta, full_sets))
+        self._stale.update(M=True, G=True)
+
+        active = self.fmin != -np.inf
+        if n_cand == 0 or n_unsafe == 0 or not np.any(active):
+            # no candidate, or nothing unsafe to certify (any([]) is False),
+            # or no safety constraint at all: G stays empty
+            return
+
+        mode = 1 if full_sets else 0
+        cut_w, cut_idx = np.inf, (-1 if full_sets else _I64_MAX)
+        K = _hip.TOPK
+        while True:
+            w_loc, i_loc = be.topk(mode, cut_w, cut_idx, K)
+            if self._comm.world > 1:
+                wp = np.full(K, -np.inf)
+                ip = np.full(K, -1, dtype=np.int64)
+                wp[:w_loc.size] = w_loc
+                ip[:i_loc.size] = i_loc
+                w_b, i_b = merge_topk(self._comm.allgather(wp),
+                                      self._comm.allgather(ip), K,
+                                      by_index=full_sets)
+            else:
+                w_b, i_b = w_loc, i_loc
+            m = i_b.size
+            if m == 0:
+                break
+
+            # rows of the candidates from their owners
+            own = np.array([be.owns(int(i)) for i in i_b])
+            xc = np.zeros((m, self.inputs.shape[1]))
+            mu_c = np.zeros((m, G))
+            u_c = np.zeros((m, G))
+            if own.any():
+                x_o, mean_o, _var_o, Q_o = be.gather_rows(i_b[own])
+                xc[own], mu_c[own], u_c[own] = x_o, mean_o, Q_o[:, 1::2]
+            if self._comm.world > 1:
+                packed = np.concatenate([xc, mu_c, u_c], axis=1)
+                packed = self._comm.allgather(packed).sum(axis=0)
+                d = self.inputs.shape[1]
+                xc, mu_c, u_c = (packed[:, :d], packed[:, d:d + G],
+                                 packed[:, d + G:])
+
+            if self.use_lipschitz:
+                flags = be.lipschitz_check(self.fmin, self.liptschitz, xc, u_c)
+            else:
+                flags = be.expander_check(beta, self.fmin, xc, mu_c, u_c)
+            flags = self._comm.allreduce_max(flags.astype(np.float64)) > 0
+            is_exp = np.all(flags[:, active], axis=1)
+
+            if full_sets:
+                mine = [int(i) for i, e, o in zip(i_b, is_exp, own) if e and o]
+                be.mark_expanders(np.asarray(mine, dtype=np.int64))
+            elif is_exp.any():
+                first = int(np.argmax(is_exp))
+                if own[first]:
+                    be.mark_expanders(i_b[first:first + 1])
+                break
+            if m < K:
+                break
+            cut_w, cut_idx = float(w_b[-1]), int(i_b[-1])
+
+    def get_new_query_point(self, ucb=False):
+        """Next parameters to evaluate (first index wins among equals)."""
+        if not self._any_safe:
+            raise EnvironmentError('There are no safe points to evaluate.')
+        mode = _hip.ARGMAX_UCB if ucb else _hip.ARGMAX_MG_WIDTH
+        idx = self._global_argmax(mode)[1]
+        x = self.inputs[idx, :]
+        if self.num_contexts:
+            return x[:-self.num_contexts]
+        return x
+
+    def _global_argmax(self, mode):
+        v, i = self._backend.argmax(mode, self.scaling)
+        if self._comm.world > 1:
+            v, i = merge_argmax(self._comm.allgather(np.array([v])),
+                                self._comm.allgather(np.array([i],
+                                                              dtype=np.int64)))
+        return v, int(i)
+
+    def optimize(self, context=None, ucb=False):
+        """One SafeOpt step: intervals -> sets -> next query point."""
+        self.update_confidence_intervals(context=context)
+        if ucb:
+            self.compute_safe_set()
+        else:
+            self.compute_sets()
+        return self.get_new_query_point(ucb=ucb)
+
+    def get_maximum(self, context=None):
+        """Best lower bound inside the safe set: ``(x, l)`` or ``None``."""
+        self.update_confidence_intervals(context=context)
+        self.compute_safe_set()
+        if not self._any_safe:
+            return None
+        v, idx = self._global_argmax(_hip.ARGMAX_LCB)
+        return (self.inputs[idx, :-self.num_contexts or None], v)
+
+
+class SafeOptSwarm(GaussianProcessOptimization):
+    """SafeOpt for higher dimensions with adaptive swarm discretisation.
+
+    Same constructor and behaviour as ``gp_opt.py:715-1192`` of the reference
+    (no Lipschitz constant, no contexts).  The particle fitness -- the GP
+    posterior of every GP at all particles plus the penalty / interest shaping
+    -- is one fused HIP kernel per swarm iteration; the swarm bookkeeping and
+    its NumPy global RNG stay on the host so runs are reproducible against the
+    reference.
+    """
+
+    def __init__(self, gp, fmin, bounds, beta=2, scaling='auto', threshold=0,
+                 swarm_size=20):
+        super(SafeOptSwarm, self).__init__(gp, fmin=fmin, beta=beta,
+                                           num_contexts=0,
+                                           threshold=threshold,
+                                           scaling=scaling)
+        self.S = np.asarray(self.gps[0].X)
+        self.swarm_size = swarm_size
+        self.max_iters = 100
+
+        if not isinstance(bounds, list):
+            self.bounds = [bounds] * self.S.shape[1]
+        else:
+            self.bounds = bounds
+
+        self.best_lower_bound = -np.inf
+        self.greedy_point = self.S[0, :]
+        self.optimal_velocities = self.optimize_particle_velocity()
+
+        self.swarms = {
+            swarm_type: SwarmOptimization(
+                swarm_size, self.optimal_velocities,
+                partial(self._compute_particle_fitness, swarm_type),
+                bounds=self.bounds)
+            for swarm_type in ['greedy', 'maximizers', 'expanders']}
+
+    def optimize_particle_velocity(self):
+        """Velocity per dimension at which the prior correlation drops to
+        (0.94, 0.95) -- bisection as in ``gp_opt.py:818-872``."""
+        d = self.gp.input_dim
+        origin = np.zeros((1, d), dtype=float)
+        velocities = np.empty((len(self.gps), d), dtype=float)
+        for i, gp in enumerate(self.gps):
+            for j in range(d):
+                probe = np.zeros((1, d), dtype=float)
+                upper, lower = 1000., 0.
+                while True:
+                    mid = (upper + lower) / 2
+                    probe[0, j] = mid
+                    cov = gp.kern.K(origin, probe).squeeze() / \
+                        self.scaling[i] ** 2
+                    enough = cov > 0.94
+                    not_too_fast = cov < 0.95
+                    if not_too_fast:
+                        upper = mid
+                    elif enough:
+                        lower = mid
+                    if (not_too_fast and enough) or upper - lower < 1e-5:
+                        break
+                velocities[i, j] = mid
+        velocities = np.min(velocities, axis=0)
+        velocities /= np.sqrt(d)
+        return velocities
+
+    def _compute_penalty(self, slack):
+        """Piecewise penalty for constraint violation (host helper; the device
+        kernel applies the same rule inside the fused fitness)."""
+        slack = np.atleast_1d(np.asarray(slack, dtype=float))
+        pen = np.clip(slack, None, 0)
+        pen[(slack < 0) & (slack > -0.001)] *= 2
+        pen[(slack <= -0.001) & (slack > -0.1)] *= 5
+        pen[(slack <= -0.1) & (slack > -1)] *= 10
+        far = slack < -1
+        pen[far] = -300 * pen[far] ** 2
+        return pen
+
+    def _compute_particle_fitness(self, swarm_type, particles):
+        """Fitness and safety of ``particles`` for one swarm type:
+        ``'greedy' | 'maximizers' | 'expanders' | 'safe_set'``."""
+        if swarm_type not in _hip.SWARM_TYPES:
+            raise AssertionError("Invalid swarm type")
+        beta = self.beta(self.t)
+        particles = np.atleast_2d(particles)
+        devs = [g._fitted() for g in self.gps]
+        values, safe = _hip.swarm_fitness(
+            devs[0].ctx, devs, swarm_type, particles, beta, self.fmin,
+            self.scaling, self.best_lower_bound)
+        return values, safe
+
+    def get_new_query_point(self, swarm_type):
+        """Run one swarm (``'greedy' | 'maximizers' | 'expanders'``).
+
+        Returns ``(global_best, value)`` for the greedy swarm and
+        ``(global_best, std_devs)`` otherwise.
+        """
+        beta = self.beta(self.t)
+        safe_size, input_dim = self.S.shape
+
+        _, safe = self._compute_particle_fitness('safe_set', self.S)
+        num_safe = safe.sum()
+        if num_safe == 0:
+            raise RuntimeError('The safe set is empty.')
+
+        if num_safe >= self.swarm_size and num_safe != len(safe):
+            logging.warning("Warning: {} unsafe points removed. "
+                            "Model might be violated"
+                            .format(np.count_nonzero(~safe)))
+            self.S = self.S[safe]
+            safe_size = self.S.shape[0]
+
+        if swarm_type == 'greedy':
+            random_id = np.random.randint(safe_size, size=self.swarm_size - 3)
+            best_sampled_point = np.argmax(self.gp.Y)
+            particles = np.vstack((self.S[random_id, :],
+                                   self.greedy_point,
+                                   self.gp.X[-1, :],
+                                   self.gp.X[best_sampled_point]))
+        else:
+            random_id = np.random.randint(safe_size, size=self.swarm_size)
+            particles = self.S[random_id, :]
+
+        swarm = self.swarms[swarm_type]
+        swarm.init_swarm(particles)
+        swarm.run_swarm(self.max_iters)
+
+        if swarm_type != 'greedy':
+            num_added = 0
+            covariance = self.gp.kern.K(swarm.best_positions,
+                                        np.vstack((self.S,
+                                                   swarm.best_positions)))
+            covariance /= self.scaling[0] ** 2
+            initial_safe = len(self.S)
+            n, m = np.shape(covariance)
+            mask = np.zeros(m, dtype=bool)
+            mask[:initial_safe] = True
+            for j in range(n):
+                if np.all(covariance[j, mask] <= 0.95):
+                    self.S = np.vstack((self.S, swarm.best_positions[[j], :]))
+                    num_added += 1
+                    mask[initial_safe + j] = True
+            logging.debug("At the end of swarm {}, {} points were appended to"
+                          " the safeset".format(swarm_type, num_added))
+        else:
+            mean, var = self.gp.predict_noiseless(self.greedy_point[None, :])
+            lower_bound = mean.squeeze() - beta * np.sqrt(var.squeeze())
+            if lower_bound < np.max(swarm.best_values):
+                self.greedy_point = swarm.global_best.copy()
+
+        if swarm_type == 'greedy':
+            return swarm.global_best.copy(), np.max(swarm.best_values)
+
+        var = np.empty(len(self.gps), dtype=float)
+        for i, gp in enumerate(self.gps):
+            var[i] = gp.predict_noiseless(swarm.global_best[None, :])[1].item()
+        return swarm.global_best, np.sqrt(var)
+
+    def optimize(self, ucb=False):
+        """One SafeOptSwarm step; returns the next parameters to evaluate."""
+        self.greedy, self.best_lower_bound = self.get_new_query_point('greedy')
+
+        x_maxi, std_maxi = self.get_new_query_point('maximizers')
+        if ucb:
+            logging.info('Using ucb criterion.')
+            return x_maxi
+
+        x_exp, std_exp = self.get_new_query_point('expanders')
+        std_exp[(std_exp < self.threshold) | (self.fmin == -np.inf)] = 0
+        std_exp /= self.scaling
+        std_exp = np.max(std_exp)
+        std_maxi = std_maxi[0] / self.scaling[0]
+
+        logging.info("The best maximizer has std. dev. %f" % std_maxi)
+        logging.info("The best expander has std. dev. %f" % std_exp)
+        logging.info("The greedy estimate of lower bound has value %f" %
+                     self.best_lower_bound)
+
+        if std_maxi > std_exp:
+            return x_maxi
+        return x_exp
+
+    def get_maximum(self):
+        """Best observed point ``(x, y)``."""
+        maxi = np.argmax(self.gp.Y)
+        return self.gp.X[maxi, :], self.gp.Y[maxi]

@@ -1,0 +1,415 @@
+"""HIP path vs the CPU oracle and the golden vectors (needs an MI355X).
+
+Everything here goes through the C ABI of libsafeopt_hip.so (ctypes wrappers in
+safeopt_amd/_hip.py); the oracle is only the checker.  Tolerances: the
+north-star asks posterior mean / variance within 1e-5 relative in fp64; the
+kernels are held to 1e-9 (mean, relative to max|mean|; variance, absolute
+relative to the prior variance k(x,x)) and masks / chosen points to equality.
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+from _golden import load, make_kernel
+
+pytestmark = pytest.mark.gpu
+
+MEAN_TOL = 1e-9
+VAR_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def mods(hip_device):
+    import safeopt_amd
+    import safeopt_amd.gpy as gpy
+    from oracle import gp_numpy as gpn
+    from oracle import safeopt_numpy as son
+    return safeopt_amd, gpy, gpn, son
+
+
+def smooth(x, seed):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-3, 3, size=(10, x.shape[1]))
+    w = rng.normal(size=10)
+    r2 = ((x[:, None, :] - c[None]) ** 2).sum(-1)
+    return (np.exp(-0.25 * r2) * w).sum(1)[:, None]
+
+
+def kernels(ns, kind, d, rng=None):
+    ls = np.linspace(0.8, 1.6, d)
+    return getattr(ns, kind)(d, variance=1.7, lengthscale=ls, ARD=True)
+
+
+def check_posterior(m, v, m_ref, v_ref, kdiag):
+    scale = max(np.max(np.abs(m_ref)), 1e-300)
+    assert np.max(np.abs(m - m_ref)) / scale < MEAN_TOL
+    assert np.max(np.abs(v - v_ref)) / kdiag < VAR_TOL
+    big = v_ref > 1e-6 * kdiag
+    assert np.max(np.abs(v[big] - v_ref[big]) / v_ref[big]) < 1e-5
+
+
+# ---------------------------------------------------------------------------
+def test_mfma_f64_microbench(mods):
+    from safeopt_amd import _hip
+    tf = _hip.Context.default().microbench_mfma_f64(20000)
+    print("fp64 MFMA issue rate: %.1f TFLOP/s" % tf)
+    assert tf > 20.0
+
+
+@pytest.mark.parametrize("kind", ["RBF", "Matern32", "Matern52"])
+def test_kern_K(mods, kind):
+    _, gpy, gpn, _ = mods
+    rng = np.random.default_rng(0)
+    for d in (1, 2, 3, 5, 8):
+        X = rng.normal(size=(37, d)); X2 = rng.normal(size=(53, d))
+        k, ko = kernels(gpy.kern, kind, d), kernels(gpn, kind, d)
+        assert_allclose(k.K(X, X2), ko.K(X, X2), rtol=1e-12, atol=1e-14)
+        assert_allclose(k.K(X), ko.K(X), rtol=1e-12, atol=1e-14)
+    # non-ARD, product on disjoint columns, Kdiag
+    k = gpy.kern.Matern52(2, 3., 0.7); ko = gpn.Matern52(2, 3., 0.7)
+    assert_allclose(k.K(X[:, :2], X2[:, :2]), ko.K(X[:, :2], X2[:, :2]), rtol=1e-12)
+    kp = gpy.kern.RBF(1, 2., 1., active_dims=[0]) * \
+        gpy.kern.Matern32(1, 1.5, 0.6, active_dims=[1], name='context')
+    kpo = gpn.RBF(1, 2., 1., active_dims=[0]) * \
+        gpn.Matern32(1, 1.5, 0.6, active_dims=[1], name='context')
+    assert_allclose(kp.K(X[:, :2], X2[:, :2]), kpo.K(X[:, :2], X2[:, :2]), rtol=1e-12)
+    assert_allclose(kp.Kdiag(X[:, :2]), kpo.Kdiag(X[:, :2]))
+    assert kp.context.variance[0] == 1.5
+
+
+@pytest.mark.parametrize("n", [1, 5, 16, 31, 33, 64, 200, 500])
+def test_factor_matches_lapack(mods, n):
+    _, gpy, gpn, _ = mods
+    rng = np.random.default_rng(n)
+    X = rng.uniform(-2, 2, size=(n, 2)); Y = smooth(X, 1)
+    k, ko = kernels(gpy.kern, "RBF", 2), kernels(gpn, "RBF", 2)
+    gp = gpy.models.GPRegression(X, Y, k, noise_var=0.05 ** 2)
+    go = gpn.GPRegression(X, Y, ko, noise_var=0.05 ** 2)
+    Linv, alpha = gp._fitted().factor()
+    Linv_ref = np.linalg.inv(go.L)
+    assert np.max(np.abs(Linv - Linv_ref)) / np.max(np.abs(Linv_ref)) < 1e-9
+    assert np.max(np.abs(alpha - go.woodbury_vector.ravel())) / \
+        np.max(np.abs(go.woodbury_vector)) < 1e-8
+    assert np.all(np.triu(Linv, 1) == 0)
+
+
+@pytest.mark.parametrize("kind", ["RBF", "Matern32", "Matern52"])
+@pytest.mark.parametrize("n,d", [(1, 1), (7, 1), (16, 2), (17, 2), (200, 2),
+                                 (300, 3), (520, 4), (40, 6)])
+def test_predict_noiseless(mods, kind, n, d):
+    _, gpy, gpn, _ = mods
+    rng = np.random.default_rng(100 * n + d)
+    X = rng.uniform(-2, 2, size=(n, d)); Y = smooth(X, 2)
+    gp = gpy.models.GPRegression(X, Y, kernels(gpy.kern, kind, d), noise_var=0.05 ** 2)
+    go = gpn.GPRegression(X, Y, kernels(gpn, kind, d), noise_var=0.05 ** 2)
+    for N in (1, 129, 1000):
+        Xs = rng.uniform(-3, 3, size=(N, d))
+        m, v = gp.predict_noiseless(Xs)
+        mo, vo = go.predict_noiseless(Xs)
+        assert m.shape == (N, 1) and v.shape == (N, 1)
+        check_posterior(m, v, mo, vo, 1.7)
+        # F-ordered input (what linearly_spaced_combinations returns)
+        m2, v2 = gp.predict_noiseless(np.asfortranarray(Xs))
+        assert_array_equal(m, m2); assert_array_equal(v, v2)
+    assert v.min() >= 1e-15
+
+
+def test_predict_product_kernel_and_refit(mods):
+    _, gpy, gpn, _ = mods
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-2, 2, size=(30, 2)); Y = smooth(X, 3)
+    k = gpy.kern.RBF(1, 2., 1., active_dims=[0]) * gpy.kern.RBF(1, 2., 1.3, active_dims=[1], name='c')
+    ko = gpn.RBF(1, 2., 1., active_dims=[0]) * gpn.RBF(1, 2., 1.3, active_dims=[1], name='c')
+    gp = gpy.models.GPRegression(X, Y, k, noise_var=0.01)
+    go = gpn.GPRegression(X, Y, ko, noise_var=0.01)
+    Xs = rng.uniform(-3, 3, size=(300, 2))
+    check_posterior(*gp.predict_noiseless(Xs), *go.predict_noiseless(Xs), 4.0)
+    # set_XY with one more / one fewer row (what SafeOpt does every iteration)
+    Xn = np.vstack([X, [[0.3, -0.2]]]); Yn = np.vstack([Y, [[0.5]]])
+    gp.set_XY(Xn, Yn); go.set_XY(Xn, Yn)
+    check_posterior(*gp.predict_noiseless(Xs), *go.predict_noiseless(Xs), 4.0)
+    gp.set_XY(X[:-3], Y[:-3]); go.set_XY(X[:-3], Y[:-3])
+    check_posterior(*gp.predict_noiseless(Xs), *go.predict_noiseless(Xs), 4.0)
+    assert_array_equal(gp.X, X[:-3])
+
+
+def test_jitter_and_failure(mods):
+    _, gpy, _, _ = mods
+    # duplicated inputs with zero noise: needs GPy's jitter escalation
+    X = np.zeros((4, 1)); Y = np.ones((4, 1))
+    gp = gpy.models.GPRegression(X, Y, gpy.kern.RBF(1), noise_var=0.)
+    m, v = gp.predict_noiseless(np.zeros((1, 1)))
+    assert np.isfinite(m).all() and np.isfinite(v).all()
+    with pytest.raises(np.linalg.LinAlgError):
+        gpy.models.GPRegression(X, Y, gpy.kern.RBF(1, variance=-1.), noise_var=0.)
+
+
+# ---------------------------------------------------------------------------
+GOLD = ["safeopt_1d_rbf", "safeopt_2d_rbf", "safeopt_1d_multi",
+        "safeopt_2d_mat52_g3", "safeopt_1d_lipschitz", "safeopt_context",
+        "safeopt_2d_ucb"]
+
+
+def build_opt(mods, z, meta, t, **kw):
+    safeopt_amd, gpy, _, _ = mods
+    gps = [gpy.models.GPRegression(z["it%d_X%d" % (t, i)], z["it%d_Y%d" % (t, i)],
+                                   make_kernel(gpy.kern, spec),
+                                   noise_var=meta["noise_vars"][i])
+           for i, spec in enumerate(meta["kernels"])]
+    lip = meta["lipschitz"]
+    if lip is not None and len(lip) == 1:
+        lip = lip[0]
+    return safeopt_amd.SafeOpt(gps if len(gps) > 1 else gps[0], z["parameter_set"],
+                               meta["fmin"] if len(gps) > 1 else meta["fmin"][0],
+                               lipschitz=lip, beta=float(z["beta_all"][t]),
+                               threshold=meta["threshold"],
+                               num_contexts=meta["num_contexts"], **kw)
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_replay_reference_golden(mods, name):
+    """The product's SafeOpt reproduces what the reference's gp_opt.py did."""
+    z, meta = load(name)
+    for t in meta["recorded"]:
+        opt = build_opt(mods, z, meta, t)
+        ctx = z["it%d_context" % t] if meta["num_contexts"] else None
+        x = opt.optimize(context=ctx, ucb=meta["ucb"])
+        assert_allclose(opt.Q, z["it%d_Q" % t], rtol=0, atol=1e-8)
+        assert_array_equal(opt.S, z["it%d_S" % t])
+        if not meta["ucb"]:
+            assert_array_equal(opt.M, z["it%d_M" % t])
+            assert_array_equal(opt.G, z["it%d_G" % t])
+        assert_array_equal(x, z["it%d_x_next" % t])
+        mx, ml = opt.get_maximum(context=ctx)
+        assert_array_equal(mx, z["it%d_max_x" % t])
+        assert_allclose(ml, z["it%d_max_l" % t], atol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["sets_1d_seed0", "sets_1d_seed7", "sets_1d_g2_seed0",
+                                  "sets_1d_g2_seed7", "sets_2d_seed3"])
+def test_expander_loop_golden(mods, name):
+    """Rank-1 expander test == the reference's add-point / re-predict loop,
+    including a case where the 22nd candidate in width order is the first
+    expander."""
+    safeopt_amd, gpy, _, _ = mods
+    z, meta = load(name)
+    gps = [gpy.models.GPRegression(z["X%d" % i], z["Y%d" % i], make_kernel(gpy.kern, spec),
+                                   noise_var=meta["noise_vars"][i])
+           for i, spec in enumerate(meta["kernels"])]
+    opt = safeopt_amd.SafeOpt(gps if len(gps) > 1 else gps[0], z["parameter_set"],
+                              meta["fmin"] if len(gps) > 1 else meta["fmin"][0],
+                              threshold=meta["threshold"])
+    opt.update_confidence_intervals()
+    opt.compute_sets()
+    assert_allclose(opt.Q, z["Q"], rtol=0, atol=1e-8)
+    assert_array_equal(opt.S, z["S"]); assert_array_equal(opt.M, z["M"])
+    assert_array_equal(opt.G, z["G"])
+    assert_array_equal(opt.get_new_query_point(), z["x_next"])
+
+
+def test_full_sets_golden(mods):
+    safeopt_amd, gpy, _, _ = mods
+    z, meta = load("safeopt_full_sets")
+    gp = gpy.models.GPRegression(z["X0"], z["Y0"], make_kernel(gpy.kern, meta["kernels"][0]),
+                                 noise_var=meta["noise_vars"][0])
+    opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"])
+    opt.update_confidence_intervals()
+    opt.compute_sets(full_sets=True)
+    assert_array_equal(opt.S, z["S"]); assert_array_equal(opt.M, z["M"])
+    assert_array_equal(opt.G, z["G"])
+
+
+def test_sets_bit_exact_on_random_intervals(mods):
+    """Set logic alone: upload arbitrary Q, compare S / M / candidate flow /
+    arg-max with the NumPy restatement bit for bit (Lipschitz certifies the
+    expanders so no GP arithmetic is involved)."""
+    safeopt_amd, gpy, gpn, son = mods
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        N = [1000, 4097, 300, 12345, 128, 77][trial]
+        G = [1, 2, 3, 1, 2, 3][trial]
+        grid = np.sort(rng.uniform(-5, 5, size=(N, 2)), axis=0)
+        gps = [gpy.models.GPRegression(np.zeros((1, 2)), np.ones((1, 1)), gpy.kern.RBF(2),
+                                       noise_var=0.01) for _ in range(G)]
+        lo = rng.normal(0.2, 1.0, size=(N, G))
+        wd = np.abs(rng.normal(0.5, 0.4, size=(N, G))) + 1e-3
+        if trial % 2 == 0:            # force exact ties in values and widths
+            lo = np.round(lo, 1); wd = np.round(wd, 1) + 0.1
+        Q = np.empty((N, 2 * G)); Q[:, ::2] = lo; Q[:, 1::2] = lo + wd
+        fmin = [0.0, -np.inf, 0.3][:G] if G > 1 else [0.0]
+        scaling = [1.0, 2.0, 0.5][:G]
+        lips = [0.8, 0.5, 1.1][:G]
+        thr = 0.15
+        opt = safeopt_amd.SafeOpt(gps if G > 1 else gps[0], grid, fmin if G > 1 else 0.0,
+                                  lipschitz=lips if G > 1 else lips[0], threshold=thr,
+                                  scaling=scaling)
+        opt.Q = Q
+        opt.compute_sets()
+        S = son.safe_set(Q, fmin)
+        assert_array_equal(opt.S, S)
+        if not S.any():
+            with pytest.raises(EnvironmentError):
+                opt.get_new_query_point()
+            continue
+        So, Mo, Go, trace = son.compute_sets(None, grid, Q, fmin, scaling, thr, 2.,
+                                             lipschitz=np.asarray(lips), return_trace=True)
+        assert_array_equal(opt.M, Mo)
+        if not (trial % 2 == 0):      # tie order of the sort is unpinned
+            assert_array_equal(opt.G, Go)
+            idx = son.query_index(Q, So, Mo, Go, scaling)
+            assert_array_equal(opt.get_new_query_point(), grid[idx])
+        assert_array_equal(opt.get_new_query_point(ucb=True),
+                           grid[son.query_index(Q, So, Mo, Go, scaling, ucb=True)])
+        assert opt.G.sum() <= 1
+
+
+def test_topk_order_and_ties(mods):
+    """Visiting order: width descending, ties -> higher index first."""
+    from safeopt_amd import _hip
+    safeopt_amd, gpy, _, _ = mods
+    N = 10000
+    rng = np.random.default_rng(3)
+    grid = rng.uniform(-1, 1, size=(N, 1))
+    gp = gpy.models.GPRegression(np.zeros((1, 1)), np.ones((1, 1)), gpy.kern.RBF(1), noise_var=0.01)
+    w = np.round(rng.uniform(0.1, 1.0, N), 2)          # many exact ties
+    Q = np.stack([np.ones(N), 1.0 + w], axis=1)
+    Q[0] = [5.0, 5.01]                                 # the single maximiser
+    opt = safeopt_amd.SafeOpt(gp, grid, 0., threshold=0., scaling=[1.0])
+    opt.Q = Q
+    be = opt._backend
+    be.maximizers(5.0)
+    n_cand, _ = be.candidates(0.01, [1.0], [0.0], False)
+    ref = np.lexsort((-np.arange(N), -w))              # w desc, index desc
+    ref = ref[ref != 0]
+    assert n_cand == ref.size
+    cut = (np.inf, np.iinfo(np.int64).max)
+    got = []
+    for _ in range(5):
+        ww, ii = be.topk(0, cut[0], cut[1], 16)
+        got.extend(ii.tolist()); cut = (ww[-1], ii[-1])
+    assert got == ref[:80].tolist()
+
+
+def test_swarm_fitness_golden(mods):
+    safeopt_amd, gpy, _, _ = mods
+    z, meta = load("swarm_2d_g2")
+    gps = [gpy.models.GPRegression(z["X0"], z["Y0"][:, [i]], make_kernel(gpy.kern, meta["kernels"][i]),
+                                   noise_var=meta["noise_vars"][i]) for i in range(2)]
+    opt = safeopt_amd.SafeOptSwarm(gps, meta["fmin"], bounds=[tuple(b) for b in meta["bounds"]],
+                                   threshold=meta["threshold"])
+    assert_allclose(opt.optimal_velocities, z["optimal_velocities"], rtol=1e-12)
+    opt.best_lower_bound = meta["fit_best_lower_bound"]
+    for st in ["greedy", "maximizers", "expanders", "safe_set"]:
+        v, s = opt._compute_particle_fitness(st, z["particles"].copy())
+        assert_allclose(v, z["fit_%s_values" % st], rtol=1e-8, atol=1e-9)
+        assert_array_equal(s, z["fit_%s_safe" % st])
+
+
+def test_swarm_optimize_golden(mods):
+    """Whole SafeOptSwarm.optimize() iterations against the reference run with
+    the same NumPy global RNG seed (host RNG order is part of the contract)."""
+    safeopt_amd, gpy, _, _ = mods
+    z, meta = load("swarm_2d_g2")
+    gps = [gpy.models.GPRegression(z["X0"], z["Y0"][:, [i]], make_kernel(gpy.kern, meta["kernels"][i]),
+                                   noise_var=meta["noise_vars"][i]) for i in range(2)]
+    opt = safeopt_amd.SafeOptSwarm(gps, meta["fmin"], bounds=[tuple(b) for b in meta["bounds"]],
+                                   threshold=meta["threshold"])
+    np.random.seed(meta["seed"])
+    x = opt.optimize()
+    assert_allclose(x, z["opt_x"][0], rtol=0, atol=1e-6)
+    assert_allclose(opt.S, z["opt0_S"], rtol=0, atol=1e-6)
+    assert_allclose(opt.best_lower_bound, z["opt0_best_lower_bound"], atol=1e-7)
+
+
+def test_swarm_empty_safe_set_raises(mods):
+    """safeopt/tests/test_swarm.py:13-22"""
+    safeopt_amd, gpy, _, _ = mods
+    gp = gpy.models.GPRegression(np.array([[0.]]), np.array([[-1.]]), noise_var=0.01 ** 2)
+    opt = safeopt_amd.SafeOptSwarm(gp, fmin=[0.], bounds=[[-1., 1.]])
+    with pytest.raises(RuntimeError):
+        opt.optimize()
+
+
+def test_rccl_world1_collectives(mods):
+    from safeopt_amd import _hip
+    ctx = _hip.Context(0)
+    uid = _hip.Context.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(uid, 0, 1)
+    assert_array_equal(ctx.allreduce_max(np.array([1.5, -2.0])), [1.5, -2.0])
+    ctx.barrier()
+
+
+# ---------------------------------------------------------------------------
+def test_full_size_config2(mods):
+    """BASELINE.json configs[1]: 2-D RBF, 200 training points, 1000 x 1000 grid.
+    Spot rows against the oracle + size-independent properties on all 1e6 rows."""
+    safeopt_amd, gpy, gpn, son = mods
+    from bench import make_config
+    cfg = make_config(2)
+    gp = gpy.models.GPRegression(cfg["X"], cfg["Y"][:, [0]], kernels_from(cfg, gpy.kern)[0],
+                                 noise_var=cfg["noise_var"])
+    go = gpn.GPRegression(cfg["X"], cfg["Y"][:, [0]], kernels_from(cfg, gpn)[0],
+                          noise_var=cfg["noise_var"])
+    grid = cfg["grid"]
+    opt = safeopt_amd.SafeOpt(gp, grid, 0., threshold=cfg["threshold"])
+    x = opt.optimize()
+    Q = opt.Q
+    rows = np.random.default_rng(0).choice(grid.shape[0], 4000, replace=False)
+    mo, vo = go.predict_noiseless(grid[rows])
+    sd = np.sqrt(vo.ravel())
+    assert_allclose(Q[rows, 0], mo.ravel() - 2 * sd, atol=1e-8)
+    assert_allclose(Q[rows, 1], mo.ravel() + 2 * sd, atol=1e-8)
+    assert np.all(Q[:, 1] >= Q[:, 0])
+    assert_array_equal(opt.S, Q[:, 0] > 0.)
+    assert opt.S.any() and not opt.S.all()
+    assert np.all(opt.M <= opt.S) and np.all(opt.G <= opt.S) and opt.G.sum() <= 1
+    l, u = Q[:, 0], Q[:, 1]
+    assert_array_equal(opt.M, opt.S & (u >= l[opt.S].max()))
+    MG = opt.M | opt.G
+    val = (u - l) / opt.scaling[0]
+    assert_array_equal(x, grid[np.flatnonzero(MG)[np.argmax(val[MG])]])
+    # idempotence: a second optimize() on unchanged data picks the same point
+    assert_array_equal(opt.optimize(), x)
+
+
+@pytest.mark.parametrize("k,side", [(2, 250), (3, 120), (4, 30)])
+def test_reduced_configs_against_oracle(mods, k, side):
+    """configs[1..3] at reduced grid size, full run of the oracle beside it:
+    identical sets and identical chosen parameter."""
+    safeopt_amd, gpy, gpn, son = mods
+    from bench import make_config, build_gps
+    cfg = make_config(k, side=side)
+    gps = build_gps(cfg, gpy)
+    gos = build_gps(cfg, gpn)
+    G = cfg["G"]
+    opt = safeopt_amd.SafeOpt(gps if G > 1 else gps[0], cfg["grid"],
+                              cfg["fmin"] if G > 1 else 0., threshold=cfg["threshold"])
+    x = opt.optimize()
+    idx, Qo, So, Mo, Go = son.optimize_grid(gos, cfg["grid"], cfg["fmin"], opt.scaling,
+                                            cfg["threshold"], 2.)
+    assert_allclose(opt.Q, Qo, rtol=0, atol=1e-8)
+    assert_array_equal(opt.S, So); assert_array_equal(opt.M, Mo)
+    assert_array_equal(opt.G, Go)
+    assert_array_equal(x, cfg["grid"][idx])
+
+
+def test_swarm_fitness_config5_reduced(mods):
+    """configs[4] (4-D RBF, 2 constraints, n=2000) on 3000 particles."""
+    safeopt_amd, gpy, gpn, son = mods
+    from bench import make_config, build_gps
+    cfg = make_config(5, side=3000)
+    gps = build_gps(cfg, gpy); gos = build_gps(cfg, gpn)
+    opt = safeopt_amd.SafeOptSwarm(gps, cfg["fmin"], bounds=[(-5., 5.)] * 4,
+                                   threshold=cfg["threshold"])
+    opt.best_lower_bound = 0.4
+    for st in ["greedy", "maximizers", "expanders", "safe_set"]:
+        v, s = opt._compute_particle_fitness(st, cfg["particles"])
+        vo, so = son.swarm_fitness(gos, cfg["particles"], st, 2., cfg["fmin"],
+                                   opt.scaling, 0.4)
+        assert_array_equal(s, so)
+        assert_allclose(v, vo, rtol=1e-7, atol=1e-8)
+
+
+def kernels_from(cfg, ns):
+    return [make_kernel(ns, spec) for spec in cfg["kernels"]]
