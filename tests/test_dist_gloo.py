@@ -1,0 +1,170 @@
+"""N > 1 path on CPU: two processes over gloo drive the product's sharded
+SafeOpt host logic (shard ranges, phase driver, top-k / arg-max merges) with the
+NumPy oracle standing in for the per-rank HIP kernels.  Result must equal the
+reference's golden vectors, i.e. the unsharded run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+class TorchComm(object):
+    """Same interface as safeopt_amd.dist.RcclComm, on torch.distributed/gloo."""
+
+    def __init__(self):
+        import torch.distributed as td
+        self.td = td
+        self.rank, self.world = td.get_rank(), td.get_world_size()
+
+    def allreduce_max(self, a):
+        import torch
+        t = torch.from_numpy(np.array(a, dtype=np.float64, copy=True))
+        self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
+        return t.numpy()
+
+    def allgather(self, a):
+        import torch
+        a = np.ascontiguousarray(a)
+        t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy())
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.td.all_gather(outs, t)
+        return np.stack([o.numpy().view(a.dtype).reshape(a.shape) for o in outs])
+
+    def barrier(self):
+        self.td.barrier()
+
+
+def _worker(rank, world, port, names, q):
+    try:
+        sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+        import torch.distributed as td
+        td.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                              rank=rank, world_size=world)
+        import safeopt_amd
+        from oracle import gp_numpy as gpn
+        from _golden import load, make_kernel
+        from _oracle_backend import OracleGridBackend
+        comm = TorchComm()
+        report = []
+        for name in names:
+            z, meta = load(name)
+            if "recorded" in meta:
+                its = meta["recorded"]
+            else:
+                its = [None]
+            for t in its:
+                pre = "" if t is None else "it%d_" % t
+                gps = [gpn.GPRegression(z[pre + "X%d" % i], z[pre + "Y%d" % i],
+                                        make_kernel(gpn, spec), noise_var=meta["noise_vars"][i])
+                       for i, spec in enumerate(meta["kernels"])]
+                lip = meta.get("lipschitz")
+                if lip is not None and len(lip) == 1:
+                    lip = lip[0]
+                beta = meta["beta"] if t is None else float(z["beta_all"][t])
+                G = len(gps)
+                opt = safeopt_amd.SafeOpt(
+                    gps if G > 1 else gps[0], z["parameter_set"],
+                    meta["fmin"] if G > 1 else meta["fmin"][0], lipschitz=lip, beta=beta,
+                    threshold=meta["threshold"], num_contexts=meta.get("num_contexts", 0),
+                    comm=comm, _backend_factory=OracleGridBackend)
+                lo, hi = opt._shard
+                assert hi - lo < z["parameter_set"].shape[0]        # really sharded
+                ctx = z[pre + "context"] if meta.get("num_contexts") else None
+                x = opt.optimize(context=ctx, ucb=meta.get("ucb", False))
+                ok = (np.array_equal(x, z[pre + "x_next"]) and
+                      np.array_equal(opt.S, z[pre + "S"]) and
+                      np.allclose(opt.Q, z[pre + "Q"], atol=1e-10, rtol=0))
+                if not meta.get("ucb", False):
+                    ok = ok and np.array_equal(opt.M, z[pre + "M"]) and \
+                        np.array_equal(opt.G, z[pre + "G"])
+                    if t is not None:
+                        mx = opt.get_maximum(context=ctx)
+                        ok = ok and np.array_equal(mx[0], z[pre + "max_x"])
+                report.append((name, t, bool(ok)))
+        td.destroy_process_group()
+        q.put((rank, report, None))
+    except Exception as e:                      # surface the traceback in rank order
+        import traceback
+        q.put((rank, [], traceback.format_exc()))
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_reproduce_unsharded_golden():
+    pytest.importorskip("torch")
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    names = ["safeopt_2d_rbf", "safeopt_1d_multi", "safeopt_1d_lipschitz", "safeopt_context",
+             "safeopt_2d_ucb", "sets_1d_seed7", "sets_1d_g2_seed0", "sets_2d_seed3"]
+    port = _free_port()
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, names, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=550) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    for rank, report, err in sorted(results):
+        assert err is None, "rank %d failed:\n%s" % (rank, err)
+        assert report and all(ok for _, _, ok in report), report
+
+
+def test_three_way_shard_single_process():
+    """Same driver, world = 3 emulated in one process (each 'rank' in turn with
+    a communicator that replays the other ranks): covers uneven shards."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import safeopt_amd
+    from oracle import gp_numpy as gpn
+    from _golden import load, make_kernel
+    from _oracle_backend import OracleGridBackend
+    import threading
+
+    class ThreadComm(object):
+        """world ranks as threads of this process, rendezvous on a barrier."""
+        def __init__(self, rank, world, shared):
+            self.rank, self.world, self.sh = rank, world, shared
+
+        def _exchange(self, a):
+            self.sh["slots"][self.rank] = np.array(a, copy=True)
+            self.sh["bar"].wait()
+            out = [np.array(s, copy=True) for s in self.sh["slots"]]
+            self.sh["bar"].wait()
+            return out
+
+        def allreduce_max(self, a):
+            return np.max(np.stack(self._exchange(np.asarray(a, dtype=float))), axis=0)
+
+        def allgather(self, a):
+            return np.stack(self._exchange(np.asarray(a)))
+
+        def barrier(self):
+            self.sh["bar"].wait()
+
+    z, meta = load("sets_1d_seed7")
+    world = 3
+    shared = dict(slots=[None] * world, bar=threading.Barrier(world))
+    out = [None] * world
+
+    def run(rank):
+        gp = gpn.GPRegression(z["X0"], z["Y0"], make_kernel(gpn, meta["kernels"][0]),
+                              noise_var=meta["noise_vars"][0])
+        opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"],
+                                  comm=ThreadComm(rank, world, shared),
+                                  _backend_factory=OracleGridBackend)
+        x = opt.optimize()
+        out[rank] = (x, opt.S.copy(), opt.M.copy(), opt.G.copy())
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ths]; [t.join(120) for t in ths]
+    for r in range(world):
+        x, S, M, G = out[r]
+        assert np.array_equal(x, z["x_next"]) and np.array_equal(S, z["S"])
+        assert np.array_equal(M, z["M"]) and np.array_equal(G, z["G"])

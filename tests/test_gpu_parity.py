@@ -251,7 +251,7 @@ def test_sets_bit_exact_on_random_intervals(mods):
             with pytest.raises(EnvironmentError):
                 opt.get_new_query_point()
             continue
-        So, Mo, Go, trace = son.compute_sets(None, grid, Q, fmin, scaling, thr, 2.,
+        So, Mo, Go, trace = son.compute_sets([None] * G, grid, Q, fmin, scaling, thr, 2.,
                                              lipschitz=np.asarray(lips), return_trace=True)
         assert_array_equal(opt.M, Mo)
         if not (trial % 2 == 0):      # tie order of the sort is unpinned

@@ -1,0 +1,162 @@
+"""Host-side logic that needs no GPU: reference plumbing tests mirrored
+(safeopt/tests/test_gps.py), grid generator, shard planner, rank merges, PSO."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+import safeopt_amd
+import safeopt_amd.gpy as gpy
+from safeopt_amd import dist
+from safeopt_amd.gp_opt import GaussianProcessOptimization
+
+
+class FakeGP(object):
+    """Duck-typed handle with host-only set_XY (the reference's seam is duck
+    typing too); kernels are the product's own objects."""
+
+    def __init__(self, X, Y, kernel):
+        self.kern = kernel
+        self.input_dim = np.atleast_2d(X).shape[1]
+        self.set_XY(X, Y)
+
+    def set_XY(self, X, Y):
+        self.X = np.array(np.atleast_2d(X), dtype=float)
+        self.Y = np.array(np.atleast_2d(Y), dtype=float)
+
+
+@pytest.fixture
+def gps():
+    return (FakeGP([[0]], [[0]], gpy.kern.RBF(1, variance=2)),
+            FakeGP([[0]], [[0]], gpy.kern.Matern32(1, variance=4)))
+
+
+def test_init(gps):                                   # test_gps.py:27-46
+    gp1, _ = gps
+    opt = GaussianProcessOptimization(gp1, fmin=0, beta=2, num_contexts=1)
+    assert opt.beta(0) == 2
+    opt = GaussianProcessOptimization(gp1, fmin=[0], beta=lambda x: 5, num_contexts=1)
+    assert opt.beta(10) == 5
+
+
+def test_multi_init(gps):                             # test_gps.py:48-60
+    opt = GaussianProcessOptimization(list(gps), fmin=0, beta=2, num_contexts=1)
+    assert_allclose(opt.scaling, np.array([np.sqrt(2), np.sqrt(4)]))
+
+
+def test_scaling(gps):                                # test_gps.py:62-75
+    gp1, gp2 = gps
+    pytest.raises(ValueError, GaussianProcessOptimization, [gp1, gp2], 2, scaling=[5])
+    opt = GaussianProcessOptimization([gp1, gp2], fmin=[1, 0], scaling=[1, 2])
+    assert_allclose(opt.scaling, np.array([1, 2]))
+
+
+def test_data_adding(gps):                            # test_gps.py:77-120
+    gp1, gp2 = gps
+    gp1.set_XY(np.array([[0.]]), np.array([[1.]]))
+    opt = GaussianProcessOptimization(gp1, 0)
+    opt.add_new_data_point(2, 3)
+    x, y = opt.data
+    assert_allclose(x, [[0], [2]]); assert_allclose(y, [[1], [3]])
+    gp1.set_XY(np.array([[0.]]), np.array([[1.]]))
+    gp2.set_XY(np.array([[0.]]), np.array([[11.]]))
+    opt = GaussianProcessOptimization([gp1, gp2], [0, 1])
+    opt.add_new_data_point(2, [2, 3])
+    assert_allclose(opt.x, [[0], [2]]); assert_allclose(opt.y, [[1, 11], [2, 3]])
+    opt.add_new_data_point(3, [2, np.nan])
+    assert_allclose(opt.x, [[0], [2], [3]])
+    assert_allclose(opt.y, [[1, 11], [2, 3], [2, np.nan]])
+    for i, gp in enumerate(opt.gps):
+        ok = ~np.isnan(opt.y[:, i])
+        assert_allclose(gp.X, opt.x[ok, :]); assert_allclose(gp.Y[:, 0], opt.y[ok, i])
+    opt.remove_last_data_point()
+    assert_allclose(opt.x, [[0], [2]]); assert_allclose(opt.y, [[1, 11], [2, 3]])
+    for i, gp in enumerate(opt.gps):
+        assert_allclose(gp.X, opt.x); assert_allclose(gp.Y[:, 0], opt.y[:, i])
+
+
+def test_contexts():                                  # test_gps.py:122-142
+    gp1 = FakeGP([[0, 0]], [[5]], gpy.kern.RBF(2, variance=2))
+    gp2 = FakeGP([[0, 0]], [[6]], gpy.kern.Matern32(2, variance=4))
+    opt = GaussianProcessOptimization([gp1, gp2], fmin=[0, 0], num_contexts=1)
+    opt.add_new_data_point(1, [3, 4], context=2)
+    assert_allclose(opt.x, [[0, 0], [1, 2]]); assert_allclose(opt.y, [[5, 6], [3, 4]])
+    for i, gp in enumerate(opt.gps):
+        assert_allclose(gp.X, opt.x); assert_allclose(gp.Y[:, 0], opt.y[:, i])
+
+
+def test_different_measurements_rejected():
+    a = FakeGP([[0.]], [[1.]], gpy.kern.RBF(1)); b = FakeGP([[1.]], [[1.]], gpy.kern.RBF(1))
+    with pytest.raises(NotImplementedError):
+        GaussianProcessOptimization([a, b], 0.)
+
+
+def test_grid_order_and_layout():
+    g = safeopt_amd.linearly_spaced_combinations([(-1, 1), (0, 3)], [3, 4])
+    assert g.shape == (12, 2) and g.flags["F_CONTIGUOUS"]
+    assert_allclose(g[:4, 0], [-1, 0, 1, -1])        # first variable fastest
+    assert_allclose(g[:4, 1], [0, 0, 0, 1])
+    g1 = safeopt_amd.linearly_spaced_combinations([(-2, 2)], 5)
+    assert g1.shape == (5, 1)
+    g3 = safeopt_amd.linearly_spaced_combinations([(0, 1)] * 3, 2)
+    assert g3.shape == (8, 3)
+
+
+def test_kernel_descriptor():
+    k = gpy.kern.RBF(2, variance=2., lengthscale=[1., 2.], ARD=True)
+    d, kinds, var, inv = k._desc(2)
+    assert d == 2 and list(kinds) == [0] and var[0] == 2.
+    assert_allclose(inv, [[1., .5]])
+    kp = gpy.kern.RBF(1, 2., 1., active_dims=[0]) * gpy.kern.Matern52(1, 3., 4., active_dims=[1], name='c')
+    d, kinds, var, inv = kp._desc()
+    assert d == 2 and list(kinds) == [0, 2]
+    assert_allclose(inv, [[1., 0.], [0., .25]])
+    assert_allclose(kp.Kdiag(np.zeros((3, 2))), [6., 6., 6.])
+    assert kp.c.variance[0] == 3. and kp.copy().c.variance[0] == 3.
+    with pytest.raises(ValueError):
+        gpy.kern.RBF(2, lengthscale=[1., 2.])          # non-ARD, two lengthscales
+    with pytest.raises(ValueError):
+        k._desc(1)
+
+
+def test_shard_range_partitions():
+    for N in (1, 7, 1000, 10 ** 6 + 3):
+        for world in (1, 2, 3, 8):
+            edges = [dist.shard_range(N, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == N
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_merge_topk_and_argmax():
+    w, i = dist.merge_topk([[3., 1., -np.inf], [3., 2., 2.]], [[5, 9, -1], [7, 4, 8]], 4)
+    assert_array_equal(i, [7, 5, 8, 4]); assert_allclose(w, [3., 3., 2., 2.])
+    w, i = dist.merge_topk([[0, 0], [0, 0]], [[9, 2], [5, -1]], 8, by_index=True)
+    assert_array_equal(i, [2, 5, 9])
+    assert dist.merge_argmax([1., 2., 2.], [3, 9, 4]) == (2., 4)   # lowest index wins
+    assert dist.merge_argmax([-np.inf, 1.], [-1, 6]) == (1., 6)
+    assert dist.merge_argmax([-np.inf], [-1]) == (-np.inf, -1)
+    lc = dist.LocalComm()
+    assert_allclose(lc.allreduce_max(np.array([1., 2.])), [1., 2.])
+    assert lc.allgather(np.arange(3)).shape == (1, 3)
+
+
+def test_swarm_optimization_reproducible():
+    """PSO on a toy fitness: deterministic under the NumPy global RNG, honours
+    the safety mask and the box."""
+    target = np.array([0.3, -0.2])
+
+    def fitness(p):
+        return -np.sum((p - target) ** 2, axis=1), np.all(np.abs(p) <= 1.0, axis=1)
+
+    def run():
+        np.random.seed(0)
+        s = safeopt_amd.SwarmOptimization(20, np.array([0.1, 0.1]), fitness,
+                                          bounds=[(-2., 2.), (-2., 2.)])
+        s.init_swarm(np.random.uniform(-1, 1, size=(20, 2)))
+        s.run_swarm(50)
+        return s.global_best.copy(), s.best_values.max()
+    a, va = run(); b, vb = run()
+    assert_array_equal(a, b)
+    assert va == vb
+    assert np.linalg.norm(a - target) < 0.05 and np.all(np.abs(a) <= 1.0)
