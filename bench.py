@@ -107,27 +107,33 @@ def cpu_baseline(cfg, sample_rows, dev_Q=None):
     from oracle import gp_numpy as gpn
     from oracle import safeopt_numpy as son
     gps = build_gps(cfg, gpn)
-    grid = np.ascontiguousarray(cfg["grid"][:sample_rows])
+    # a contiguous block of rows from the middle of the grid (the block around
+    # the training data, so the sample contains safe, maximiser and unsafe rows)
+    N = cfg["grid"].shape[0]
+    start = max(0, (N - sample_rows) // 2)
+    grid = np.ascontiguousarray(cfg["grid"][start:start + sample_rows])
     scaling = np.sqrt([2.0] * cfg["G"])
     try:
         from threadpoolctl import threadpool_info
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         cores = os.cpu_count() or 1
-    son.optimize_grid(gps, grid[:4096], cfg["fmin"], scaling, cfg["threshold"],
-                      cfg["beta"])                              # warm-up
+    son.confidence_intervals(gps, grid[:8192], cfg["beta"])    # warm-up
     t0 = time.perf_counter()
-    idx, Q, S, M, G = son.optimize_grid(gps, grid, cfg["fmin"], scaling,
-                                        cfg["threshold"], cfg["beta"])
+    try:
+        idx, Q, S, M, G = son.optimize_grid(gps, grid, cfg["fmin"], scaling,
+                                            cfg["threshold"], cfg["beta"])
+    except EnvironmentError:          # sample without a safe row: sweep only
+        Q = son.confidence_intervals(gps, grid, cfg["beta"])
     dt = time.perf_counter() - t0
     out = dict(value=sample_rows / dt, unit="candidates/s", cores=int(cores),
                kind="port",
                sample="oracle optimize_grid (NumPy/OpenBLAS restatement of "
-                      "gp_opt.py:453-649 + GPy predict) on the first %d rows "
-                      "of the same grid, %.1f s" % (sample_rows, dt))
+                      "gp_opt.py:453-649 + GPy predict) on rows [%d, %d) of "
+                      "the same grid, %.1f s" % (start, start + sample_rows, dt))
     parity = None
     if dev_Q is not None:
-        dq = dev_Q[:sample_rows]
+        dq = dev_Q[start:start + sample_rows]
         lo, up = Q[:, ::2], Q[:, 1::2]
         mean_o, mean_d = 0.5 * (lo + up), 0.5 * (dq[:, ::2] + dq[:, 1::2])
         var_o = ((up - lo) / (2 * cfg["beta"])) ** 2
@@ -242,6 +248,8 @@ def main():
     }
     if args.config != 5:
         res["chosen_x"] = [float(v) for v in np.atleast_1d(last["x"])]
+    if world == 1:
+        res["mfma_f64_microbench_tflops"] = ctx.microbench_mfma_f64(20000)
     if world == 1 and not args.no_cpu_baseline and args.config != 5:
         rows = min(args.cpu_rows, units)
         base, parity = cpu_baseline(cfg, rows, dev_Q=opt.Q)

@@ -48,12 +48,13 @@ struct KernDesc {
 
 // One GP as the sweep kernels see it.  All pointers are device pointers.
 struct GpDev {
-  const double* Apack;  // L^-1 in MFMA A-operand order: [nblk][n_pad/4][64]
+  const double* Apack;  // L^-1 in MFMA A-operand order: [nblk][n_pad/4][64],
+                        // zero above the diagonal and in the padding rows
   const double* Xpad;   // training inputs, [n_pad][d], zero padded
   const double* alpha;  // Ky^-1 y, [n_pad], zero padded
   int n;                // training points
   int n_pad;            // n rounded up to 16
-  int nblk;             // n_pad / 16
+  int nblk;             // row blocks of 16, rounded up to even
   int pad_;
   KernDesc kern;
 };

@@ -290,6 +290,31 @@ __global__ void k_s2(const double* Tt, int64_t ld, int n, int m, double prior,
   (void)m;
 }
 
+// out[c][i] = sum_{j<=i} Li[i][j] in[c][j]   (rows of Li are contiguous)
+__global__ void k_cand_lower(const double* Li, int64_t ld, int n, int m,
+                             const double* in, int64_t ldv, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= n || c >= m) return;
+  const double* row = Li + int64_t(i) * ld;
+  const double* v = in + int64_t(c) * ldv;
+  double s = 0.0;
+  for (int j = 0; j <= i; ++j) s = fma(row[j], v[j], s);
+  out[int64_t(c) * ldv + i] = s;
+}
+
+// out[c][j] = sum_{i>=j} Li[i][j] in[c][i]   (coalesced over j)
+__global__ void k_cand_lower_t(const double* Li, int64_t ld, int n, int m,
+                               const double* in, int64_t ldv, double* out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y * blockDim.y + threadIdx.y;
+  if (j >= n || c >= m) return;
+  const double* v = in + int64_t(c) * ldv;
+  double s = 0.0;
+  for (int i = j; i < n; ++i) s = fma(Li[int64_t(i) * ld + j], v[i], s);
+  out[int64_t(c) * ldv + j] = s;
+}
+
 // Wpack[s*64 + lane] = Wt[lane & 15][4 s + (lane >> 4)]  (A operand: cand x j)
 __global__ void k_pack_w(const double* Wt, int64_t ld, int n, int m, int nsteps,
                          double* Wpack) {
@@ -353,7 +378,9 @@ int factor_gp(sgp_gp* gp, int* info) {
   SGP_TRY(sgp_d2h(ctx, info, info_dev, sizeof(int)));
   if (*info != 0) return 0;
 
-  const int nblk = np / 16, nsteps = np / 4;
+  // row blocks rounded up to even (one all-zero block) so the sweep can guard
+  // accumulator slots in aligned pairs
+  const int nblk = ((np / 16) + 1) & ~1, nsteps = np / 4;
   const int64_t total = int64_t(nblk) * nsteps * 64;
   SGP_TRY(sgp_reserve(ctx, &gp->Apack, size_t(total) * sizeof(double)));
   hipLaunchKernelGGL(k_pack, dim3(unsigned((total + 255) / 256)), dim3(256), 0,
@@ -403,10 +430,15 @@ int expander_operands(sgp_gp* gp, const double* xc_dev, int m,
   SGP_TRY(launch_kernel_matrix(ctx, gp->kern, xc_dev, m,
                                static_cast<double*>(gp->X.p), n, Kc, nf, 0,
                                0.0, INT64_MAX));
-  // T^T[c][i] = sum_j Kc[c][j] Li[i][j]
-  SGP_TRY(gemm(ctx, true, m, n, n, 1.0, Kc, nf, Li, nf, 0.0, Tt, nf));
-  // W^T[c][j] = sum_i T^T[c][i] Li[i][j]
-  SGP_TRY(gemm(ctx, false, m, n, n, 1.0, Tt, nf, Li, nf, 0.0, Wt, nf));
+  // T^T[c][i] = sum_j Li[i][j] Kc[c][j] ; W^T[c][j] = sum_i Li[i][j] T^T[c][i]
+  {
+    dim3 blk(64, 4), grd((n + 63) / 64, (m + 3) / 4);
+    hipLaunchKernelGGL(k_cand_lower, grd, blk, 0, ctx->stream, Li, int64_t(nf),
+                       n, m, Kc, int64_t(nf), Tt);
+    hipLaunchKernelGGL(k_cand_lower_t, grd, blk, 0, ctx->stream, Li,
+                       int64_t(nf), n, m, Tt, int64_t(nf), Wt);
+    SGP_HIP(ctx, hipGetLastError());
+  }
   const double prior = gp->kern.kdiag + gp->noise_var + 1e-8 + gp->jitter;
   hipLaunchKernelGGL(k_s2, dim3(m), dim3(256), 0, ctx->stream, Tt, int64_t(nf),
                      n, m, prior, resid_dev, delta, inv_s2);

@@ -39,6 +39,40 @@ __device__ __forceinline__ double kern_eval(const KernDesc& kd, const double* x,
   return out;
 }
 
+// Hyper-parameters of one GP hoisted out of the inner loops.  The common case
+// (one stationary part) keeps everything in registers / SGPRs; products of
+// parts fall back to the descriptor loop.
+template <int D>
+struct KernFast {
+  const KernDesc* kd;
+  bool single;
+  int kind0;
+  double var0;
+  double il0[D];
+
+  __device__ __forceinline__ explicit KernFast(const KernDesc& k) : kd(&k) {
+    single = k.n_parts == 1;
+    kind0 = k.kind[0];
+    var0 = k.variance[0];
+#pragma unroll
+    for (int i = 0; i < D; ++i) il0[i] = k.inv_ls[0][i];
+  }
+
+  __device__ __forceinline__ double operator()(const double* x,
+                                               const double* y) const {
+    if (single) {
+      double r2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const double t = (x[i] - y[i]) * il0[i];
+        r2 = fma(t, t, r2);
+      }
+      return var0 * k_of_r2(kind0, r2);
+    }
+    return kern_eval<D>(*kd, x, y);
+  }
+};
+
 // Sum over the four 16-lane groups of a wave: lanes l, l^16, l^32, l^48.
 __device__ __forceinline__ double sum_lane_groups(double v) {
   v += __shfl_xor(v, 16, 64);

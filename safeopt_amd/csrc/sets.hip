@@ -105,7 +105,8 @@ __global__ __launch_bounds__(T) void k_maximizers(const double* Q,
 __global__ __launch_bounds__(T) void k_candidates(
     const double* Q, const uint8_t* S, const uint8_t* M, int64_t N, int G,
     double max_var, Vec8 scaling, Vec8 thr_beta, int full_sets, uint8_t* cand,
-    double* w, uint8_t* Gm, unsigned long long* counts) {
+    double* w, uint8_t* Gm, unsigned* block_counts) {
+  __shared__ unsigned shc[2 * (T / 64)];
   const int64_t i = int64_t(blockIdx.x) * T + threadIdx.x;
   bool c = false, unsafe = false;
   if (i < N) {
@@ -127,10 +128,44 @@ __global__ __launch_bounds__(T) void k_candidates(
     w[i] = wmax;
     Gm[i] = 0;
   }
+  // one (candidates, unsafe) pair per block; summed by k_sum_counts
   const unsigned long long bc = __ballot(c), bu = __ballot(unsafe);
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
-    if (bc) atomicAdd(&counts[0], (unsigned long long)__popcll(bc));
-    if (bu) atomicAdd(&counts[1], (unsigned long long)__popcll(bu));
+    shc[2 * wave] = unsigned(__popcll(bc));
+    shc[2 * wave + 1] = unsigned(__popcll(bu));
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    unsigned t = 0;
+    for (int wv = 0; wv < T / 64; ++wv) t += shc[2 * wv + threadIdx.x];
+    block_counts[2 * blockIdx.x + threadIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_sum_counts(const unsigned* bc,
+                                                     int64_t nblocks,
+                                                     unsigned long long* out) {
+  __shared__ unsigned long long sh[2][1024 / 64];
+  unsigned long long a = 0, b = 0;
+  for (int64_t e = threadIdx.x; e < nblocks; e += blockDim.x) {
+    a += bc[2 * e];
+    b += bc[2 * e + 1];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = a;
+    sh[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    unsigned long long t = 0;
+    for (int wv = 0; wv < 1024 / 64; ++wv) t += sh[threadIdx.x][wv];
+    out[threadIdx.x] = t;
   }
 }
 
@@ -176,10 +211,6 @@ __global__ __launch_bounds__(T) void k_topk(const uint8_t* cand,
     }
     // empty slots carry (-inf, -1); make them lose against every real entry
     Pair win = block_best<false>(best, sh);
-    if (win.i < 0) {
-      // a real entry with v == -inf could be shadowed; none exists because
-      // interval widths are finite
-    }
     if (threadIdx.x == 0) {
       out_w[int64_t(blockIdx.x) * k + r] = win.v;
       out_idx[int64_t(blockIdx.x) * k + r] = win.i;
@@ -188,7 +219,14 @@ __global__ __launch_bounds__(T) void k_topk(const uint8_t* cand,
       ++found;
       cut = win;
     } else {
-      cut = Pair{-INFINITY, -1};  // nothing left: later rounds stay empty
+      // nothing left: the remaining slots are empty (wave-uniform exit)
+      if (threadIdx.x == 0) {
+        for (int rr = r + 1; rr < k; ++rr) {
+          out_w[int64_t(blockIdx.x) * k + rr] = -INFINITY;
+          out_idx[int64_t(blockIdx.x) * k + rr] = -1;
+        }
+      }
+      break;
     }
   }
   if (n_out && threadIdx.x == 0) *n_out = found;
@@ -352,12 +390,16 @@ int launch_candidates(sgp_grid* g, double max_var, const double* scaling,
   sgp_ctx* ctx = g->ctx;
   unsigned long long* counts =
       static_cast<unsigned long long*>(sgp_scratch(ctx, 1, 64));
-  if (!counts) return -1;
-  SGP_HIP(ctx, hipMemsetAsync(counts, 0, 16, ctx->stream));
-  hipLaunchKernelGGL(k_candidates, dim3(nblk(g->N, T)), dim3(T), 0, ctx->stream,
-                     g->Q, g->S, g->M, g->N, g->G, max_var,
-                     vec8(scaling, g->G, 1.0), vec8(thr_beta, g->G, 0.0),
-                     full_sets, g->cand, g->w, g->Gm, counts);
+  const unsigned nb = nblk(g->N, T);
+  unsigned* bc = static_cast<unsigned*>(
+      sgp_scratch(ctx, 2, size_t(nb) * 2 * sizeof(unsigned)));
+  if (!counts || !bc) return -1;
+  hipLaunchKernelGGL(k_candidates, dim3(nb), dim3(T), 0, ctx->stream, g->Q,
+                     g->S, g->M, g->N, g->G, max_var, vec8(scaling, g->G, 1.0),
+                     vec8(thr_beta, g->G, 0.0), full_sets, g->cand, g->w, g->Gm,
+                     bc);
+  hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, ctx->stream, bc,
+                     int64_t(nb), counts);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

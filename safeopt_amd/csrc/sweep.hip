@@ -32,7 +32,6 @@ constexpr int kATile = kIB * kSteps * 64;           // doubles (32 KB)
 constexpr int kXTile = kJC * SGP_MAX_D;             // doubles
 constexpr int kBuf = kATile + kXTile + kJC;         // + alpha chunk
 constexpr size_t kLdsBytes = (2 * size_t(kBuf) + kWaves) * sizeof(double);
-constexpr int kStageVec = kATile / 2 / kThreads;    // double2 per thread (4)
 
 enum { MODE_CONF = 0, MODE_FITNESS = 1 };
 
@@ -45,76 +44,84 @@ struct SweepParams {
   FitnessArgs fit;
 };
 
-struct Stage {
-  double2 a[kStageVec];
-  double x;
-};
-
-// Issue the global loads of the A chunk of j-block `jb` for the row-block chunk
-// starting at global row block b0 (+ the X / alpha rows of that j-block).
-// LDS image: slot-major, A[slot][step][lane]; slot = row block - b0 + shift so
-// that the last row block of the chunk always sits in slot 15.
-__device__ __forceinline__ void stage_load(Stage& st, const GpDev& gp, int D,
-                                           int b0, int shift, int jb, int tid) {
+// Asynchronous global -> LDS copy of one A chunk (LDS-DMA, no VGPR round trip).
+// LDS image: slot-major A[slot][step][lane]; slot = row block - b0 + shift so
+// that the last row block of the chunk always sits in slot 15.  A slot is 2 KB
+// = two 1 KB pieces (k-steps {0,1} and {2,3}); wave w issues pieces w, w+8,
+// w+16, w+24.  Only the slots the next j-block reads are fetched (`lo` = its
+// first active slot, even); above-diagonal blocks inside a fetched pair come
+// from the zero part of the packed matrix.
+__device__ __forceinline__ void stage_dma(const GpDev& gp, double* buf, int b0,
+                                          int shift, int jb, int lo, int tid) {
   const int nsteps_total = gp.n_pad >> 2;
-  const int within = tid & 127;           // double2 index inside one slot
-  const int sg = jb * kSteps + (within >> 5);
-  const int l2 = within & 31;
+  const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-  for (int k = 0; k < kStageVec; ++k) {
-    const int slot = (tid >> 7) + 4 * k;
-    const int bg = b0 + slot - shift;
-    double2 v = make_double2(0.0, 0.0);
-    if (slot >= shift && jb <= bg) {      // lower triangle only
-      const double* src =
-          gp.Apack + (int64_t(bg) * nsteps_total + sg) * 64 + l2 * 2;
-      v = *reinterpret_cast<const double2*>(src);
+  for (int k = 0; k < 4; ++k) {
+    const int piece = wave + 8 * k;       // wave-uniform
+    const int slot = piece >> 1;
+    const int half = piece & 1;
+    if (slot >= lo) {
+      const int bg = b0 + slot - shift;
+      const double* src = gp.Apack +
+          (int64_t(bg) * nsteps_total + jb * kSteps + 2 * half) * 64 + lane * 2;
+      double* dst = buf + piece * 128;    // wave-uniform LDS base
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
-    st.a[k] = v;
   }
-  st.x = 0.0;
+}
+
+// X rows / alpha entries of j-block jb: one double per thread through VGPRs.
+__device__ __forceinline__ double stage_x_load(const GpDev& gp, int D, int jb,
+                                               int tid) {
   const int j0 = jb * kJC;
+  if (tid < kJC * D) return gp.Xpad[j0 * D + tid];
+  if (tid >= 256 && tid < 256 + kJC) return gp.alpha[j0 + (tid - 256)];
+  return 0.0;
+}
+
+__device__ __forceinline__ void stage_x_store(double v, double* buf, int D,
+                                              int tid) {
   if (tid < kJC * D) {
-    st.x = gp.Xpad[j0 * D + tid];
+    buf[kATile + tid] = v;
   } else if (tid >= 256 && tid < 256 + kJC) {
-    st.x = gp.alpha[j0 + (tid - 256)];
+    buf[kATile + kXTile + (tid - 256)] = v;
   }
 }
 
-__device__ __forceinline__ void stage_store(const Stage& st, double* buf, int D,
-                                            int tid) {
-  double2* a2 = reinterpret_cast<double2*>(buf);
-  const int within = tid & 127;
+// A operands of slots b, b+1 for the 4 k-steps of the staged j-block.
+__device__ __forceinline__ void load_ops(double (&ops)[8], const double* aT,
+                                         int b) {
 #pragma unroll
-  for (int k = 0; k < kStageVec; ++k) {
-    const int slot = (tid >> 7) + 4 * k;
-    a2[slot * 128 + within] = st.a[k];
-  }
-  if (tid < kJC * D) {
-    buf[kATile + tid] = st.x;
-  } else if (tid >= 256 && tid < 256 + kJC) {
-    buf[kATile + kXTile + (tid - 256)] = st.x;
+  for (int q = 0; q < 4; ++q) {
+    ops[2 * q] = aT[(b * kSteps + q) * 64];
+    ops[2 * q + 1] = aT[((b + 1) * kSteps + q) * 64];
   }
 }
 
-// One 16-wide j-block (4 MFMA k-steps) against accumulator slots lo..15.
-// Slots are guarded in pairs by wave-uniform branches, so a slot below `lo`
-// costs nothing except (for odd lo) one zero block: the staged image holds
-// zeros above the diagonal.  Each guarded group interleaves two independent
-// accumulator chains.
+// One 16-wide j-block (4 MFMA k-steps) against accumulator slots lo..15
+// (lo even).  Slot pairs are guarded by wave-uniform branches (the active set
+// is a suffix), each pair interleaves two independent accumulator chains, and
+// the A operands of pair g+1 are fetched from LDS while pair g's 8 MFMAs run.
 __device__ __forceinline__ void mfma_jblock(int lo, double4_t (&acc)[kIB],
                                             const double* aT,
                                             const double (&kv)[4]) {
+  double opsA[8], opsB[8];
+  const int g0 = lo >> 1;
 #pragma unroll
-  for (int b = 0; b < kIB; b += 2) {
-    if (b + 1 >= lo) {
+  for (int g = 0; g < kIB / 2; ++g) {
+    if (g >= g0) {
+      double(&cur)[8] = (g & 1) ? opsB : opsA;
+      double(&nxt)[8] = (g & 1) ? opsA : opsB;
+      if (g == g0) load_ops(cur, aT, 2 * g);
+      if (g + 1 < kIB / 2) load_ops(nxt, aT, 2 * g + 2);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const double a0 = aT[(b * kSteps + q) * 64];
-        const double a1 = aT[((b + 1) * kSteps + q) * 64];
-        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, kv[q], acc[b], 0, 0, 0);
-        acc[b + 1] =
-            __builtin_amdgcn_mfma_f64_16x16x4f64(a1, kv[q], acc[b + 1], 0, 0, 0);
+        acc[2 * g] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+            cur[2 * q], kv[q], acc[2 * g], 0, 0, 0);
+        acc[2 * g + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+            cur[2 * q + 1], kv[q], acc[2 * g + 1], 0, 0, 0);
       }
     }
   }
@@ -133,29 +140,22 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
   const int nchunks = (gp.nblk + kIB - 1) / kIB;
   double sumsq = 0.0, mean = 0.0;
 
-  // single stationary part (the common case): hyper-parameters in SGPRs
-  const bool single = gp.kern.n_parts == 1;
-  const int kind0 = gp.kern.kind[0];
-  const double var0 = gp.kern.variance[0];
-  double il0[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) il0[k] = gp.kern.inv_ls[0][k];
+  const KernFast<D> kf(gp.kern);
 
 #pragma unroll 1
   for (int c = 0; c < nchunks; ++c) {
     const int b0 = c * kIB;
-    const int nib = min(kIB, gp.nblk - b0);
+    const int nib = min(kIB, gp.nblk - b0);    // even (nblk is even)
     const int shift = kIB - nib;
-    const int njb = b0 + nib;                  // j-blocks feeding this chunk
+    const int njb = min(b0 + nib, gp.n_pad >> 4);  // j-blocks feeding this chunk
     const bool last = (c == nchunks - 1);
 
     double4_t acc[kIB];
 #pragma unroll
     for (int b = 0; b < kIB; ++b) acc[b] = double4_t{0.0, 0.0, 0.0, 0.0};
 
-    Stage st;
-    stage_load(st, gp, D, b0, shift, 0, tid);
-    stage_store(st, lds, D, tid);
+    stage_dma(gp, lds, b0, shift, 0, shift, tid);
+    stage_x_store(stage_x_load(gp, D, 0, tid), lds, D, tid);
     __syncthreads();
 
 #pragma unroll 1
@@ -163,37 +163,28 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
       double* cur = lds + (jb & 1) * kBuf;
       double* nxt = lds + ((jb & 1) ^ 1) * kBuf;
       const bool more = (jb + 1 < njb);
-      if (more) stage_load(st, gp, D, b0, shift, jb + 1, tid);
+      double xs = 0.0;
+      if (more) {
+        const int lo_n = shift + (max(0, jb + 1 - b0) & ~1);
+        stage_dma(gp, nxt, b0, shift, jb + 1, lo_n, tid);
+        xs = stage_x_load(gp, D, jb + 1, tid);
+      }
 
       const double* xT = cur + kATile;
       const double* alT = cur + kATile + kXTile;
       double kv[4];
-      if (single) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const double* y = xT + (q * 4 + (lane >> 4)) * D;
-          double r2 = 0.0;
-#pragma unroll
-          for (int k = 0; k < D; ++k) {
-            const double t = (x[k] - y[k]) * il0[k];
-            r2 = fma(t, t, r2);
-          }
-          kv[q] = var0 * k_of_r2(kind0, r2);
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          kv[q] = kern_eval<D>(gp.kern, x, xT + (q * 4 + (lane >> 4)) * D);
-      }
+      for (int q = 0; q < 4; ++q)
+        kv[q] = kf(x, xT + (q * 4 + (lane >> 4)) * D);
       if (last) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
       }
-      const int lo = shift + max(0, jb - b0);
+      const int lo = shift + (max(0, jb - b0) & ~1);
       mfma_jblock(lo, acc, cur + lane, kv);
 
-      if (more) stage_store(st, nxt, D, tid);
+      if (more) stage_x_store(xs, nxt, D, tid);
       __syncthreads();
     }
 
@@ -350,13 +341,21 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
   for (int g = 0; g < G; ++g) {
     if (!ea.active[g]) continue;
     const GpDev& gp = gps[g];
+    const KernFast<D> kf(gp.kern);
     const double* W = ea.Wpack + int64_t(g) * ea.wstride + lane;
+    const double* Xj = gp.Xpad + (lane >> 4) * D;
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    const int nsteps = gp.n_pad >> 2;
-    for (int s = 0; s < nsteps; ++s) {
-      const int j = s * 4 + (lane >> 4);
-      const double kv = kern_eval<D>(gp.kern, x, gp.Xpad + j * D);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[s * 64], kv, acc, 0, 0, 0);
+    const int nsteps = gp.n_pad >> 2;  // multiple of 4 (n_pad is 16-aligned)
+#pragma unroll 1
+    for (int s0 = 0; s0 < nsteps; s0 += 4) {
+      double a[4], kv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] = W[(s0 + q) * 64];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) kv[q] = kf(x, Xj + (s0 + q) * 4 * D);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], kv[q], acc, 0, 0, 0);
     }
     const double mu = ea.mean[int64_t(g) * pts.N + rrow];
     const double var = ea.var[int64_t(g) * pts.N + rrow];
@@ -366,7 +365,7 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
       const int cand = (lane >> 4) + 4 * r;
       bool hit = false;
       if (cand < ea.m && unsafe) {
-        const double kxc = kern_eval<D>(gp.kern, x, ea.xc + cand * D);
+        const double kxc = kf(x, ea.xc + cand * D);
         const double cx = kxc - acc[r];
         const double mu2 = mu + cx * ea.delta[g * 16 + cand];
         const double var2 =
