@@ -177,6 +177,11 @@ int sgp_profile_read(sgp_ctx* ctx, double* total_ms, int64_t* launches,
                      double* flops);
 /* fp64 MFMA issue-rate microbenchmark (v_mfma_f64_16x16x4_f64), TFLOP/s      */
 int sgp_microbench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops);
+/* issue-rate probes: mode 0/1/5 = 8/4/16 MFMA chains, 2/4 = MFMA + 8/2 v_fma_f64
+ * per MFMA, 3 = v_fma_f64 only; lds_bytes of dynamic LDS only limit residency.
+ * tflops2 = { MFMA TFLOP/s, VALU-FMA TFLOP/s }                               */
+int sgp_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
+                   double* tflops2);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,7 @@ PROTOTYPES = {
     "sgp_profile_enable": (C.c_int, [vp, C.c_int]),
     "sgp_profile_read": (C.c_int, [vp, c_double_p, c_i64_p, c_double_p]),
     "sgp_microbench_mfma_f64": (C.c_int, [vp, C.c_int, c_double_p]),
+    "sgp_microbench": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_double_p]),
 }
 
 _lib = None
@@ -188,6 +189,11 @@ class Context(object):
         t = C.c_double(0)
         self.check(lib().sgp_microbench_mfma_f64(self.h, iters, C.byref(t)))
         return t.value
+
+    def microbench(self, mode, iters=20000, lds_bytes=0):
+        t = np.zeros(2)
+        self.check(lib().sgp_microbench(self.h, mode, iters, lds_bytes, dptr(t)))
+        return float(t[0]), float(t[1])
 
     # -- RCCL
     @staticmethod

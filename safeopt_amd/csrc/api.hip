@@ -665,15 +665,16 @@ int sgp_grid_expander_check(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   // device layout: xc | resid[G][16] | delta[G][16] | inv_s2[G][16] | flags | W
   const size_t bx = size_t(SGP_TOPK) * d * 8, bv = size_t(G) * 16 * 8,
                bf = size_t(SGP_TOPK) * G * 4 + 64;
-  const size_t total = bx + 3 * bv + bf + size_t(G) * wstride * 8;
+  const size_t total = bx + 4 * bv + bf + size_t(G) * wstride * 8;
   char* buf = static_cast<char*>(sgp_scratch(ctx, 7, total));
   SGP_CHECK(ctx, buf, "device allocation failed: %s", ctx->err.c_str());
   double* dxc = reinterpret_cast<double*>(buf);
   double* dres = reinterpret_cast<double*>(buf + bx);
   double* ddel = reinterpret_cast<double*>(buf + bx + bv);
   double* dis2 = reinterpret_cast<double*>(buf + bx + 2 * bv);
-  int32_t* dfl = reinterpret_cast<int32_t*>(buf + bx + 3 * bv);
-  double* dW = reinterpret_cast<double*>(buf + bx + 3 * bv + bf);
+  double* dtn2 = reinterpret_cast<double*>(buf + bx + 3 * bv);
+  int32_t* dfl = reinterpret_cast<int32_t*>(buf + bx + 4 * bv);
+  double* dW = reinterpret_cast<double*>(buf + bx + 4 * bv + bf);
   std::vector<double> resid(size_t(G) * 16, 0.0);
   for (int c = 0; c < m; ++c)
     for (int i = 0; i < G; ++i) resid[size_t(i) * 16 + c] = u_c[c * G + i] - mu_c[c * G + i];
@@ -690,12 +691,13 @@ int sgp_grid_expander_check(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   for (int i = 0; i < G; ++i) {
     if (!ea.active[i]) continue;
     SGP_TRY(expander_operands(gps[i], dxc, m, dres + i * 16, dW + i * wstride,
-                              ddel + i * 16, dis2 + i * 16));
+                              ddel + i * 16, dis2 + i * 16, dtn2 + i * 16));
   }
   ea.Wpack = dW;
   ea.xc = dxc;
   ea.delta = ddel;
   ea.inv_s2 = dis2;
+  ea.tn2 = dtn2;
   ea.m = m;
   ea.beta = beta;
   ea.S = g->S;
@@ -791,7 +793,16 @@ int sgp_profile_read(sgp_ctx* ctx, double* total_ms, int64_t* launches,
 
 int sgp_microbench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops) {
   SGP_HIP(ctx, hipSetDevice(ctx->device));
-  return launch_microbench(ctx, iters, tflops);
+  double t[2];
+  SGP_TRY(launch_microbench(ctx, 0, iters, 0, t));
+  *tflops = t[0];
+  return 0;
+}
+
+int sgp_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
+                   double* tflops2) {
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_microbench(ctx, mode, iters, lds_bytes, tflops2);
 }
 
 // ---- RCCL -----------------------------------------------------------------------

@@ -133,7 +133,7 @@ int launch_kernel_matrix(sgp_ctx* ctx, const KernDesc& kd, const double* X1,
 int factor_gp(sgp_gp* gp, int* info);  // Kmat -> Linv, Apack, alpha
 int expander_operands(sgp_gp* gp, const double* xc_dev, int m,
                       const double* resid_dev, double* Wpack, double* delta,
-                      double* inv_s2);
+                      double* inv_s2, double* tn2);
 
 // sweep.hip
 struct SweepPoints {
@@ -171,6 +171,7 @@ struct ExpanderArgs {
   const double* xc;      // [m][d]
   const double* delta;   // [G][16]  (u_c - mu_c) / s2
   const double* inv_s2;  // [G][16]
+  const double* tn2;     // [G][16]  |L^-1 k(X, x_c)|^2
   int m;
   double beta;
   double fmin[SGP_MAX_GPS];
@@ -184,7 +185,8 @@ struct ExpanderArgs {
 int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
                           const GpDev* gps_host, int G, int d, SweepPoints pts,
                           ExpanderArgs ea);
-int launch_microbench(sgp_ctx* ctx, int iters, double* tflops);
+int launch_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
+                      double* tflops);
 
 // sets.hip
 int launch_reduce_max(sgp_ctx* ctx, const double* in, int64_t n, double* out);

@@ -268,7 +268,8 @@ __global__ void k_pad_rows(const double* X, int n, int n_pad, int d,
 // ---- operands of the rank-1 expander test ---------------------------------------
 // s2_c = k(x_c,x_c) + noise + 1e-8 + jitter - |t_c|^2 ; delta = resid / s2
 __global__ void k_s2(const double* Tt, int64_t ld, int n, int m, double prior,
-                     const double* resid, double* delta, double* inv_s2) {
+                     const double* resid, double* delta, double* inv_s2,
+                     double* tn2) {
   __shared__ double sh[256 / 64];
   const int c = blockIdx.x;
   double s = 0.0;
@@ -286,33 +287,9 @@ __global__ void k_s2(const double* Tt, int64_t ld, int n, int m, double prior,
     const double s2 = prior - tot;
     inv_s2[c] = 1.0 / s2;
     delta[c] = resid[c] / s2;
+    tn2[c] = tot;
   }
   (void)m;
-}
-
-// out[c][i] = sum_{j<=i} Li[i][j] in[c][j]   (rows of Li are contiguous)
-__global__ void k_cand_lower(const double* Li, int64_t ld, int n, int m,
-                             const double* in, int64_t ldv, double* out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int c = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= n || c >= m) return;
-  const double* row = Li + int64_t(i) * ld;
-  const double* v = in + int64_t(c) * ldv;
-  double s = 0.0;
-  for (int j = 0; j <= i; ++j) s = fma(row[j], v[j], s);
-  out[int64_t(c) * ldv + i] = s;
-}
-
-// out[c][j] = sum_{i>=j} Li[i][j] in[c][i]   (coalesced over j)
-__global__ void k_cand_lower_t(const double* Li, int64_t ld, int n, int m,
-                               const double* in, int64_t ldv, double* out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int c = blockIdx.y * blockDim.y + threadIdx.y;
-  if (j >= n || c >= m) return;
-  const double* v = in + int64_t(c) * ldv;
-  double s = 0.0;
-  for (int i = j; i < n; ++i) s = fma(Li[int64_t(i) * ld + j], v[i], s);
-  out[int64_t(c) * ldv + j] = s;
 }
 
 // Wpack[s*64 + lane] = Wt[lane & 15][4 s + (lane >> 4)]  (A operand: cand x j)
@@ -416,7 +393,7 @@ int factor_gp(sgp_gp* gp, int* info) {
 // w_c = Ky^-1 k(X, x_c) packed as an MFMA A operand, delta_c, 1/s2_c.
 int expander_operands(sgp_gp* gp, const double* xc_dev, int m,
                       const double* resid_dev, double* Wpack, double* delta,
-                      double* inv_s2) {
+                      double* inv_s2, double* tn2) {
   sgp_ctx* ctx = gp->ctx;
   const int n = int(gp->n), nf = gp->n_f, np = gp->n_pad;
   double* Li = static_cast<double*>(gp->Linv.p);
@@ -430,18 +407,12 @@ int expander_operands(sgp_gp* gp, const double* xc_dev, int m,
   SGP_TRY(launch_kernel_matrix(ctx, gp->kern, xc_dev, m,
                                static_cast<double*>(gp->X.p), n, Kc, nf, 0,
                                0.0, INT64_MAX));
-  // T^T[c][i] = sum_j Li[i][j] Kc[c][j] ; W^T[c][j] = sum_i Li[i][j] T^T[c][i]
-  {
-    dim3 blk(64, 4), grd((n + 63) / 64, (m + 3) / 4);
-    hipLaunchKernelGGL(k_cand_lower, grd, blk, 0, ctx->stream, Li, int64_t(nf),
-                       n, m, Kc, int64_t(nf), Tt);
-    hipLaunchKernelGGL(k_cand_lower_t, grd, blk, 0, ctx->stream, Li,
-                       int64_t(nf), n, m, Tt, int64_t(nf), Wt);
-    SGP_HIP(ctx, hipGetLastError());
-  }
+  // T^T[c][i] = sum_j Kc[c][j] Li[i][j] ; W^T[c][j] = sum_i T^T[c][i] Li[i][j]
+  SGP_TRY(gemm(ctx, true, m, n, n, 1.0, Kc, nf, Li, nf, 0.0, Tt, nf));
+  SGP_TRY(gemm(ctx, false, m, n, n, 1.0, Tt, nf, Li, nf, 0.0, Wt, nf));
   const double prior = gp->kern.kdiag + gp->noise_var + 1e-8 + gp->jitter;
   hipLaunchKernelGGL(k_s2, dim3(m), dim3(256), 0, ctx->stream, Tt, int64_t(nf),
-                     n, m, prior, resid_dev, delta, inv_s2);
+                     n, m, prior, resid_dev, delta, inv_s2, tn2);
   const int nsteps = np / 4;
   hipLaunchKernelGGL(k_pack_w, dim3((nsteps * 64 + 255) / 256), dim3(256), 0,
                      ctx->stream, Wt, int64_t(nf), n, m, nsteps, Wpack);

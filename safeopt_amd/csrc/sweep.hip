@@ -100,11 +100,14 @@ __device__ __forceinline__ void load_ops(double (&ops)[8], const double* aT,
   }
 }
 
-// One 16-wide j-block (4 MFMA k-steps) against accumulator slots lo..15
-// (lo even).  Slot pairs are guarded by wave-uniform branches (the active set
-// is a suffix), each pair interleaves two independent accumulator chains, and
-// the A operands of pair g+1 are fetched from LDS while pair g's 8 MFMAs run.
-__device__ __forceinline__ void mfma_jblock(int lo, double4_t (&acc)[kIB],
+// One 16-wide j-block (4 MFMA k-steps) against accumulator slots lo..hi.
+// Slots are visited in aligned pairs behind wave-uniform branches (the active
+// set is a contiguous range); a fully active pair interleaves two independent
+// accumulator chains, a half-active pair (odd lo, or the even-padding block at
+// the top) runs one chain.  The A operands of pair g+1 are fetched from LDS
+// while pair g's MFMAs run.
+__device__ __forceinline__ void mfma_jblock(int lo, int hi,
+                                            double4_t (&acc)[kIB],
                                             const double* aT,
                                             const double (&kv)[4]) {
   double opsA[8], opsB[8];
@@ -116,12 +119,25 @@ __device__ __forceinline__ void mfma_jblock(int lo, double4_t (&acc)[kIB],
       double(&nxt)[8] = (g & 1) ? opsA : opsB;
       if (g == g0) load_ops(cur, aT, 2 * g);
       if (g + 1 < kIB / 2) load_ops(nxt, aT, 2 * g + 2);
+      const bool a0 = (2 * g >= lo), a1 = (2 * g + 1 <= hi);
+      if (a0 && a1) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[2 * g] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-            cur[2 * q], kv[q], acc[2 * g], 0, 0, 0);
-        acc[2 * g + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-            cur[2 * q + 1], kv[q], acc[2 * g + 1], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+          acc[2 * g] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+              cur[2 * q], kv[q], acc[2 * g], 0, 0, 0);
+          acc[2 * g + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+              cur[2 * q + 1], kv[q], acc[2 * g + 1], 0, 0, 0);
+        }
+      } else if (a1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc[2 * g + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+              cur[2 * q + 1], kv[q], acc[2 * g + 1], 0, 0, 0);
+      } else if (a0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc[2 * g] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+              cur[2 * q], kv[q], acc[2 * g], 0, 0, 0);
       }
     }
   }
@@ -149,6 +165,8 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
     const int shift = kIB - nib;
     const int njb = min(b0 + nib, gp.n_pad >> 4);  // j-blocks feeding this chunk
     const bool last = (c == nchunks - 1);
+    // last real slot: the even-padding row block (if any) is never computed
+    const int hi = (last && (gp.nblk > (gp.n_pad >> 4))) ? kIB - 2 : kIB - 1;
 
     double4_t acc[kIB];
 #pragma unroll
@@ -181,8 +199,8 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
         for (int q = 0; q < 4; ++q)
           mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
       }
-      const int lo = shift + (max(0, jb - b0) & ~1);
-      mfma_jblock(lo, acc, cur + lane, kv);
+      const int lo = shift + max(0, jb - b0);
+      mfma_jblock(lo, hi, acc, cur + lane, kv);
 
       if (more) stage_x_store(xs, nxt, D, tid);
       __syncthreads();
@@ -342,6 +360,36 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
     if (!ea.active[g]) continue;
     const GpDev& gp = gps[g];
     const KernFast<D> kf(gp.kern);
+    const double mu = ea.mean[int64_t(g) * pts.N + rrow];
+    const double var = ea.var[int64_t(g) * pts.N + rrow];
+    const double kdiag = gp.kern.kdiag;
+
+    // Exact pre-filter.  |c(x)| <= k(x,x_c) + |L^-1 k_x| |L^-1 k_c| with
+    // |L^-1 k_x|^2 = k(x,x) - var(x), so an upper bound of the updated lower
+    // confidence bound costs ONE covariance evaluation per (row, candidate)
+    // instead of n.  Rows far from x_c and from the data (most of the unsafe
+    // set) cannot reach fmin and skip the n-term contraction below.
+    double kxc[4];
+    bool possible = false;
+    const double qx = fmax(kdiag - var, 0.0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cand = (lane >> 4) + 4 * r;
+      kxc[r] = 0.0;
+      if (cand < ea.m && unsafe) {
+        kxc[r] = kf(x, ea.xc + cand * D);
+        const double cmax =
+            (fabs(kxc[r]) + sqrt(qx * ea.tn2[g * 16 + cand])) * (1.0 + 1e-9);
+        const double mu2 = mu + fabs(ea.delta[g * 16 + cand]) * cmax;
+        const double var2 =
+            fmax(var - cmax * cmax * ea.inv_s2[g * 16 + cand], 1e-15);
+        const double l2max = mu2 - ea.beta * sqrt(var2);
+        possible = possible ||
+                   (l2max + 1e-9 * (fabs(mu2) + 1.0) >= ea.fmin[g]);
+      }
+    }
+    if (__ballot(possible) == 0ull) continue;  // wave-uniform
+
     const double* W = ea.Wpack + int64_t(g) * ea.wstride + lane;
     const double* Xj = gp.Xpad + (lane >> 4) * D;
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -357,16 +405,13 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
       for (int q = 0; q < 4; ++q)
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], kv[q], acc, 0, 0, 0);
     }
-    const double mu = ea.mean[int64_t(g) * pts.N + rrow];
-    const double var = ea.var[int64_t(g) * pts.N + rrow];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       // f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 r
       const int cand = (lane >> 4) + 4 * r;
       bool hit = false;
       if (cand < ea.m && unsafe) {
-        const double kxc = kf(x, ea.xc + cand * D);
-        const double cx = kxc - acc[r];
+        const double cx = kxc[r] - acc[r];
         const double mu2 = mu + cx * ea.delta[g * 16 + cand];
         const double var2 =
             fmax(var - cx * cx * ea.inv_s2[g * 16 + cand], 1e-15);
@@ -385,24 +430,50 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
   }
 }
 
-// ---- fp64 MFMA issue-rate microbenchmark --------------------------------------
+// ---- fp64 issue-rate microbenchmarks ---------------------------------------------
+// MODE 0: 8 independent MFMA chains   1: 4 chains   2: 8 chains + 8 v_fma_f64
+// per MFMA   3: v_fma_f64 only (16 chains)   4: 8 MFMA chains + 2 v_fma_f64 per
+// MFMA   5: 16 MFMA chains
+template <int MODE>
 __global__ __launch_bounds__(256) void k_mfma_bench(double* out, int iters) {
-  double4_t a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0,
-            a6 = a0, a7 = a0;
+  extern __shared__ double dyn_lds[];  // only limits residency
+  constexpr int NA = (MODE == 1) ? 4 : (MODE == 5 ? 16 : 8);
+  double4_t acc[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) acc[i] = double4_t{0, 0, 0, 0};
+  double f[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) f[i] = 1.0 + i * 1e-3 + threadIdx.x * 1e-6;
   const double av = 1.0 + threadIdx.x * 1e-9, bv = 1.0 - threadIdx.x * 1e-9;
-  for (int i = 0; i < iters; ++i) {
-    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a1, 0, 0, 0);
-    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a2, 0, 0, 0);
-    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a3, 0, 0, 0);
-    a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a4, 0, 0, 0);
-    a5 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a5, 0, 0, 0);
-    a6 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a6, 0, 0, 0);
-    a7 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a7, 0, 0, 0);
+  const double m = 0.999999, c = 1e-7;
+  for (int it = 0; it < iters; ++it) {
+    if (MODE != 3) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i], 0, 0, 0);
+        if (MODE == 2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = fma(f[j], m, c);
+        }
+        if (MODE == 4) {
+          f[(2 * i) & 15] = fma(f[(2 * i) & 15], m, c);
+          f[(2 * i + 1) & 15] = fma(f[(2 * i + 1) & 15], m, c);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) f[j] = fma(f[j], m, c);
+    }
   }
   double s = 0;
-  for (int r = 0; r < 4; ++r)
-    s += a0[r] + a1[r] + a2[r] + a3[r] + a4[r] + a5[r] + a6[r] + a7[r];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+    for (int r = 0; r < 4; ++r) s += acc[i][r];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += f[i];
+  if (dyn_lds == nullptr) s += 1.0;
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -514,21 +585,44 @@ int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
   return 0;
 }
 
-int launch_microbench(sgp_ctx* ctx, int iters, double* tflops) {
+template <int MODE>
+int run_microbench(sgp_ctx* ctx, int iters, int lds_bytes, int nblocks,
+                   double* out, float* ms) {
+  if (lds_bytes > 64 * 1024)
+    SGP_HIP(ctx, hipFuncSetAttribute(
+                     reinterpret_cast<const void*>(&k_mfma_bench<MODE>),
+                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  hipLaunchKernelGGL(k_mfma_bench<MODE>, dim3(nblocks), dim3(256), lds_bytes,
+                     ctx->stream, out, 16);  // warm-up
+  SGP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(k_mfma_bench<MODE>, dim3(nblocks), dim3(256), lds_bytes,
+                     ctx->stream, out, iters);
+  SGP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  SGP_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  SGP_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return 0;
+}
+
+// tflops[0] = MFMA flops rate, tflops[1] = VALU FMA flops rate
+int launch_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
+                      double* tflops) {
   const int nblocks = ctx->num_cu * 8;
   double* out = static_cast<double*>(
       sgp_scratch(ctx, 0, size_t(nblocks) * 256 * sizeof(double)));
   if (!out) return -1;
-  hipLaunchKernelGGL(k_mfma_bench, dim3(nblocks), dim3(256), 0, ctx->stream,
-                     out, 16);  // warm-up
-  SGP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(k_mfma_bench, dim3(nblocks), dim3(256), 0, ctx->stream,
-                     out, iters);
-  SGP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  SGP_HIP(ctx, hipEventSynchronize(ctx->ev1));
   float ms = 0.f;
-  SGP_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-  const double flops = double(nblocks) * 4.0 * iters * 8.0 * 2048.0;
-  *tflops = flops / (double(ms) * 1e-3) / 1e12;
+  int na = 8, valu_per_it = 0;
+  switch (mode) {
+    case 0: SGP_TRY(run_microbench<0>(ctx, iters, lds_bytes, nblocks, out, &ms)); break;
+    case 1: SGP_TRY(run_microbench<1>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;
+    case 2: SGP_TRY(run_microbench<2>(ctx, iters, lds_bytes, nblocks, out, &ms)); valu_per_it = 64; break;
+    case 3: SGP_TRY(run_microbench<3>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 0; valu_per_it = 64; break;
+    case 4: SGP_TRY(run_microbench<4>(ctx, iters, lds_bytes, nblocks, out, &ms)); valu_per_it = 16; break;
+    case 5: SGP_TRY(run_microbench<5>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 16; break;
+    default: sgp_set_error(ctx, "unknown microbench mode %d", mode); return -2;
+  }
+  const double waves = double(nblocks) * 4.0;
+  tflops[0] = waves * iters * na * 2048.0 / (double(ms) * 1e-3) / 1e12;
+  tflops[1] = waves * iters * valu_per_it * 128.0 / (double(ms) * 1e-3) / 1e12;
   return 0;
 }
