@@ -128,11 +128,15 @@ int sgp_grid_gather_rows(sgp_grid* grid, const int64_t* gidx, int m, double* x,
  *   mu2 = mu_i(x) + c(x) (u_i(x_c) - mu_i(x_c)) / s2,
  *   var2 = max(var_i(x) - c(x)^2 / s2, 1e-15),
  *   c(x) = k(x,x_c) - k(X,x)^T Ky^-1 k(X,x_c),  s2 = var_i(x_c)+noise+1e-8.
- * xc (m,d), mu_c/u_c (m,G) come from sgp_grid_gather_rows on the owner.      */
+ * xc (m,d), mu_c/u_c (m,G) come from sgp_grid_gather_rows on the owner.
+ * near_frac > 0 restricts the scan to rows with k(x,x_c) >= near_frac*k(x,x)
+ * (a cheap first probe: a hit there already proves the candidate an expander;
+ * no hit proves nothing, repeat with near_frac = 0 for the exact answer).     */
 int sgp_grid_expander_check(sgp_grid* grid, sgp_gp* const* gps, int G,
                             double beta, const double* fmin, int m,
                             const double* xc, const double* mu_c,
-                            const double* u_c, int32_t* flags);
+                            const double* u_c, double near_frac,
+                            int32_t* flags);
 /* Lipschitz variant, gp_opt.py:558-576: flags[c*G+i] = any over unsafe rows
  * of u_i(x_c) - L_i * ||x_c - x||_2 >= fmin_i                                */
 int sgp_grid_lipschitz_check(sgp_grid* grid, int G, const double* fmin,

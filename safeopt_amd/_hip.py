@@ -62,7 +62,8 @@ PROTOTYPES = {
                                        c_double_p, c_double_p, c_double_p]),
     "sgp_grid_expander_check": (C.c_int, [vp, vpp, C.c_int, C.c_double,
                                           c_double_p, C.c_int, c_double_p,
-                                          c_double_p, c_double_p, c_i32_p]),
+                                          c_double_p, c_double_p, C.c_double,
+                                          c_i32_p]),
     "sgp_grid_lipschitz_check": (C.c_int, [vp, C.c_int, c_double_p,
                                            c_double_p, C.c_int, c_double_p,
                                            c_double_p, c_i32_p]),
@@ -384,7 +385,7 @@ class DeviceGrid(object):
                 dptr(var), dptr(Qr)))
         return x, mean, var, Qr
 
-    def expander_check(self, gps, beta, fmin, xc, mu_c, u_c):
+    def expander_check(self, gps, beta, fmin, xc, mu_c, u_c, near_frac=0.0):
         fmin = f64(fmin)
         xc = f64(xc).reshape(-1, self.d)
         m = xc.shape[0]
@@ -393,7 +394,8 @@ class DeviceGrid(object):
         flags = np.zeros((m, self.G), dtype=np.int32)
         self.ctx.check(lib().sgp_grid_expander_check(
             self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin), m,
-            dptr(xc), dptr(mu_c), dptr(u_c), flags.ctypes.data_as(c_i32_p)))
+            dptr(xc), dptr(mu_c), dptr(u_c), float(near_frac),
+            flags.ctypes.data_as(c_i32_p)))
         return flags
 
     def lipschitz_check(self, fmin, lipschitz, xc, u_c):

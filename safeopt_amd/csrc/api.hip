@@ -396,7 +396,7 @@ int sgp_grid_create(sgp_ctx* ctx, const double* base, int64_t N, int d,
   g->G = G;
   g->goff = global_offset;
   const size_t nd = size_t(N) * sizeof(double);
-  g->partial_cap = N / 128 + 2;
+  g->partial_cap = N / 64 + 2;
   struct {
     void** p;
     size_t bytes;
@@ -651,7 +651,7 @@ int sgp_grid_download(sgp_grid* g, int what, void* out) {
 int sgp_grid_expander_check(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
                             const double* fmin, int m, const double* xc,
                             const double* mu_c, const double* u_c,
-                            int32_t* flags) {
+                            double near_frac, int32_t* flags) {
   sgp_ctx* ctx = g->ctx;
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
@@ -705,6 +705,7 @@ int sgp_grid_expander_check(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   ea.var = g->var;
   ea.flags = dfl;
   ea.wstride = wstride;
+  ea.near_frac = near_frac;
   SweepPoints sp{g->pts, g->N, 1, g->N};
   SGP_TRY(launch_expander_check(ctx, g->gpdev, host, G, d, sp, ea));
   std::vector<int32_t> fl(size_t(SGP_TOPK) * G);

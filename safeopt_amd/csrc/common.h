@@ -181,6 +181,7 @@ struct ExpanderArgs {
   const double* var;
   int32_t* flags;        // [16][G] device
   int64_t wstride;       // doubles between consecutive GPs in Wpack
+  double near_frac;      // >0: only rows with k(x,x_c) >= near_frac * k(x,x)
 };
 int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
                           const GpDev* gps_host, int G, int d, SweepPoints pts,

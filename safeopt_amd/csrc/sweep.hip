@@ -18,20 +18,20 @@
 // are processed in chunks of 16 MFMA row blocks (256 rows) held in 16
 // accumulators per wave; the triangular structure is exploited at 16x16 block
 // granularity (a j-block only feeds row blocks >= its own index).
+#include <stdlib.h>
+
 #include "kern_eval.h"
 
 namespace {
 
-constexpr int kThreads = 512;
-constexpr int kWaves = 8;
-constexpr int kTilePts = 16 * kWaves;  // 128 candidate rows per workgroup
+constexpr int kMaxWaves = 8;
 constexpr int kIB = 16;                // accumulator slots = 256 rows of L^-1
 constexpr int kJC = 16;                // training points per staged chunk
 constexpr int kSteps = kJC / 4;        // MFMA k-steps per chunk (one j-block)
 constexpr int kATile = kIB * kSteps * 64;           // doubles (32 KB)
 constexpr int kXTile = kJC * SGP_MAX_D;             // doubles
 constexpr int kBuf = kATile + kXTile + kJC;         // + alpha chunk
-constexpr size_t kLdsBytes = (2 * size_t(kBuf) + kWaves) * sizeof(double);
+constexpr size_t kLdsBytes = (2 * size_t(kBuf) + kMaxWaves) * sizeof(double);
 
 enum { MODE_CONF = 0, MODE_FITNESS = 1 };
 
@@ -51,13 +51,14 @@ struct SweepParams {
 // w+16, w+24.  Only the slots the next j-block reads are fetched (`lo` = its
 // first active slot, even); above-diagonal blocks inside a fetched pair come
 // from the zero part of the packed matrix.
+template <int NW>
 __device__ __forceinline__ void stage_dma(const GpDev& gp, double* buf, int b0,
                                           int shift, int jb, int lo, int tid) {
   const int nsteps_total = gp.n_pad >> 2;
   const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int piece = wave + 8 * k;       // wave-uniform
+  for (int k = 0; k < 32 / NW; ++k) {
+    const int piece = wave + NW * k;      // wave-uniform
     const int slot = piece >> 1;
     const int half = piece & 1;
     if (slot >= lo) {
@@ -77,7 +78,7 @@ __device__ __forceinline__ double stage_x_load(const GpDev& gp, int D, int jb,
                                                int tid) {
   const int j0 = jb * kJC;
   if (tid < kJC * D) return gp.Xpad[j0 * D + tid];
-  if (tid >= 256 && tid < 256 + kJC) return gp.alpha[j0 + (tid - 256)];
+  if (tid >= 128 && tid < 128 + kJC) return gp.alpha[j0 + (tid - 128)];
   return 0.0;
 }
 
@@ -85,8 +86,8 @@ __device__ __forceinline__ void stage_x_store(double v, double* buf, int D,
                                               int tid) {
   if (tid < kJC * D) {
     buf[kATile + tid] = v;
-  } else if (tid >= 256 && tid < 256 + kJC) {
-    buf[kATile + kXTile + (tid - 256)] = v;
+  } else if (tid >= 128 && tid < 128 + kJC) {
+    buf[kATile + kXTile + (tid - 128)] = v;
   }
 }
 
@@ -106,6 +107,7 @@ __device__ __forceinline__ void load_ops(double (&ops)[8], const double* aT,
 // accumulator chains, a half-active pair (odd lo, or the even-padding block at
 // the top) runs one chain.  The A operands of pair g+1 are fetched from LDS
 // while pair g's MFMAs run.
+template <bool SLOT>
 __device__ __forceinline__ void mfma_jblock(int lo, int hi,
                                             double4_t (&acc)[kIB],
                                             const double* aT,
@@ -119,7 +121,7 @@ __device__ __forceinline__ void mfma_jblock(int lo, int hi,
       double(&nxt)[8] = (g & 1) ? opsA : opsB;
       if (g == g0) load_ops(cur, aT, 2 * g);
       if (g + 1 < kIB / 2) load_ops(nxt, aT, 2 * g + 2);
-      const bool a0 = (2 * g >= lo), a1 = (2 * g + 1 <= hi);
+      const bool a0 = !SLOT || (2 * g >= lo), a1 = !SLOT || (2 * g + 1 <= hi);
       if (a0 && a1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -146,7 +148,7 @@ __device__ __forceinline__ void mfma_jblock(int lo, int hi,
 // Posterior mean / variance of one GP at this lane's candidate row.
 // Must be called by every thread of the workgroup (contains barriers).
 // On return every lane holds the values of row (lane & 15) of its wave.
-template <int D>
+template <int D, int NW, bool SLOT>
 __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
                                                  const double (&x)[D],
                                                  double* lds, double& mean_out,
@@ -172,7 +174,7 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
 #pragma unroll
     for (int b = 0; b < kIB; ++b) acc[b] = double4_t{0.0, 0.0, 0.0, 0.0};
 
-    stage_dma(gp, lds, b0, shift, 0, shift, tid);
+    stage_dma<NW>(gp, lds, b0, shift, 0, shift, tid);
     stage_x_store(stage_x_load(gp, D, 0, tid), lds, D, tid);
     __syncthreads();
 
@@ -184,7 +186,7 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
       double xs = 0.0;
       if (more) {
         const int lo_n = shift + (max(0, jb + 1 - b0) & ~1);
-        stage_dma(gp, nxt, b0, shift, jb + 1, lo_n, tid);
+        stage_dma<NW>(gp, nxt, b0, shift, jb + 1, lo_n, tid);
         xs = stage_x_load(gp, D, jb + 1, tid);
       }
 
@@ -200,7 +202,7 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
           mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
       }
       const int lo = shift + max(0, jb - b0);
-      mfma_jblock(lo, hi, acc, cur + lane, kv);
+      mfma_jblock<SLOT>(lo, hi, acc, cur + lane, kv);
 
       if (more) stage_x_store(xs, nxt, D, tid);
       __syncthreads();
@@ -229,8 +231,10 @@ __device__ __forceinline__ double swarm_penalty(double slack) {
   return pen;
 }
 
-template <int D>
-__global__ __launch_bounds__(kThreads, 2) void k_sweep(SweepParams p) {
+template <int D, int NW, bool SLOT>
+__global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
+  constexpr int kWaves = NW;
+  constexpr int kTilePts = 16 * NW;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* red = lds + 2 * kBuf;  // all LDS lives in the one dynamic region
 
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_sweep(SweepParams p) {
 #pragma unroll 1
   for (int g = 0; g < Geff; ++g) {
     double mean, var;
-    posterior_one_gp<D>(p.gps[g], x, lds, mean, var);
+    posterior_one_gp<D, NW, SLOT>(p.gps[g], x, lds, mean, var);
     const double sd = sqrt(var);
     if (conf) {
       // update_confidence_intervals + compute_safe_set (gp_opt.py:453-481)
@@ -385,7 +389,8 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
             fmax(var - cmax * cmax * ea.inv_s2[g * 16 + cand], 1e-15);
         const double l2max = mu2 - ea.beta * sqrt(var2);
         possible = possible ||
-                   (l2max + 1e-9 * (fabs(mu2) + 1.0) >= ea.fmin[g]);
+                   ((l2max + 1e-9 * (fabs(mu2) + 1.0) >= ea.fmin[g]) &&
+                    (kxc[r] >= ea.near_frac * kdiag));
       }
     }
     if (__ballot(possible) == 0ull) continue;  // wave-uniform
@@ -477,17 +482,27 @@ __global__ __launch_bounds__(256) void k_mfma_bench(double* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int D>
-int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
+int sweep_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SGP_SWEEP_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+template <int D, int NW, bool SLOT>
+int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep<D>),
+                     reinterpret_cast<const void*>(&k_sweep<D, NW, SLOT>),
                      hipFuncAttributeMaxDynamicSharedMemorySize,
                      int(kLdsBytes)));
     attr_set = true;
   }
-  const int nblocks = sweep_num_blocks(p.pts.N);
+  const int tile = 16 * NW;
+  const int nblocks = int((p.pts.N + tile - 1) / tile);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profiling) {
     if (ctx->prof_used + 2 > ctx->prof_events.size()) {
@@ -503,11 +518,21 @@ int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
     ctx->prof_flops += flops;
     SGP_HIP(ctx, hipEventRecord(e0, ctx->stream));
   }
-  hipLaunchKernelGGL(k_sweep<D>, dim3(nblocks), dim3(kThreads), kLdsBytes,
-                     ctx->stream, p);
+  hipLaunchKernelGGL((k_sweep<D, NW, SLOT>), dim3(nblocks), dim3(64 * NW),
+                     kLdsBytes, ctx->stream, p);
   SGP_HIP(ctx, hipGetLastError());
   if (e1) SGP_HIP(ctx, hipEventRecord(e1, ctx->stream));
   return 0;
+}
+
+template <int D>
+int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
+  switch (sweep_variant()) {
+    case 1: return launch_sweep_v<D, 8, true>(ctx, p, flops);
+    case 2: return launch_sweep_v<D, 4, false>(ctx, p, flops);
+    case 3: return launch_sweep_v<D, 4, true>(ctx, p, flops);
+    default: return launch_sweep_v<D, 8, false>(ctx, p, flops);
+  }
 }
 
 int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
@@ -535,7 +560,11 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
 
 }  // namespace
 
-int sweep_num_blocks(int64_t N) { return int((N + kTilePts - 1) / kTilePts); }
+int sweep_tile_rows() { return (sweep_variant() & 2) ? 64 : 128; }
+int sweep_num_blocks(int64_t N) {
+  const int t = sweep_tile_rows();
+  return int((N + t - 1) / t);
+}
 
 int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
                       int G, int d, SweepPoints pts, ConfOut out) {

@@ -194,8 +194,9 @@ class _HipGridBackend(object):
     def gather_rows(self, gidx):
         return self.grid.gather_rows(gidx)
 
-    def expander_check(self, beta, fmin, xc, mu_c, u_c):
-        return self.grid.expander_check(self._dev(), beta, fmin, xc, mu_c, u_c)
+    def expander_check(self, beta, fmin, xc, mu_c, u_c, near_frac=0.0):
+        return self.grid.expander_check(self._dev(), beta, fmin, xc, mu_c, u_c,
+                                        near_frac)
 
     def lipschitz_check(self, fmin, lipschitz, xc, u_c):
         return self.grid.lipschitz_check(fmin, lipschitz, xc, u_c)
@@ -449,7 +450,10 @@ class SafeOpt(GaussianProcessOptimization):
 
         mode = 1 if full_sets else 0
         cut_w, cut_idx = np.inf, (-1 if full_sets else _I64_MAX)
-        K = _hip.TOPK
+        # The first expander in visiting order is very often the very first
+        # candidate, so the first pass fetches and tests only that one; later
+        # passes take SGP_TOPK candidates at a time.
+        K = _hip.TOPK if full_sets else 1
         while True:
             w_loc, i_loc = be.topk(mode, cut_w, cut_idx, K)
             if self._comm.world > 1:
@@ -481,12 +485,8 @@ class SafeOpt(GaussianProcessOptimization):
                 xc, mu_c, u_c = (packed[:, :d], packed[:, d:d + G],
                                  packed[:, d + G:])
 
-            if self.use_lipschitz:
-                flags = be.lipschitz_check(self.fmin, self.liptschitz, xc, u_c)
-            else:
-                flags = be.expander_check(beta, self.fmin, xc, mu_c, u_c)
-            flags = self._comm.allreduce_max(flags.astype(np.float64)) > 0
-            is_exp = np.all(flags[:, active], axis=1)
+            is_exp = self._expander_flags(beta, xc, mu_c, u_c, active,
+                                          probe=not full_sets)
 
             if full_sets:
                 mine = [int(i) for i, e, o in zip(i_b, is_exp, own) if e and o]
@@ -499,6 +499,31 @@ class SafeOpt(GaussianProcessOptimization):
             if m < K:
                 break
             cut_w, cut_idx = float(w_b[-1]), int(i_b[-1])
+            K = _hip.TOPK
+
+    def _expander_flags(self, beta, xc, mu_c, u_c, active, probe):
+        """Which of the candidates are expanders (all ranks agree).
+
+        ``probe``: first scan only the rows strongly correlated with the
+        candidate; a hit there already certifies it (``any`` over a subset).
+        Only when the FIRST candidate in visiting order is not certified that
+        way is the exact scan over all unsafe rows run.
+        """
+        be = self._backend
+
+        def run(**kw):
+            if self.use_lipschitz:
+                f = be.lipschitz_check(self.fmin, self.liptschitz, xc, u_c)
+            else:
+                f = be.expander_check(beta, self.fmin, xc, mu_c, u_c, **kw)
+            f = self._comm.allreduce_max(f.astype(np.float64)) > 0
+            return np.all(f[:, active], axis=1)
+
+        if probe and not self.use_lipschitz:
+            hit = run(near_frac=0.5)
+            if hit[0]:
+                return hit
+        return run()
 
     def get_new_query_point(self, ucb=False):
         """Next parameters to evaluate (first index wins among equals)."""

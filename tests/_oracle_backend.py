@@ -83,7 +83,7 @@ class OracleGridBackend(object):
         li = np.asarray(gidx) - self.lo
         return self.x[li], self.mean[li], self.var[li], self.Q[li]
 
-    def expander_check(self, beta, fmin, xc, mu_c, u_c):
+    def expander_check(self, beta, fmin, xc, mu_c, u_c, near_frac=0.0):
         m, G = xc.shape[0], len(self.gps)
         flags = np.zeros((m, G), dtype=np.int32)
         unsafe = ~self.S
@@ -92,9 +92,16 @@ class OracleGridBackend(object):
                 if fmin[i] == -np.inf or not unsafe.any():
                     continue
                 gp.set_XY(np.vstack([gp.X, xc[[c]]]), np.vstack([gp.Y, [[u_c[c, i]]]]))
-                m2, v2 = gp.predict_noiseless(self.x[unsafe])
+                rows = self.x[unsafe]
+                if near_frac > 0:        # the product's cheap first probe
+                    kx = gp.kern.K(rows, xc[[c]]).ravel()
+                    rows = rows[kx >= near_frac * gp.kern.Kdiag(xc[[c]])[0]]
+                hit = False
+                if rows.shape[0]:
+                    m2, v2 = gp.predict_noiseless(rows)
+                    hit = np.any(m2.ravel() - beta * np.sqrt(v2.ravel()) >= fmin[i])
                 gp.set_XY(gp.X[:-1], gp.Y[:-1])
-                flags[c, i] = np.any(m2.ravel() - beta * np.sqrt(v2.ravel()) >= fmin[i])
+                flags[c, i] = hit
         return flags
 
     def lipschitz_check(self, fmin, lipschitz, xc, u_c):
