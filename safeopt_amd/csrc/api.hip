@@ -246,7 +246,7 @@ void sgp_gp_destroy(sgp_gp* gp) {
   sgp_ctx* ctx = gp->ctx;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DevBuf* bufs[] = {&gp->X, &gp->Y, &gp->Xpad, &gp->alpha, &gp->Apack,
+  DevBuf* bufs[] = {&gp->X, &gp->Y, &gp->Xpad, &gp->Xs, &gp->alpha, &gp->Apack,
                     &gp->Linv, &gp->Kmat, &gp->work, &gp->tvec};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);

@@ -51,10 +51,12 @@ struct GpDev {
   const double* Apack;  // L^-1 in MFMA A-operand order: [nblk][n_pad/4][64],
                         // zero above the diagonal and in the padding rows
   const double* Xpad;   // training inputs, [n_pad][d], zero padded
+  const double* Xs;     // = Xpad * (1/lengthscale) for single-part kernels,
+                        //   else = Xpad (KernFast::operator() convention)
   const double* alpha;  // Ky^-1 y, [n_pad], zero padded
   int n;                // training points
   int n_pad;            // n rounded up to 16
-  int nblk;             // row blocks of 16, rounded up to even
+  int nblk;             // n_pad / 16
   int pad_;
   KernDesc kern;
 };
@@ -94,7 +96,7 @@ struct sgp_gp {
   int64_t n = 0;
   int n_pad = 0;  // multiple of 16 (sweep blocks)
   int n_f = 0;    // multiple of 32 (factorisation leaves)
-  DevBuf X, Y, Xpad, alpha, Apack, Linv, Kmat, work, tvec;
+  DevBuf X, Y, Xpad, Xs, alpha, Apack, Linv, Kmat, work, tvec;
   GpDev dev;      // filled by set_data
 };
 

@@ -257,11 +257,14 @@ __global__ void k_trmv_lower_t(const double* Li, int64_t ld, int n,
   out[j] = s;
 }
 
+// Xpad = zero-padded X; Xs = Xpad scaled per column (scale == nullptr: copy)
 __global__ void k_pad_rows(const double* X, int n, int n_pad, int d,
-                           double* Xpad) {
+                           KernDesc kd, double* Xpad, double* Xs) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_pad * d) return;
-  Xpad[e] = (e < n * d) ? X[e] : 0.0;
+  const double v = (e < n * d) ? X[e] : 0.0;
+  Xpad[e] = v;
+  Xs[e] = (kd.n_parts == 1) ? v * kd.inv_ls[0][e % d] : v;
 }
 
 
@@ -355,9 +358,7 @@ int factor_gp(sgp_gp* gp, int* info) {
   SGP_TRY(sgp_d2h(ctx, info, info_dev, sizeof(int)));
   if (*info != 0) return 0;
 
-  // row blocks rounded up to even (one all-zero block) so the sweep can guard
-  // accumulator slots in aligned pairs
-  const int nblk = ((np / 16) + 1) & ~1, nsteps = np / 4;
+  const int nblk = np / 16, nsteps = np / 4;
   const int64_t total = int64_t(nblk) * nsteps * 64;
   SGP_TRY(sgp_reserve(ctx, &gp->Apack, size_t(total) * sizeof(double)));
   hipLaunchKernelGGL(k_pack, dim3(unsigned((total + 255) / 256)), dim3(256), 0,
@@ -374,13 +375,16 @@ int factor_gp(sgp_gp* gp, int* info) {
   SGP_HIP(ctx, hipGetLastError());
   SGP_TRY(sgp_reserve(ctx, &gp->Xpad,
                       size_t(np) * gp->kern.d * sizeof(double)));
+  SGP_TRY(sgp_reserve(ctx, &gp->Xs, size_t(np) * gp->kern.d * sizeof(double)));
   hipLaunchKernelGGL(k_pad_rows, dim3((np * gp->kern.d + 255) / 256), dim3(256),
                      0, ctx->stream, static_cast<double*>(gp->X.p), n, np,
-                     gp->kern.d, static_cast<double*>(gp->Xpad.p));
+                     gp->kern.d, gp->kern, static_cast<double*>(gp->Xpad.p),
+                     static_cast<double*>(gp->Xs.p));
   SGP_HIP(ctx, hipGetLastError());
 
   gp->dev.Apack = static_cast<double*>(gp->Apack.p);
   gp->dev.Xpad = static_cast<double*>(gp->Xpad.p);
+  gp->dev.Xs = static_cast<double*>(gp->Xs.p);
   gp->dev.alpha = static_cast<double*>(gp->alpha.p);
   gp->dev.n = n;
   gp->dev.n_pad = np;

@@ -2,11 +2,43 @@
 // for one lane): RBF / Matern-3/2 / Matern-5/2, ARD lengthscales, products of
 // parts on arbitrary column subsets.  Reference call sites: gp.kern.K reached
 // through gp.predict_noiseless (safeopt/gp_opt.py:469, 591, 929, 973).
+//
+// fp64 VALU work is not free next to the fp64 matrix pipe on gfx950 (they
+// share the FP64 units: MFMA-only 49 TF/s, v_fma_f64-only 66, interleaved sum
+// ~52 -- scripts/microbench.py), so the per-element cost of the covariance is
+// trimmed: inputs pre-scaled by 1/lengthscale, and exp() through a 32-entry
+// 2^(j/32) table (one LDS bank row, conflict free) + a degree-6 polynomial:
+// ~13 fp64 ops instead of the library's ~27, accurate to ~1.5 ulp.
 #pragma once
 
 #include "common.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kExpTabSize = 32;
+
+// Fill the 2^(j/32) table (call by all threads, then barrier).
+__device__ __forceinline__ void exp_tab_init(double* tab) {
+  if (threadIdx.x < kExpTabSize) tab[threadIdx.x] = exp2(threadIdx.x * (1.0 / 32.0));
+}
+
+// exp(x) for x <= 0 (any x works; large negative x underflows to 0).
+__device__ __forceinline__ double exp_tab(double x, const double* tab) {
+  x = fmax(x, -745.2);
+  const double kf = rint(x * 46.16624130844683);       // 32 / ln 2
+  double r = fma(kf, -0.02166084937925916, x);         // ln2/32, high part
+  r = fma(kf, -1.3239129268154012e-11, r);             //         low part
+  const int k = int(kf);
+  const double t = tab[k & 31];
+  // exp(r), |r| <= ln2/64: truncation r^7/5040 < 4e-18
+  double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
+  p = fma(r, p, 1.0 / 24.0);
+  p = fma(r, p, 1.0 / 6.0);
+  p = fma(r, p, 0.5);
+  p = fma(r, p, 1.0);
+  p = fma(r, p, 1.0);
+  return ldexp(t * p, k >> 5);
+}
 
 __device__ __forceinline__ double k_of_r2(int kind, double r2) {
   if (kind == SGP_RBF) return exp(-0.5 * r2);
@@ -19,7 +51,19 @@ __device__ __forceinline__ double k_of_r2(int kind, double r2) {
   return (1.0 + a + (5.0 / 3.0) * r2) * exp(-a);
 }
 
-// k(x, y) for the product kernel `kd`; x and y are D-vectors in registers/LDS.
+__device__ __forceinline__ double k_of_r2_tab(int kind, double r2,
+                                              const double* tab) {
+  if (kind == SGP_RBF) return exp_tab(-0.5 * r2, tab);
+  const double r = sqrt(r2);
+  if (kind == SGP_MATERN32) {
+    const double a = 1.7320508075688772 * r;
+    return (1.0 + a) * exp_tab(-a, tab);
+  }
+  const double a = 2.23606797749979 * r;
+  return (1.0 + a + (5.0 / 3.0) * r2) * exp_tab(-a, tab);
+}
+
+// k(x, y) for the product kernel `kd`; x and y are raw D-vectors.
 template <int D>
 __device__ __forceinline__ double kern_eval(const KernDesc& kd, const double* x,
                                             const double* y) {
@@ -40,8 +84,9 @@ __device__ __forceinline__ double kern_eval(const KernDesc& kd, const double* x,
 }
 
 // Hyper-parameters of one GP hoisted out of the inner loops.  The common case
-// (one stationary part) keeps everything in registers / SGPRs; products of
-// parts fall back to the descriptor loop.
+// (one stationary part) works on inputs pre-scaled by 1/lengthscale and keeps
+// everything in registers; products of parts fall back to the descriptor loop
+// on raw inputs.
 template <int D>
 struct KernFast {
   const KernDesc* kd;
@@ -58,8 +103,31 @@ struct KernFast {
     for (int i = 0; i < D; ++i) il0[i] = k.inv_ls[0][i];
   }
 
-  __device__ __forceinline__ double operator()(const double* x,
-                                               const double* y) const {
+  // candidate row -> the form operator() expects (scaled when `single`)
+  __device__ __forceinline__ void prep(const double* x, double* xs) const {
+#pragma unroll
+    for (int i = 0; i < D; ++i) xs[i] = single ? x[i] * il0[i] : x[i];
+  }
+
+  // xs from prep(); ys = row of GpDev::Xs (pre-scaled when `single`)
+  __device__ __forceinline__ double operator()(const double* xs,
+                                               const double* ys,
+                                               const double* tab) const {
+    if (single) {
+      double r2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const double t = xs[i] - ys[i];
+        r2 = fma(t, t, r2);
+      }
+      return var0 * k_of_r2_tab(kind0, r2, tab);
+    }
+    return kern_eval<D>(*kd, xs, ys);
+  }
+
+  // both arguments raw (unscaled) rows
+  __device__ __forceinline__ double raw(const double* x, const double* y,
+                                        const double* tab) const {
     if (single) {
       double r2 = 0.0;
 #pragma unroll
@@ -67,7 +135,7 @@ struct KernFast {
         const double t = (x[i] - y[i]) * il0[i];
         r2 = fma(t, t, r2);
       }
-      return var0 * k_of_r2(kind0, r2);
+      return var0 * k_of_r2_tab(kind0, r2, tab);
     }
     return kern_eval<D>(*kd, x, y);
   }

@@ -31,7 +31,8 @@ constexpr int kSteps = kJC / 4;        // MFMA k-steps per chunk (one j-block)
 constexpr int kATile = kIB * kSteps * 64;           // doubles (32 KB)
 constexpr int kXTile = kJC * SGP_MAX_D;             // doubles
 constexpr int kBuf = kATile + kXTile + kJC;         // + alpha chunk
-constexpr size_t kLdsBytes = (2 * size_t(kBuf) + kMaxWaves) * sizeof(double);
+constexpr int kTabOff = 2 * kBuf + kMaxWaves;           // exp table (32 doubles)
+constexpr size_t kLdsBytes = (size_t(kTabOff) + kExpTabSize) * sizeof(double);
 
 enum { MODE_CONF = 0, MODE_FITNESS = 1 };
 
@@ -61,7 +62,7 @@ __device__ __forceinline__ void stage_dma(const GpDev& gp, double* buf, int b0,
     const int piece = wave + NW * k;      // wave-uniform
     const int slot = piece >> 1;
     const int half = piece & 1;
-    if (slot >= lo) {
+    if (slot >= shift && slot >= (lo & ~1)) {
       const int bg = b0 + slot - shift;
       const double* src = gp.Apack +
           (int64_t(bg) * nsteps_total + jb * kSteps + 2 * half) * 64 + lane * 2;
@@ -77,7 +78,7 @@ __device__ __forceinline__ void stage_dma(const GpDev& gp, double* buf, int b0,
 __device__ __forceinline__ double stage_x_load(const GpDev& gp, int D, int jb,
                                                int tid) {
   const int j0 = jb * kJC;
-  if (tid < kJC * D) return gp.Xpad[j0 * D + tid];
+  if (tid < kJC * D) return gp.Xs[j0 * D + tid];
   if (tid >= 128 && tid < 128 + kJC) return gp.alpha[j0 + (tid - 128)];
   return 0.0;
 }
@@ -101,15 +102,14 @@ __device__ __forceinline__ void load_ops(double (&ops)[8], const double* aT,
   }
 }
 
-// One 16-wide j-block (4 MFMA k-steps) against accumulator slots lo..hi.
-// Slots are visited in aligned pairs behind wave-uniform branches (the active
-// set is a contiguous range); a fully active pair interleaves two independent
-// accumulator chains, a half-active pair (odd lo, or the even-padding block at
-// the top) runs one chain.  The A operands of pair g+1 are fetched from LDS
-// while pair g's MFMAs run.
-template <bool SLOT>
-__device__ __forceinline__ void mfma_jblock(int lo, int hi,
-                                            double4_t (&acc)[kIB],
+// One 16-wide j-block (4 MFMA k-steps) against accumulator slots lo..15.
+// Slots are visited in aligned pairs (2g, 2g+1) behind wave-uniform branches
+// (the active set is a suffix); every pair interleaves two independent
+// accumulator chains and the A operands of the next pair are fetched from LDS
+// while this pair's 8 MFMAs run.  For odd lo the lower slot of the first pair
+// multiplies a zero block (above-diagonal part of the packed matrix, or the
+// zero-filled slot below the first row block of the chunk).
+__device__ __forceinline__ void mfma_jblock(int lo, double4_t (&acc)[kIB],
                                             const double* aT,
                                             const double (&kv)[4]) {
   double opsA[8], opsB[8];
@@ -121,25 +121,12 @@ __device__ __forceinline__ void mfma_jblock(int lo, int hi,
       double(&nxt)[8] = (g & 1) ? opsA : opsB;
       if (g == g0) load_ops(cur, aT, 2 * g);
       if (g + 1 < kIB / 2) load_ops(nxt, aT, 2 * g + 2);
-      const bool a0 = !SLOT || (2 * g >= lo), a1 = !SLOT || (2 * g + 1 <= hi);
-      if (a0 && a1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[2 * g] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-              cur[2 * q], kv[q], acc[2 * g], 0, 0, 0);
-          acc[2 * g + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-              cur[2 * q + 1], kv[q], acc[2 * g + 1], 0, 0, 0);
-        }
-      } else if (a1) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc[2 * g + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-              cur[2 * q + 1], kv[q], acc[2 * g + 1], 0, 0, 0);
-      } else if (a0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc[2 * g] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-              cur[2 * q], kv[q], acc[2 * g], 0, 0, 0);
+      for (int q = 0; q < 4; ++q) {
+        acc[2 * g] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+            cur[2 * q], kv[q], acc[2 * g], 0, 0, 0);
+        acc[2 * g + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+            cur[2 * q + 1], kv[q], acc[2 * g + 1], 0, 0, 0);
       }
     }
   }
@@ -148,32 +135,40 @@ __device__ __forceinline__ void mfma_jblock(int lo, int hi,
 // Posterior mean / variance of one GP at this lane's candidate row.
 // Must be called by every thread of the workgroup (contains barriers).
 // On return every lane holds the values of row (lane & 15) of its wave.
-template <int D, int NW, bool SLOT>
+template <int D, int NW>
 __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
                                                  const double (&x)[D],
                                                  double* lds, double& mean_out,
                                                  double& var_out) {
+  const double* tab = lds + kTabOff;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int nchunks = (gp.nblk + kIB - 1) / kIB;
   double sumsq = 0.0, mean = 0.0;
 
   const KernFast<D> kf(gp.kern);
+  double xs[D];
+  kf.prep(x, xs);
 
 #pragma unroll 1
   for (int c = 0; c < nchunks; ++c) {
     const int b0 = c * kIB;
-    const int nib = min(kIB, gp.nblk - b0);    // even (nblk is even)
+    const int nib = min(kIB, gp.nblk - b0);
     const int shift = kIB - nib;
-    const int njb = min(b0 + nib, gp.n_pad >> 4);  // j-blocks feeding this chunk
+    const int njb = b0 + nib;                  // j-blocks feeding this chunk
     const bool last = (c == nchunks - 1);
-    // last real slot: the even-padding row block (if any) is never computed
-    const int hi = (last && (gp.nblk > (gp.n_pad >> 4))) ? kIB - 2 : kIB - 1;
 
     double4_t acc[kIB];
 #pragma unroll
     for (int b = 0; b < kIB; ++b) acc[b] = double4_t{0.0, 0.0, 0.0, 0.0};
 
+    if (shift & 1) {
+      // the slot below the first row block pairs with it: keep it zero
+      for (int i = tid; i < kSteps * 64; i += 64 * NW) {
+        lds[(shift - 1) * kSteps * 64 + i] = 0.0;
+        lds[kBuf + (shift - 1) * kSteps * 64 + i] = 0.0;
+      }
+    }
     stage_dma<NW>(gp, lds, b0, shift, 0, shift, tid);
     stage_x_store(stage_x_load(gp, D, 0, tid), lds, D, tid);
     __syncthreads();
@@ -183,11 +178,11 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
       double* cur = lds + (jb & 1) * kBuf;
       double* nxt = lds + ((jb & 1) ^ 1) * kBuf;
       const bool more = (jb + 1 < njb);
-      double xs = 0.0;
+      double xstage = 0.0;
       if (more) {
-        const int lo_n = shift + (max(0, jb + 1 - b0) & ~1);
+        const int lo_n = shift + max(0, jb + 1 - b0);
         stage_dma<NW>(gp, nxt, b0, shift, jb + 1, lo_n, tid);
-        xs = stage_x_load(gp, D, jb + 1, tid);
+        xstage = stage_x_load(gp, D, jb + 1, tid);
       }
 
       const double* xT = cur + kATile;
@@ -195,16 +190,16 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
       double kv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        kv[q] = kf(x, xT + (q * 4 + (lane >> 4)) * D);
+        kv[q] = kf(xs, xT + (q * 4 + (lane >> 4)) * D, tab);
       if (last) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
       }
       const int lo = shift + max(0, jb - b0);
-      mfma_jblock<SLOT>(lo, hi, acc, cur + lane, kv);
+      mfma_jblock(lo, acc, cur + lane, kv);
 
-      if (more) stage_x_store(xs, nxt, D, tid);
+      if (more) stage_x_store(xstage, nxt, D, tid);
       __syncthreads();
     }
 
@@ -231,12 +226,13 @@ __device__ __forceinline__ double swarm_penalty(double slack) {
   return pen;
 }
 
-template <int D, int NW, bool SLOT>
+template <int D, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   constexpr int kWaves = NW;
   constexpr int kTilePts = 16 * NW;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* red = lds + 2 * kBuf;  // all LDS lives in the one dynamic region
+  exp_tab_init(lds + kTabOff);   // visible after the first staging barrier
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -262,7 +258,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
 #pragma unroll 1
   for (int g = 0; g < Geff; ++g) {
     double mean, var;
-    posterior_one_gp<D, NW, SLOT>(p.gps[g], x, lds, mean, var);
+    posterior_one_gp<D, NW>(p.gps[g], x, lds, mean, var);
     const double sd = sqrt(var);
     if (conf) {
       // update_confidence_intervals + compute_safe_set (gp_opt.py:453-481)
@@ -345,6 +341,9 @@ template <int D>
 __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
                                                   SweepPoints pts,
                                                   ExpanderArgs ea) {
+  __shared__ double tab[kExpTabSize];
+  exp_tab_init(tab);
+  __syncthreads();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -381,7 +380,7 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
       const int cand = (lane >> 4) + 4 * r;
       kxc[r] = 0.0;
       if (cand < ea.m && unsafe) {
-        kxc[r] = kf(x, ea.xc + cand * D);
+        kxc[r] = kf.raw(x, ea.xc + cand * D, tab);
         const double cmax =
             (fabs(kxc[r]) + sqrt(qx * ea.tn2[g * 16 + cand])) * (1.0 + 1e-9);
         const double mu2 = mu + fabs(ea.delta[g * 16 + cand]) * cmax;
@@ -396,7 +395,9 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
     if (__ballot(possible) == 0ull) continue;  // wave-uniform
 
     const double* W = ea.Wpack + int64_t(g) * ea.wstride + lane;
-    const double* Xj = gp.Xpad + (lane >> 4) * D;
+    const double* Xj = gp.Xs + (lane >> 4) * D;
+    double xs[D];
+    kf.prep(x, xs);
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
     const int nsteps = gp.n_pad >> 2;  // multiple of 4 (n_pad is 16-aligned)
 #pragma unroll 1
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
 #pragma unroll
       for (int q = 0; q < 4; ++q) a[q] = W[(s0 + q) * 64];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) kv[q] = kf(x, Xj + (s0 + q) * 4 * D);
+      for (int q = 0; q < 4; ++q) kv[q] = kf(xs, Xj + (s0 + q) * 4 * D, tab);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], kv[q], acc, 0, 0, 0);
@@ -491,12 +492,12 @@ int sweep_variant() {
   return v;
 }
 
-template <int D, int NW, bool SLOT>
+template <int D, int NW>
 int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep<D, NW, SLOT>),
+                     reinterpret_cast<const void*>(&k_sweep<D, NW>),
                      hipFuncAttributeMaxDynamicSharedMemorySize,
                      int(kLdsBytes)));
     attr_set = true;
@@ -518,7 +519,7 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
     ctx->prof_flops += flops;
     SGP_HIP(ctx, hipEventRecord(e0, ctx->stream));
   }
-  hipLaunchKernelGGL((k_sweep<D, NW, SLOT>), dim3(nblocks), dim3(64 * NW),
+  hipLaunchKernelGGL((k_sweep<D, NW>), dim3(nblocks), dim3(64 * NW),
                      kLdsBytes, ctx->stream, p);
   SGP_HIP(ctx, hipGetLastError());
   if (e1) SGP_HIP(ctx, hipEventRecord(e1, ctx->stream));
@@ -527,12 +528,8 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
 
 template <int D>
 int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
-  switch (sweep_variant()) {
-    case 1: return launch_sweep_v<D, 8, true>(ctx, p, flops);
-    case 2: return launch_sweep_v<D, 4, false>(ctx, p, flops);
-    case 3: return launch_sweep_v<D, 4, true>(ctx, p, flops);
-    default: return launch_sweep_v<D, 8, false>(ctx, p, flops);
-  }
+  if (sweep_variant() & 2) return launch_sweep_v<D, 4>(ctx, p, flops);
+  return launch_sweep_v<D, 8>(ctx, p, flops);
 }
 
 int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
