@@ -831,7 +831,7 @@ int sgp_comm_init(sgp_ctx* ctx, const void* id128, int rank, int world) {
 }
 
 int sgp_comm_allreduce_max(sgp_ctx* ctx, double* buf, int n) {
-  if (ctx->world <= 1 || n <= 0) return 0;
+  if ((ctx->world <= 1 && !ctx->comm) || n <= 0) return 0;
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   SGP_CHECK(ctx, ctx->comm, "sgp_comm_init was not called");
   double* d = static_cast<double*>(sgp_scratch(ctx, 6, size_t(n) * 8));
@@ -846,7 +846,7 @@ int sgp_comm_allreduce_max(sgp_ctx* ctx, double* buf, int n) {
 int sgp_comm_allgather(sgp_ctx* ctx, const void* send, void* recv,
                        int64_t nbytes) {
   if (nbytes <= 0) return 0;
-  if (ctx->world <= 1) {
+  if (ctx->world <= 1 && !ctx->comm) {
     memcpy(recv, send, size_t(nbytes));
     return 0;
   }

@@ -116,31 +116,81 @@ def _fetch_uid(addr, port, timeout):
     return buf
 
 
+def _file_rendezvous(rank, world, port, timeout):
+    """Single-node exchange of the ncclUniqueId through /tmp.
+
+    All workers of one ``torch.distributed.run`` launch share the agent as
+    parent process, so (parent pid, MASTER_PORT) names the launch.
+    """
+    from . import _hip
+    path = os.path.join(os.environ.get("SAFEOPT_RDZV_DIR", "/tmp"),
+                        "safeopt_rdzv_%d_%d.bin" % (os.getppid(), port))
+    if rank == 0:
+        uid = _hip.Context.comm_unique_id()
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)                  # atomic publish
+        return uid, path
+    deadline = time.time() + timeout
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid, None
+        except OSError:
+            pass
+        if time.time() > deadline:
+            raise RuntimeError("rendezvous file %s did not appear" % path)
+        time.sleep(0.02)
+
+
 def init_from_env(ctx=None, timeout=300.0):
     """Create the communicator from the torchrun-style environment
     (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT).
 
     Returns ``(ctx, comm)``; with ``WORLD_SIZE`` unset or 1 it is a
-    ``LocalComm`` and no socket / RCCL call is made.
+    ``LocalComm`` and no RCCL call is made (``SAFEOPT_FORCE_RCCL=1`` builds a
+    one-rank RCCL communicator instead, to exercise that path).  The
+    ncclUniqueId travels through a file in /tmp when MASTER_ADDR is local
+    (one node -- the supported topology), otherwise over a TCP socket on
+    MASTER_PORT+17 (``SAFEOPT_RDZV=tcp|file`` overrides).
     """
     from . import _hip
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if ctx is None:
         ctx = _hip.Context.default()
-    if world <= 1:
+    force = os.environ.get("SAFEOPT_FORCE_RCCL", "0") == "1"
+    if world <= 1 and not force:
         return ctx, LocalComm()
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    # a port next to the launcher's, so a c10d store on MASTER_PORT can coexist
-    port = int(os.environ.get("SAFEOPT_RDZV_PORT",
-                              int(os.environ.get("MASTER_PORT", "29500")) + 17))
-    if rank == 0:
-        uid = _hip.Context.comm_unique_id()
-        _serve_uid(addr, port, uid, world, timeout)
+    mport = int(os.environ.get("MASTER_PORT", "29500"))
+    mode = os.environ.get("SAFEOPT_RDZV",
+                          "file" if addr in ("127.0.0.1", "localhost", "::1")
+                          else "tcp")
+    cleanup = None
+    if mode == "file":
+        uid, cleanup = _file_rendezvous(rank, world, mport, timeout)
     else:
-        uid = _fetch_uid(addr, port, timeout)
-    ctx.comm_init(uid, rank, world)
-    return ctx, RcclComm(ctx)
+        # a port next to the launcher's, so a c10d store on MASTER_PORT can coexist
+        port = int(os.environ.get("SAFEOPT_RDZV_PORT", mport + 17))
+        if rank == 0:
+            uid = _hip.Context.comm_unique_id()
+            if world > 1:
+                _serve_uid(addr, port, uid, world, timeout)
+        else:
+            uid = _fetch_uid(addr, port, timeout)
+    ctx.comm_init(uid, rank, world)            # returns once every rank joined
+    comm = RcclComm(ctx)
+    comm.barrier()
+    if cleanup:
+        try:
+            os.remove(cleanup)
+        except OSError:
+            pass
+    return ctx, comm
 
 
 # ---------------------------------------------------------------------------

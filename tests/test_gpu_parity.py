@@ -413,3 +413,19 @@ def test_swarm_fitness_config5_reduced(mods):
 
 def kernels_from(cfg, ns):
     return [make_kernel(ns, spec) for spec in cfg["kernels"]]
+
+
+def test_torchrun_launch_with_rccl(mods, tmp_path):
+    """The driver's launch line (torch.distributed.run, one rank) with the RCCL
+    communicator forced on: rendezvous file, comm init, collectives, bench JSON."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAFEOPT_FORCE_RCCL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(repo, "bench.py"),
+           "--gpus", "1", "--steps", "2", "--warmup", "1", "--side", "200", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=repo)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["roofline"]["achieved"] > 0
