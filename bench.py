@@ -246,6 +246,16 @@ def main():
         },
         "hip_event_ms_per_step": ev_ms / args.steps,
     }
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc
+    # passes (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process)
+    try:
+        with open(os.path.join(REPO, "profiles", "traffic.json")) as f:
+            tr = json.load(f).get("config%d" % args.config)
+        if tr and args.side is None and world == 1:
+            res["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            res["roofline"]["traffic_source"] = tr["note"]
+    except (OSError, ValueError):
+        pass
     if args.config != 5:
         res["chosen_x"] = [float(v) for v in np.atleast_1d(last["x"])]
     if world == 1:
