@@ -520,8 +520,12 @@ int sgp_grid_candidates(sgp_grid* g, double max_var, const double* scaling,
                         int64_t* counts) {
   sgp_ctx* ctx = g->ctx;
   SGP_HIP(ctx, hipSetDevice(ctx->device));
-  SGP_TRY(launch_candidates(g, max_var, scaling, thr_beta, full_sets));
-  return sgp_d2h(ctx, counts, ctx->scratch[1].p, 2 * sizeof(int64_t));
+  unsigned long long* cd =
+      static_cast<unsigned long long*>(sgp_scratch(ctx, 1, 64));
+  SGP_CHECK(ctx, cd, "device allocation failed: %s", ctx->err.c_str());
+  SGP_TRY(launch_candidates(g, max_var, nullptr, scaling, thr_beta, full_sets,
+                            cd));
+  return sgp_d2h(ctx, counts, cd, 2 * sizeof(int64_t));
 }
 
 int sgp_grid_topk(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, int k,
@@ -648,12 +652,12 @@ int sgp_grid_download(sgp_grid* g, int what, void* out) {
   return -2;
 }
 
-int sgp_grid_expander_check(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
+// Enqueue the expander test (operands + scan); flags stay on the device.
+static int enqueue_expander(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
                             const double* fmin, int m, const double* xc,
                             const double* mu_c, const double* u_c,
-                            double near_frac, int32_t* flags) {
+                            double near_frac, int32_t** flags_dev) {
   sgp_ctx* ctx = g->ctx;
-  SGP_HIP(ctx, hipSetDevice(ctx->device));
   SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
   SGP_CHECK(ctx, m >= 1 && m <= SGP_TOPK, "m = %d not in 1..%d", m, SGP_TOPK);
   GpDev host[SGP_MAX_GPS];
@@ -662,7 +666,7 @@ int sgp_grid_expander_check(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   int np_max = 0;
   for (int i = 0; i < G; ++i) np_max = host[i].n_pad > np_max ? host[i].n_pad : np_max;
   const int64_t wstride = int64_t(np_max / 4) * 64;
-  // device layout: xc | resid[G][16] | delta[G][16] | inv_s2[G][16] | flags | W
+  // device layout: xc | resid[G][16] | delta | inv_s2 | tn2 | flags | W
   const size_t bx = size_t(SGP_TOPK) * d * 8, bv = size_t(G) * 16 * 8,
                bf = size_t(SGP_TOPK) * G * 4 + 64;
   const size_t total = bx + 4 * bv + bf + size_t(G) * wstride * 8;
@@ -675,14 +679,22 @@ int sgp_grid_expander_check(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   double* dtn2 = reinterpret_cast<double*>(buf + bx + 3 * bv);
   int32_t* dfl = reinterpret_cast<int32_t*>(buf + bx + 4 * bv);
   double* dW = reinterpret_cast<double*>(buf + bx + 4 * bv + bf);
-  std::vector<double> resid(size_t(G) * 16, 0.0);
+  // one pinned staging block: xc | resid | gp descriptors
+  const size_t hb = bx + bv + sizeof(GpDev) * SGP_MAX_GPS;
+  SGP_CHECK(ctx, hb <= ctx->pinned_cap / 2, "staging buffer too small");
+  char* stage = static_cast<char*>(ctx->pinned) + ctx->pinned_cap / 2;
+  memset(stage, 0, bx + bv);
+  memcpy(stage, xc, size_t(m) * d * 8);
+  double* resid = reinterpret_cast<double*>(stage + bx);
   for (int c = 0; c < m; ++c)
     for (int i = 0; i < G; ++i) resid[size_t(i) * 16 + c] = u_c[c * G + i] - mu_c[c * G + i];
-  SGP_TRY(sgp_h2d(ctx, dxc, xc, size_t(m) * d * 8));
-  SGP_TRY(sgp_h2d(ctx, dres, resid.data(), bv));
-  SGP_HIP(ctx, hipMemsetAsync(dfl, 0, bf, ctx->stream));
-  SGP_HIP(ctx, hipMemcpyAsync(g->gpdev, host, sizeof(GpDev) * G,
+  memcpy(stage + bx + bv, host, sizeof(GpDev) * G);
+  // previous users of the staging block have completed (every call syncs)
+  SGP_HIP(ctx, hipMemcpyAsync(dxc, stage, bx + bv, hipMemcpyHostToDevice,
+                              ctx->stream));
+  SGP_HIP(ctx, hipMemcpyAsync(g->gpdev, stage + bx + bv, sizeof(GpDev) * G,
                               hipMemcpyHostToDevice, ctx->stream));
+  SGP_HIP(ctx, hipMemsetAsync(dfl, 0, bf, ctx->stream));
   ExpanderArgs ea{};
   for (int i = 0; i < SGP_MAX_GPS; ++i) {
     ea.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
@@ -708,9 +720,95 @@ int sgp_grid_expander_check(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   ea.near_frac = near_frac;
   SweepPoints sp{g->pts, g->N, 1, g->N};
   SGP_TRY(launch_expander_check(ctx, g->gpdev, host, G, d, sp, ea));
+  *flags_dev = dfl;
+  return 0;
+}
+
+int sgp_grid_expander_check(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
+                            const double* fmin, int m, const double* xc,
+                            const double* mu_c, const double* u_c,
+                            double near_frac, int32_t* flags) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  int32_t* dfl = nullptr;
+  SGP_TRY(enqueue_expander(g, gps, G, beta, fmin, m, xc, mu_c, u_c, near_frac,
+                           &dfl));
   std::vector<int32_t> fl(size_t(SGP_TOPK) * G);
   SGP_TRY(sgp_d2h(ctx, fl.data(), dfl, fl.size() * 4));
   memcpy(flags, fl.data(), size_t(m) * G * 4);
+  return 0;
+}
+
+// Single-rank fast path, front half of compute_sets (gp_opt.py:511-552) with
+// ONE stream sync: M, max_var, candidate mask, counts and the first candidate
+// in visiting order together with its rows.
+int sgp_grid_sets_front(sgp_grid* g, double max_l, const double* scaling,
+                        const double* thr_beta, double* out5, double* x_top,
+                        double* mean_top, double* q_top) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  const int d = g->d, G = g->G;
+  // result block: [0] max width | [1..2] counts (u64) | [3] w_top | [4] idx_top
+  //               (i64) | [5] n_found (int) | x[d] | mean[G] | q[2G]
+  const size_t nres = 6 + size_t(d) + 3 * size_t(G);
+  double* res = static_cast<double*>(sgp_scratch(ctx, 1, (nres + 8) * 8));
+  SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
+  SGP_TRY(launch_maximizers(g, max_l));
+  SGP_TRY(launch_reduce_max(ctx, g->partial, (g->N + 255) / 256, res));
+  SGP_TRY(launch_candidates(g, 0.0, res, scaling, thr_beta, 0,
+                            reinterpret_cast<unsigned long long*>(res + 1)));
+  SGP_TRY(launch_topk(g, 0, INFINITY, INT64_MAX, 1, res + 3,
+                      reinterpret_cast<int64_t*>(res + 4),
+                      reinterpret_cast<int*>(res + 5)));
+  SGP_TRY(launch_gather_top(g, reinterpret_cast<int64_t*>(res + 4), res + 6,
+                            res + 6 + d, res + 6 + d + G));
+  std::vector<double> host(nres);
+  SGP_TRY(sgp_d2h(ctx, host.data(), res, nres * 8));
+  unsigned long long cnt[2];
+  int64_t idx;
+  int nfound;
+  memcpy(cnt, &host[1], 16);
+  memcpy(&idx, &host[4], 8);
+  memcpy(&nfound, &host[5], 4);
+  out5[0] = host[0];
+  out5[1] = double(cnt[0]);
+  out5[2] = double(cnt[1]);
+  out5[3] = host[3];
+  out5[4] = (nfound > 0) ? double(idx) : -1.0;
+  memcpy(x_top, &host[6], size_t(d) * 8);
+  memcpy(mean_top, &host[6 + d], size_t(G) * 8);
+  memcpy(q_top, &host[6 + d + G], size_t(2 * G) * 8);
+  return 0;
+}
+
+// Back half for ONE candidate (the common case: the first candidate is the
+// expander): probe scan, conditional G mark and the M|G arg-max with one sync.
+int sgp_grid_sets_back(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
+                       const double* fmin, const double* xc, const double* mu_c,
+                       const double* u_c, double near_frac, int64_t gidx_c,
+                       const double* scaling, int32_t* flags, double* value,
+                       int64_t* gidx) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t li = gidx_c - g->goff;
+  SGP_CHECK(ctx, li >= 0 && li < g->N, "candidate %lld is not owned by this shard",
+            (long long)gidx_c);
+  int32_t* dfl = nullptr;
+  SGP_TRY(enqueue_expander(g, gps, G, beta, fmin, 1, xc, mu_c, u_c, near_frac,
+                           &dfl));
+  SGP_TRY(launch_mark_if(g, li, dfl, fmin));
+  // results right behind the flags block: value (f64) | index (i64)
+  char* res = reinterpret_cast<char*>(dfl) + size_t(SGP_TOPK) * G * 4;
+  res += (8 - (reinterpret_cast<uintptr_t>(res) & 7)) & 7;
+  SGP_TRY(launch_argmax(g, SGP_ARGMAX_MG_WIDTH, scaling,
+                        reinterpret_cast<double*>(res),
+                        reinterpret_cast<int64_t*>(res + 8)));
+  const size_t span = size_t(res + 16 - reinterpret_cast<char*>(dfl));
+  std::vector<char> host(span);
+  SGP_TRY(sgp_d2h(ctx, host.data(), dfl, span));
+  memcpy(flags, host.data(), size_t(G) * 4);
+  memcpy(value, host.data() + (span - 16), 8);
+  memcpy(gidx, host.data() + (span - 8), 8);
   return 0;
 }
 

@@ -195,8 +195,13 @@ int launch_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
 int launch_reduce_max(sgp_ctx* ctx, const double* in, int64_t n, double* out);
 int launch_safe_set(sgp_grid* g, const double* fmin);  // from Q -> S, partial
 int launch_maximizers(sgp_grid* g, double max_l);
-int launch_candidates(sgp_grid* g, double max_var, const double* scaling,
-                      const double* thr_beta, int full_sets);
+int launch_candidates(sgp_grid* g, double max_var, const double* max_width_dev,
+                      const double* scaling, const double* thr_beta,
+                      int full_sets, unsigned long long* counts_dev);
+int launch_gather_top(sgp_grid* g, const int64_t* gidx_dev, double* x,
+                      double* mean, double* Q);
+int launch_mark_if(sgp_grid* g, int64_t li, const int32_t* flags_dev,
+                   const double* fmin);
 int launch_topk(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, int k,
                 double* w_out_dev, int64_t* idx_out_dev, int* n_out_dev);
 int launch_lipschitz(sgp_grid* g, int G, const double* fmin,

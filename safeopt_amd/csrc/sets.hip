@@ -104,9 +104,12 @@ __global__ __launch_bounds__(T) void k_maximizers(const double* Q,
 // candidate mask + widths; counts[0] += #candidates, counts[1] += #unsafe
 __global__ __launch_bounds__(T) void k_candidates(
     const double* Q, const uint8_t* S, const uint8_t* M, int64_t N, int G,
-    double max_var, Vec8 scaling, Vec8 thr_beta, int full_sets, uint8_t* cand,
-    double* w, uint8_t* Gm, unsigned* block_counts) {
+    double max_var, const double* max_width_dev, Vec8 scaling, Vec8 thr_beta,
+    int full_sets, uint8_t* cand, double* w, uint8_t* Gm,
+    unsigned* block_counts) {
   __shared__ unsigned shc[2 * (T / 64)];
+  // single-rank fast path: max(u0[M]-l0[M]) is still on the device
+  if (max_width_dev) max_var = max_width_dev[0] / scaling.v[0];
   const int64_t i = int64_t(blockIdx.x) * T + threadIdx.x;
   bool c = false, unsafe = false;
   if (i < N) {
@@ -337,6 +340,35 @@ __global__ void k_gather_rows(const double* pts, const double* mean,
     qo[j * 2 * G + q] = Q[li * 2 * G + q];
 }
 
+// rows of ONE candidate whose GLOBAL index is still on the device (-1: none)
+__global__ void k_gather_top(const double* pts, const double* mean,
+                             const double* Q, int64_t N, int d, int G,
+                             const int64_t* gidx, int64_t goff, double* x,
+                             double* mo, double* qo) {
+  const int64_t gi = gidx[0];
+  if (gi < 0) return;
+  const int64_t li = gi - goff;
+  for (int k = threadIdx.x; k < d; k += blockDim.x)
+    x[k] = pts[int64_t(k) * N + li];
+  for (int g = threadIdx.x; g < G; g += blockDim.x)
+    mo[g] = mean[int64_t(g) * N + li];
+  for (int q = threadIdx.x; q < 2 * G; q += blockDim.x)
+    qo[q] = Q[li * 2 * G + q];
+}
+
+// G[row] = 1 when every active GP certified the (single) candidate
+__global__ void k_mark_if(uint8_t* Gm, int64_t li, const int32_t* flags, int G,
+                          Vec8 fmin) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  bool ok = true, any = false;
+  for (int g = 0; g < G; ++g) {
+    if (fmin.v[g] == -INFINITY) continue;
+    any = true;
+    ok = ok && (flags[g] != 0);
+  }
+  if (ok && any) Gm[li] = 1;
+}
+
 __global__ void k_mark(uint8_t* Gm, const int64_t* lidx, int m) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < m) Gm[lidx[j]] = 1;
@@ -385,19 +417,18 @@ int launch_maximizers(sgp_grid* g, double max_l) {
   return 0;
 }
 
-int launch_candidates(sgp_grid* g, double max_var, const double* scaling,
-                      const double* thr_beta, int full_sets) {
+int launch_candidates(sgp_grid* g, double max_var, const double* max_width_dev,
+                      const double* scaling, const double* thr_beta,
+                      int full_sets, unsigned long long* counts) {
   sgp_ctx* ctx = g->ctx;
-  unsigned long long* counts =
-      static_cast<unsigned long long*>(sgp_scratch(ctx, 1, 64));
   const unsigned nb = nblk(g->N, T);
   unsigned* bc = static_cast<unsigned*>(
       sgp_scratch(ctx, 2, size_t(nb) * 2 * sizeof(unsigned)));
   if (!counts || !bc) return -1;
   hipLaunchKernelGGL(k_candidates, dim3(nb), dim3(T), 0, ctx->stream, g->Q,
-                     g->S, g->M, g->N, g->G, max_var, vec8(scaling, g->G, 1.0),
-                     vec8(thr_beta, g->G, 0.0), full_sets, g->cand, g->w, g->Gm,
-                     bc);
+                     g->S, g->M, g->N, g->G, max_var, max_width_dev,
+                     vec8(scaling, g->G, 1.0), vec8(thr_beta, g->G, 0.0),
+                     full_sets, g->cand, g->w, g->Gm, bc);
   hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, ctx->stream, bc,
                      int64_t(nb), counts);
   SGP_HIP(ctx, hipGetLastError());
@@ -465,6 +496,25 @@ int launch_gather_rows(sgp_grid* g, const int64_t* lidx_dev, int m, double* x,
   hipLaunchKernelGGL(k_gather_rows, dim3(m), dim3(64), 0, ctx->stream, g->pts,
                      g->mean, g->var, g->Q, g->N, g->d, g->G, lidx_dev, m, x,
                      mean, var, Q);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_gather_top(sgp_grid* g, const int64_t* gidx_dev, double* x,
+                      double* mean, double* Q) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_gather_top, dim3(1), dim3(64), 0, ctx->stream, g->pts,
+                     g->mean, g->Q, g->N, g->d, g->G, gidx_dev, g->goff, x,
+                     mean, Q);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_mark_if(sgp_grid* g, int64_t li, const int32_t* flags_dev,
+                   const double* fmin) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_mark_if, dim3(1), dim3(64), 0, ctx->stream, g->Gm, li,
+                     flags_dev, g->G, vec8(fmin, g->G, -INFINITY));
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

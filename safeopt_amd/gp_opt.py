@@ -204,6 +204,14 @@ class _HipGridBackend(object):
     def mark_expanders(self, gidx):
         self.grid.mark_expanders(gidx)
 
+    # single-rank fast paths (one stream sync each)
+    def sets_front(self, max_l, scaling, thr_beta):
+        return self.grid.sets_front(max_l, scaling, thr_beta)
+
+    def sets_back(self, beta, fmin, xc, mu_c, u_c, near_frac, gidx_c, scaling):
+        return self.grid.sets_back(self._dev(), beta, fmin, xc, mu_c, u_c,
+                                   near_frac, gidx_c, scaling)
+
     def argmax(self, mode, scaling):
         return self.grid.argmax(mode, scaling)
 
@@ -284,6 +292,7 @@ class SafeOpt(GaussianProcessOptimization):
         self._any_safe = False
         self._max_l = -np.inf
         self._ci_fresh = False
+        self._argmax_cache = None
 
     # -- host mirrors ---------------------------------------------------------
     def _mirror(self, name, what):
@@ -324,6 +333,7 @@ class SafeOpt(GaussianProcessOptimization):
         np.copyto(self._Q, value)
         self._stale.update(Q=False, S=True)
         self._ci_fresh = True
+        self._argmax_cache = None
 
     @property
     def S(self):
@@ -405,6 +415,7 @@ class SafeOpt(GaussianProcessOptimization):
         self._max_l, self._any_safe = red[0], bool(red[1] > 0)
         self._stale.update(Q=True, S=True)
         self._ci_fresh = True
+        self._argmax_cache = None
 
     def compute_safe_set(self):
         """``S = all(l_i > fmin_i)``; fused into the sweep, nothing to redo."""
@@ -428,11 +439,38 @@ class SafeOpt(GaussianProcessOptimization):
         thr_beta = np.broadcast_to(
             np.asarray(self.threshold, dtype=float) * beta, (G,)).copy()
 
+        self._argmax_cache = None
         if not self._any_safe:
             # M = G = False everywhere
             be.maximizers(np.inf)
             be.candidates(np.inf, self.scaling, thr_beta, False)
             self._stale.update(M=True, G=True)
+            return
+
+        active = self.fmin != -np.inf
+        if (self._comm.world == 1 and not full_sets and not self.use_lipschitz
+                and hasattr(be, 'sets_front')):
+            # One GPU: the whole front half in one call, and -- when the first
+            # candidate in visiting order is certified by the cheap probe,
+            # which is the common case -- the back half in a second one.
+            out5, x_c, mu_c, q_c = be.sets_front(self._max_l, self.scaling,
+                                                 thr_beta)
+            self._stale.update(M=True, G=True)
+            n_cand, n_unsafe, idx_c = out5[1], out5[2], int(out5[4])
+            if n_cand == 0 or n_unsafe == 0 or not np.any(active) or idx_c < 0:
+                return
+            flags, val, idx = be.sets_back(beta, self.fmin, x_c, mu_c,
+                                           q_c[1::2], 0.5, idx_c, self.scaling)
+            if np.all(flags[active] != 0):
+                self._argmax_cache = (val, int(idx))
+                return
+            # not certified by the probe: exact scan, then the general loop
+            hit = self._expander_flags(beta, x_c[None, :], mu_c[None, :],
+                                       q_c[None, 1::2], active, probe=False)
+            if hit[0]:
+                be.mark_expanders(np.array([idx_c], dtype=np.int64))
+                return
+            self._visit_candidates(beta, active, False, float(out5[3]), idx_c)
             return
 
         width = self._comm.allreduce_max(
@@ -442,18 +480,22 @@ class SafeOpt(GaussianProcessOptimization):
             be.candidates(max_var, self.scaling, thr_beta, full_sets))
         self._stale.update(M=True, G=True)
 
-        active = self.fmin != -np.inf
         if n_cand == 0 or n_unsafe == 0 or not np.any(active):
             # no candidate, or nothing unsafe to certify (any([]) is False),
             # or no safety constraint at all: G stays empty
             return
+        self._visit_candidates(beta, active, full_sets, np.inf,
+                               -1 if full_sets else _I64_MAX)
 
+    def _visit_candidates(self, beta, active, full_sets, cut_w, cut_idx):
+        """Expander loop of gp_opt.py:557-612 from the cut onwards."""
+        be = self._backend
+        G = len(self.gps)
         mode = 1 if full_sets else 0
-        cut_w, cut_idx = np.inf, (-1 if full_sets else _I64_MAX)
         # The first expander in visiting order is very often the very first
         # candidate, so the first pass fetches and tests only that one; later
         # passes take SGP_TOPK candidates at a time.
-        K = _hip.TOPK if full_sets else 1
+        K = _hip.TOPK if (full_sets or cut_idx != _I64_MAX) else 1
         while True:
             w_loc, i_loc = be.topk(mode, cut_w, cut_idx, K)
             if self._comm.world > 1:
@@ -530,7 +572,11 @@ class SafeOpt(GaussianProcessOptimization):
         if not self._any_safe:
             raise EnvironmentError('There are no safe points to evaluate.')
         mode = _hip.ARGMAX_UCB if ucb else _hip.ARGMAX_MG_WIDTH
-        idx = self._global_argmax(mode)[1]
+        cached = getattr(self, '_argmax_cache', None)
+        if not ucb and cached is not None:
+            idx = cached[1]          # arg-max already done with the sets
+        else:
+            idx = self._global_argmax(mode)[1]
         x = self.inputs[idx, :]
         if self.num_contexts:
             return x[:-self.num_contexts]
