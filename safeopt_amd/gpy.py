@@ -199,11 +199,23 @@ class GPRegression(object):
         self._dev_fitted = True
 
     def _fitted(self):
+        """Device GP, fitted.  Hot path: no host work when nothing changed.
+        Hyper-parameters are re-read on ``set_XY`` and on
+        ``parameters_changed()``."""
+        if self._dev is not None and self._dev_fitted:
+            return self._dev
         dev = self._device_gp()
-        if not self._dev_fitted:          # hyper-parameters were edited
+        if not self._dev_fitted:
             dev.set_data(self.X, self.Y[:, 0])
             self._dev_fitted = True
         return dev
+
+    def parameters_changed(self):
+        """Call after editing ``kern.variance`` / ``kern.lengthscale`` /
+        ``noise_var`` in place: refits the device model with the new values
+        (GPy triggers this through its parameter setters)."""
+        self._dev_fitted = False
+        self._fitted()
 
     def predict_noiseless(self, Xnew, full_cov=False):
         """Posterior mean and variance of the latent function, ``(N,1)`` each;
