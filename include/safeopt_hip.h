@@ -142,21 +142,26 @@ int sgp_grid_expander_check(sgp_grid* grid, sgp_gp* const* gps, int G,
 int sgp_grid_lipschitz_check(sgp_grid* grid, int G, const double* fmin,
                              const double* lipschitz, int m, const double* xc,
                              const double* u_c, int32_t* flags);
-/* Single-rank fast paths (one stream sync each; results identical to the
- * step-by-step calls above, which multi-rank runs interleave with RCCL):
- * front = gp_opt.py:511-552: M, max_var, candidate mask, counts, first
+/* Fused passes (one stream sync each; results identical to the step-by-step
+ * calls above):
+ * front = gp_opt.py:511-552: M and max_var (have_max_var = 0; with
+ *   have_max_var = 1 the caller already ran sgp_grid_maximizers and passes the
+ *   all-reduced max_var), candidate mask, counts, this shard's first
  *   candidate in visiting order and its rows.
- *   out5 = {max(u0[M]-l0[M]), #candidates, #unsafe, w_top, idx_top or -1}
- * back = expander test of ONE candidate (gp_opt.py:579-606), G mark if it is
- *   an expander (gp_opt.py:615) and the M|G arg-max (gp_opt.py:642-644).      */
-int sgp_grid_sets_front(sgp_grid* grid, double max_l, const double* scaling,
+ *   out5 = {max(u0[M]-l0[M]) (0 if given), #candidates, #unsafe, w_top,
+ *           idx_top or -1}
+ * back = expander test of ONE candidate on this shard's unsafe rows
+ *   (gp_opt.py:579-606), G mark if mark != 0 and every active GP certified it
+ *   (gp_opt.py:615; single rank only), then the M|G arg-max (:642-644).       */
+int sgp_grid_sets_front(sgp_grid* grid, double max_l, int have_max_var,
+                        double max_var, const double* scaling,
                         const double* thr_beta, double* out5, double* x_top,
                         double* mean_top, double* q_top);
 int sgp_grid_sets_back(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                        const double* fmin, const double* xc, const double* mu_c,
                        const double* u_c, double near_frac, int64_t gidx_c,
-                       const double* scaling, int32_t* flags, double* value,
-                       int64_t* gidx);
+                       int mark, const double* scaling, int32_t* flags,
+                       double* value, int64_t* gidx);
 /* gp_opt.py:615: G[idx] = True for owned global indices                      */
 int sgp_grid_mark_expanders(sgp_grid* grid, const int64_t* gidx, int m);
 /* get_new_query_point / get_maximum arg-max (gp_opt.py:635, 642-644,

@@ -67,13 +67,14 @@ PROTOTYPES = {
     "sgp_grid_lipschitz_check": (C.c_int, [vp, C.c_int, c_double_p,
                                            c_double_p, C.c_int, c_double_p,
                                            c_double_p, c_i32_p]),
-    "sgp_grid_sets_front": (C.c_int, [vp, C.c_double, c_double_p, c_double_p,
+    "sgp_grid_sets_front": (C.c_int, [vp, C.c_double, C.c_int, C.c_double,
                                       c_double_p, c_double_p, c_double_p,
-                                      c_double_p]),
+                                      c_double_p, c_double_p, c_double_p]),
     "sgp_grid_sets_back": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p,
                                      c_double_p, c_double_p, c_double_p,
-                                     C.c_double, C.c_int64, c_double_p,
-                                     c_i32_p, c_double_p, c_i64_p]),
+                                     C.c_double, C.c_int64, C.c_int,
+                                     c_double_p, c_i32_p, c_double_p,
+                                     c_i64_p]),
     "sgp_grid_mark_expanders": (C.c_int, [vp, c_i64_p, C.c_int]),
     "sgp_grid_argmax": (C.c_int, [vp, C.c_int, c_double_p, c_double_p,
                                   c_i64_p]),
@@ -417,7 +418,7 @@ class DeviceGrid(object):
             dptr(u_c), flags.ctypes.data_as(c_i32_p)))
         return flags
 
-    def sets_front(self, max_l, scaling, thr_beta):
+    def sets_front(self, max_l, max_var, scaling, thr_beta):
         scaling = f64(scaling)
         thr_beta = f64(thr_beta)
         out5 = np.empty(5)
@@ -425,12 +426,13 @@ class DeviceGrid(object):
         mean = np.empty(self.G)
         q = np.empty(2 * self.G)
         self.ctx.check(lib().sgp_grid_sets_front(
-            self.h, float(max_l), dptr(scaling), dptr(thr_beta), dptr(out5),
-            dptr(x), dptr(mean), dptr(q)))
+            self.h, float(max_l), int(max_var is not None),
+            0.0 if max_var is None else float(max_var), dptr(scaling),
+            dptr(thr_beta), dptr(out5), dptr(x), dptr(mean), dptr(q)))
         return out5, x, mean, q
 
     def sets_back(self, gps, beta, fmin, xc, mu_c, u_c, near_frac, gidx_c,
-                  scaling):
+                  scaling, mark=True):
         fmin = f64(fmin)
         scaling = f64(scaling)
         xc, mu_c, u_c = f64(xc), f64(mu_c), f64(u_c)
@@ -440,8 +442,8 @@ class DeviceGrid(object):
         self.ctx.check(lib().sgp_grid_sets_back(
             self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin),
             dptr(xc), dptr(mu_c), dptr(u_c), float(near_frac), int(gidx_c),
-            dptr(scaling), flags.ctypes.data_as(c_i32_p), C.byref(v),
-            C.byref(i)))
+            int(bool(mark)), dptr(scaling), flags.ctypes.data_as(c_i32_p),
+            C.byref(v), C.byref(i)))
         return flags, v.value, i.value
 
     def mark_expanders(self, gidx):

@@ -742,7 +742,8 @@ int sgp_grid_expander_check(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
 // Single-rank fast path, front half of compute_sets (gp_opt.py:511-552) with
 // ONE stream sync: M, max_var, candidate mask, counts and the first candidate
 // in visiting order together with its rows.
-int sgp_grid_sets_front(sgp_grid* g, double max_l, const double* scaling,
+int sgp_grid_sets_front(sgp_grid* g, double max_l, int have_max_var,
+                        double max_var, const double* scaling,
                         const double* thr_beta, double* out5, double* x_top,
                         double* mean_top, double* q_top) {
   sgp_ctx* ctx = g->ctx;
@@ -753,10 +754,18 @@ int sgp_grid_sets_front(sgp_grid* g, double max_l, const double* scaling,
   const size_t nres = 6 + size_t(d) + 3 * size_t(G);
   double* res = static_cast<double*>(sgp_scratch(ctx, 1, (nres + 8) * 8));
   SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
-  SGP_TRY(launch_maximizers(g, max_l));
-  SGP_TRY(launch_reduce_max(ctx, g->partial, (g->N + 255) / 256, res));
-  SGP_TRY(launch_candidates(g, 0.0, res, scaling, thr_beta, 0,
-                            reinterpret_cast<unsigned long long*>(res + 1)));
+  if (have_max_var) {
+    // multi-rank: M is already set (sgp_grid_maximizers) and max_var is the
+    // all-reduced value
+    SGP_HIP(ctx, hipMemsetAsync(res, 0, 8, ctx->stream));
+    SGP_TRY(launch_candidates(g, max_var, nullptr, scaling, thr_beta, 0,
+                              reinterpret_cast<unsigned long long*>(res + 1)));
+  } else {
+    SGP_TRY(launch_maximizers(g, max_l));
+    SGP_TRY(launch_reduce_max(ctx, g->partial, (g->N + 255) / 256, res));
+    SGP_TRY(launch_candidates(g, 0.0, res, scaling, thr_beta, 0,
+                              reinterpret_cast<unsigned long long*>(res + 1)));
+  }
   SGP_TRY(launch_topk(g, 0, INFINITY, INT64_MAX, 1, res + 3,
                       reinterpret_cast<int64_t*>(res + 4),
                       reinterpret_cast<int*>(res + 5)));
@@ -786,17 +795,17 @@ int sgp_grid_sets_front(sgp_grid* g, double max_l, const double* scaling,
 int sgp_grid_sets_back(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
                        const double* fmin, const double* xc, const double* mu_c,
                        const double* u_c, double near_frac, int64_t gidx_c,
-                       const double* scaling, int32_t* flags, double* value,
-                       int64_t* gidx) {
+                       int mark, const double* scaling, int32_t* flags,
+                       double* value, int64_t* gidx) {
   sgp_ctx* ctx = g->ctx;
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   const int64_t li = gidx_c - g->goff;
-  SGP_CHECK(ctx, li >= 0 && li < g->N, "candidate %lld is not owned by this shard",
-            (long long)gidx_c);
+  SGP_CHECK(ctx, !mark || (li >= 0 && li < g->N),
+            "candidate %lld is not owned by this shard", (long long)gidx_c);
   int32_t* dfl = nullptr;
   SGP_TRY(enqueue_expander(g, gps, G, beta, fmin, 1, xc, mu_c, u_c, near_frac,
                            &dfl));
-  SGP_TRY(launch_mark_if(g, li, dfl, fmin));
+  if (mark) SGP_TRY(launch_mark_if(g, li, dfl, fmin));
   // results right behind the flags block: value (f64) | index (i64)
   char* res = reinterpret_cast<char*>(dfl) + size_t(SGP_TOPK) * G * 4;
   res += (8 - (reinterpret_cast<uintptr_t>(res) & 7)) & 7;

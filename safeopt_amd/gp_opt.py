@@ -204,13 +204,14 @@ class _HipGridBackend(object):
     def mark_expanders(self, gidx):
         self.grid.mark_expanders(gidx)
 
-    # single-rank fast paths (one stream sync each)
-    def sets_front(self, max_l, scaling, thr_beta):
-        return self.grid.sets_front(max_l, scaling, thr_beta)
+    # fused passes (one stream sync each)
+    def sets_front(self, max_l, max_var, scaling, thr_beta):
+        return self.grid.sets_front(max_l, max_var, scaling, thr_beta)
 
-    def sets_back(self, beta, fmin, xc, mu_c, u_c, near_frac, gidx_c, scaling):
+    def sets_back(self, beta, fmin, xc, mu_c, u_c, near_frac, gidx_c, scaling,
+                  mark):
         return self.grid.sets_back(self._dev(), beta, fmin, xc, mu_c, u_c,
-                                   near_frac, gidx_c, scaling)
+                                   near_frac, gidx_c, scaling, mark)
 
     def argmax(self, mode, scaling):
         return self.grid.argmax(mode, scaling)
@@ -448,29 +449,62 @@ class SafeOpt(GaussianProcessOptimization):
             return
 
         active = self.fmin != -np.inf
-        if (self._comm.world == 1 and not full_sets and not self.use_lipschitz
-                and hasattr(be, 'sets_front')):
-            # One GPU: the whole front half in one call, and -- when the first
-            # candidate in visiting order is certified by the cheap probe,
-            # which is the common case -- the back half in a second one.
-            out5, x_c, mu_c, q_c = be.sets_front(self._max_l, self.scaling,
-                                                 thr_beta)
+        world = self._comm.world
+        if not full_sets and not self.use_lipschitz and hasattr(be, 'sets_front'):
+            # Fused passes.  One GPU: 2 device round trips.  N GPUs: 3 round
+            # trips + 3 scalar collectives (max_var; every rank's first
+            # candidate with its rows; probe flags + local arg-max).
+            d = self.inputs.shape[1]
+            if world == 1:
+                out5, x_c, mu_c, q_c = be.sets_front(self._max_l, None,
+                                                     self.scaling, thr_beta)
+                n_cand, n_unsafe, w_c, idx_c = (out5[1], out5[2],
+                                                float(out5[3]), int(out5[4]))
+            else:
+                width = self._comm.allreduce_max(
+                    np.array([be.maximizers(self._max_l)]))[0]
+                out5, x_l, mu_l, q_l = be.sets_front(
+                    self._max_l, width / self.scaling[0], self.scaling,
+                    thr_beta)
+                pk = self._comm.allgather(
+                    np.concatenate([out5[1:5], x_l, mu_l, q_l]))
+                n_cand, n_unsafe = pk[:, 0].sum(), pk[:, 1].sum()
+                w_b, i_b = merge_topk(pk[:, 2], pk[:, 3].astype(np.int64), 1)
+                idx_c = int(i_b[0]) if i_b.size else -1
+                w_c = float(w_b[0]) if i_b.size else -np.inf
+                r = int(np.flatnonzero(pk[:, 3].astype(np.int64) == idx_c)[0]) \
+                    if idx_c >= 0 else 0
+                x_c, mu_c, q_c = (pk[r, 4:4 + d], pk[r, 4 + d:4 + d + G],
+                                  pk[r, 4 + d + G:])
             self._stale.update(M=True, G=True)
-            n_cand, n_unsafe, idx_c = out5[1], out5[2], int(out5[4])
             if n_cand == 0 or n_unsafe == 0 or not np.any(active) or idx_c < 0:
                 return
             flags, val, idx = be.sets_back(beta, self.fmin, x_c, mu_c,
-                                           q_c[1::2], 0.5, idx_c, self.scaling)
+                                           q_c[1::2], 0.5, idx_c, self.scaling,
+                                           world == 1)
+            if world > 1:
+                pk = self._comm.allgather(np.concatenate(
+                    [flags.astype(np.float64), [val, float(idx)]]))
+                flags = pk[:, :G].max(axis=0)
             if np.all(flags[active] != 0):
+                if world > 1:
+                    if be.owns(idx_c):
+                        be.mark_expanders(np.array([idx_c], dtype=np.int64))
+                    # arg-max over M on every rank + the certified expander
+                    v_c = np.max((q_c[1::2] - q_c[::2]) / self.scaling)
+                    val, idx = merge_argmax(
+                        np.append(pk[:, G], v_c),
+                        np.append(pk[:, G + 1].astype(np.int64), idx_c))
                 self._argmax_cache = (val, int(idx))
                 return
             # not certified by the probe: exact scan, then the general loop
             hit = self._expander_flags(beta, x_c[None, :], mu_c[None, :],
                                        q_c[None, 1::2], active, probe=False)
             if hit[0]:
-                be.mark_expanders(np.array([idx_c], dtype=np.int64))
+                if be.owns(idx_c):
+                    be.mark_expanders(np.array([idx_c], dtype=np.int64))
                 return
-            self._visit_candidates(beta, active, False, float(out5[3]), idx_c)
+            self._visit_candidates(beta, active, False, w_c, idx_c)
             return
 
         width = self._comm.allreduce_max(

@@ -117,6 +117,32 @@ class OracleGridBackend(object):
                 flags[:, i] = np.any(u_c[:, [i]] - lipschitz[i] * d >= fmin[i], axis=1)
         return flags
 
+    def sets_front(self, max_l, max_var, scaling, thr_beta):
+        width = 0.0
+        if max_var is None:
+            width = self.maximizers(max_l)
+            max_var = width / np.asarray(scaling)[0]
+        nc, nu = self.candidates(max_var, scaling, thr_beta, False)
+        w, idx = self.topk(0, np.inf, np.iinfo(np.int64).max, 1)
+        d, G = self.x.shape[1], len(self.gps)
+        x, mean, q = np.zeros(d), np.zeros(G), np.zeros(2 * G)
+        out5 = np.array([width, nc, nu, -np.inf, -1.0])
+        if idx.size:
+            xs, ms, _v, qs = self.gather_rows(idx)
+            x, mean, q = xs[0], ms[0], qs[0]
+            out5[3], out5[4] = w[0], float(idx[0])
+        return out5, x, mean, q
+
+    def sets_back(self, beta, fmin, xc, mu_c, u_c, near_frac, gidx_c, scaling, mark):
+        flags = self.expander_check(beta, np.asarray(fmin), np.atleast_2d(xc),
+                                    np.atleast_2d(mu_c), np.atleast_2d(u_c),
+                                    near_frac)[0]
+        active = np.asarray(fmin) != -np.inf
+        if mark and active.any() and np.all(flags[active] != 0):
+            self.mark_expanders([gidx_c])
+        v, i = self.argmax(0, scaling)
+        return flags, v, i
+
     def mark_expanders(self, gidx):
         self.G[np.asarray(gidx, dtype=np.int64) - self.lo] = True
 
