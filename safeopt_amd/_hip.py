@@ -99,6 +99,27 @@ PROTOTYPES = {
 _lib = None
 
 
+class _stdout_to_stderr(object):
+    """RCCL prints a version banner on stdout when a communicator is created;
+    keep stdout clean (bench.py promises exactly one JSON line there)."""
+
+    def __enter__(self):
+        import sys
+        try:
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+        except OSError:
+            self.saved = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.saved is not None:
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+        return False
+
+
 class HipError(RuntimeError):
     """A call into libsafeopt_hip.so failed (HIP / RCCL / argument error)."""
 
@@ -208,14 +229,17 @@ class Context(object):
     @staticmethod
     def comm_unique_id():
         buf = C.create_string_buffer(128)
-        rc = lib().sgp_comm_unique_id(buf)
+        with _stdout_to_stderr():
+            rc = lib().sgp_comm_unique_id(buf)
         if rc != 0:
             raise HipError(lib().sgp_last_error(None).decode())
         return buf.raw
 
     def comm_init(self, uid, rank, world):
         buf = C.create_string_buffer(uid, 128)
-        self.check(lib().sgp_comm_init(self.h, buf, rank, world))
+        with _stdout_to_stderr():
+            rc = lib().sgp_comm_init(self.h, buf, rank, world)
+        self.check(rc)
         self.rank, self.world = rank, world
 
     def allreduce_max(self, a):
