@@ -115,6 +115,10 @@ class _stdout_to_stderr(object):
 
     def __exit__(self, *exc):
         if self.saved is not None:
+            try:                      # RCCL uses buffered C stdio: flush it
+                C.CDLL(None).fflush(None)   # while fd 1 still is stderr
+            except Exception:
+                pass
             os.dup2(self.saved, 1)
             os.close(self.saved)
         return False
