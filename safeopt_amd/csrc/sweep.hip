@@ -18,8 +18,6 @@
 // are processed in chunks of 16 MFMA row blocks (256 rows) held in 16
 // accumulators per wave; the triangular structure is exploited at 16x16 block
 // granularity (a j-block only feeds row blocks >= its own index).
-#include <stdlib.h>
-
 #include "kern_eval.h"
 
 namespace {
@@ -483,15 +481,6 @@ __global__ __launch_bounds__(256) void k_mfma_bench(double* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-int sweep_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SGP_SWEEP_VARIANT");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-
 template <int D, int NW>
 int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static bool attr_set = false;
@@ -528,8 +517,7 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
 
 template <int D>
 int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
-  if (sweep_variant() & 2) return launch_sweep_v<D, 4>(ctx, p, flops);
-  return launch_sweep_v<D, 8>(ctx, p, flops);
+  return launch_sweep_v<D, kMaxWaves>(ctx, p, flops);
 }
 
 int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
@@ -557,10 +545,8 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
 
 }  // namespace
 
-int sweep_tile_rows() { return (sweep_variant() & 2) ? 64 : 128; }
 int sweep_num_blocks(int64_t N) {
-  const int t = sweep_tile_rows();
-  return int((N + t - 1) / t);
+  return int((N + 16 * kMaxWaves - 1) / (16 * kMaxWaves));
 }
 
 int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
