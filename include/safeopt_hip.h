@@ -69,6 +69,14 @@ void sgp_gp_destroy(sgp_gp* gp);
  * after 5 jitter escalations (GPy jitchol); jitter_used: diagonal jitter.    */
 int sgp_gp_set_data(sgp_gp* gp, const double* X, const double* Y, int64_t n,
                     int* chol_info, double* jitter_used);
+/* gp.set_XY with ONE more / ONE fewer row -- what add_new_data_point
+ * (gp_opt.py:230-255 -> :227) and remove_last_data_point (:269-278 -> :275) do
+ * every iteration: bordered update of L^-1 and alpha, O(n^2) instead of the
+ * O(n^3) re-factorisation.  append: info = 0 ok,
+ * > 0 the bordered pivot is not positive (refit with sgp_gp_set_data, which
+ * applies GPy's jitter), -1 no spare capacity (same remedy).                  */
+int sgp_gp_append(sgp_gp* gp, const double* x, double y, int* info);
+int sgp_gp_pop(sgp_gp* gp);
 /* gp.predict_noiseless / gp._raw_predict (gp_opt.py:469, 591, 929, 973, 1117,
  * 1132; utilities.py:203, 282, 355).  Xnew element (r,c) at
  * Xnew[r*stride_row + c*stride_col] (strides in elements: C or F order).
@@ -100,6 +108,15 @@ int sgp_grid_set_context(sgp_grid* grid, const double* c, int nc);
  * out2 = { max(l0[S]) or -inf, any(S) }  (local rows).                       */
 int sgp_grid_confidence(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                         const double* fmin, double* out2);
+/* update_confidence_intervals after ONE sgp_gp_append on the GPs flagged in
+ * which[]: closed-form rank-1 update of the resident mean/var,
+ *   c(x) = k(x,x*) - k(X,x)^T Ky^-1 k(X,x*),  mean += c r / s2,
+ *   var = max(var - c^2 / s2, 1e-15),
+ * O(n) per row instead of the O(n^2) sweep, then Q and S for all GPs from the
+ * resident mean/var with the given beta.  out2 as sgp_grid_confidence.        */
+int sgp_grid_rank1_update(sgp_grid* grid, sgp_gp* const* gps, int G,
+                          const int* which, double beta, const double* fmin,
+                          double* out2);
 /* replace Q by host values (N x 2G row-major) and recompute S (tests, and
  * users who edit opt.Q by hand).                                             */
 int sgp_grid_upload_Q(sgp_grid* grid, const double* Q, const double* fmin,

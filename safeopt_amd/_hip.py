@@ -39,6 +39,8 @@ PROTOTYPES = {
     "sgp_gp_destroy": (None, [vp]),
     "sgp_gp_set_data": (C.c_int, [vp, c_double_p, c_double_p, C.c_int64,
                                   c_int_p, c_double_p]),
+    "sgp_gp_append": (C.c_int, [vp, c_double_p, C.c_double, c_int_p]),
+    "sgp_gp_pop": (C.c_int, [vp]),
     "sgp_gp_predict": (C.c_int, [vp, c_double_p, C.c_int64, C.c_int64,
                                  C.c_int64, c_double_p, c_double_p]),
     "sgp_gp_get_factor": (C.c_int, [vp, c_double_p, c_double_p]),
@@ -52,6 +54,8 @@ PROTOTYPES = {
     "sgp_grid_set_context": (C.c_int, [vp, c_double_p, C.c_int]),
     "sgp_grid_confidence": (C.c_int, [vp, vpp, C.c_int, C.c_double,
                                       c_double_p, c_double_p]),
+    "sgp_grid_rank1_update": (C.c_int, [vp, vpp, C.c_int, c_int_p, C.c_double,
+                                        c_double_p, c_double_p]),
     "sgp_grid_upload_Q": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
     "sgp_grid_maximizers": (C.c_int, [vp, C.c_double, c_double_p]),
     "sgp_grid_candidates": (C.c_int, [vp, C.c_double, c_double_p, c_double_p,
@@ -292,6 +296,10 @@ class DeviceGP(object):
         self.h = h
         self.n = 0
         self.jitter = 0.0
+        # data version: bumped by every change; `appended` = the last change
+        # was a one-row append whose rank-1 record is on the device
+        self.version = 0
+        self.appended = False
 
     def __del__(self):
         try:
@@ -313,6 +321,29 @@ class DeviceGP(object):
         self.ctx.check(rc)
         self.n = X.shape[0]
         self.jitter = jit.value
+        self.version += 1
+        self.appended = False
+
+    def append(self, x, y):
+        """One more observation by a bordered update; False = not possible
+        (no capacity / pivot not positive): the caller refits with set_data."""
+        x = f64(x).reshape(self.d)
+        info = C.c_int(0)
+        self.ctx.check(lib().sgp_gp_append(self.h, dptr(x), float(y),
+                                           C.byref(info)))
+        if info.value != 0:
+            return False
+        self.n += 1
+        self.version += 1
+        self.appended = True
+        return True
+
+    def pop(self):
+        """Drop the last observation (O(n^2))."""
+        self.ctx.check(lib().sgp_gp_pop(self.h))
+        self.n -= 1
+        self.version += 1
+        self.appended = False
 
     def predict(self, Xnew):
         Xnew = np.asarray(Xnew, dtype=np.float64)
@@ -374,6 +405,15 @@ class DeviceGrid(object):
         self.ctx.check(lib().sgp_grid_confidence(
             self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin),
             dptr(out)))
+        return out[0], bool(out[1])
+
+    def rank1_update(self, gps, which, beta, fmin):
+        fmin = f64(fmin)
+        w = np.ascontiguousarray(which, dtype=np.int32)
+        out = np.empty(2)
+        self.ctx.check(lib().sgp_grid_rank1_update(
+            self.h, _gp_array(gps), len(gps), w.ctypes.data_as(c_int_p),
+            float(beta), dptr(fmin), dptr(out)))
         return out[0], bool(out[1])
 
     def upload_Q(self, Qh, fmin):

@@ -247,7 +247,8 @@ void sgp_gp_destroy(sgp_gp* gp) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   DevBuf* bufs[] = {&gp->X, &gp->Y, &gp->Xpad, &gp->Xs, &gp->alpha, &gp->Apack,
-                    &gp->Linv, &gp->Kmat, &gp->work, &gp->tvec};
+                    &gp->Linv, &gp->Kmat, &gp->work, &gp->tvec, &gp->updw,
+                    &gp->upd};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   delete gp;
@@ -263,8 +264,10 @@ int sgp_gp_set_data(sgp_gp* gp, const double* X, const double* Y, int64_t n,
   gp->n = n;
   gp->n_pad = int((n + 15) / 16) * 16;
   gp->n_f = int((n + 31) / 32) * 32;
-  SGP_TRY(sgp_reserve(ctx, &gp->X, size_t(n) * d * sizeof(double)));
-  SGP_TRY(sgp_reserve(ctx, &gp->Y, size_t(n) * sizeof(double)));
+  // row capacity: room for 64+ one-row appends before the next reallocation
+  if (gp->ld < gp->n_f) gp->ld = int((n + 64 + 63) / 64) * 64;
+  SGP_TRY(sgp_reserve(ctx, &gp->X, size_t(gp->ld) * d * sizeof(double)));
+  SGP_TRY(sgp_reserve(ctx, &gp->Y, size_t(gp->ld) * sizeof(double)));
   SGP_TRY(sgp_h2d(ctx, gp->X.p, X, size_t(n) * d * sizeof(double)));
   SGP_TRY(sgp_h2d(ctx, gp->Y.p, Y, size_t(n) * sizeof(double)));
   // GPy util.linalg.jitchol: plain attempt, then jitter = mean(diag)*1e-6,
@@ -290,6 +293,27 @@ int sgp_gp_set_data(sgp_gp* gp, const double* X, const double* Y, int64_t n,
     return info > 0 ? info : -2;
   }
   return 0;
+}
+
+int sgp_gp_append(sgp_gp* gp, const double* x, double y, int* info) {
+  sgp_ctx* ctx = gp->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, gp->n > 0, "GP has no data");
+  *info = -1;
+  if (gp->n + 1 > gp->ld) return 0;  // no room: caller refits with set_data
+  const int d = gp->kern.d;
+  double* X = static_cast<double*>(gp->X.p);
+  double* Y = static_cast<double*>(gp->Y.p);
+  SGP_TRY(sgp_h2d(ctx, X + size_t(gp->n) * d, x, size_t(d) * sizeof(double)));
+  SGP_TRY(sgp_h2d(ctx, Y + gp->n, &y, sizeof(double)));
+  return append_gp(gp, y, info);
+}
+
+int sgp_gp_pop(sgp_gp* gp) {
+  sgp_ctx* ctx = gp->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, gp->n > 1, "cannot remove the only training point");
+  return pop_gp(gp);
 }
 
 int sgp_gp_predict(sgp_gp* gp, const double* Xnew, int64_t N,
@@ -344,7 +368,7 @@ int sgp_gp_get_factor(sgp_gp* gp, double* Linv, double* alpha) {
   const int64_t n = gp->n;
   if (Linv) {
     SGP_HIP(ctx, hipMemcpy2DAsync(Linv, n * sizeof(double), gp->Linv.p,
-                                  size_t(gp->n_f) * sizeof(double),
+                                  size_t(gp->ld) * sizeof(double),
                                   n * sizeof(double), n, hipMemcpyDeviceToHost,
                                   ctx->stream));
     SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -494,6 +518,36 @@ int sgp_grid_confidence(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   for (int i = 0; i < SGP_MAX_GPS; ++i) co.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
   SGP_TRY(launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co));
   return finish_safe_partials(g, sweep_num_blocks(g->N), out2);
+}
+
+int sgp_grid_rank1_update(sgp_grid* g, sgp_gp* const* gps, int G,
+                          const int* which, double beta, const double* fmin,
+                          double* out2) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  GpDev host[SGP_MAX_GPS];
+  SGP_TRY(collect_gps(ctx, gps, G, g->d, host));
+  Rank1Args ra{};
+  for (int i = 0; i < SGP_MAX_GPS; ++i) {
+    ra.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
+    ra.which[i] = (i < G) ? which[i] : 0;
+    if (i < G && which[i])
+      SGP_CHECK(ctx, gps[i]->upd_valid,
+                "GP %d has no append record for a rank-1 update", i);
+  }
+  SGP_HIP(ctx, hipMemcpyAsync(g->gpdev, host, sizeof(GpDev) * G,
+                              hipMemcpyHostToDevice, ctx->stream));
+  SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host[] is on the stack
+  ra.Q = g->Q;
+  ra.mean = g->mean;
+  ra.var = g->var;
+  ra.S = g->S;
+  ra.partial = g->partial;
+  ra.beta = beta;
+  SweepPoints sp{g->pts, g->N, 1, g->N};
+  SGP_TRY(launch_rank1(ctx, g->gpdev, G, g->d, sp, ra));
+  return finish_safe_partials(g, rank1_num_blocks(g->N), out2);
 }
 
 int sgp_grid_upload_Q(sgp_grid* g, const double* Q, const double* fmin,

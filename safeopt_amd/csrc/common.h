@@ -58,6 +58,12 @@ struct GpDev {
   int n_pad;            // n rounded up to 16
   int nblk;             // n_pad / 16
   int pad_;
+  // record of the last one-row append (sgp_gp_append), consumed by the
+  // rank-1 update of the resident posterior: w = Ky_old^-1 k(X_old, x*)
+  // (zero padded to n_pad), upd[0] = (y* - mu(x*)) / s2, upd[1] = 1 / s2,
+  // upd[2..2+d) = x*
+  const double* upd_w;
+  const double* upd;
   KernDesc kern;
 };
 
@@ -96,7 +102,9 @@ struct sgp_gp {
   int64_t n = 0;
   int n_pad = 0;  // multiple of 16 (sweep blocks)
   int n_f = 0;    // multiple of 32 (factorisation leaves)
-  DevBuf X, Y, Xpad, Xs, alpha, Apack, Linv, Kmat, work, tvec;
+  int ld = 0;     // leading dimension / row capacity of Linv, Kmat, work
+  bool upd_valid = false;  // dev.upd* describes the step to the current data
+  DevBuf X, Y, Xpad, Xs, alpha, Apack, Linv, Kmat, work, tvec, updw, upd;
   GpDev dev;      // filled by set_data
 };
 
@@ -133,6 +141,9 @@ int launch_kernel_matrix(sgp_ctx* ctx, const KernDesc& kd, const double* X1,
                          int64_t ld, int symmetric_diag, double diag_add,
                          int64_t n_valid);
 int factor_gp(sgp_gp* gp, int* info);  // Kmat -> Linv, Apack, alpha
+int append_gp(sgp_gp* gp, double y, int* info);  // row n already in gp->X
+int pop_gp(sgp_gp* gp);
+int publish_gp(sgp_gp* gp);  // Apack / Xpad / Xs / dev descriptor from Linv
 int expander_operands(sgp_gp* gp, const double* xc_dev, int m,
                       const double* resid_dev, double* Wpack, double* delta,
                       double* inv_s2, double* tn2);
@@ -188,6 +199,19 @@ struct ExpanderArgs {
 int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
                           const GpDev* gps_host, int G, int d, SweepPoints pts,
                           ExpanderArgs ea);
+struct Rank1Args {
+  double* Q;
+  double* mean;
+  double* var;
+  uint8_t* S;
+  double* partial;
+  double beta;
+  double fmin[SGP_MAX_GPS];
+  int which[SGP_MAX_GPS];
+};
+int rank1_num_blocks(int64_t N);
+int launch_rank1(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d,
+                 SweepPoints pts, Rank1Args ra);
 int launch_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
                       double* tflops);
 

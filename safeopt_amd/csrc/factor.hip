@@ -332,65 +332,198 @@ int launch_kernel_matrix(sgp_ctx* ctx, const KernDesc& kd, const double* X1,
   return 0;
 }
 
-// Build Ky (with gp->jitter), factor, invert, pack, alpha.  *info = 0 or the
-// 1-based index of the first non-positive pivot.
-int factor_gp(sgp_gp* gp, int* info) {
+// Everything the sweeps read, derived from the dense L^-1 (ld = gp->ld),
+// gp->X and gp->alpha (first n entries valid): packed operand matrix, padded /
+// pre-scaled inputs, zero-padded alpha, device descriptor.
+int publish_gp(sgp_gp* gp) {
   sgp_ctx* ctx = gp->ctx;
-  const int n = int(gp->n), nf = gp->n_f, np = gp->n_pad;
-  const size_t mat = size_t(nf) * nf * sizeof(double);
-  SGP_TRY(sgp_reserve(ctx, &gp->Kmat, mat));
-  SGP_TRY(sgp_reserve(ctx, &gp->Linv, mat));
-  SGP_TRY(sgp_reserve(ctx, &gp->work, mat));
-  SGP_TRY(sgp_reserve(ctx, &gp->tvec, size_t(nf) * sizeof(double) + 64));
-  double* K = static_cast<double*>(gp->Kmat.p);
+  const int n = int(gp->n), np = gp->n_pad, d = gp->kern.d;
   double* Li = static_cast<double*>(gp->Linv.p);
-  double* T = static_cast<double*>(gp->work.p);
-  double* tv = static_cast<double*>(gp->tvec.p);
-  int* info_dev = reinterpret_cast<int*>(tv + nf);
-
-  // padded rows of X are never read: n_valid = n turns them into identity
-  SGP_TRY(launch_kernel_matrix(ctx, gp->kern, static_cast<double*>(gp->X.p),
-                               nf, static_cast<double*>(gp->X.p), nf, K, nf, 1,
-                               gp->noise_var + 1e-8 + gp->jitter, n));
-  SGP_HIP(ctx, hipMemsetAsync(Li, 0, mat, ctx->stream));
-  SGP_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
-  SGP_TRY(factor_rec(ctx, K, Li, T, nf, 0, nf, info_dev));
-  SGP_TRY(sgp_d2h(ctx, info, info_dev, sizeof(int)));
-  if (*info != 0) return 0;
-
   const int nblk = np / 16, nsteps = np / 4;
   const int64_t total = int64_t(nblk) * nsteps * 64;
   SGP_TRY(sgp_reserve(ctx, &gp->Apack, size_t(total) * sizeof(double)));
   hipLaunchKernelGGL(k_pack, dim3(unsigned((total + 255) / 256)), dim3(256), 0,
-                     ctx->stream, Li, int64_t(nf), n, nblk, nsteps,
+                     ctx->stream, Li, int64_t(gp->ld), n, nblk, nsteps,
                      static_cast<double*>(gp->Apack.p));
-  SGP_HIP(ctx, hipGetLastError());
-  SGP_TRY(sgp_reserve(ctx, &gp->alpha, size_t(np) * sizeof(double)));
-  hipLaunchKernelGGL(k_trmv_lower, dim3((n + 127) / 128), dim3(128), 0,
-                     ctx->stream, Li, int64_t(nf), n,
-                     static_cast<double*>(gp->Y.p), tv);
-  hipLaunchKernelGGL(k_trmv_lower_t, dim3((np + 127) / 128), dim3(128), 0,
-                     ctx->stream, Li, int64_t(nf), n, tv,
-                     static_cast<double*>(gp->alpha.p), np);
-  SGP_HIP(ctx, hipGetLastError());
-  SGP_TRY(sgp_reserve(ctx, &gp->Xpad,
-                      size_t(np) * gp->kern.d * sizeof(double)));
-  SGP_TRY(sgp_reserve(ctx, &gp->Xs, size_t(np) * gp->kern.d * sizeof(double)));
-  hipLaunchKernelGGL(k_pad_rows, dim3((np * gp->kern.d + 255) / 256), dim3(256),
-                     0, ctx->stream, static_cast<double*>(gp->X.p), n, np,
-                     gp->kern.d, gp->kern, static_cast<double*>(gp->Xpad.p),
+  SGP_TRY(sgp_reserve(ctx, &gp->Xpad, size_t(np) * d * sizeof(double)));
+  SGP_TRY(sgp_reserve(ctx, &gp->Xs, size_t(np) * d * sizeof(double)));
+  hipLaunchKernelGGL(k_pad_rows, dim3((np * d + 255) / 256), dim3(256), 0,
+                     ctx->stream, static_cast<double*>(gp->X.p), n, np, d,
+                     gp->kern, static_cast<double*>(gp->Xpad.p),
                      static_cast<double*>(gp->Xs.p));
   SGP_HIP(ctx, hipGetLastError());
-
   gp->dev.Apack = static_cast<double*>(gp->Apack.p);
   gp->dev.Xpad = static_cast<double*>(gp->Xpad.p);
   gp->dev.Xs = static_cast<double*>(gp->Xs.p);
   gp->dev.alpha = static_cast<double*>(gp->alpha.p);
+  gp->dev.upd_w = static_cast<double*>(gp->updw.p);
+  gp->dev.upd = static_cast<double*>(gp->upd.p);
   gp->dev.n = n;
   gp->dev.n_pad = np;
   gp->dev.nblk = nblk;
   gp->dev.kern = gp->kern;
   return 0;
+}
+
+// Build Ky (with gp->jitter), factor, invert, pack, alpha.  *info = 0 or the
+// 1-based index of the first non-positive pivot.  Buffers are sized for
+// gp->ld >= n_f rows so later one-row appends need no reallocation.
+int factor_gp(sgp_gp* gp, int* info) {
+  sgp_ctx* ctx = gp->ctx;
+  const int n = int(gp->n), nf = gp->n_f, np = gp->n_pad, ld = gp->ld;
+  const size_t mat = size_t(ld) * ld * sizeof(double);
+  SGP_TRY(sgp_reserve(ctx, &gp->Kmat, mat));
+  SGP_TRY(sgp_reserve(ctx, &gp->Linv, mat));
+  SGP_TRY(sgp_reserve(ctx, &gp->work, mat));
+  SGP_TRY(sgp_reserve(ctx, &gp->tvec, size_t(ld) * sizeof(double) + 64));
+  SGP_TRY(sgp_reserve(ctx, &gp->alpha, size_t(ld + 16) * sizeof(double)));
+  SGP_TRY(sgp_reserve(ctx, &gp->updw, size_t(ld + 16) * sizeof(double)));
+  SGP_TRY(sgp_reserve(ctx, &gp->upd, size_t(SGP_MAX_D + 2) * sizeof(double)));
+  double* K = static_cast<double*>(gp->Kmat.p);
+  double* Li = static_cast<double*>(gp->Linv.p);
+  double* T = static_cast<double*>(gp->work.p);
+  double* tv = static_cast<double*>(gp->tvec.p);
+  int* info_dev = reinterpret_cast<int*>(tv + ld);
+  gp->upd_valid = false;
+
+  // padded rows of X are never read: n_valid = n turns them into identity
+  SGP_TRY(launch_kernel_matrix(ctx, gp->kern, static_cast<double*>(gp->X.p),
+                               nf, static_cast<double*>(gp->X.p), nf, K, ld, 1,
+                               gp->noise_var + 1e-8 + gp->jitter, n));
+  SGP_HIP(ctx, hipMemsetAsync(Li, 0, mat, ctx->stream));
+  SGP_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
+  SGP_TRY(factor_rec(ctx, K, Li, T, ld, 0, nf, info_dev));
+  SGP_TRY(sgp_d2h(ctx, info, info_dev, sizeof(int)));
+  if (*info != 0) return 0;
+
+  hipLaunchKernelGGL(k_trmv_lower, dim3((n + 127) / 128), dim3(128), 0,
+                     ctx->stream, Li, int64_t(ld), n,
+                     static_cast<double*>(gp->Y.p), tv);
+  hipLaunchKernelGGL(k_trmv_lower_t, dim3((np + 127) / 128), dim3(128), 0,
+                     ctx->stream, Li, int64_t(ld), n, tv,
+                     static_cast<double*>(gp->alpha.p), np);
+  SGP_HIP(ctx, hipGetLastError());
+  return publish_gp(gp);
+}
+
+// ---- one-row updates --------------------------------------------------------------
+// Bordered Cholesky: with k = k(X, x*), t = L^-1 k, w = L^-T t = Ky^-1 k,
+// s2 = k(x*,x*) + noise + 1e-8 + jitter - |t|^2:
+//   new row of L^-1 = [ -w^T / s , 1 / s ],
+//   alpha <- [ alpha - w r / s2 ; r / s2 ],  r = y* - k^T alpha  (= y* - mu(x*)).
+// The record {w, r/s2, 1/s2, x*} is kept for the rank-1 update of the resident
+// posterior (k_rank1).  One workgroup; n <= a few thousand.
+__global__ __launch_bounds__(1024) void k_append_finish(
+    double* Li, int64_t ld, int n, int d, const double* kc, const double* Tt,
+    const double* Wt, double prior, double y, const double* xnew, double* alpha,
+    double* updw, double* upd, int n_pad_new, int* info) {
+  __shared__ double sh[2][1024 / 64];
+  double a = 0.0, b = 0.0;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    a = fma(Tt[j], Tt[j], a);
+    b = fma(kc[j], alpha[j], b);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = a;
+    sh[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  double tn2 = 0.0, mu = 0.0;
+  for (int w = 0; w < int(blockDim.x >> 6); ++w) {
+    tn2 += sh[0][w];
+    mu += sh[1][w];
+  }
+  const double s2 = prior - tn2;
+  // GPy would retry with jitter here; report and let the host refit instead
+  if (!(s2 > 1e-12 * prior) || !isfinite(s2)) {
+    if (threadIdx.x == 0) info[0] = n + 1;
+    return;
+  }
+  const double sd = sqrt(s2);
+  const double r = y - mu;
+  for (int j = threadIdx.x; j < n_pad_new; j += blockDim.x) {
+    if (j < n) {
+      const double w = Wt[j];
+      Li[int64_t(n) * ld + j] = -w / sd;
+      alpha[j] -= w * r / s2;
+      updw[j] = w;
+    } else {
+      if (j == n) {
+        Li[int64_t(n) * ld + n] = 1.0 / sd;
+        alpha[n] = r / s2;
+      } else {
+        alpha[j] = 0.0;
+      }
+      updw[j] = 0.0;
+    }
+  }
+  if (threadIdx.x == 0) {
+    upd[0] = r / s2;
+    upd[1] = 1.0 / s2;
+    info[0] = 0;
+  }
+  if (threadIdx.x < d) upd[2 + threadIdx.x] = xnew[threadIdx.x];
+}
+
+// gp->X already holds the new row at index gp->n (uploaded by the caller);
+// gp->Y gets y.  On success n grows by one; *info != 0 leaves the GP untouched.
+int append_gp(sgp_gp* gp, double y, int* info) {
+  sgp_ctx* ctx = gp->ctx;
+  const int n = int(gp->n), ld = gp->ld, d = gp->kern.d;
+  double* Li = static_cast<double*>(gp->Linv.p);
+  double* X = static_cast<double*>(gp->X.p);
+  double* buf = static_cast<double*>(sgp_scratch(ctx, 3, size_t(3) * ld * 8 + 64));
+  if (!buf) return -1;
+  double* Kc = buf;
+  double* Tt = buf + ld;
+  double* Wt = buf + 2 * size_t(ld);
+  int* info_dev = reinterpret_cast<int*>(buf + 3 * size_t(ld));
+  const double* xnew = X + size_t(n) * d;
+  SGP_TRY(launch_kernel_matrix(ctx, gp->kern, xnew, 1, X, n, Kc, ld, 0, 0.0,
+                               INT64_MAX));
+  SGP_TRY(gemm(ctx, true, 1, n, n, 1.0, Kc, ld, Li, ld, 0.0, Tt, ld));
+  SGP_TRY(gemm(ctx, false, 1, n, n, 1.0, Tt, ld, Li, ld, 0.0, Wt, ld));
+  const int np_new = (n + 1 + 15) / 16 * 16;
+  const double prior = gp->kern.kdiag + gp->noise_var + 1e-8 + gp->jitter;
+  hipLaunchKernelGGL(k_append_finish, dim3(1), dim3(1024), 0, ctx->stream, Li,
+                     int64_t(ld), n, d, Kc, Tt, Wt, prior, y, xnew,
+                     static_cast<double*>(gp->alpha.p),
+                     static_cast<double*>(gp->updw.p),
+                     static_cast<double*>(gp->upd.p), np_new, info_dev);
+  SGP_HIP(ctx, hipGetLastError());
+  SGP_TRY(sgp_d2h(ctx, info, info_dev, sizeof(int)));
+  if (*info != 0) return 0;
+  gp->n = n + 1;
+  gp->n_pad = np_new;
+  gp->n_f = (n + 1 + 31) / 32 * 32;
+  gp->upd_valid = true;
+  return publish_gp(gp);
+}
+
+// Drop the last row: the leading principal block of a lower-triangular inverse
+// is the inverse of the leading block, so only alpha has to be recomputed.
+int pop_gp(sgp_gp* gp) {
+  sgp_ctx* ctx = gp->ctx;
+  const int n = int(gp->n) - 1, ld = gp->ld;
+  double* Li = static_cast<double*>(gp->Linv.p);
+  double* tv = static_cast<double*>(gp->tvec.p);
+  gp->n = n;
+  gp->n_pad = (n + 15) / 16 * 16;
+  gp->n_f = (n + 31) / 32 * 32;
+  gp->upd_valid = false;
+  hipLaunchKernelGGL(k_trmv_lower, dim3((n + 127) / 128), dim3(128), 0,
+                     ctx->stream, Li, int64_t(ld), n,
+                     static_cast<double*>(gp->Y.p), tv);
+  hipLaunchKernelGGL(k_trmv_lower_t, dim3((gp->n_pad + 127) / 128), dim3(128),
+                     0, ctx->stream, Li, int64_t(ld), n, tv,
+                     static_cast<double*>(gp->alpha.p), gp->n_pad);
+  SGP_HIP(ctx, hipGetLastError());
+  return publish_gp(gp);
 }
 
 // For m <= 16 candidates xc (m x d, device) and residuals u_c - mu_c (device):
@@ -399,10 +532,9 @@ int expander_operands(sgp_gp* gp, const double* xc_dev, int m,
                       const double* resid_dev, double* Wpack, double* delta,
                       double* inv_s2, double* tn2) {
   sgp_ctx* ctx = gp->ctx;
-  const int n = int(gp->n), nf = gp->n_f, np = gp->n_pad;
+  const int n = int(gp->n), nf = gp->ld, np = gp->n_pad;
   double* Li = static_cast<double*>(gp->Linv.p);
-  // work (n_f x n_f) is free after the factorisation: rows 0..15 = Kc,
-  // rows 16..31 = T^T, rows 32..47 = W^T  (n_f >= 32; use a scratch if not)
+  // rows 0..15 = Kc, rows 16..31 = T^T, rows 32..47 = W^T (pitch = ld)
   double* buf = static_cast<double*>(sgp_scratch(ctx, 3, size_t(48) * nf * 8));
   if (!buf) return -1;
   double* Kc = buf;

@@ -434,6 +434,77 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
   }
 }
 
+// ---- rank-1 update of the resident posterior --------------------------------------
+// After one appended observation (x*, y*) the posterior at every row changes by
+// a closed form (the same algebra as the expander test); per row and updated
+// GP this is n covariance evaluations and n FMAs on the VALU -- no n^2 term.
+// Lane (r, q) = (lane & 15, lane >> 4) handles row r and training points
+// j = q (mod 4); the four partial dot products are folded with two shuffles.
+template <int D>
+__global__ __launch_bounds__(256) void k_rank1(const GpDev* gps, int G,
+                                               SweepPoints pts, Rank1Args ra) {
+  __shared__ double tab[kExpTabSize];
+  __shared__ double red[4];
+  exp_tab_init(tab);
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t row = int64_t(blockIdx.x) * 64 + wave * 16 + (lane & 15);
+  const bool valid = row < pts.N;
+  const int64_t rrow = valid ? row : pts.N - 1;
+  const bool writer = valid && (lane < 16);
+
+  double x[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+    x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
+
+  bool safe = true;
+  double l0 = 0.0;
+  for (int g = 0; g < G; ++g) {
+    double mean = ra.mean[int64_t(g) * pts.N + rrow];
+    double var = ra.var[int64_t(g) * pts.N + rrow];
+    if (ra.which[g]) {
+      const GpDev& gp = gps[g];
+      const KernFast<D> kf(gp.kern);
+      double xs[D];
+      kf.prep(x, xs);
+      const double* Xj = gp.Xs + (lane >> 4) * D;
+      const double* w = gp.upd_w + (lane >> 4);
+      double dot = 0.0;
+      const int nsteps = gp.n_pad >> 2;
+#pragma unroll 4
+      for (int s = 0; s < nsteps; ++s)
+        dot = fma(w[s * 4], kf(xs, Xj + s * 4 * D, tab), dot);
+      dot = sum_lane_groups(dot);
+      const double cx = kf.raw(x, gp.upd + 2, tab) - dot;
+      mean = fma(cx, gp.upd[0], mean);
+      var = fmax(var - cx * cx * gp.upd[1], 1e-15);
+      if (writer) {
+        ra.mean[int64_t(g) * pts.N + row] = mean;
+        ra.var[int64_t(g) * pts.N + row] = var;
+      }
+    }
+    const double sd = sqrt(var);
+    const double lo = mean - ra.beta * sd;
+    const double up = mean + ra.beta * sd;
+    if (g == 0) l0 = lo;
+    safe = safe && (lo > ra.fmin[g]);
+    if (writer) {
+      const double2 q = make_double2(lo, up);
+      *reinterpret_cast<double2*>(ra.Q + (row * G + g) * 2) = q;
+    }
+  }
+  if (writer) ra.S[row] = safe ? 1 : 0;
+  double v = (writer && safe) ? l0 : -INFINITY;
+  v = wave_max(v);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (tid == 0)
+    ra.partial[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
 // ---- fp64 issue-rate microbenchmarks ---------------------------------------------
 // MODE 0: 8 independent MFMA chains   1: 4 chains   2: 8 chains + 8 v_fma_f64
 // per MFMA   3: v_fma_f64 only (16 chains)   4: 8 MFMA chains + 2 v_fma_f64 per
@@ -616,6 +687,29 @@ int run_microbench(sgp_ctx* ctx, int iters, int lds_bytes, int nblocks,
 }
 
 // tflops[0] = MFMA flops rate, tflops[1] = VALU FMA flops rate
+int rank1_num_blocks(int64_t N) { return int((N + 63) / 64); }
+
+int launch_rank1(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d,
+                 SweepPoints pts, Rank1Args ra) {
+  if (pts.N <= 0) return 0;
+  const int nblocks = rank1_num_blocks(pts.N);
+#define R1_CASE(DD)                                                           \
+  case DD:                                                                    \
+    hipLaunchKernelGGL(k_rank1<DD>, dim3(nblocks), dim3(256), 0, ctx->stream, \
+                       gps_dev, G, pts, ra);                                  \
+    break;
+  switch (d) {
+    R1_CASE(1) R1_CASE(2) R1_CASE(3) R1_CASE(4)
+    R1_CASE(5) R1_CASE(6) R1_CASE(7) R1_CASE(8)
+    default:
+      sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
+      return -2;
+  }
+#undef R1_CASE
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
 int launch_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
                       double* tflops) {
   const int nblocks = ctx->num_cu * 8;

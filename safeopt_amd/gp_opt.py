@@ -166,6 +166,14 @@ class _HipGridBackend(object):
                                     global_offset)
         self.lo = int(global_offset)
         self.hi = self.lo + self.grid.N
+        # which data version of every GP the resident mean/var reflect
+        self._seen = [None] * len(gps)
+        self._rank1_streak = 0
+        #: after one new observation update the resident posterior in closed
+        #: form (O(n) per row) instead of re-running the O(n^2) sweep; a full
+        #: sweep is forced every `refresh_every` updates to bound the drift
+        self.incremental = True
+        self.refresh_every = 16
 
     def _dev(self):
         return [g._fitted() for g in self.gps]
@@ -175,11 +183,30 @@ class _HipGridBackend(object):
 
     def set_context(self, c):
         self.grid.set_context(c)
+        self._seen = [None] * len(self.gps)      # rows changed: full sweep
 
     def confidence(self, beta, fmin):
-        return self.grid.confidence(self._dev(), beta, fmin)
+        devs = self._dev()
+        tags = [(id(dv), dv.version) for dv in devs]
+        which = [0] * len(devs)
+        rank1 = self.incremental and self._rank1_streak < self.refresh_every
+        for i, dv in enumerate(devs):
+            if self._seen[i] == tags[i]:
+                continue                                  # up to date
+            if (rank1 and dv.appended and self._seen[i] is not None
+                    and self._seen[i] == (id(dv), dv.version - 1)):
+                which[i] = 1                              # one append behind
+            else:
+                rank1 = False
+        self._seen = tags
+        if rank1 and any(which):
+            self._rank1_streak += 1
+            return self.grid.rank1_update(devs, which, beta, fmin)
+        self._rank1_streak = 0
+        return self.grid.confidence(devs, beta, fmin)
 
     def upload_Q(self, Q, fmin):
+        self._seen = [None] * len(self.gps)      # mean/var no longer match Q
         return self.grid.upload_Q(Q, fmin)
 
     def maximizers(self, max_l):

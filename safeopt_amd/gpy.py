@@ -169,6 +169,10 @@ class GPRegression(object):
         self._ctx = _hip.Context.default(device)
         self._dev = None
         self._dev_key = None
+        self._dev_fitted = False
+        #: one-row changes of the data use bordered updates (set False to
+        #: re-factorise from scratch on every ``set_XY`` like GPy)
+        self.incremental = True
         self.X = X
         self.Y = Y
         self.set_XY(X, Y)
@@ -193,8 +197,21 @@ class GPRegression(object):
         Y = np.array(np.atleast_2d(Y), dtype=float)
         if X.shape[0] != Y.shape[0] or X.shape[1] != self.input_dim:
             raise ValueError("inconsistent X %r / Y %r" % (X.shape, Y.shape))
+        old_X, old_Y = self.X, self.Y
         self.X, self.Y = X, Y
         dev = self._device_gp()
+        n = X.shape[0]
+        # what SafeOpt does every iteration is one row more (or one fewer):
+        # bordered O(n^2) update instead of the O(n^3) re-factorisation
+        if self._dev_fitted and dev.n == old_X.shape[0] and self.incremental:
+            if (n == dev.n + 1 and np.array_equal(X[:-1], old_X)
+                    and np.array_equal(Y[:-1], old_Y)):
+                if dev.append(X[-1], Y[-1, 0]):
+                    return
+            elif (n == dev.n - 1 and n >= 1 and np.array_equal(X, old_X[:-1])
+                    and np.array_equal(Y, old_Y[:-1])):
+                dev.pop()
+                return
         dev.set_data(X, Y[:, 0])
         self._dev_fitted = True
 

@@ -429,3 +429,69 @@ def test_torchrun_launch_with_rccl(mods, tmp_path):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["roofline"]["achieved"] > 0
+
+
+# ---------------------------------------------------------------------------
+# one-row updates
+def test_append_pop_match_refit(mods):
+    """sgp_gp_append / sgp_gp_pop == a fresh fit, across the 16/32/64 padding
+    boundaries, and the rank-1 record is consistent with the oracle."""
+    _, gpy, gpn, _ = mods
+    rng = np.random.default_rng(21)
+    X = rng.uniform(-2, 2, size=(90, 2)); Y = smooth(X, 5)
+    Xs = rng.uniform(-3, 3, size=(500, 2))
+    gp = gpy.models.GPRegression(X[:29], Y[:29], kernels(gpy.kern, "Matern52", 2), noise_var=0.05 ** 2)
+    for n in range(30, 71):
+        v0 = gp._dev.version
+        gp.set_XY(X[:n], Y[:n])
+        assert gp._dev.appended and gp._dev.version == v0 + 1 and gp._dev.n == n
+        if n in (30, 31, 32, 33, 47, 48, 49, 63, 64, 65, 70):
+            go = gpn.GPRegression(X[:n], Y[:n], kernels(gpn, "Matern52", 2), noise_var=0.05 ** 2)
+            check_posterior(*gp.predict_noiseless(Xs), *go.predict_noiseless(Xs), 1.7)
+            Linv, alpha = gp._dev.factor()
+            assert np.max(np.abs(Linv - np.linalg.inv(go.L))) < 1e-8
+            assert np.max(np.abs(alpha - go.woodbury_vector.ravel())) < 1e-8 * np.max(np.abs(alpha))
+    for n in range(69, 40, -1):
+        gp.set_XY(X[:n], Y[:n])
+        assert not gp._dev.appended and gp._dev.n == n
+    go = gpn.GPRegression(X[:41], Y[:41], kernels(gpn, "Matern52", 2), noise_var=0.05 ** 2)
+    check_posterior(*gp.predict_noiseless(Xs), *go.predict_noiseless(Xs), 1.7)
+    # a change that is not a one-row append/pop refits
+    gp.set_XY(X[10:60], Y[10:60])
+    go = gpn.GPRegression(X[10:60], Y[10:60], kernels(gpn, "Matern52", 2), noise_var=0.05 ** 2)
+    check_posterior(*gp.predict_noiseless(Xs), *go.predict_noiseless(Xs), 1.7)
+    # duplicate point with (almost) no noise: bordered pivot ~ 0 -> falls back to a refit
+    g2 = gpy.models.GPRegression(X[:5], Y[:5], gpy.kern.RBF(2), noise_var=0.)
+    g2.set_XY(np.vstack([X[:5], X[4:5]]), np.vstack([Y[:5], Y[4:5]]))
+    assert np.isfinite(g2.predict_noiseless(Xs[:4])[0]).all()
+
+
+@pytest.mark.parametrize("name,last", [("safeopt_1d_rbf", 19), ("safeopt_2d_rbf", 11),
+                                       ("safeopt_1d_multi", 9), ("safeopt_2d_mat52_g3", 7)])
+def test_bo_loop_with_rank1_updates_matches_reference(mods, name, last):
+    """The whole sequential BO loop of the reference run (optimize -> measure ->
+    add_new_data_point), with every posterior after the first obtained by the
+    closed-form rank-1 update: same chosen parameter at every iteration."""
+    safeopt_amd, gpy, _, _ = mods
+    z, meta = load(name)
+    G = len(meta["kernels"])
+    gps = [gpy.models.GPRegression(z["it0_X%d" % i], z["it0_Y%d" % i], make_kernel(gpy.kern, spec),
+                                   noise_var=meta["noise_vars"][i])
+           for i, spec in enumerate(meta["kernels"])]
+    opt = safeopt_amd.SafeOpt(gps if G > 1 else gps[0], z["parameter_set"],
+                              meta["fmin"] if G > 1 else meta["fmin"][0], threshold=meta["threshold"])
+    n0 = z["it0_X0"].shape[0]
+    Yall = np.hstack([z["it%d_Y%d" % (last, i)] for i in range(G)])
+    for t in range(last + 1):
+        x = opt.optimize()
+        assert_array_equal(x, z["x_next_all"][t]), t
+        if t in meta["recorded"]:
+            assert_allclose(opt.Q, z["it%d_Q" % t], rtol=0, atol=1e-8)
+            assert_array_equal(opt.S, z["it%d_S" % t]); assert_array_equal(opt.M, z["it%d_M" % t])
+            assert_array_equal(opt.G, z["it%d_G" % t])
+        if t < last:
+            opt.add_new_data_point(x, Yall[n0 + t][None, :])
+    assert opt._backend._rank1_streak > 0          # the incremental path really ran
+    # remove_last_data_point -> pop -> full sweep again
+    opt.remove_last_data_point()
+    assert_array_equal(opt.optimize(), z["x_next_all"][last - 1])
