@@ -506,6 +506,7 @@ __global__ __launch_bounds__(256) void k_rank1(const GpDev* gps, int G,
 }
 
 // ---- fp64 issue-rate microbenchmarks ---------------------------------------------
+// MODE 6: 16 chains of v_mfma_f64_4x4x4_4b_f64 (512 flop each)
 // MODE 0: 8 independent MFMA chains   1: 4 chains   2: 8 chains + 8 v_fma_f64
 // per MFMA   3: v_fma_f64 only (16 chains)   4: 8 MFMA chains + 2 v_fma_f64 per
 // MFMA   5: 16 MFMA chains
@@ -522,7 +523,11 @@ __global__ __launch_bounds__(256) void k_mfma_bench(double* out, int iters) {
   const double av = 1.0 + threadIdx.x * 1e-9, bv = 1.0 - threadIdx.x * 1e-9;
   const double m = 0.999999, c = 1e-7;
   for (int it = 0; it < iters; ++it) {
-    if (MODE != 3) {
+    if (MODE == 6) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        f[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, f[j], 0, 0, 0);
+    } else if (MODE != 3) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i], 0, 0, 0);
@@ -725,6 +730,7 @@ int launch_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
     case 3: SGP_TRY(run_microbench<3>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 0; valu_per_it = 64; break;
     case 4: SGP_TRY(run_microbench<4>(ctx, iters, lds_bytes, nblocks, out, &ms)); valu_per_it = 16; break;
     case 5: SGP_TRY(run_microbench<5>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 16; break;
+    case 6: SGP_TRY(run_microbench<6>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;  // 16 x 512 flop
     default: sgp_set_error(ctx, "unknown microbench mode %d", mode); return -2;
   }
   const double waves = double(nblocks) * 4.0;
