@@ -221,6 +221,11 @@ int sgp_microbench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops);
 /* issue-rate probes: mode 0/1/5 = 8/4/16 MFMA chains, 2/4 = MFMA + 8/2 v_fma_f64
  * per MFMA, 3 = v_fma_f64 only; lds_bytes of dynamic LDS only limit residency.
  * tflops2 = { MFMA TFLOP/s, VALU-FMA TFLOP/s }                               */
+/* operand-layout probe (test hook): ONE v_mfma_f64_16x16x4_f64 (which = 0;
+ * c, d hold 4 values per lane) or v_mfma_f64_4x4x4_4b_f64 (which = 1; 1 value
+ * per lane) with the given per-lane operands                                  */
+int sgp_probe_mfma(sgp_ctx* ctx, int which, const double* a64, const double* b64,
+                   const double* c, double* d);
 int sgp_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
                    double* tflops2);
 

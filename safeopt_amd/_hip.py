@@ -98,6 +98,8 @@ PROTOTYPES = {
     "sgp_profile_read": (C.c_int, [vp, c_double_p, c_i64_p, c_double_p]),
     "sgp_microbench_mfma_f64": (C.c_int, [vp, C.c_int, c_double_p]),
     "sgp_microbench": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_double_p]),
+    "sgp_probe_mfma": (C.c_int, [vp, C.c_int, c_double_p, c_double_p,
+                                 c_double_p, c_double_p]),
 }
 
 _lib = None
@@ -227,6 +229,15 @@ class Context(object):
         t = C.c_double(0)
         self.check(lib().sgp_microbench_mfma_f64(self.h, iters, C.byref(t)))
         return t.value
+
+    def probe_mfma(self, which, a, b, c=None):
+        a, b = f64(a).reshape(64), f64(b).reshape(64)
+        nc = 256 if which == 0 else 64
+        c = np.zeros(nc) if c is None else f64(c).reshape(nc)
+        d = np.empty(nc)
+        self.check(lib().sgp_probe_mfma(self.h, which, dptr(a), dptr(b),
+                                        dptr(c), dptr(d)))
+        return d
 
     def microbench(self, mode, iters=20000, lds_bytes=0):
         t = np.zeros(2)

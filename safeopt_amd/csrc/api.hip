@@ -961,6 +961,19 @@ int sgp_microbench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops) {
   return 0;
 }
 
+int sgp_probe_mfma(sgp_ctx* ctx, int which, const double* a64, const double* b64,
+                   const double* c, double* d) {
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  const int nc = which == 0 ? 256 : 64;
+  double* buf = static_cast<double*>(sgp_scratch(ctx, 0, (128 + 2 * 256) * 8));
+  SGP_CHECK(ctx, buf, "device allocation failed: %s", ctx->err.c_str());
+  SGP_TRY(sgp_h2d(ctx, buf, a64, 64 * 8));
+  SGP_TRY(sgp_h2d(ctx, buf + 64, b64, 64 * 8));
+  SGP_TRY(sgp_h2d(ctx, buf + 128, c, size_t(nc) * 8));
+  SGP_TRY(launch_probe_mfma(ctx, which, buf, buf + 64, buf + 128, buf + 384));
+  return sgp_d2h(ctx, d, buf + 384, size_t(nc) * 8);
+}
+
 int sgp_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
                    double* tflops2) {
   SGP_HIP(ctx, hipSetDevice(ctx->device));

@@ -209,6 +209,8 @@ struct Rank1Args {
   double fmin[SGP_MAX_GPS];
   int which[SGP_MAX_GPS];
 };
+int launch_probe_mfma(sgp_ctx* ctx, int which, const double* a, const double* b,
+                      const double* c, double* d);
 int rank1_num_blocks(int64_t N);
 int launch_rank1(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d,
                  SweepPoints pts, Rank1Args ra);

@@ -505,6 +505,19 @@ __global__ __launch_bounds__(256) void k_rank1(const GpDev* gps, int G,
     ra.partial[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
+// ---- operand-layout probe (test hook): one MFMA with caller-given lane values ------
+__global__ void k_probe_mfma(int which, const double* a, const double* b,
+                             const double* c, double* d) {
+  const int l = threadIdx.x;
+  if (which == 0) {
+    double4_t acc = {c[l * 4], c[l * 4 + 1], c[l * 4 + 2], c[l * 4 + 3]};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[l], b[l], acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) d[l * 4 + r] = acc[r];
+  } else {
+    d[l] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[l], b[l], c[l], 0, 0, 0);
+  }
+}
+
 // ---- fp64 issue-rate microbenchmarks ---------------------------------------------
 // MODE 6: 16 chains of v_mfma_f64_4x4x4_4b_f64 (512 flop each)
 // MODE 0: 8 independent MFMA chains   1: 4 chains   2: 8 chains + 8 v_fma_f64
@@ -692,6 +705,14 @@ int run_microbench(sgp_ctx* ctx, int iters, int lds_bytes, int nblocks,
 }
 
 // tflops[0] = MFMA flops rate, tflops[1] = VALU FMA flops rate
+int launch_probe_mfma(sgp_ctx* ctx, int which, const double* a, const double* b,
+                      const double* c, double* d) {
+  hipLaunchKernelGGL(k_probe_mfma, dim3(1), dim3(64), 0, ctx->stream, which, a,
+                     b, c, d);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
 int rank1_num_blocks(int64_t N) { return int((N + 63) / 64); }
 
 int launch_rank1(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d,
