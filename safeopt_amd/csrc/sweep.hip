@@ -60,7 +60,7 @@ __device__ __forceinline__ void stage_dma(const GpDev& gp, double* buf, int b0,
     const int piece = wave + NW * k;      // wave-uniform
     const int slot = piece >> 1;
     const int half = piece & 1;
-    if (slot >= shift && slot >= (lo & ~1)) {
+    if (slot >= lo) {
       const int bg = b0 + slot - shift;
       const double* src = gp.Apack +
           (int64_t(bg) * nsteps_total + jb * kSteps + 2 * half) * 64 + lane * 2;
@@ -90,41 +90,54 @@ __device__ __forceinline__ void stage_x_store(double v, double* buf, int D,
   }
 }
 
-// A operands of slots b, b+1 for the 4 k-steps of the staged j-block.
-__device__ __forceinline__ void load_ops(double (&ops)[8], const double* aT,
-                                         int b) {
+// ---- matrix part ------------------------------------------------------------------
+// v_mfma_f64_4x4x4_4b_f64 is the fp64 matrix instruction that reaches the chip's
+// peak on gfx950 (74.6 TFLOP/s measured vs 49 for v_mfma_f64_16x16x4_f64,
+// scripts/microbench.py).  Its operand maps (scripts/probe_mfma_layout.py):
+//   A[blk][i][k] <- lane 16k + 4blk + i     B[blk][k][j] <- lane 16k + 4blk + j
+//   D[blk][i][j] -> lane 16i + 4blk + j
+// With n = 4 blk + j the B and D maps are those of the 16x16x4 shape (k or row
+// = lane >> 4, column = lane & 15), i.e. one instruction is a 4-row x 16-column
+// x 4-deep product whose 4x4 A block is replicated over blk.  A 16-row block of
+// L^-1 therefore takes four instructions (r = 0..3, rows 4r..4r+3) on the four
+// components of the same accumulator the 16x16x4 form used, fed by the SAME
+// covariance register; the A block comes from LDS with a broadcast read
+// (address depends on lane>>4 and lane&3 only).
+//
+// One "group" = slot s, k-step pair sp: 4 ds_read_b128 (r = 0..3; each lane gets
+// the values of both steps) -> 8 MFMAs.  Groups are guarded by wave-uniform
+// branches (active slots are a suffix) and software pipelined: the next
+// group's operands are read while this group's MFMAs execute.
+__device__ __forceinline__ void load_group(double (&ops)[8], const double* aL,
+                                           int slot, int sp) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    ops[2 * q] = aT[(b * kSteps + q) * 64];
-    ops[2 * q + 1] = aT[((b + 1) * kSteps + q) * 64];
+  for (int r = 0; r < 4; ++r) {
+    const double2 v = *reinterpret_cast<const double2*>(
+        aL + slot * 256 + sp * 128 + r * 32);
+    ops[2 * r] = v.x;
+    ops[2 * r + 1] = v.y;
   }
 }
 
-// One 16-wide j-block (4 MFMA k-steps) against accumulator slots lo..15.
-// Slots are visited in aligned pairs (2g, 2g+1) behind wave-uniform branches
-// (the active set is a suffix); every pair interleaves two independent
-// accumulator chains and the A operands of the next pair are fetched from LDS
-// while this pair's 8 MFMAs run.  For odd lo the lower slot of the first pair
-// multiplies a zero block (above-diagonal part of the packed matrix, or the
-// zero-filled slot below the first row block of the chunk).
 __device__ __forceinline__ void mfma_jblock(int lo, double4_t (&acc)[kIB],
-                                            const double* aT,
+                                            const double* aL,
                                             const double (&kv)[4]) {
   double opsA[8], opsB[8];
-  const int g0 = lo >> 1;
+  const int g0 = 2 * lo;
 #pragma unroll
-  for (int g = 0; g < kIB / 2; ++g) {
+  for (int g = 0; g < 2 * kIB; ++g) {
     if (g >= g0) {
       double(&cur)[8] = (g & 1) ? opsB : opsA;
       double(&nxt)[8] = (g & 1) ? opsA : opsB;
-      if (g == g0) load_ops(cur, aT, 2 * g);
-      if (g + 1 < kIB / 2) load_ops(nxt, aT, 2 * g + 2);
+      const int slot = g >> 1, sp = g & 1;
+      if (g == g0) load_group(cur, aL, slot, sp);
+      if (g + 1 < 2 * kIB) load_group(nxt, aL, (g + 1) >> 1, (g + 1) & 1);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[2 * g] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-            cur[2 * q], kv[q], acc[2 * g], 0, 0, 0);
-        acc[2 * g + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-            cur[2 * q + 1], kv[q], acc[2 * g + 1], 0, 0, 0);
+      for (int e = 0; e < 2; ++e) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[slot][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+              cur[2 * r + e], kv[2 * sp + e], acc[slot][r], 0, 0, 0);
       }
     }
   }
@@ -160,13 +173,6 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
 #pragma unroll
     for (int b = 0; b < kIB; ++b) acc[b] = double4_t{0.0, 0.0, 0.0, 0.0};
 
-    if (shift & 1) {
-      // the slot below the first row block pairs with it: keep it zero
-      for (int i = tid; i < kSteps * 64; i += 64 * NW) {
-        lds[(shift - 1) * kSteps * 64 + i] = 0.0;
-        lds[kBuf + (shift - 1) * kSteps * 64 + i] = 0.0;
-      }
-    }
     stage_dma<NW>(gp, lds, b0, shift, 0, shift, tid);
     stage_x_store(stage_x_load(gp, D, 0, tid), lds, D, tid);
     __syncthreads();
@@ -195,7 +201,7 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
           mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
       }
       const int lo = shift + max(0, jb - b0);
-      mfma_jblock(lo, acc, cur + lane, kv);
+      mfma_jblock(lo, acc, cur + (lane >> 4) * 8 + (lane & 3) * 2, kv);
 
       if (more) stage_x_store(xstage, nxt, D, tid);
       __syncthreads();
