@@ -542,10 +542,14 @@ __global__ __launch_bounds__(256) void k_mfma_bench(double* out, int iters) {
   const double av = 1.0 + threadIdx.x * 1e-9, bv = 1.0 - threadIdx.x * 1e-9;
   const double m = 0.999999, c = 1e-7;
   for (int it = 0; it < iters; ++it) {
-    if (MODE == 6) {
+    if (MODE == 6 || MODE == 7 || MODE == 8) {
+      // 16 / 4 / 2 independent chains, 16 instructions per iteration
+      constexpr int NC = (MODE == 6) ? 16 : (MODE == 7 ? 4 : 2);
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        f[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, f[j], 0, 0, 0);
+      for (int rep = 0; rep < 16 / NC; ++rep)
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+          f[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, f[j], 0, 0, 0);
     } else if (MODE != 3) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
@@ -758,6 +762,8 @@ int launch_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
     case 4: SGP_TRY(run_microbench<4>(ctx, iters, lds_bytes, nblocks, out, &ms)); valu_per_it = 16; break;
     case 5: SGP_TRY(run_microbench<5>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 16; break;
     case 6: SGP_TRY(run_microbench<6>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;  // 16 x 512 flop
+    case 7: SGP_TRY(run_microbench<7>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;
+    case 8: SGP_TRY(run_microbench<8>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;
     default: sgp_set_error(ctx, "unknown microbench mode %d", mode); return -2;
   }
   const double waves = double(nblocks) * 4.0;
