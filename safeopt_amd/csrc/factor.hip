@@ -218,30 +218,21 @@ int factor_rec(sgp_ctx* ctx, double* A, double* Li, double* T, int64_t ld,
 }
 
 // ---- pack L^-1 into MFMA A-operand order ----------------------------------------
-// One 2 KB record per (16-row block b, 16-column block jb), stored in exactly
-// the order the sweep's ds_read_b128 of v_mfma_f64_4x4x4_4b_f64 A operands
-// wants it:  within = (((sp*4 + r)*4 + k)*4 + i)*2 + e  holds
-//   Linv[16 b + 4 r + i][16 jb + 4 (2 sp + e) + k]
-// (r = 4-row group = accumulator component, k = lane >> 4, i = lane & 3,
-// sp/e = k-step pair / step inside the pair).  Zero outside the n x n lower
-// triangle.
+// Apack[(b * nsteps + s) * 64 + lane] = Linv[16 b + (lane & 15)][4 s + (lane >> 4)]
+// (zero outside the n x n lower triangle): lane = 16 k + row, which is the A
+// operand map of v_mfma_f64_16x16x4_f64 AND of v_mfma_f64_4x4x4_4b_f64 when its
+// four blocks are four 4-row groups (A[blk][i][k] <- lane 16k + 4blk + i).
 __global__ void k_pack(const double* Li, int64_t ld, int n, int nblk,
                        int nsteps, double* Apack) {
   const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t total = int64_t(nblk) * nsteps * 64;
   if (e >= total) return;
-  const int within = int(e & 255);
-  const int64_t rec = e >> 8;
-  const int njb = nsteps >> 2;
-  const int jb = int(rec % njb);
-  const int b = int(rec / njb);
-  const int e2 = within & 1;
-  const int ii = (within >> 1) & 3;
-  const int kk = (within >> 3) & 3;
-  const int r = (within >> 5) & 3;
-  const int sp = within >> 7;
-  const int i = 16 * b + 4 * r + ii;
-  const int j = 16 * jb + 4 * (2 * sp + e2) + kk;
+  const int lane = int(e & 63);
+  const int64_t bs = e >> 6;
+  const int s = int(bs % nsteps);
+  const int b = int(bs / nsteps);
+  const int i = 16 * b + (lane & 15);
+  const int j = 4 * s + (lane >> 4);
   double v = 0.0;
   if (i < n && j <= i) v = Li[int64_t(i) * ld + j];
   Apack[e] = v;

@@ -96,48 +96,64 @@ __device__ __forceinline__ void stage_x_store(double v, double* buf, int D,
 // scripts/microbench.py).  Its operand maps (scripts/probe_mfma_layout.py):
 //   A[blk][i][k] <- lane 16k + 4blk + i     B[blk][k][j] <- lane 16k + 4blk + j
 //   D[blk][i][j] -> lane 16i + 4blk + j
-// With n = 4 blk + j the B and D maps are those of the 16x16x4 shape (k or row
-// = lane >> 4, column = lane & 15), i.e. one instruction is a 4-row x 16-column
-// x 4-deep product whose 4x4 A block is replicated over blk.  A 16-row block of
-// L^-1 therefore takes four instructions (r = 0..3, rows 4r..4r+3) on the four
-// components of the same accumulator the 16x16x4 form used, fed by the SAME
-// covariance register; the A block comes from LDS with a broadcast read
-// (address depends on lane>>4 and lane&3 only).
-//
-// One "group" = slot s, k-step pair sp: 4 ds_read_b128 (r = 0..3; each lane gets
-// the values of both steps) -> 8 MFMAs.  Groups are guarded by wave-uniform
-// branches (active slots are a suffix) and software pipelined: the next
-// group's operands are read while this group's MFMAs execute.
-__device__ __forceinline__ void load_group(double (&ops)[8], const double* aL,
-                                           int slot, int sp) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const double2 v = *reinterpret_cast<const double2*>(
-        aL + slot * 256 + sp * 128 + r * 32);
-    ops[2 * r] = v.x;
-    ops[2 * r + 1] = v.y;
+// Used with blk = 4-row group: the A operand is then the SAME register the
+// 16x16x4 form takes (lane = 16k + row, row = 4blk + i), one instruction is a
+// 16-row x 4-column x 4-deep product, and a 16-column slab needs four of them
+// (m = 0..3) whose B operands are the covariance register with column quad m
+// broadcast to all four quads of each 16-lane row -- two ds_swizzle_b32 per
+// operand, done once per k-step and reused by every row block.  Accumulator
+// component m of a slot holds rows 4((l>>2)&3) + (l>>4), column 4m + (l&3).
+__device__ __forceinline__ double quad_bcast(double v, int m) {
+  // src lane = (lane & 0b110011) | (m << 2)   (BITMASK_PERM: and 0x13, or m<<2)
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  int slo, shi;
+  switch (m) {
+    case 0: slo = __builtin_amdgcn_ds_swizzle(lo, 0x13 | (0 << 5));
+            shi = __builtin_amdgcn_ds_swizzle(hi, 0x13 | (0 << 5)); break;
+    case 1: slo = __builtin_amdgcn_ds_swizzle(lo, 0x13 | (4 << 5));
+            shi = __builtin_amdgcn_ds_swizzle(hi, 0x13 | (4 << 5)); break;
+    case 2: slo = __builtin_amdgcn_ds_swizzle(lo, 0x13 | (8 << 5));
+            shi = __builtin_amdgcn_ds_swizzle(hi, 0x13 | (8 << 5)); break;
+    default: slo = __builtin_amdgcn_ds_swizzle(lo, 0x13 | (12 << 5));
+             shi = __builtin_amdgcn_ds_swizzle(hi, 0x13 | (12 << 5)); break;
   }
+  return __hiloint2double(shi, slo);
 }
 
+// A operands of one slot: the 4 k-steps of the staged j-block.
+__device__ __forceinline__ void load_slot(double (&ops)[4], const double* aT,
+                                          int slot) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) ops[q] = aT[(slot * kSteps + q) * 64];
+}
+
+// One 16-wide j-block against accumulator slots lo..15.  Slots are guarded by
+// wave-uniform branches (the active set is a suffix); a slot is 16 MFMAs on
+// four independent accumulators, and the next slot's A operands are read from
+// LDS while they execute.
 __device__ __forceinline__ void mfma_jblock(int lo, double4_t (&acc)[kIB],
-                                            const double* aL,
+                                            const double* aT,
                                             const double (&kv)[4]) {
-  double opsA[8], opsB[8];
-  const int g0 = 2 * lo;
+  double kb[4][4];  // [k-step][column quad]
 #pragma unroll
-  for (int g = 0; g < 2 * kIB; ++g) {
-    if (g >= g0) {
-      double(&cur)[8] = (g & 1) ? opsB : opsA;
-      double(&nxt)[8] = (g & 1) ? opsA : opsB;
-      const int slot = g >> 1, sp = g & 1;
-      if (g == g0) load_group(cur, aL, slot, sp);
-      if (g + 1 < 2 * kIB) load_group(nxt, aL, (g + 1) >> 1, (g + 1) & 1);
+  for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
+    for (int m = 0; m < 4; ++m) kb[q][m] = quad_bcast(kv[q], m);
+
+  double opsA[4], opsB[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc[slot][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
-              cur[2 * r + e], kv[2 * sp + e], acc[slot][r], 0, 0, 0);
+  for (int s = 0; s < kIB; ++s) {
+    if (s >= lo) {
+      double(&cur)[4] = (s & 1) ? opsB : opsA;
+      double(&nxt)[4] = (s & 1) ? opsA : opsB;
+      if (s == lo) load_slot(cur, aT, s);
+      if (s + 1 < kIB) load_slot(nxt, aT, s + 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[s][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(cur[q], kb[q][m],
+                                                         acc[s][m], 0, 0, 0);
       }
     }
   }
@@ -155,7 +171,7 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int nchunks = (gp.nblk + kIB - 1) / kIB;
-  double sumsq = 0.0, mean = 0.0;
+  double sq[4] = {0.0, 0.0, 0.0, 0.0}, mean = 0.0;
 
   const KernFast<D> kf(gp.kern);
   double xs[D];
@@ -201,7 +217,7 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
           mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
       }
       const int lo = shift + max(0, jb - b0);
-      mfma_jblock(lo, acc, cur + (lane >> 4) * 8 + (lane & 3) * 2, kv);
+      mfma_jblock(lo, acc, cur + lane, kv);
 
       if (more) stage_x_store(xstage, nxt, D, tid);
       __syncthreads();
@@ -210,11 +226,24 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
 #pragma unroll
     for (int b = 0; b < kIB; ++b) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sumsq = fma(acc[b][r], acc[b][r], sumsq);
+      for (int m = 0; m < 4; ++m) sq[m] = fma(acc[b][m], acc[b][m], sq[m]);
     }
   }
 
-  sumsq = sum_lane_groups(sumsq);
+  // sq[m] holds partial sums for column 4m + (lane & 3) over this lane's rows:
+  // fold the 16 lanes that share (lane & 3), then pick the quad of this lane's
+  // own column (lane & 15) = 4 ((lane >> 2) & 3) + (lane & 3).
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    double v = sq[m];
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    sq[m] = v;
+  }
+  const int mq = (lane >> 2) & 3;
+  double sumsq = (mq == 0) ? sq[0] : (mq == 1) ? sq[1] : (mq == 2) ? sq[2] : sq[3];
   mean = sum_lane_groups(mean);
   mean_out = mean;
   var_out = fmax(gp.kern.kdiag - sumsq, 1e-15);  // GPy: clip(var, 1e-15, inf)
