@@ -18,6 +18,8 @@
 // are processed in chunks of 16 MFMA row blocks (256 rows) held in 16
 // accumulators per wave; the triangular structure is exploited at 16x16 block
 // granularity (a j-block only feeds row blocks >= its own index).
+#include <stdlib.h>
+
 #include "kern_eval.h"
 
 namespace {
@@ -38,6 +40,8 @@ struct SweepParams {
   const GpDev* gps;
   int G;
   int mode;
+  int ablate;  // timing experiments only (SGP_ABLATE): 1 no eval, 2 no MFMA,
+               // 4 no staging/barrier in the j loop
   SweepPoints pts;
   ConfOut conf;
   FitnessArgs fit;
@@ -166,7 +170,7 @@ template <int D, int NW>
 __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
                                                  const double (&x)[D],
                                                  double* lds, double& mean_out,
-                                                 double& var_out) {
+                                                 double& var_out, int ablate) {
   const double* tab = lds + kTabOff;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -199,7 +203,7 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
       double* nxt = lds + ((jb & 1) ^ 1) * kBuf;
       const bool more = (jb + 1 < njb);
       double xstage = 0.0;
-      if (more) {
+      if (more && !(ablate & 4)) {
         const int lo_n = shift + max(0, jb + 1 - b0);
         stage_dma<NW>(gp, nxt, b0, shift, jb + 1, lo_n, tid);
         xstage = stage_x_load(gp, D, jb + 1, tid);
@@ -208,19 +212,31 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
       const double* xT = cur + kATile;
       const double* alT = cur + kATile + kXTile;
       double kv[4];
+      if (ablate & 1) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        kv[q] = kf(xs, xT + (q * 4 + (lane >> 4)) * D, tab);
+        for (int q = 0; q < 4; ++q) kv[q] = xs[0] * 1e-3 + q;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          kv[q] = kf(xs, xT + (q * 4 + (lane >> 4)) * D, tab);
+      }
       if (last) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
       }
       const int lo = shift + max(0, jb - b0);
-      mfma_jblock(lo, acc, cur + lane, kv);
+      if (!(ablate & 2)) {
+        mfma_jblock(lo, acc, cur + lane, kv);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q][0] += kv[q];
+      }
 
-      if (more) stage_x_store(xstage, nxt, D, tid);
-      __syncthreads();
+      if (!(ablate & 4)) {
+        if (more) stage_x_store(xstage, nxt, D, tid);
+        __syncthreads();
+      }
     }
 
 #pragma unroll
@@ -291,7 +307,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
 #pragma unroll 1
   for (int g = 0; g < Geff; ++g) {
     double mean, var;
-    posterior_one_gp<D, NW>(p.gps[g], x, lds, mean, var);
+    posterior_one_gp<D, NW>(p.gps[g], x, lds, mean, var, p.ablate);
     const double sd = sqrt(var);
     if (conf) {
       // update_confidence_intervals + compute_safe_set (gp_opt.py:453-481)
@@ -682,6 +698,7 @@ int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
   SweepParams p;
   p.gps = gps_dev;
   p.G = G;
+  p.ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
   p.mode = MODE_CONF;
   p.pts = pts;
   p.conf = out;
@@ -695,6 +712,7 @@ int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,
   SweepParams p;
   p.gps = gps_dev;
   p.G = G;
+  p.ablate = 0;
   p.mode = MODE_FITNESS;
   p.pts = pts;
   p.conf = ConfOut{};
