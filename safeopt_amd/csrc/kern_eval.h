@@ -125,6 +125,48 @@ struct KernFast {
     return kern_eval<D>(*kd, xs, ys);
   }
 
+  // NV evaluations in one go: ys[q] = rows q*stride of the (pre-scaled when
+  // `single`) training inputs.  The kind switch sits OUTSIDE the loop so the NV
+  // dependent chains (distance, exp polynomial) are interleaved by the
+  // scheduler instead of running one after the other.
+  template <int NV>
+  __device__ __forceinline__ void many(const double* xs, const double* ys,
+                                       int stride, const double* tab,
+                                       double (&out)[NV]) const {
+    if (single) {
+      double r2[NV];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        r2[q] = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          const double t = xs[i] - ys[q * stride + i];
+          r2[q] = fma(t, t, r2[q]);
+        }
+      }
+      if (kind0 == SGP_RBF) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) out[q] = var0 * exp_tab(-0.5 * r2[q], tab);
+      } else if (kind0 == SGP_MATERN32) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const double a = 1.7320508075688772 * sqrt(r2[q]);
+          out[q] = var0 * (1.0 + a) * exp_tab(-a, tab);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const double a = 2.23606797749979 * sqrt(r2[q]);
+          out[q] = var0 * (1.0 + a + (5.0 / 3.0) * r2[q]) * exp_tab(-a, tab);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NV; ++q)
+        out[q] = kern_eval<D>(*kd, xs, ys + q * stride);
+    }
+  }
+
   // both arguments raw (unscaled) rows
   __device__ __forceinline__ double raw(const double* x, const double* y,
                                         const double* tab) const {

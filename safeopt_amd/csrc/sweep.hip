@@ -216,9 +216,7 @@ __device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
 #pragma unroll
         for (int q = 0; q < 4; ++q) kv[q] = xs[0] * 1e-3 + q;
       } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          kv[q] = kf(xs, xT + (q * 4 + (lane >> 4)) * D, tab);
+        kf.template many<4>(xs, xT + (lane >> 4) * D, 4 * D, tab, kv);
       }
       if (last) {
 #pragma unroll
@@ -454,8 +452,7 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
       double a[4], kv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) a[q] = W[(s0 + q) * 64];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) kv[q] = kf(xs, Xj + (s0 + q) * 4 * D, tab);
+      kf.template many<4>(xs, Xj + s0 * 4 * D, 4 * D, tab, kv);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], kv[q], acc, 0, 0, 0);
@@ -525,9 +522,13 @@ __global__ __launch_bounds__(256) void k_rank1(const GpDev* gps, int G,
       const double* w = gp.upd_w + (lane >> 4);
       double dot = 0.0;
       const int nsteps = gp.n_pad >> 2;
-#pragma unroll 4
-      for (int s = 0; s < nsteps; ++s)
-        dot = fma(w[s * 4], kf(xs, Xj + s * 4 * D, tab), dot);
+#pragma unroll 1
+      for (int s = 0; s < nsteps; s += 4) {   // n_pad is a multiple of 16
+        double kq[4];
+        kf.template many<4>(xs, Xj + s * 4 * D, 4 * D, tab, kq);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dot = fma(w[(s + q) * 4], kq[q], dot);
+      }
       dot = sum_lane_groups(dot);
       const double cx = kf.raw(x, gp.upd + 2, tab) - dot;
       mean = fma(cx, gp.upd[0], mean);
