@@ -18,8 +18,6 @@
 // are processed in chunks of 16 MFMA row blocks (256 rows) held in 16
 // accumulators per wave; the triangular structure is exploited at 16x16 block
 // granularity (a j-block only feeds row blocks >= its own index).
-#include <stdlib.h>
-
 #include "kern_eval.h"
 
 namespace {
@@ -40,8 +38,6 @@ struct SweepParams {
   const GpDev* gps;
   int G;
   int mode;
-  int ablate;  // timing experiments only (SGP_ABLATE): 1 no eval, 2 no MFMA,
-               // 4 no staging/barrier in the j loop
   SweepPoints pts;
   ConfOut conf;
   FitnessArgs fit;
@@ -163,106 +159,6 @@ __device__ __forceinline__ void mfma_jblock(int lo, double4_t (&acc)[kIB],
   }
 }
 
-// Posterior mean / variance of one GP at this lane's candidate row.
-// Must be called by every thread of the workgroup (contains barriers).
-// On return every lane holds the values of row (lane & 15) of its wave.
-template <int D, int NW>
-__device__ __forceinline__ void posterior_one_gp(const GpDev& gp,
-                                                 const double (&x)[D],
-                                                 double* lds, double& mean_out,
-                                                 double& var_out, int ablate) {
-  const double* tab = lds + kTabOff;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int nchunks = (gp.nblk + kIB - 1) / kIB;
-  double sq[4] = {0.0, 0.0, 0.0, 0.0}, mean = 0.0;
-
-  const KernFast<D> kf(gp.kern);
-  double xs[D];
-  kf.prep(x, xs);
-
-#pragma unroll 1
-  for (int c = 0; c < nchunks; ++c) {
-    const int b0 = c * kIB;
-    const int nib = min(kIB, gp.nblk - b0);
-    const int shift = kIB - nib;
-    const int njb = b0 + nib;                  // j-blocks feeding this chunk
-    const bool last = (c == nchunks - 1);
-
-    double4_t acc[kIB];
-#pragma unroll
-    for (int b = 0; b < kIB; ++b) acc[b] = double4_t{0.0, 0.0, 0.0, 0.0};
-
-    stage_dma<NW>(gp, lds, b0, shift, 0, shift, tid);
-    stage_x_store(stage_x_load(gp, D, 0, tid), lds, D, tid);
-    __syncthreads();
-
-#pragma unroll 1
-    for (int jb = 0; jb < njb; ++jb) {
-      double* cur = lds + (jb & 1) * kBuf;
-      double* nxt = lds + ((jb & 1) ^ 1) * kBuf;
-      const bool more = (jb + 1 < njb);
-      double xstage = 0.0;
-      if (more && !(ablate & 4)) {
-        const int lo_n = shift + max(0, jb + 1 - b0);
-        stage_dma<NW>(gp, nxt, b0, shift, jb + 1, lo_n, tid);
-        xstage = stage_x_load(gp, D, jb + 1, tid);
-      }
-
-      const double* xT = cur + kATile;
-      const double* alT = cur + kATile + kXTile;
-      double kv[4];
-      if (ablate & 1) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) kv[q] = xs[0] * 1e-3 + q;
-      } else {
-        kf.template many<4>(xs, xT + (lane >> 4) * D, 4 * D, tab, kv);
-      }
-      if (last) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
-      }
-      const int lo = shift + max(0, jb - b0);
-      if (!(ablate & 2)) {
-        mfma_jblock(lo, acc, cur + lane, kv);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q][0] += kv[q];
-      }
-
-      if (!(ablate & 4)) {
-        if (more) stage_x_store(xstage, nxt, D, tid);
-        __syncthreads();
-      }
-    }
-
-#pragma unroll
-    for (int b = 0; b < kIB; ++b) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) sq[m] = fma(acc[b][m], acc[b][m], sq[m]);
-    }
-  }
-
-  // sq[m] holds partial sums for column 4m + (lane & 3) over this lane's rows:
-  // fold the 16 lanes that share (lane & 3), then pick the quad of this lane's
-  // own column (lane & 15) = 4 ((lane >> 2) & 3) + (lane & 3).
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    double v = sq[m];
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    sq[m] = v;
-  }
-  const int mq = (lane >> 2) & 3;
-  double sumsq = (mq == 0) ? sq[0] : (mq == 1) ? sq[1] : (mq == 2) ? sq[2] : sq[3];
-  mean = sum_lane_groups(mean);
-  mean_out = mean;
-  var_out = fmax(gp.kern.kdiag - sumsq, 1e-15);  // GPy: clip(var, 1e-15, inf)
-}
-
 // SafeOptSwarm._compute_penalty (gp_opt.py:874-899) for one value.
 __device__ __forceinline__ double swarm_penalty(double slack) {
   double pen = fmin(slack, 0.0);
@@ -273,112 +169,266 @@ __device__ __forceinline__ double swarm_penalty(double slack) {
   return pen;
 }
 
+// Position in the flattened stage sequence of one workgroup:
+//   for tile: for gp: for chunk (16 row blocks of L^-1): for jb (16 columns)
+// A stage's LDS image (A chunk, X rows, alpha) depends on (gp, chunk, jb) only,
+// so the image of the NEXT stage is always prefetched while the current one is
+// consumed -- also across chunk, GP and tile boundaries.  The kernel is
+// persistent (one workgroup per CU walks over tiles) so that nothing but the
+// very first stage of a launch pays an exposed global -> LDS latency.
+struct StagePos {
+  int64_t tile;
+  int g, c, jb;
+  // derived, per (g, c)
+  int b0, nib, shift, njb, nchunks;
+};
+
+__device__ __forceinline__ void stage_derive(StagePos& sp, const GpDev* gps) {
+  const int nblk = gps[sp.g].nblk;
+  sp.nchunks = (nblk + kIB - 1) / kIB;
+  sp.b0 = sp.c * kIB;
+  sp.nib = min(kIB, nblk - sp.b0);
+  sp.shift = kIB - sp.nib;
+  sp.njb = sp.b0 + sp.nib;
+}
+
+// Advance to the following stage; returns false after the last stage of the
+// last tile of this workgroup.
+__device__ __forceinline__ bool stage_next(StagePos& sp, const GpDev* gps,
+                                           int Geff, int64_t ntiles,
+                                           int64_t tile_stride) {
+  if (++sp.jb < sp.njb) return true;
+  sp.jb = 0;
+  if (++sp.c >= sp.nchunks) {
+    sp.c = 0;
+    if (++sp.g >= Geff) {
+      sp.g = 0;
+      sp.tile += tile_stride;
+      if (sp.tile >= ntiles) return false;
+    }
+  }
+  stage_derive(sp, gps);
+  return true;
+}
+
+template <int NW>
+__device__ __forceinline__ void stage_issue(const StagePos& sp, const GpDev* gps,
+                                            double* buf, int D, int tid,
+                                            double& xstage) {
+  const GpDev& gp = gps[sp.g];
+  const int lo = sp.shift + max(0, sp.jb - sp.b0);
+  stage_dma<NW>(gp, buf, sp.b0, sp.shift, sp.jb, lo, tid);
+  xstage = stage_x_load(gp, D, sp.jb, tid);
+}
+
 template <int D, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   constexpr int kWaves = NW;
   constexpr int kTilePts = 16 * NW;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* red = lds + 2 * kBuf;  // all LDS lives in the one dynamic region
+  const double* tab = lds + kTabOff;
   exp_tab_init(lds + kTabOff);   // visible after the first staging barrier
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int64_t row = int64_t(blockIdx.x) * kTilePts + wave * 16 + (lane & 15);
-  const bool valid = row < p.pts.N;
-  const int64_t rrow = valid ? row : p.pts.N - 1;
-
-  double x[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k)
-    x[k] = p.pts.base[rrow * p.pts.stride_row + k * p.pts.stride_col];
-
-  const bool writer = valid && (lane < 16);
   const bool conf = p.mode == MODE_CONF;
   const int st = p.fit.swarm_type;
   const int Geff = (!conf && st == SGP_SWARM_GREEDY) ? 1 : p.G;
+  const int64_t ntiles = (p.pts.N + kTilePts - 1) / kTilePts;
 
-  // running state of the per-row epilogue (confidence sweep / swarm fitness)
+  StagePos cur;
+  cur.tile = blockIdx.x;
+  cur.g = cur.c = cur.jb = 0;
+  if (cur.tile >= ntiles) return;
+  stage_derive(cur, p.gps);
+
+  // candidate rows of the current tile (and, prefetched, of the next one)
+  auto load_x = [&](int64_t tile, double (&xo)[D]) {
+    int64_t r = tile * kTilePts + wave * 16 + (lane & 15);
+    r = r < p.pts.N ? r : p.pts.N - 1;
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      xo[k] = p.pts.base[r * p.pts.stride_row + k * p.pts.stride_col];
+  };
+  double x[D], xnext[D];
+  load_x(cur.tile, x);
+#pragma unroll
+  for (int k = 0; k < D; ++k) xnext[k] = x[k];
+
+  {
+    double xs0;
+    stage_issue<NW>(cur, p.gps, lds, D, tid, xs0);
+    stage_x_store(xs0, lds, D, tid);
+  }
+  __syncthreads();
+
+  // per-GP state
+  double xs[D];
+  double sq[4] = {0.0, 0.0, 0.0, 0.0}, mean = 0.0;
+  double4_t acc[kIB];
+#pragma unroll
+  for (int b = 0; b < kIB; ++b) acc[b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  // per-tile state of the row epilogue (confidence sweep / swarm fitness)
   bool safe = true;
   double l0 = 0.0, values = 0.0, interest = 1.0, total_pen = 0.0, lower = 0.0;
 
+  int bufsel = 0;
+  bool more = true;
 #pragma unroll 1
-  for (int g = 0; g < Geff; ++g) {
-    double mean, var;
-    posterior_one_gp<D, NW>(p.gps[g], x, lds, mean, var, p.ablate);
-    const double sd = sqrt(var);
-    if (conf) {
-      // update_confidence_intervals + compute_safe_set (gp_opt.py:453-481)
-      const double lo = mean - p.conf.beta * sd;
-      const double up = mean + p.conf.beta * sd;
-      if (g == 0) l0 = lo;
-      safe = safe && (lo > p.conf.fmin[g]);
-      if (writer) {
-        p.conf.mean[int64_t(g) * p.pts.N + row] = mean;
-        p.conf.var[int64_t(g) * p.pts.N + row] = var;
-        if (p.conf.Q) {
-          const double2 q = make_double2(lo, up);
-          *reinterpret_cast<double2*>(p.conf.Q + (row * p.G + g) * 2) = q;
+  while (more) {
+    const GpDev& gp = p.gps[cur.g];
+    const KernFast<D> kf(gp.kern);
+    if (cur.c == 0 && cur.jb == 0) kf.prep(x, xs);
+
+    double* cbuf = lds + bufsel * kBuf;
+    double* nbuf = lds + (bufsel ^ 1) * kBuf;
+
+    // prefetch the next stage (and the rows of the next tile)
+    StagePos nxt = cur;
+    more = stage_next(nxt, p.gps, Geff, ntiles, gridDim.x);
+    double xstage = 0.0;
+    if (more) stage_issue<NW>(nxt, p.gps, nbuf, D, tid, xstage);
+    const bool tile_ends = !more || nxt.tile != cur.tile;
+    const bool gp_ends = tile_ends || nxt.g != cur.g;
+    const bool chunk_ends = gp_ends || nxt.c != cur.c;
+    if (more && tile_ends) load_x(nxt.tile, xnext);
+
+    // this stage: 16 training points against the active row blocks
+    const double* xT = cbuf + kATile;
+    const double* alT = cbuf + kATile + kXTile;
+    double kv[4];
+    kf.template many<4>(xs, xT + (lane >> 4) * D, 4 * D, tab, kv);
+    if (cur.c == cur.nchunks - 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
+    }
+    mfma_jblock(cur.shift + max(0, cur.jb - cur.b0), acc, cbuf + lane, kv);
+
+    if (chunk_ends) {
+#pragma unroll
+      for (int b = 0; b < kIB; ++b) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          sq[m] = fma(acc[b][m], acc[b][m], sq[m]);
+          acc[b][m] = 0.0;
         }
       }
-    } else {
-      // SafeOptSwarm._compute_particle_fitness, gp_opt.py:925-1013
-      const FitnessArgs& f = p.fit;
-      lower = mean - f.beta * sd;
-      if (g == 0) {
-        values = sd / f.scaling[0];
-        if (st == SGP_SWARM_EXPANDERS) interest = double(p.G);
-        if (st == SGP_SWARM_MAXIMIZERS) {
-          const double upper = mean + f.beta * sd;
-          const double z = 10.0 * (upper - f.best_lower_bound) / f.scaling[0];
-          interest = 1.0 / (1.0 + exp(-z));  // scipy.special.expit
+    }
+
+    if (gp_ends) {
+      // sq[m]: partial sums for column 4m + (lane & 3) over this lane's rows.
+      // Fold the 16 lanes that share (lane & 3), then pick the quad of this
+      // lane's own column (lane & 15) = 4 ((lane >> 2) & 3) + (lane & 3).
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        double v = sq[m];
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        sq[m] = v;
+      }
+      const int mq = (lane >> 2) & 3;
+      const double sumsq =
+          (mq == 0) ? sq[0] : (mq == 1) ? sq[1] : (mq == 2) ? sq[2] : sq[3];
+      const double mu = sum_lane_groups(mean);
+      const double var = fmax(gp.kern.kdiag - sumsq, 1e-15);  // GPy clip
+      const double sd = sqrt(var);
+      sq[0] = sq[1] = sq[2] = sq[3] = 0.0;
+      mean = 0.0;
+
+      const int g = cur.g;
+      const int64_t row = cur.tile * kTilePts + wave * 16 + (lane & 15);
+      const bool writer = (row < p.pts.N) && (lane < 16);
+      if (conf) {
+        // update_confidence_intervals + compute_safe_set (gp_opt.py:453-481)
+        const double lo = mu - p.conf.beta * sd;
+        const double up = mu + p.conf.beta * sd;
+        if (g == 0) l0 = lo;
+        safe = safe && (lo > p.conf.fmin[g]);
+        if (writer) {
+          p.conf.mean[int64_t(g) * p.pts.N + row] = mu;
+          p.conf.var[int64_t(g) * p.pts.N + row] = var;
+          if (p.conf.Q) {
+            const double2 q = make_double2(lo, up);
+            *reinterpret_cast<double2*>(p.conf.Q + (row * p.G + g) * 2) = q;
+          }
         }
       } else {
-        values = fmax(values, sd / f.scaling[g]);
-      }
-      if (f.fmin[g] != -INFINITY) {
-        double slack = lower - f.fmin[g];
-        safe = safe && (slack >= 0.0);
-        if (st != SGP_SWARM_SAFE_SET) {
-          slack = slack / f.scaling[g];
-          total_pen += swarm_penalty(slack);
-          if (st == SGP_SWARM_EXPANDERS) {
-            // scipy.stats.norm.pdf(slack, scale=0.2)
-            const double z = slack / 0.2;
-            interest *= exp(-0.5 * z * z) / 2.5066282746310002 / 0.2;
+        // SafeOptSwarm._compute_particle_fitness, gp_opt.py:925-1013
+        const FitnessArgs& f = p.fit;
+        lower = mu - f.beta * sd;
+        if (g == 0) {
+          values = sd / f.scaling[0];
+          if (st == SGP_SWARM_EXPANDERS) interest = double(p.G);
+          if (st == SGP_SWARM_MAXIMIZERS) {
+            const double upper = mu + f.beta * sd;
+            const double z = 10.0 * (upper - f.best_lower_bound) / f.scaling[0];
+            interest = 1.0 / (1.0 + exp(-z));  // scipy.special.expit
+          }
+        } else {
+          values = fmax(values, sd / f.scaling[g]);
+        }
+        if (f.fmin[g] != -INFINITY) {
+          double slack = lower - f.fmin[g];
+          safe = safe && (slack >= 0.0);
+          if (st != SGP_SWARM_SAFE_SET) {
+            slack = slack / f.scaling[g];
+            total_pen += swarm_penalty(slack);
+            if (st == SGP_SWARM_EXPANDERS) {
+              // scipy.stats.norm.pdf(slack, scale=0.2)
+              const double z = slack / 0.2;
+              interest *= exp(-0.5 * z * z) / 2.5066282746310002 / 0.2;
+            }
           }
         }
       }
-    }
-  }
 
-  if (conf) {
-    if (p.conf.S) {
-      if (writer) p.conf.S[row] = safe ? 1 : 0;
-      // block maximum of l0 over safe rows -> one partial per workgroup
-      double v = (writer && safe) ? l0 : -INFINITY;
-      v = wave_max(v);
-      if (lane == 0) red[wave] = v;
-      __syncthreads();
-      if (tid == 0) {
-        double m = red[0];
+      if (tile_ends) {
+        if (conf) {
+          if (p.conf.S) {
+            if (writer) p.conf.S[row] = safe ? 1 : 0;
+            // maximum of l0 over the safe rows of the tile -> one partial
+            double v = (writer && safe) ? l0 : -INFINITY;
+            v = wave_max(v);
+            if (lane == 0) red[wave] = v;
+            __syncthreads();
+            if (tid == 0) {
+              double m = red[0];
 #pragma unroll
-        for (int w = 1; w < kWaves; ++w) m = fmax(m, red[w]);
-        p.conf.partial[blockIdx.x] = m;
+              for (int w = 1; w < kWaves; ++w) m = fmax(m, red[w]);
+              p.conf.partial[cur.tile] = m;
+            }
+          }
+        } else if (writer) {
+          double out;
+          bool ok = safe;
+          if (st == SGP_SWARM_GREEDY) {
+            out = lower;
+            ok = true;
+          } else if (st == SGP_SWARM_SAFE_SET) {
+            out = lower;
+          } else {
+            out = (values + total_pen) * interest;
+          }
+          p.fit.values[row] = out;
+          p.fit.safe[row] = ok ? 1 : 0;
+        }
+        safe = true;
+        l0 = values = total_pen = lower = 0.0;
+        interest = 1.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = xnext[k];
       }
     }
-  } else if (writer) {
-    double out;
-    if (st == SGP_SWARM_GREEDY) {
-      out = lower;
-      safe = true;
-    } else if (st == SGP_SWARM_SAFE_SET) {
-      out = lower;
-    } else {
-      out = (values + total_pen) * interest;
-    }
-    p.fit.values[row] = out;
-    p.fit.safe[row] = safe ? 1 : 0;
+
+    if (more) stage_x_store(xstage, nbuf, D, tid);
+    __syncthreads();
+    bufsel ^= 1;
+    cur = nxt;
   }
 }
 
@@ -637,7 +687,10 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
     attr_set = true;
   }
   const int tile = 16 * NW;
-  const int nblocks = int((p.pts.N + tile - 1) / tile);
+  const int64_t ntiles = (p.pts.N + tile - 1) / tile;
+  // persistent: one workgroup per CU (256 VGPRs x 512 threads fill it) walks
+  // over the tiles
+  const int nblocks = int(ntiles < ctx->num_cu ? ntiles : ctx->num_cu);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profiling) {
     if (ctx->prof_used + 2 > ctx->prof_events.size()) {
@@ -699,7 +752,6 @@ int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
   SweepParams p;
   p.gps = gps_dev;
   p.G = G;
-  p.ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
   p.mode = MODE_CONF;
   p.pts = pts;
   p.conf = out;
@@ -713,7 +765,6 @@ int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,
   SweepParams p;
   p.gps = gps_dev;
   p.G = G;
-  p.ablate = 0;
   p.mode = MODE_FITNESS;
   p.pts = pts;
   p.conf = ConfOut{};
