@@ -18,6 +18,9 @@
 // are processed in chunks of 16 MFMA row blocks (256 rows) held in 16
 // accumulators per wave; the triangular structure is exploited at 16x16 block
 // granularity (a j-block only feeds row blocks >= its own index).
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "kern_eval.h"
 
 namespace {
@@ -38,6 +41,7 @@ struct SweepParams {
   const GpDev* gps;
   int G;
   int mode;
+  long long* dbg;  // phase timing (SGP_PHASE_DEBUG=1), normally null
   SweepPoints pts;
   ConfOut conf;
   FitnessArgs fit;
@@ -276,6 +280,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
 
   int bufsel = 0;
   bool more = true;
+  long long tph[6] = {0, 0, 0, 0, 0, 0};
+  long long t0 = p.dbg ? __builtin_readcyclecounter() : 0;
+#define PHASE(i)                                            \
+  if (p.dbg) {                                              \
+    const long long t1 = __builtin_readcyclecounter();      \
+    tph[i] += t1 - t0;                                      \
+    t0 = t1;                                                \
+  }
 #pragma unroll 1
   while (more) {
     const GpDev& gp = p.gps[cur.g];
@@ -294,6 +306,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     const bool gp_ends = tile_ends || nxt.g != cur.g;
     const bool chunk_ends = gp_ends || nxt.c != cur.c;
     if (more && tile_ends) load_x(nxt.tile, xnext);
+    PHASE(0)
 
     // this stage: 16 training points against the active row blocks
     const double* xT = cbuf + kATile;
@@ -305,7 +318,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       for (int q = 0; q < 4; ++q)
         mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
     }
+    PHASE(1)
     mfma_jblock(cur.shift + max(0, cur.jb - cur.b0), acc, cbuf + lane, kv);
+    PHASE(2)
 
     if (chunk_ends) {
 #pragma unroll
@@ -425,11 +440,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       }
     }
 
+    PHASE(3)
     if (more) stage_x_store(xstage, nbuf, D, tid);
     __syncthreads();
+    PHASE(4)
     bufsel ^= 1;
     cur = nxt;
   }
+  if (p.dbg && lane == 0) {
+    for (int i = 0; i < 5; ++i)
+      p.dbg[(int64_t(blockIdx.x) * kWaves + wave) * 8 + i] = tph[i];
+  }
+#undef PHASE
 }
 
 // ---- expander check ---------------------------------------------------------
@@ -706,10 +728,30 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
     ctx->prof_flops += flops;
     SGP_HIP(ctx, hipEventRecord(e0, ctx->stream));
   }
+  SweepParams pp = p;
+  pp.dbg = nullptr;
+  static const bool phase_debug = getenv("SGP_PHASE_DEBUG") != nullptr;
+  if (phase_debug) {
+    pp.dbg = static_cast<long long*>(
+        sgp_scratch(ctx, 0, size_t(nblocks) * NW * 8 * sizeof(long long)));
+    SGP_HIP(ctx, hipMemsetAsync(pp.dbg, 0, size_t(nblocks) * NW * 64, ctx->stream));
+  }
   hipLaunchKernelGGL((k_sweep<D, NW>), dim3(nblocks), dim3(64 * NW),
-                     kLdsBytes, ctx->stream, p);
+                     kLdsBytes, ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
   if (e1) SGP_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  if (phase_debug) {
+    std::vector<long long> h(size_t(nblocks) * NW * 8);
+    SGP_TRY(sgp_d2h(ctx, h.data(), pp.dbg, h.size() * sizeof(long long)));
+    double tot[5] = {0, 0, 0, 0, 0};
+    for (size_t w = 0; w < size_t(nblocks) * NW; ++w)
+      for (int i = 0; i < 5; ++i) tot[i] += double(h[w * 8 + i]);
+    const double nw = double(nblocks) * NW;
+    fprintf(stderr,
+            "[k_sweep phases, cycles/wave] prefetch %.0f eval %.0f mfma %.0f "
+            "epilogue %.0f barrier %.0f\n",
+            tot[0] / nw, tot[1] / nw, tot[2] / nw, tot[3] / nw, tot[4] / nw);
+  }
   return 0;
 }
 
