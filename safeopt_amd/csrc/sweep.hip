@@ -47,6 +47,21 @@ struct SweepParams {
   FitnessArgs fit;
 };
 
+// The descriptor fields the stage pipeline touches every iteration, hoisted out
+// of the device array once per GP (they live in SGPRs across the stage loop).
+struct GpView {
+  const double* Apack;
+  const double* Xs;
+  const double* alpha;
+  int nsteps_total;
+  __device__ __forceinline__ void load(const GpDev& gp) {
+    Apack = gp.Apack;
+    Xs = gp.Xs;
+    alpha = gp.alpha;
+    nsteps_total = gp.n_pad >> 2;
+  }
+};
+
 // Asynchronous global -> LDS copy of one A chunk (LDS-DMA, no VGPR round trip).
 // LDS image: slot-major A[slot][step][lane]; slot = row block - b0 + shift so
 // that the last row block of the chunk always sits in slot 15.  A slot is 2 KB
@@ -55,9 +70,9 @@ struct SweepParams {
 // first active slot, even); above-diagonal blocks inside a fetched pair come
 // from the zero part of the packed matrix.
 template <int NW>
-__device__ __forceinline__ void stage_dma(const GpDev& gp, double* buf, int b0,
+__device__ __forceinline__ void stage_dma(const GpView& gp, double* buf, int b0,
                                           int shift, int jb, int lo, int tid) {
-  const int nsteps_total = gp.n_pad >> 2;
+  const int nsteps_total = gp.nsteps_total;
   const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
   for (int k = 0; k < 32 / NW; ++k) {
@@ -77,7 +92,7 @@ __device__ __forceinline__ void stage_dma(const GpDev& gp, double* buf, int b0,
 }
 
 // X rows / alpha entries of j-block jb: one double per thread through VGPRs.
-__device__ __forceinline__ double stage_x_load(const GpDev& gp, int D, int jb,
+__device__ __forceinline__ double stage_x_load(const GpView& gp, int D, int jb,
                                                int tid) {
   const int j0 = jb * kJC;
   if (tid < kJC * D) return gp.Xs[j0 * D + tid];
@@ -216,10 +231,9 @@ __device__ __forceinline__ bool stage_next(StagePos& sp, const GpDev* gps,
 }
 
 template <int NW>
-__device__ __forceinline__ void stage_issue(const StagePos& sp, const GpDev* gps,
+__device__ __forceinline__ void stage_issue(const StagePos& sp, const GpView& gp,
                                             double* buf, int D, int tid,
                                             double& xstage) {
-  const GpDev& gp = gps[sp.g];
   const int lo = sp.shift + max(0, sp.jb - sp.b0);
   stage_dma<NW>(gp, buf, sp.b0, sp.shift, sp.jb, lo, tid);
   xstage = stage_x_load(gp, D, sp.jb, tid);
@@ -261,9 +275,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
 #pragma unroll
   for (int k = 0; k < D; ++k) xnext[k] = x[k];
 
+  GpView gv_next;          // GP of the stage being prefetched
+  gv_next.load(p.gps[0]);
+  KernFast<D> kf(p.gps[0].kern);
+  double kdiag = p.gps[0].kern.kdiag;
   {
     double xs0;
-    stage_issue<NW>(cur, p.gps, lds, D, tid, xs0);
+    stage_issue<NW>(cur, gv_next, lds, D, tid, xs0);
     stage_x_store(xs0, lds, D, tid);
   }
   __syncthreads();
@@ -290,8 +308,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   }
 #pragma unroll 1
   while (more) {
-    const GpDev& gp = p.gps[cur.g];
-    const KernFast<D> kf(gp.kern);
     if (cur.c == 0 && cur.jb == 0) kf.prep(x, xs);
 
     double* cbuf = lds + bufsel * kBuf;
@@ -301,9 +317,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     StagePos nxt = cur;
     more = stage_next(nxt, p.gps, Geff, ntiles, gridDim.x);
     double xstage = 0.0;
-    if (more) stage_issue<NW>(nxt, p.gps, nbuf, D, tid, xstage);
     const bool tile_ends = !more || nxt.tile != cur.tile;
     const bool gp_ends = tile_ends || nxt.g != cur.g;
+    if (more) {
+      if (gp_ends && Geff > 1) gv_next.load(p.gps[nxt.g]);
+      stage_issue<NW>(nxt, gv_next, nbuf, D, tid, xstage);
+    }
     const bool chunk_ends = gp_ends || nxt.c != cur.c;
     if (more && tile_ends) load_x(nxt.tile, xnext);
     PHASE(0)
@@ -350,7 +369,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       const double sumsq =
           (mq == 0) ? sq[0] : (mq == 1) ? sq[1] : (mq == 2) ? sq[2] : sq[3];
       const double mu = sum_lane_groups(mean);
-      const double var = fmax(gp.kern.kdiag - sumsq, 1e-15);  // GPy clip
+      const double var = fmax(kdiag - sumsq, 1e-15);  // GPy clip
       const double sd = sqrt(var);
       sq[0] = sq[1] = sq[2] = sq[3] = 0.0;
       mean = 0.0;
@@ -440,6 +459,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       }
     }
 
+    if (gp_ends && more && Geff > 1) {   // hyper-parameters of the next GP
+      kf = KernFast<D>(p.gps[nxt.g].kern);
+      kdiag = p.gps[nxt.g].kern.kdiag;
+    }
     PHASE(3)
     if (more) stage_x_store(xstage, nbuf, D, tid);
     __syncthreads();
