@@ -73,7 +73,10 @@ template <int NW>
 __device__ __forceinline__ void stage_dma(const GpView& gp, double* buf, int b0,
                                           int shift, int jb, int lo, int tid) {
   const int nsteps_total = gp.nsteps_total;
-  const int wave = tid >> 6, lane = tid & 63;
+  // the wave index as an SGPR: slot tests become scalar branches and the DMA
+  // source address is a scalar base + a constant per-lane offset
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
 #pragma unroll
   for (int k = 0; k < 32 / NW; ++k) {
     const int piece = wave + NW * k;      // wave-uniform
@@ -735,7 +738,8 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   const int64_t ntiles = (p.pts.N + tile - 1) / tile;
   // persistent: one workgroup per CU (256 VGPRs x 512 threads fill it) walks
   // over the tiles
-  const int nblocks = int(ntiles < ctx->num_cu ? ntiles : ctx->num_cu);
+  const int64_t resident = int64_t(ctx->num_cu) * (kMaxWaves / NW);
+  const int nblocks = int(ntiles < resident ? ntiles : resident);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profiling) {
     if (ctx->prof_used + 2 > ctx->prof_events.size()) {
@@ -780,6 +784,8 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
 
 template <int D>
 int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
+  static const int nw = getenv("SGP_SWEEP_NW") ? atoi(getenv("SGP_SWEEP_NW")) : 8;
+  if (nw == 4) return launch_sweep_v<D, 4>(ctx, p, flops);
   return launch_sweep_v<D, kMaxWaves>(ctx, p, flops);
 }
 
@@ -808,8 +814,10 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
 
 }  // namespace
 
-int sweep_num_blocks(int64_t N) {
-  return int((N + 16 * kMaxWaves - 1) / (16 * kMaxWaves));
+int sweep_num_blocks(int64_t N) {   // = number of tiles = number of partials
+  static const int nw = getenv("SGP_SWEEP_NW") ? atoi(getenv("SGP_SWEEP_NW")) : 8;
+  const int t = 16 * (nw == 4 ? 4 : kMaxWaves);
+  return int((N + t - 1) / t);
 }
 
 int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
