@@ -685,8 +685,22 @@ __global__ __launch_bounds__(256) void k_mfma_bench(double* out, int iters) {
   for (int i = 0; i < 16; ++i) f[i] = 1.0 + i * 1e-3 + threadIdx.x * 1e-6;
   const double av = 1.0 + threadIdx.x * 1e-9, bv = 1.0 - threadIdx.x * 1e-9;
   const double m = 0.999999, c = 1e-7;
+  double a4[4], b16[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a4[q] = av + q * 1e-3;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) b16[j] = bv + j * 1e-3;
   for (int it = 0; it < iters; ++it) {
-    if (MODE == 6 || MODE == 7 || MODE == 8) {
+    if (MODE == 9) {
+      // the sweep's operand pattern: 4 A registers, 16 B registers, 16
+      // accumulators -- every MFMA reads a different (A, B, C) triple
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          f[4 * q + m] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+              a4[q], b16[4 * q + m], f[4 * q + m], 0, 0, 0);
+    } else if (MODE == 6 || MODE == 7 || MODE == 8) {
       // 16 / 4 / 2 independent chains, 16 instructions per iteration
       constexpr int NC = (MODE == 6) ? 16 : (MODE == 7 ? 4 : 2);
 #pragma unroll
@@ -936,6 +950,7 @@ int launch_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
     case 6: SGP_TRY(run_microbench<6>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;  // 16 x 512 flop
     case 7: SGP_TRY(run_microbench<7>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;
     case 8: SGP_TRY(run_microbench<8>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;
+    case 9: SGP_TRY(run_microbench<9>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;
     default: sgp_set_error(ctx, "unknown microbench mode %d", mode); return -2;
   }
   const double waves = double(nblocks) * 4.0;
