@@ -752,7 +752,8 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   const int64_t ntiles = (p.pts.N + tile - 1) / tile;
   // persistent: one workgroup per CU (256 VGPRs x 512 threads fill it) walks
   // over the tiles
-  const int64_t resident = int64_t(ctx->num_cu) * (kMaxWaves / NW);
+  const int64_t resident = int64_t(ctx->num_cu) *
+      (getenv("SGP_ONE_WG") ? 1 : (kMaxWaves / NW));
   const int nblocks = int(ntiles < resident ? ntiles : resident);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profiling) {
