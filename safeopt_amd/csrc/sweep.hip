@@ -799,7 +799,7 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
 
 template <int D>
 int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
-  static const int nw = getenv("SGP_SWEEP_NW") ? atoi(getenv("SGP_SWEEP_NW")) : 8;
+  static const int nw = getenv("SGP_SWEEP_NW") ? atoi(getenv("SGP_SWEEP_NW")) : 4;
   if (nw == 4) return launch_sweep_v<D, 4>(ctx, p, flops);
   return launch_sweep_v<D, kMaxWaves>(ctx, p, flops);
 }
@@ -830,7 +830,7 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
 }  // namespace
 
 int sweep_num_blocks(int64_t N) {   // = number of tiles = number of partials
-  static const int nw = getenv("SGP_SWEEP_NW") ? atoi(getenv("SGP_SWEEP_NW")) : 8;
+  static const int nw = getenv("SGP_SWEEP_NW") ? atoi(getenv("SGP_SWEEP_NW")) : 4;
   const int t = 16 * (nw == 4 ? 4 : kMaxWaves);
   return int((N + t - 1) / t);
 }
