@@ -69,35 +69,29 @@ struct GpView {
 // w+16, w+24.  Only the slots the next j-block reads are fetched (`lo` = its
 // first active slot, even); above-diagonal blocks inside a fetched pair come
 // from the zero part of the packed matrix.
-// One piece (index k of this wave) of that copy.
-template <int NW>
-__device__ __forceinline__ void stage_dma_piece(const GpView& gp, double* buf,
-                                                int b0, int shift, int jb, int lo,
-                                                int wave, int lane, int k) {
-  const int piece = wave + NW * k;      // wave-uniform
-  const int slot = piece >> 1;
-  const int half = piece & 1;
-  if (slot >= lo) {
-    const int bg = b0 + slot - shift;
-    const double* src = gp.Apack +
-        (int64_t(bg) * gp.nsteps_total + jb * kSteps + 2 * half) * 64 + lane * 2;
-    double* dst = buf + piece * 128;    // wave-uniform LDS base
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)src,
-        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  }
-}
-
 template <int NW>
 __device__ __forceinline__ void stage_dma(const GpView& gp, double* buf, int b0,
                                           int shift, int jb, int lo, int tid) {
+  const int nsteps_total = gp.nsteps_total;
   // the wave index as an SGPR: slot tests become scalar branches and the DMA
   // source address is a scalar base + a constant per-lane offset
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
 #pragma unroll
-  for (int k = 0; k < 32 / NW; ++k)
-    stage_dma_piece<NW>(gp, buf, b0, shift, jb, lo, wave, lane, k);
+  for (int k = 0; k < 32 / NW; ++k) {
+    const int piece = wave + NW * k;      // wave-uniform
+    const int slot = piece >> 1;
+    const int half = piece & 1;
+    if (slot >= lo) {
+      const int bg = b0 + slot - shift;
+      const double* src = gp.Apack +
+          (int64_t(bg) * nsteps_total + jb * kSteps + 2 * half) * 64 + lane * 2;
+      double* dst = buf + piece * 128;    // wave-uniform LDS base
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  }
 }
 
 // X rows / alpha entries of j-block jb: one double per thread through VGPRs.
@@ -159,19 +153,9 @@ __device__ __forceinline__ void load_slot(double (&ops)[4], const double* aT,
 // wave-uniform branches (the active set is a suffix); a slot is 16 MFMAs on
 // four independent accumulators, and the next slot's A operands are read from
 // LDS while they execute.
-struct NoHook {
-  __device__ __forceinline__ void operator()(int) const {}
-};
-
-// `between(s)` runs after slot s (whether or not the slot was active): the
-// persistent kernel hangs the next stage's LDS-DMA pieces there, so that their
-// issue (which blocks while the CU's vector-memory queue is full) is spread
-// over the MFMA stream instead of stalling all waves right after the barrier.
-template <class Hook>
 __device__ __forceinline__ void mfma_jblock(int lo, double4_t (&acc)[kIB],
                                             const double* aT,
-                                            const double (&kv)[4],
-                                            const Hook& between) {
+                                            const double (&kv)[4]) {
   double kb[4][4];  // [k-step][column quad]
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -194,14 +178,7 @@ __device__ __forceinline__ void mfma_jblock(int lo, double4_t (&acc)[kIB],
                                                          acc[s][m], 0, 0, 0);
       }
     }
-    between(s);
   }
-}
-
-__device__ __forceinline__ void mfma_jblock(int lo, double4_t (&acc)[kIB],
-                                            const double* aT,
-                                            const double (&kv)[4]) {
-  mfma_jblock(lo, acc, aT, kv, NoHook());
 }
 
 // SafeOptSwarm._compute_penalty (gp_opt.py:874-899) for one value.
@@ -347,7 +324,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     const bool gp_ends = tile_ends || nxt.g != cur.g;
     if (more) {
       if (gp_ends && Geff > 1) gv_next.load(p.gps[nxt.g]);
-      xstage = stage_x_load(gv_next, D, nxt.jb, tid);
+      stage_issue<NW>(nxt, gv_next, nbuf, D, tid, xstage);
     }
     const bool chunk_ends = gp_ends || nxt.c != cur.c;
     if (more && tile_ends) load_x(nxt.tile, xnext);
@@ -364,20 +341,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
         mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
     }
     PHASE(1)
-    {
-      // the next stage's A chunk: piece k of this wave after slot 2k + 1
-      const int lo_n = nxt.shift + max(0, nxt.jb - nxt.b0);
-      const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-      auto dma_hook = [&](int s) {
-        constexpr int kPer = 32 / NW;                 // pieces per wave
-        constexpr int kEvery = kIB / kPer;            // slots between pieces
-        if (more && (s % kEvery) == kEvery - 1)
-          stage_dma_piece<NW>(gv_next, nbuf, nxt.b0, nxt.shift, nxt.jb, lo_n,
-                              wave_s, lane, s / kEvery);
-      };
-      mfma_jblock(cur.shift + max(0, cur.jb - cur.b0), acc, cbuf + lane, kv,
-                  dma_hook);
-    }
+    mfma_jblock(cur.shift + max(0, cur.jb - cur.b0), acc, cbuf + lane, kv);
     PHASE(2)
 
     if (chunk_ends) {
