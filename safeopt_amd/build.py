@@ -24,6 +24,8 @@ BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
         "-I", os.path.join(REPO, "include"), "-I", CSRC, "-Wall",
         "-Wno-unused-function"]
 EXTRA = {"sets.hip": ["-ffp-contract=off"]}
+# e.g. SGP_HIPCC_FLAGS=-DSGP_INSTRUMENT for scripts/ablate.py (use --force)
+USER = os.environ.get("SGP_HIPCC_FLAGS", "").split()
 
 
 def _hipcc():
@@ -48,7 +50,7 @@ def build(force=False, verbose=False):
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            jobs.append([hipcc] + BASE + EXTRA.get(src, []) + ["-c", s, "-o", o])
+            jobs.append([hipcc] + BASE + EXTRA.get(src, []) + USER + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -13,11 +13,15 @@
 //     mean(pt) = alpha . K[:, pt]                      (2n flops / row)
 // K (n x N doubles, 1.6 GB at n=200, N=1e6) is never written to memory.
 //
-// Work split: workgroup = 8 waves = 128 rows; wave w owns 16 rows (the MFMA
-// N dimension); all waves share the staged A chunk through LDS.  The rows of A
-// are processed in chunks of 16 MFMA row blocks (256 rows) held in 16
-// accumulators per wave; the triangular structure is exploited at 16x16 block
-// granularity (a j-block only feeds row blocks >= its own index).
+// Work split: workgroup = 4 waves = 64 rows, two workgroups per CU (each SIMD
+// hosts one wave of either); wave w owns 16 rows (the MFMA N dimension); the
+// waves of a workgroup share the staged A chunk through LDS.  The rows of A are
+// processed in chunks of 16 MFMA row blocks (256 rows) held in 16 accumulator
+// slots per wave; the triangular structure is exploited at 16x16 block
+// granularity (a j-block only feeds row blocks >= its own index).  The kernel
+// is persistent: 2 x num_CU workgroups walk over the row tiles, and the
+// (tile, GP, chunk, j-block) loop nest is flattened into one stage sequence so
+// that the LDS-DMA of stage s+1 always runs under the MFMAs of stage s.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -25,7 +29,8 @@
 
 namespace {
 
-constexpr int kMaxWaves = 8;
+constexpr int kMaxWaves = 8;         // waves per CU at 256 VGPRs
+constexpr int kSweepWaves = 4;       // waves per workgroup (two workgroups per CU)
 constexpr int kIB = 16;                // accumulator slots = 256 rows of L^-1
 constexpr int kJC = 16;                // training points per staged chunk
 constexpr int kSteps = kJC / 4;        // MFMA k-steps per chunk (one j-block)
@@ -37,11 +42,23 @@ constexpr size_t kLdsBytes = (size_t(kTabOff) + kExpTabSize) * sizeof(double);
 
 enum { MODE_CONF = 0, MODE_FITNESS = 1 };
 
+// Timing experiments ("what does the kernel cost without X"; results are wrong
+// with any bit set): built only with -DSGP_INSTRUMENT, selected at run time by
+// SGP_ABLATE=<mask>: 1 no stage barrier, 2 no LDS-DMA, 4 no covariance
+// evaluation, 8 no MFMA.  profiles/r01/ablation.txt holds the numbers.
+#ifdef SGP_INSTRUMENT
+#define SGP_ABL(mask) (p.ablate & (mask))
+#else
+#define SGP_ABL(mask) false
+#endif
+
 struct SweepParams {
   const GpDev* gps;
   int G;
   int mode;
-  long long* dbg;  // phase timing (SGP_PHASE_DEBUG=1), normally null
+#ifdef SGP_INSTRUMENT
+  int ablate;      // timing experiments (scripts/ablate.py), see SGP_ABL
+#endif
   SweepPoints pts;
   ConfOut conf;
   FitnessArgs fit;
@@ -301,14 +318,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
 
   int bufsel = 0;
   bool more = true;
-  long long tph[6] = {0, 0, 0, 0, 0, 0};
-  long long t0 = p.dbg ? __builtin_readcyclecounter() : 0;
-#define PHASE(i)                                            \
-  if (p.dbg) {                                              \
-    const long long t1 = __builtin_readcyclecounter();      \
-    tph[i] += t1 - t0;                                      \
-    t0 = t1;                                                \
-  }
 #pragma unroll 1
   while (more) {
     if (cur.c == 0 && cur.jb == 0) kf.prep(x, xs);
@@ -324,25 +333,27 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     const bool gp_ends = tile_ends || nxt.g != cur.g;
     if (more) {
       if (gp_ends && Geff > 1) gv_next.load(p.gps[nxt.g]);
-      stage_issue<NW>(nxt, gv_next, nbuf, D, tid, xstage);
+      if (!SGP_ABL(2)) stage_issue<NW>(nxt, gv_next, nbuf, D, tid, xstage);
     }
     const bool chunk_ends = gp_ends || nxt.c != cur.c;
     if (more && tile_ends) load_x(nxt.tile, xnext);
-    PHASE(0)
 
     // this stage: 16 training points against the active row blocks
     const double* xT = cbuf + kATile;
     const double* alT = cbuf + kATile + kXTile;
     double kv[4];
-    kf.template many<4>(xs, xT + (lane >> 4) * D, 4 * D, tab, kv);
+    if (!SGP_ABL(4)) {
+      kf.template many<4>(xs, xT + (lane >> 4) * D, 4 * D, tab, kv);
+    } else {
+      kv[0] = xs[0]; kv[1] = xs[0] + 1.0; kv[2] = xs[0] + 2.0; kv[3] = xs[0] + 3.0;
+    }
     if (cur.c == cur.nchunks - 1) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
     }
-    PHASE(1)
-    mfma_jblock(cur.shift + max(0, cur.jb - cur.b0), acc, cbuf + lane, kv);
-    PHASE(2)
+    if (!SGP_ABL(8))
+      mfma_jblock(cur.shift + max(0, cur.jb - cur.b0), acc, cbuf + lane, kv);
 
     if (chunk_ends) {
 #pragma unroll
@@ -466,304 +477,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       kf = KernFast<D>(p.gps[nxt.g].kern);
       kdiag = p.gps[nxt.g].kern.kdiag;
     }
-    PHASE(3)
     if (more) stage_x_store(xstage, nbuf, D, tid);
-    __syncthreads();
-    PHASE(4)
+    if (!SGP_ABL(1)) __syncthreads();
     bufsel ^= 1;
-    cur = nxt;
-  }
-  if (p.dbg && lane == 0) {
-    for (int i = 0; i < 5; ++i)
-      p.dbg[(int64_t(blockIdx.x) * kWaves + wave) * 8 + i] = tph[i];
-  }
-#undef PHASE
-}
-
-// ---- warp-specialised sweep ----------------------------------------------------
-// Same stage pipeline, but the two waves that share a SIMD take different
-// jobs so that the matrix pipe is not left idle while covariances are being
-// evaluated (PMC: in the symmetric kernel the MFMA pipe is busy ~45 % of the
-// time, the rest is VALU phases and waits that both waves hit together):
-//   waves 0-3 (consumers): read the covariance operands of stage k from LDS
-//     and run the MFMAs; accumulators, chunk folding and the row epilogue.
-//   waves 4-7 (producers): while stage k is being multiplied, issue the LDS-DMA
-//     of stage k+1's A chunk, evaluate stage k+1's covariances (training rows
-//     prefetched from global into registers one stage earlier) and publish
-//     them -- plus the partial posterior mean -- through LDS.
-// Waves w and w+4 of a workgroup land on the same SIMD (dispatch order
-// 0,2,1,3 cyclic), so every SIMD gets exactly one consumer and one producer.
-// One __syncthreads() per stage; a tile is 64 rows (16 per consumer).
-constexpr int kWsKV = 4 * 4 * 64;                       // doubles per kv buffer
-constexpr int kWsOffA = 0;                              // 2 x kATile
-constexpr int kWsOffKV = 2 * kATile;                    // 2 x kWsKV
-constexpr int kWsOffRes = kWsOffKV + 2 * kWsKV;         // 2 x 4 x 64 (mean)
-constexpr int kWsOffRed = kWsOffRes + 2 * 4 * 64;       // 8
-constexpr int kWsOffTab = kWsOffRed + 8;                // 32
-constexpr size_t kWsLdsBytes = size_t(kWsOffTab + kExpTabSize) * sizeof(double);
-
-template <int D>
-__global__ __launch_bounds__(512, 2) void k_sweep_ws(SweepParams p) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* red = lds + kWsOffRed;
-  const double* tab = lds + kWsOffTab;
-  exp_tab_init(lds + kWsOffTab);
-  __syncthreads();   // the producers read the table before their first barrier
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave >= 4;
-  const int cw = wave & 3;                      // consumer this wave serves / is
-  const bool conf = p.mode == MODE_CONF;
-  const int st = p.fit.swarm_type;
-  const int Geff = (!conf && st == SGP_SWARM_GREEDY) ? 1 : p.G;
-  constexpr int kTile = 64;
-  const int64_t ntiles = (p.pts.N + kTile - 1) / kTile;
-
-  StagePos cur;
-  cur.tile = blockIdx.x;
-  cur.g = cur.c = cur.jb = 0;
-  if (cur.tile >= ntiles) return;
-  stage_derive(cur, p.gps);
-
-  auto load_x = [&](int64_t tile, double (&xo)[D]) {
-    int64_t r = tile * kTile + cw * 16 + (lane & 15);
-    r = r < p.pts.N ? r : p.pts.N - 1;
-#pragma unroll
-    for (int k = 0; k < D; ++k)
-      xo[k] = p.pts.base[r * p.pts.stride_row + k * p.pts.stride_col];
-  };
-
-  if (producer) {
-    // ===================== producer ==========================================
-    // p1 = stage whose covariances are computed now (S_{k+1}); p2 = stage whose
-    // training rows are being fetched (S_{k+2}).
-    StagePos p1 = cur, p2 = cur;
-    bool has1 = true, has2 = true;
-    GpView gv1;                       // GP of p1 (A chunk DMA)
-    gv1.load(p.gps[0]);
-    KernFast<D> kf(p.gps[0].kern);
-    double x[D], xs[D];
-    load_x(cur.tile, x);
-    kf.prep(x, xs);
-    double mean = 0.0;
-
-    // training rows (pre-scaled) + alpha of one stage: rows 4q + (lane >> 4)
-    double xr[4][D], ar[4], xr2[4][D], ar2[4];
-    auto fetch_rows = [&](const StagePos& sp, double (&xo)[4][D], double (&ao)[4]) {
-      const GpDev& gp = p.gps[sp.g];
-      const double* X = gp.Xs + (int64_t(sp.jb) * 16 + (lane >> 4)) * D;
-      const double* A = gp.alpha + sp.jb * 16 + (lane >> 4);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) xo[q][k] = X[q * 4 * D + k];
-        ao[q] = A[q * 4];
-      }
-    };
-    auto produce = [&](const StagePos& sp, const double (&xo)[4][D],
-                       const double (&ao)[4], double* kvbuf, double* resbuf) {
-      // covariances of stage sp for consumer cw -> kvbuf[cw][q][lane]
-      double kv[4];
-      kf.template many<4>(xs, &xo[0][0], D, tab, kv);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) kvbuf[(cw * 4 + q) * 64 + lane] = kv[q];
-      if (sp.c == sp.nchunks - 1) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mean = fma(ao[q], kv[q], mean);
-        if (sp.jb == sp.njb - 1) {          // last stage of this GP
-          resbuf[cw * 64 + lane] = sum_lane_groups(mean);
-          mean = 0.0;
-        }
-      }
-    };
-    auto issue_dma = [&](const StagePos& sp, double* abuf) {
-      const int lo = sp.shift + max(0, sp.jb - sp.b0);
-      stage_dma<4>(gv1, abuf, sp.b0, sp.shift, sp.jb, lo, (wave - 4) * 64 + lane);
-    };
-
-    // prologue: S_0 fully, rows of S_1
-    fetch_rows(p1, xr, ar);
-    issue_dma(p1, lds + kWsOffA);
-    has2 = stage_next(p2, p.gps, Geff, ntiles, gridDim.x);
-    if (has2) fetch_rows(p2, xr2, ar2);
-    produce(p1, xr, ar, lds + kWsOffKV, lds + kWsOffRes);
-    __syncthreads();
-
-    int k = 0;
-    bool more = true;
-#pragma unroll 1
-    while (more) {
-      // advance: p1 <- S_{k+1}
-      const StagePos prev = p1;
-      has1 = stage_next(p1, p.gps, Geff, ntiles, gridDim.x);
-      more = has1;
-      if (has1) {
-        if (p1.g != prev.g || p1.tile != prev.tile) {
-          if (Geff > 1) {
-            gv1.load(p.gps[p1.g]);
-            kf = KernFast<D>(p.gps[p1.g].kern);
-          }
-          if (p1.tile != prev.tile) load_x(p1.tile, x);
-          kf.prep(x, xs);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-          for (int kk = 0; kk < D; ++kk) xr[q][kk] = xr2[q][kk];
-          ar[q] = ar2[q];
-        }
-        issue_dma(p1, lds + kWsOffA + ((k + 1) & 1) * kATile);
-        if (has2) has2 = stage_next(p2, p.gps, Geff, ntiles, gridDim.x);
-        if (has2) fetch_rows(p2, xr2, ar2);
-        produce(p1, xr, ar, lds + kWsOffKV + ((k + 1) & 1) * kWsKV,
-                lds + kWsOffRes + ((k + 1) & 1) * 256);
-      }
-      // tile epilogue of the consumers uses one extra barrier per tile
-      const bool tile_ends = !has1 || p1.tile != prev.tile;
-      if (tile_ends && conf && p.conf.S) __syncthreads();
-      __syncthreads();
-      ++k;
-    }
-    return;
-  }
-
-  // ======================= consumer ============================================
-  double sq[4] = {0.0, 0.0, 0.0, 0.0};
-  double4_t acc[kIB];
-#pragma unroll
-  for (int b = 0; b < kIB; ++b) acc[b] = double4_t{0.0, 0.0, 0.0, 0.0};
-  bool safe = true;
-  double l0 = 0.0, values = 0.0, interest = 1.0, total_pen = 0.0, lower = 0.0;
-  double kdiag = p.gps[0].kern.kdiag;
-  __syncthreads();   // prologue barrier of the producers
-
-  int k = 0;
-  bool more = true;
-#pragma unroll 1
-  while (more) {
-    StagePos nxt = cur;
-    more = stage_next(nxt, p.gps, Geff, ntiles, gridDim.x);
-    const bool tile_ends = !more || nxt.tile != cur.tile;
-    const bool gp_ends = tile_ends || nxt.g != cur.g;
-    const bool chunk_ends = gp_ends || nxt.c != cur.c;
-
-    const double* abuf = lds + kWsOffA + (k & 1) * kATile;
-    const double* kvb = lds + kWsOffKV + (k & 1) * kWsKV + cw * 256 + lane;
-    double kv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) kv[q] = kvb[q * 64];
-    mfma_jblock(cur.shift + max(0, cur.jb - cur.b0), acc, abuf + lane, kv);
-
-    if (chunk_ends) {
-#pragma unroll
-      for (int b = 0; b < kIB; ++b) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          sq[m] = fma(acc[b][m], acc[b][m], sq[m]);
-          acc[b][m] = 0.0;
-        }
-      }
-    }
-
-    if (gp_ends) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        double v = sq[m];
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        sq[m] = v;
-      }
-      const int mq = (lane >> 2) & 3;
-      const double sumsq =
-          (mq == 0) ? sq[0] : (mq == 1) ? sq[1] : (mq == 2) ? sq[2] : sq[3];
-      const double mu = lds[kWsOffRes + (k & 1) * 256 + cw * 64 + lane];
-      const double var = fmax(kdiag - sumsq, 1e-15);  // GPy clip
-      const double sd = sqrt(var);
-      sq[0] = sq[1] = sq[2] = sq[3] = 0.0;
-
-      const int g = cur.g;
-      const int64_t row = cur.tile * kTile + cw * 16 + (lane & 15);
-      const bool writer = (row < p.pts.N) && (lane < 16);
-      if (conf) {
-        const double lo = mu - p.conf.beta * sd;
-        const double up = mu + p.conf.beta * sd;
-        if (g == 0) l0 = lo;
-        safe = safe && (lo > p.conf.fmin[g]);
-        if (writer) {
-          p.conf.mean[int64_t(g) * p.pts.N + row] = mu;
-          p.conf.var[int64_t(g) * p.pts.N + row] = var;
-          if (p.conf.Q) {
-            const double2 q = make_double2(lo, up);
-            *reinterpret_cast<double2*>(p.conf.Q + (row * p.G + g) * 2) = q;
-          }
-        }
-      } else {
-        const FitnessArgs& f = p.fit;
-        lower = mu - f.beta * sd;
-        if (g == 0) {
-          values = sd / f.scaling[0];
-          if (st == SGP_SWARM_EXPANDERS) interest = double(p.G);
-          if (st == SGP_SWARM_MAXIMIZERS) {
-            const double upper = mu + f.beta * sd;
-            const double z = 10.0 * (upper - f.best_lower_bound) / f.scaling[0];
-            interest = 1.0 / (1.0 + exp(-z));
-          }
-        } else {
-          values = fmax(values, sd / f.scaling[g]);
-        }
-        if (f.fmin[g] != -INFINITY) {
-          double slack = lower - f.fmin[g];
-          safe = safe && (slack >= 0.0);
-          if (st != SGP_SWARM_SAFE_SET) {
-            slack = slack / f.scaling[g];
-            total_pen += swarm_penalty(slack);
-            if (st == SGP_SWARM_EXPANDERS) {
-              const double z = slack / 0.2;
-              interest *= exp(-0.5 * z * z) / 2.5066282746310002 / 0.2;
-            }
-          }
-        }
-      }
-
-      if (tile_ends) {
-        if (conf) {
-          if (p.conf.S) {
-            if (writer) p.conf.S[row] = safe ? 1 : 0;
-            double v = (writer && safe) ? l0 : -INFINITY;
-            v = wave_max(v);
-            if (lane == 0) red[cw] = v;
-            __syncthreads();
-            if (tid == 0)
-              p.conf.partial[cur.tile] =
-                  fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-          }
-        } else if (writer) {
-          double out;
-          bool ok = safe;
-          if (st == SGP_SWARM_GREEDY) {
-            out = lower;
-            ok = true;
-          } else if (st == SGP_SWARM_SAFE_SET) {
-            out = lower;
-          } else {
-            out = (values + total_pen) * interest;
-          }
-          p.fit.values[row] = out;
-          p.fit.safe[row] = ok ? 1 : 0;
-        }
-        safe = true;
-        l0 = values = total_pen = lower = 0.0;
-        interest = 1.0;
-      }
-      if (more && Geff > 1) kdiag = p.gps[nxt.g].kern.kdiag;
-    }
-
-    __syncthreads();
-    ++k;
     cur = nxt;
   }
 }
@@ -1038,10 +754,9 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   }
   const int tile = 16 * NW;
   const int64_t ntiles = (p.pts.N + tile - 1) / tile;
-  // persistent: one workgroup per CU (256 VGPRs x 512 threads fill it) walks
-  // over the tiles
-  const int64_t resident = int64_t(ctx->num_cu) *
-      (getenv("SGP_ONE_WG") ? 1 : (kMaxWaves / NW));
+  // persistent: as many workgroups as are resident at once (256 VGPRs per
+  // thread -> 8 waves per CU) walk over the tiles
+  const int64_t resident = int64_t(ctx->num_cu) * (kMaxWaves / NW);
   const int nblocks = int(ntiles < resident ? ntiles : resident);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profiling) {
@@ -1059,63 +774,12 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
     SGP_HIP(ctx, hipEventRecord(e0, ctx->stream));
   }
   SweepParams pp = p;
-  pp.dbg = nullptr;
-  static const bool phase_debug = getenv("SGP_PHASE_DEBUG") != nullptr;
-  if (phase_debug) {
-    pp.dbg = static_cast<long long*>(
-        sgp_scratch(ctx, 0, size_t(nblocks) * NW * 8 * sizeof(long long)));
-    SGP_HIP(ctx, hipMemsetAsync(pp.dbg, 0, size_t(nblocks) * NW * 64, ctx->stream));
-  }
+#ifdef SGP_INSTRUMENT
+  static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
+  pp.ablate = ablate;
+#endif
   hipLaunchKernelGGL((k_sweep<D, NW>), dim3(nblocks), dim3(64 * NW),
                      kLdsBytes, ctx->stream, pp);
-  SGP_HIP(ctx, hipGetLastError());
-  if (e1) SGP_HIP(ctx, hipEventRecord(e1, ctx->stream));
-  if (phase_debug) {
-    std::vector<long long> h(size_t(nblocks) * NW * 8);
-    SGP_TRY(sgp_d2h(ctx, h.data(), pp.dbg, h.size() * sizeof(long long)));
-    double tot[5] = {0, 0, 0, 0, 0};
-    for (size_t w = 0; w < size_t(nblocks) * NW; ++w)
-      for (int i = 0; i < 5; ++i) tot[i] += double(h[w * 8 + i]);
-    const double nw = double(nblocks) * NW;
-    fprintf(stderr,
-            "[k_sweep phases, cycles/wave] prefetch %.0f eval %.0f mfma %.0f "
-            "epilogue %.0f barrier %.0f\n",
-            tot[0] / nw, tot[1] / nw, tot[2] / nw, tot[3] / nw, tot[4] / nw);
-  }
-  return 0;
-}
-
-template <int D>
-int launch_sweep_ws(sgp_ctx* ctx, const SweepParams& p, double flops) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep_ws<D>),
-                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                     int(kWsLdsBytes)));
-    attr_set = true;
-  }
-  const int64_t ntiles = (p.pts.N + 63) / 64;
-  const int nblocks = int(ntiles < ctx->num_cu ? ntiles : ctx->num_cu);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ctx->profiling) {
-    if (ctx->prof_used + 2 > ctx->prof_events.size()) {
-      for (int i = 0; i < 2; ++i) {
-        hipEvent_t e;
-        SGP_HIP(ctx, hipEventCreate(&e));
-        ctx->prof_events.push_back(e);
-      }
-    }
-    e0 = ctx->prof_events[ctx->prof_used];
-    e1 = ctx->prof_events[ctx->prof_used + 1];
-    ctx->prof_used += 2;
-    ctx->prof_flops += flops;
-    SGP_HIP(ctx, hipEventRecord(e0, ctx->stream));
-  }
-  SweepParams pp = p;
-  pp.dbg = nullptr;
-  hipLaunchKernelGGL((k_sweep_ws<D>), dim3(nblocks), dim3(512), kWsLdsBytes,
-                     ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
   if (e1) SGP_HIP(ctx, hipEventRecord(e1, ctx->stream));
   return 0;
@@ -1123,11 +787,7 @@ int launch_sweep_ws(sgp_ctx* ctx, const SweepParams& p, double flops) {
 
 template <int D>
 int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
-  static const bool ws = getenv("SGP_SWEEP_WS") != nullptr;
-  if (ws) return launch_sweep_ws<D>(ctx, p, flops);
-  static const int nw = getenv("SGP_SWEEP_NW") ? atoi(getenv("SGP_SWEEP_NW")) : 4;
-  if (nw == 4) return launch_sweep_v<D, 4>(ctx, p, flops);
-  return launch_sweep_v<D, kMaxWaves>(ctx, p, flops);
+  return launch_sweep_v<D, kSweepWaves>(ctx, p, flops);
 }
 
 int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
@@ -1156,9 +816,7 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
 }  // namespace
 
 int sweep_num_blocks(int64_t N) {   // = number of tiles = number of partials
-  static const int nw = getenv("SGP_SWEEP_NW") ? atoi(getenv("SGP_SWEEP_NW")) : 4;
-  static const bool ws = getenv("SGP_SWEEP_WS") != nullptr;
-  const int t = ws ? 64 : 16 * (nw == 4 ? 4 : kMaxWaves);
+  constexpr int t = 16 * kSweepWaves;
   return int((N + t - 1) / t);
 }
 
