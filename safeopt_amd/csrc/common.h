@@ -44,14 +44,27 @@ struct KernDesc {
   double variance[SGP_MAX_PARTS];
   double inv_ls[SGP_MAX_PARTS][SGP_MAX_D];
   double kdiag;  // product of the variances = k(x, x)
+  // Single-part kernels: inputs are stored pre-multiplied by scale0 =
+  // inv_ls[0] * kern_unit(kind[0]), in units where the exponent of the
+  // covariance is a plain square / norm (see kern_eval.h, KernFast).
+  double scale0[SGP_MAX_D];
 };
+
+// Input scaling of the fast covariance path: with z = x * inv_ls * kern_unit,
+//   RBF      exp(-r^2/2)   = 2^(-|dz|^2 / 32)        kern_unit = sqrt(16 / ln 2)
+//   Matern   exp(-sqrt(nu2) r) = 2^(-|dz| / 32)      kern_unit = sqrt(3|5) * 32 / ln 2
+inline double kern_unit(int kind) {
+  return kind == SGP_RBF ? 4.804489635145799
+                         : (kind == SGP_MATERN32 ? 79.962275540715
+                                                 : 103.23085383134594);
+}
 
 // One GP as the sweep kernels see it.  All pointers are device pointers.
 struct GpDev {
   const double* Apack;  // L^-1 in MFMA A-operand order: [nblk][n_pad/4][64],
                         // zero above the diagonal and in the padding rows
   const double* Xpad;   // training inputs, [n_pad][d], zero padded
-  const double* Xs;     // = Xpad * (1/lengthscale) for single-part kernels,
+  const double* Xs;     // = Xpad * kern.scale0 for single-part kernels,
                         //   else = Xpad (KernFast::operator() convention)
   const double* alpha;  // Ky^-1 y, [n_pad], zero padded
   int n;                // training points

@@ -259,14 +259,14 @@ __global__ void k_trmv_lower_t(const double* Li, int64_t ld, int n,
   out[j] = s;
 }
 
-// Xpad = zero-padded X; Xs = Xpad scaled per column (scale == nullptr: copy)
+// Xpad = zero-padded X; Xs = Xpad * scale0 per column (products of parts: copy)
 __global__ void k_pad_rows(const double* X, int n, int n_pad, int d,
                            KernDesc kd, double* Xpad, double* Xs) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_pad * d) return;
   const double v = (e < n * d) ? X[e] : 0.0;
   Xpad[e] = v;
-  Xs[e] = (kd.n_parts == 1) ? v * kd.inv_ls[0][e % d] : v;
+  Xs[e] = (kd.n_parts == 1) ? v * kd.scale0[e % d] : v;
 }
 
 

@@ -3,12 +3,21 @@
 // parts on arbitrary column subsets.  Reference call sites: gp.kern.K reached
 // through gp.predict_noiseless (safeopt/gp_opt.py:469, 591, 929, 973).
 //
-// fp64 VALU work is not free next to the fp64 matrix pipe on gfx950 (they
-// share the FP64 units: MFMA-only 49 TF/s, v_fma_f64-only 66, interleaved sum
-// ~52 -- scripts/microbench.py), so the per-element cost of the covariance is
-// trimmed: inputs pre-scaled by 1/lengthscale, and exp() through a 32-entry
-// 2^(j/32) table (one LDS bank row, conflict free) + a degree-6 polynomial:
-// ~13 fp64 ops instead of the library's ~27, accurate to ~1.5 ulp.
+// fp64 VALU work is not free next to the fp64 matrix pipe on gfx950: the two
+// do not overlap (SQ_VALU_MFMA_COEXEC_CYCLES = 0; profiles/r01/ablation.txt:
+// removing the evaluation shortens the sweep by exactly its own VALU time), so
+// the per-element cost of the covariance is trimmed to the bone:
+//   * inputs are stored pre-multiplied by 1/lengthscale AND by a per-kind unit
+//     (common.h, kern_unit) chosen so that the covariance is
+//         RBF     var * 2^(u/32),                   u = -|dz|^2
+//         Matern  var * poly(u) * 2^(u/32),         u = -|dz|
+//     -- no argument scaling, no clamp, and the range reduction w = u - rint(u)
+//     is exact (no two-word ln2 constant);
+//   * 2^(w/32), |w| <= 1/2, is a degree-6 polynomial (truncation < 4e-18);
+//     2^(j/32) comes from a 32-entry LDS table (every entry has its own banks:
+//     conflict free), the integer part goes through v_ldexp_f64.
+// RBF: 16 fp64 ops per value (d = 2), Matern-5/2: ~30, against ~27 + distance
+// for the library exp alone; accurate to ~2 ulp.
 #pragma once
 
 #include "common.h"
@@ -22,77 +31,78 @@ __device__ __forceinline__ void exp_tab_init(double* tab) {
   if (threadIdx.x < kExpTabSize) tab[threadIdx.x] = exp2(threadIdx.x * (1.0 / 32.0));
 }
 
-// exp(x) for x <= 0 (any x works; large negative x underflows to 0).
-__device__ __forceinline__ double exp_tab(double x, const double* tab) {
-  x = fmax(x, -745.2);
-  const double kf = rint(x * 46.16624130844683);       // 32 / ln 2
-  double r = fma(kf, -0.02166084937925916, x);         // ln2/32, high part
-  r = fma(kf, -1.3239129268154012e-11, r);             //         low part
+// (ln2/32)^i / i!
+#define SGP_E1 0.02166084939249829
+#define SGP_E2 0.0002345961982022468
+#define SGP_E3 1.693850972437182e-06
+#define SGP_E4 9.172562701824643e-09
+#define SGP_E5 3.973709984549416e-11
+#define SGP_E6 1.4345655584131934e-13
+
+// 2^(u/32) for u <= 0 (any finite u works; very negative u underflows to 0:
+// the int conversion saturates and v_ldexp_f64 flushes).
+__device__ __forceinline__ double exp2_32(double u, const double* tab) {
+  const double kf = rint(u);
+  const double w = u - kf;                 // exact, |w| <= 1/2
   const int k = int(kf);
   const double t = tab[k & 31];
-  // exp(r), |r| <= ln2/64: truncation r^7/5040 < 4e-18
-  double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
-  p = fma(r, p, 1.0 / 24.0);
-  p = fma(r, p, 1.0 / 6.0);
-  p = fma(r, p, 0.5);
-  p = fma(r, p, 1.0);
-  p = fma(r, p, 1.0);
+  double p = fma(w, SGP_E6, SGP_E5);
+  p = fma(w, p, SGP_E4);
+  p = fma(w, p, SGP_E3);
+  p = fma(w, p, SGP_E2);
+  p = fma(w, p, SGP_E1);
+  p = fma(w, p, 1.0);
   return ldexp(t * p, k >> 5);
 }
 
-// Four exp() at once, written step-major with scheduling fences: the compiler
-// otherwise runs the four ~20-deep dependent chains one after the other (it
+// Four 2^(u/32) at once, written step-major with scheduling fences: the
+// compiler otherwise runs the four dependent chains one after the other (it
 // minimises live registers at the 256-VGPR limit), which leaves the kernel
 // latency bound; step-major order keeps 4 independent instructions in flight.
 #define SGP_FENCE() __builtin_amdgcn_sched_barrier(0)
-__device__ __forceinline__ void exp_tab4(const double (&xin)[4],
-                                         const double* tab, double (&out)[4]) {
-  double x[4], kf[4], r[4], t[4], p[4];
+__device__ __forceinline__ void exp2_32x4(const double (&u)[4], const double* tab,
+                                          double (&out)[4]) {
+  double kf[4], w[4], t[4], p[4];
   int k[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) x[q] = fmax(xin[q], -745.2);
-  SGP_FENCE();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) kf[q] = rint(x[q] * 46.16624130844683);
+  for (int q = 0; q < 4; ++q) kf[q] = rint(u[q]);
   SGP_FENCE();
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     k[q] = int(kf[q]);
-    r[q] = fma(kf[q], -0.02166084937925916, x[q]);
+    w[q] = u[q] - kf[q];
   }
   SGP_FENCE();
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     t[q] = tab[k[q] & 31];
-    r[q] = fma(kf[q], -1.3239129268154012e-11, r[q]);
+    p[q] = fma(w[q], SGP_E6, SGP_E5);
   }
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) p[q] = fma(r[q], 1.0 / 720.0, 1.0 / 120.0);
+  for (int q = 0; q < 4; ++q) p[q] = fma(w[q], p[q], SGP_E4);
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) p[q] = fma(r[q], p[q], 1.0 / 24.0);
+  for (int q = 0; q < 4; ++q) p[q] = fma(w[q], p[q], SGP_E3);
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) p[q] = fma(r[q], p[q], 1.0 / 6.0);
+  for (int q = 0; q < 4; ++q) p[q] = fma(w[q], p[q], SGP_E2);
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) p[q] = fma(r[q], p[q], 0.5);
+  for (int q = 0; q < 4; ++q) p[q] = fma(w[q], p[q], SGP_E1);
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) p[q] = fma(r[q], p[q], 1.0);
-  SGP_FENCE();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) p[q] = fma(r[q], p[q], 1.0);
+  for (int q = 0; q < 4; ++q) p[q] = fma(w[q], p[q], 1.0);
   SGP_FENCE();
 #pragma unroll
   for (int q = 0; q < 4; ++q) out[q] = ldexp(t[q] * p[q], k[q] >> 5);
   SGP_FENCE();
 }
 
-// Four square roots, step-major (rsq seed + two Goldschmidt steps + a final
-// correction: <= 1 ulp for normal inputs; 0 maps to ~1e-150, which is 0 for
-// the Matern factors).
+// Four square roots, step-major: v_rsq_f64 seed (relative error 5e-8 on
+// gfx950), one Goldschmidt step and a final correction -- bit-identical to the
+// correctly rounded sqrt on 4M random inputs (scripts/dev/sqrt_accuracy.hip).
+// 0 maps to ~1e-150, which is 0 for the Matern factors.
 __device__ __forceinline__ void sqrt4(const double (&xin)[4], double (&out)[4]) {
   double x[4], y[4], g[4], h[4], r[4];
 #pragma unroll
@@ -108,17 +118,14 @@ __device__ __forceinline__ void sqrt4(const double (&xin)[4], double (&out)[4]) 
   }
   SGP_FENCE();
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int q = 0; q < 4; ++q) r[q] = fma(-h[q], g[q], 0.5);
+  SGP_FENCE();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = fma(-h[q], g[q], 0.5);
-    SGP_FENCE();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      g[q] = fma(g[q], r[q], g[q]);
-      h[q] = fma(h[q], r[q], h[q]);
-    }
-    SGP_FENCE();
+  for (int q = 0; q < 4; ++q) {
+    g[q] = fma(g[q], r[q], g[q]);
+    h[q] = fma(h[q], r[q], h[q]);
   }
+  SGP_FENCE();
 #pragma unroll
   for (int q = 0; q < 4; ++q) r[q] = fma(-g[q], g[q], x[q]);
   SGP_FENCE();
@@ -136,18 +143,6 @@ __device__ __forceinline__ double k_of_r2(int kind, double r2) {
   }
   const double a = 2.23606797749979 * r;  // sqrt(5) r
   return (1.0 + a + (5.0 / 3.0) * r2) * exp(-a);
-}
-
-__device__ __forceinline__ double k_of_r2_tab(int kind, double r2,
-                                              const double* tab) {
-  if (kind == SGP_RBF) return exp_tab(-0.5 * r2, tab);
-  const double r = sqrt(r2);
-  if (kind == SGP_MATERN32) {
-    const double a = 1.7320508075688772 * r;
-    return (1.0 + a) * exp_tab(-a, tab);
-  }
-  const double a = 2.23606797749979 * r;
-  return (1.0 + a + (5.0 / 3.0) * r2) * exp_tab(-a, tab);
 }
 
 // k(x, y) for the product kernel `kd`; x and y are raw D-vectors.
@@ -171,29 +166,40 @@ __device__ __forceinline__ double kern_eval(const KernDesc& kd, const double* x,
 }
 
 // Hyper-parameters of one GP hoisted out of the inner loops.  The common case
-// (one stationary part) works on inputs pre-scaled by 1/lengthscale and keeps
-// everything in registers; products of parts fall back to the descriptor loop
-// on raw inputs.
+// (one stationary part) works on inputs pre-multiplied by KernDesc::scale0 and
+// keeps everything in registers; products of parts fall back to the descriptor
+// loop on raw inputs.
 template <int D>
 struct KernFast {
   const KernDesc* kd;
   bool single;
   int kind0;
   double var0;
-  double il0[D];
+  double m1, m2;   // Matern polynomial in u = -|dz|: var0 + u (m1 + u m2)
+  double sc[D];
 
   __device__ __forceinline__ explicit KernFast(const KernDesc& k) : kd(&k) {
     single = k.n_parts == 1;
     kind0 = k.kind[0];
     var0 = k.variance[0];
+    // 1 + a (+ a^2/3), a = -u ln2/32, times var0
+    m1 = -var0 * SGP_E1;
+    m2 = (kind0 == SGP_MATERN52) ? var0 * 0.00015639746546816451 : 0.0;
 #pragma unroll
-    for (int i = 0; i < D; ++i) il0[i] = k.inv_ls[0][i];
+    for (int i = 0; i < D; ++i) sc[i] = k.scale0[i];
   }
 
   // candidate row -> the form operator() expects (scaled when `single`)
   __device__ __forceinline__ void prep(const double* x, double* xs) const {
 #pragma unroll
-    for (int i = 0; i < D; ++i) xs[i] = single ? x[i] * il0[i] : x[i];
+    for (int i = 0; i < D; ++i) xs[i] = single ? x[i] * sc[i] : x[i];
+  }
+
+  // covariance from the squared distance in scaled units
+  __device__ __forceinline__ double of_r2s(double r2, const double* tab) const {
+    if (kind0 == SGP_RBF) return var0 * exp2_32(-r2, tab);
+    const double u = -sqrt(r2);
+    return fma(u, fma(u, m2, m1), var0) * exp2_32(u, tab);
   }
 
   // xs from prep(); ys = row of GpDev::Xs (pre-scaled when `single`)
@@ -207,7 +213,7 @@ struct KernFast {
         const double t = xs[i] - ys[i];
         r2 = fma(t, t, r2);
       }
-      return var0 * k_of_r2_tab(kind0, r2, tab);
+      return of_r2s(r2, tab);
     }
     return kern_eval<D>(*kd, xs, ys);
   }
@@ -222,7 +228,7 @@ struct KernFast {
                                        double (&out)[NV]) const {
     static_assert(NV == 4, "the batched evaluation is written for 4 values");
     if (single) {
-      double r2[4], arg[4], e[4];
+      double r2[4], u[4], e[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         r2[q] = 0.0;
@@ -234,26 +240,19 @@ struct KernFast {
       }
       if (kind0 == SGP_RBF) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) arg[q] = -0.5 * r2[q];
-        exp_tab4(arg, tab, e);
+        for (int q = 0; q < 4; ++q) u[q] = -r2[q];
+        exp2_32x4(u, tab, e);
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[q] = var0 * e[q];
       } else {
         double rr[4];
         sqrt4(r2, rr);
-        const double c = (kind0 == SGP_MATERN32) ? 1.7320508075688772
-                                                 : 2.23606797749979;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) arg[q] = -c * rr[q];
-        exp_tab4(arg, tab, e);
-        if (kind0 == SGP_MATERN32) {
+        for (int q = 0; q < 4; ++q) u[q] = -rr[q];
+        exp2_32x4(u, tab, e);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) out[q] = var0 * (1.0 - arg[q]) * e[q];
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            out[q] = var0 * (1.0 - arg[q] + (5.0 / 3.0) * r2[q]) * e[q];
-        }
+        for (int q = 0; q < 4; ++q)
+          out[q] = fma(u[q], fma(u[q], m2, m1), var0) * e[q];
       }
     } else {
 #pragma unroll
@@ -269,10 +268,10 @@ struct KernFast {
       double r2 = 0.0;
 #pragma unroll
       for (int i = 0; i < D; ++i) {
-        const double t = (x[i] - y[i]) * il0[i];
+        const double t = (x[i] - y[i]) * sc[i];
         r2 = fma(t, t, r2);
       }
-      return var0 * k_of_r2_tab(kind0, r2, tab);
+      return of_r2s(r2, tab);
     }
     return kern_eval<D>(*kd, x, y);
   }

@@ -45,7 +45,7 @@ enum { MODE_CONF = 0, MODE_FITNESS = 1 };
 // Timing experiments ("what does the kernel cost without X"; results are wrong
 // with any bit set): built only with -DSGP_INSTRUMENT, selected at run time by
 // SGP_ABLATE=<mask>: 1 no stage barrier, 2 no LDS-DMA, 4 no covariance
-// evaluation, 8 no MFMA.  profiles/r01/ablation.txt holds the numbers.
+// evaluation, 8 no MFMA, 16 no mean/var/Q stores, 32 no per-GP epilogue at all.  profiles/r01/ablation.txt holds the numbers.
 #ifdef SGP_INSTRUMENT
 #define SGP_ABL(mask) (p.ablate & (mask))
 #else
@@ -66,48 +66,63 @@ struct SweepParams {
 
 // The descriptor fields the stage pipeline touches every iteration, hoisted out
 // of the device array once per GP (they live in SGPRs across the stage loop).
+// (The pointers come out of a descriptor in memory, so the compiler would emit
+// FLAT loads for them; a FLAT load also counts on lgkmcnt, and every LDS wait
+// of the stage would then sit out a global-memory latency.  Hence the explicit
+// global address space.)
+typedef const __attribute__((address_space(1))) double* gptr_t;
 struct GpView {
-  const double* Apack;
-  const double* Xs;
-  const double* alpha;
+  gptr_t Apack;
+  gptr_t Xs;
+  gptr_t alpha;
   int nsteps_total;
+  // wave-uniform values, pinned to SGPRs (they are loaded through VGPRs and
+  // would otherwise stay there -- or get spilled to scratch at 256 VGPRs)
+  static __device__ __forceinline__ gptr_t uniform(const double* q) {
+    const uint64_t v = reinterpret_cast<uint64_t>(q);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
+    return (gptr_t)reinterpret_cast<const double*>((uint64_t(hi) << 32) | lo);
+  }
   __device__ __forceinline__ void load(const GpDev& gp) {
-    Apack = gp.Apack;
-    Xs = gp.Xs;
-    alpha = gp.alpha;
-    nsteps_total = gp.n_pad >> 2;
+    Apack = uniform(gp.Apack);
+    Xs = uniform(gp.Xs);
+    alpha = uniform(gp.alpha);
+    nsteps_total = __builtin_amdgcn_readfirstlane(gp.n_pad >> 2);
   }
 };
 
 // Asynchronous global -> LDS copy of one A chunk (LDS-DMA, no VGPR round trip).
 // LDS image: slot-major A[slot][step][lane]; slot = row block - b0 + shift so
 // that the last row block of the chunk always sits in slot 15.  A slot is 2 KB
-// = two 1 KB pieces (k-steps {0,1} and {2,3}); wave w issues pieces w, w+8,
-// w+16, w+24.  Only the slots the next j-block reads are fetched (`lo` = its
-// first active slot, even); above-diagonal blocks inside a fetched pair come
-// from the zero part of the packed matrix.
+// = two 1 KB instructions (k-steps {0,1} and {2,3}, the second through the
+// instruction offset, which applies to the global and the LDS address alike);
+// wave w copies slots w, w + NW, ...  Only the slots the j-block reads are
+// fetched (`lo` = its first active slot).  Everything but the per-lane offset
+// is scalar, and the address of the next slot is one 64-bit add away: the
+// wave's issue slots are the scarce resource of this loop (scripts/
+// stagebench.py), so the bookkeeping per copy is kept to a handful of SALU ops.
 template <int NW>
 __device__ __forceinline__ void stage_dma(const GpView& gp, double* buf, int b0,
                                           int shift, int jb, int lo, int tid) {
-  const int nsteps_total = gp.nsteps_total;
-  // the wave index as an SGPR: slot tests become scalar branches and the DMA
-  // source address is a scalar base + a constant per-lane offset
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
+  const int64_t row_stride = int64_t(gp.nsteps_total) * 64;   // doubles / row block
+  gptr_t src = gp.Apack + (int64_t(b0 - shift + wave) * gp.nsteps_total +
+                           jb * kSteps) * 64 + lane * 2;
+  double* dst = buf + wave * (2 * 128);                       // wave-uniform
 #pragma unroll
-  for (int k = 0; k < 32 / NW; ++k) {
-    const int piece = wave + NW * k;      // wave-uniform
-    const int slot = piece >> 1;
-    const int half = piece & 1;
-    if (slot >= lo) {
-      const int bg = b0 + slot - shift;
-      const double* src = gp.Apack +
-          (int64_t(bg) * nsteps_total + jb * kSteps + 2 * half) * 64 + lane * 2;
-      double* dst = buf + piece * 128;    // wave-uniform LDS base
+  for (int k = 0; k < kIB / NW; ++k) {
+    if (wave + NW * k >= lo) {
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)src,
           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)dst, 16, 1024, 0);
     }
+    src += NW * row_stride;
+    dst += NW * (2 * 128);
   }
 }
 
@@ -115,9 +130,10 @@ __device__ __forceinline__ void stage_dma(const GpView& gp, double* buf, int b0,
 __device__ __forceinline__ double stage_x_load(const GpView& gp, int D, int jb,
                                                int tid) {
   const int j0 = jb * kJC;
-  if (tid < kJC * D) return gp.Xs[j0 * D + tid];
-  if (tid >= 128 && tid < 128 + kJC) return gp.alpha[j0 + (tid - 128)];
-  return 0.0;
+  const bool isx = tid < kJC * D;
+  const bool isa = tid >= 128 && tid < 128 + kJC;
+  gptr_t src = isx ? gp.Xs + (j0 * D + tid) : gp.alpha + (j0 + (tid - 128));
+  return (isx || isa) ? *src : 0.0;
 }
 
 __device__ __forceinline__ void stage_x_store(double v, double* buf, int D,
@@ -366,7 +382,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       }
     }
 
-    if (gp_ends) {
+    if (gp_ends && !SGP_ABL(32)) {
       // sq[m]: partial sums for column 4m + (lane & 3) over this lane's rows.
       // Fold the 16 lanes that share (lane & 3), then pick the quad of this
       // lane's own column (lane & 15) = 4 ((lane >> 2) & 3) + (lane & 3).
@@ -397,7 +413,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
         const double up = mu + p.conf.beta * sd;
         if (g == 0) l0 = lo;
         safe = safe && (lo > p.conf.fmin[g]);
-        if (writer) {
+        if (writer && !SGP_ABL(16)) {
           p.conf.mean[int64_t(g) * p.pts.N + row] = mu;
           p.conf.var[int64_t(g) * p.pts.N + row] = var;
           if (p.conf.Q) {
@@ -742,6 +758,74 @@ __global__ __launch_bounds__(256) void k_mfma_bench(double* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// One stage of the sweep's inner loop in isolation (scripts/microbench.py):
+//   STAGE 0  mfma_jblock only (B-operand swizzles, slot guards, A operand reads)
+//   STAGE 1  + the stage barrier
+//   STAGE 2  + the LDS-DMA of the next A chunk (8 x 1 KB per wave) + barrier
+//   STAGE 3  + the 4 covariance evaluations per lane (RBF, d = 2)
+//   STAGE 4  covariance evaluations + mfma_jblock, no DMA, no barrier
+// `lo` = first active accumulator slot (0: all 16 slots, 9: config 2's average).
+template <int STAGE>
+__global__ __launch_bounds__(256, 2) void k_stage_bench(const double* src,
+                                                        double* out, int iters,
+                                                        int lo) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const double* tab = lds + kTabOff;
+  exp_tab_init(lds + kTabOff);
+  for (int i = tid; i < 2 * kBuf; i += 256) lds[i] = 1e-3 * (i % 97);
+  __syncthreads();
+  double4_t acc[kIB];
+#pragma unroll
+  for (int b = 0; b < kIB; ++b) acc[b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  double kv[4] = {1.0 + lane * 1e-3, 1.1, 1.2 - lane * 1e-3, 1.3};
+  const double xs[2] = {lane * 0.01, 0.3 + blockIdx.x * 1e-4};
+  GpView gv;
+  gv.Apack = (gptr_t)src;
+  gv.Xs = (gptr_t)src;
+  gv.alpha = (gptr_t)src;
+  gv.nsteps_total = kSteps;
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+    double* cbuf = lds + (it & 1) * kBuf;
+    double* nbuf = lds + ((it & 1) ^ 1) * kBuf;
+    if (STAGE == 2 || STAGE == 3) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int piece = wave + 4 * k;
+        if ((piece >> 1) >= lo) {
+          const double* g = src + piece * 128 + lane * 2;
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)g,
+              (__attribute__((address_space(3))) void*)(nbuf + piece * 128), 16,
+              0, 0);
+        }
+      }
+    }
+    if (STAGE >= 3) {
+      const double* xT = cbuf + kATile + (lane >> 4) * 2;
+      double r2[4], u[4], e[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double t0 = xs[0] - xT[q * 8], t1 = xs[1] - xT[q * 8 + 1];
+        r2[q] = fma(t1, t1, t0 * t0);
+        u[q] = -r2[q];
+      }
+      exp2_32x4(u, tab, e);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) kv[q] = 2.0 * e[q];
+    }
+    mfma_jblock(lo, acc, cbuf + lane, kv);
+    if (STAGE >= 1 && STAGE <= 3) __syncthreads();
+  }
+  double s = 0;
+#pragma unroll
+  for (int b = 0; b < kIB; ++b)
+    for (int r = 0; r < 4; ++r) s += acc[b][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <int D, int NW>
 int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static bool attr_set = false;
@@ -937,6 +1021,37 @@ int launch_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
     case 7: SGP_TRY(run_microbench<7>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;
     case 8: SGP_TRY(run_microbench<8>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;
     case 9: SGP_TRY(run_microbench<9>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;
+    case 20: case 21: case 22: case 23: case 24: {
+      // stage probes: lds_bytes carries `lo`; two 4-wave workgroups per CU
+      const int lo = lds_bytes, nb = ctx->num_cu * 2;
+      double* src = static_cast<double*>(sgp_scratch(ctx, 1, size_t(kATile) * 8));
+      if (!src) return -1;
+      SGP_HIP(ctx, hipMemsetAsync(src, 0, size_t(kATile) * 8, ctx->stream));
+#define STAGE_RUN(S)                                                            \
+  SGP_HIP(ctx, hipFuncSetAttribute(                                             \
+                   reinterpret_cast<const void*>(&k_stage_bench<S>),            \
+                   hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsBytes)));\
+  hipLaunchKernelGGL(k_stage_bench<S>, dim3(nb), dim3(256), kLdsBytes,          \
+                     ctx->stream, src, out, 16, lo);                            \
+  SGP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));                          \
+  hipLaunchKernelGGL(k_stage_bench<S>, dim3(nb), dim3(256), kLdsBytes,          \
+                     ctx->stream, src, out, iters, lo);                         \
+  SGP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+      switch (mode) {
+        case 20: STAGE_RUN(0) break;
+        case 21: STAGE_RUN(1) break;
+        case 22: STAGE_RUN(2) break;
+        case 23: STAGE_RUN(3) break;
+        default: STAGE_RUN(4) break;
+      }
+#undef STAGE_RUN
+      SGP_HIP(ctx, hipEventSynchronize(ctx->ev1));
+      SGP_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+      tflops[0] = double(nb) * 4.0 * iters * (16 - lo) * 16 * 512.0 /
+                  (double(ms) * 1e-3) / 1e12;
+      tflops[1] = double(ms) * 1e6 / iters;     // ns per stage
+      return 0;
+    }
     default: sgp_set_error(ctx, "unknown microbench mode %d", mode); return -2;
   }
   const double waves = double(nblocks) * 4.0;
