@@ -178,15 +178,22 @@ struct KernFast {
   double m1, m2;   // Matern polynomial in u = -|dz|: var0 + u (m1 + u m2)
   double sc[D];
 
+  // wave-uniform hyper-parameters, pinned to SGPRs (the sweep runs at the
+  // 256-VGPR limit)
+  static __device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  }
+
   __device__ __forceinline__ explicit KernFast(const KernDesc& k) : kd(&k) {
-    single = k.n_parts == 1;
-    kind0 = k.kind[0];
-    var0 = k.variance[0];
+    single = __builtin_amdgcn_readfirstlane(int(k.n_parts == 1)) != 0;
+    kind0 = __builtin_amdgcn_readfirstlane(k.kind[0]);
+    var0 = uni(k.variance[0]);
     // 1 + a (+ a^2/3), a = -u ln2/32, times var0
-    m1 = -var0 * SGP_E1;
-    m2 = (kind0 == SGP_MATERN52) ? var0 * 0.00015639746546816451 : 0.0;
+    m1 = uni(-var0 * SGP_E1);
+    m2 = uni((kind0 == SGP_MATERN52) ? var0 * 0.00015639746546816451 : 0.0);
 #pragma unroll
-    for (int i = 0; i < D; ++i) sc[i] = k.scale0[i];
+    for (int i = 0; i < D; ++i) sc[i] = uni(k.scale0[i]);
   }
 
   // candidate row -> the form operator() expects (scaled when `single`)

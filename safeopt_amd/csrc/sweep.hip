@@ -275,7 +275,7 @@ __device__ __forceinline__ void stage_issue(const StagePos& sp, const GpView& gp
   xstage = stage_x_load(gp, D, sp.jb, tid);
 }
 
-template <int D, int NW>
+template <int D, int NW, int MODE>
 __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   constexpr int kWaves = NW;
   constexpr int kTilePts = 16 * NW;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const bool conf = p.mode == MODE_CONF;
+  constexpr bool conf = MODE == MODE_CONF;   // compile-time: no dead state
   const int st = p.fit.swarm_type;
   const int Geff = (!conf && st == SGP_SWARM_GREEDY) ? 1 : p.G;
   const int64_t ntiles = (p.pts.N + kTilePts - 1) / kTilePts;
@@ -826,12 +826,12 @@ __global__ __launch_bounds__(256, 2) void k_stage_bench(const double* src,
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int D, int NW>
+template <int D, int NW, int MODE>
 int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep<D, NW>),
+                     reinterpret_cast<const void*>(&k_sweep<D, NW, MODE>),
                      hipFuncAttributeMaxDynamicSharedMemorySize,
                      int(kLdsBytes)));
     attr_set = true;
@@ -862,7 +862,7 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
   pp.ablate = ablate;
 #endif
-  hipLaunchKernelGGL((k_sweep<D, NW>), dim3(nblocks), dim3(64 * NW),
+  hipLaunchKernelGGL((k_sweep<D, NW, MODE>), dim3(nblocks), dim3(64 * NW),
                      kLdsBytes, ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
   if (e1) SGP_HIP(ctx, hipEventRecord(e1, ctx->stream));
@@ -871,7 +871,9 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
 
 template <int D>
 int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
-  return launch_sweep_v<D, kSweepWaves>(ctx, p, flops);
+  if (p.mode == MODE_CONF)
+    return launch_sweep_v<D, kSweepWaves, MODE_CONF>(ctx, p, flops);
+  return launch_sweep_v<D, kSweepWaves, MODE_FITNESS>(ctx, p, flops);
 }
 
 int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
