@@ -80,6 +80,17 @@ def main(d):
     for k, v in l.items():
         if "sweep" in k:
             print("PMC %-16s %s" % (k, {n: sum(x[0] for x in vals) / len(vals) for n, vals in v.items()}))
+    for sub in ("pmc_issue_cfg2", "pmc_coexec_cfg2"):
+        for k, v in pmc(os.path.join(d, sub)).items():
+            if "sweep" in k:
+                print("PMC %-16s %s" % (k, {n: "%.4g" % (sum(x[0] for x in vals) / len(vals))
+                                            for n, vals in sorted(v.items())}))
+    for name, title in (("stagebench.txt", "scripts/stagebench.py"),
+                        ("ablation.txt", "scripts/ablate.sh (instrumented build; results invalid by design)")):
+        f = os.path.join(d, name)
+        if os.path.exists(f):
+            print("\n== %s" % title)
+            print(open(f).read())
     mb = os.path.join(d, "microbench.txt")
     if os.path.exists(mb):
         print("\n== scripts/microbench.py")
