@@ -20,7 +20,7 @@ def stats(path, title):
         return
     print("== rocprofv3 --kernel-trace --stats : %s" % title)
     print("%-30s %6s %12s %12s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
         print("%-30s %6s %12.1f %12.2f %8s" % (key(r["Name"]), r["Calls"],
               float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, r["Percentage"]))
     print()
@@ -31,7 +31,7 @@ def pmc(path):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     if not files:
         return agg
-    for x in csv.DictReader(open(files[0])):
+    for x in csv.DictReader(open(max(files, key=os.path.getmtime))):
         agg[key(x["Kernel_Name"])][x["Counter_Name"]].append(
             (float(x["Counter_Value"]), int(x["End_Timestamp"]) - int(x["Start_Timestamp"])))
     return agg
