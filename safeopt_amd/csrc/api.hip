@@ -958,7 +958,7 @@ int sgp_profile_read(sgp_ctx* ctx, double* total_ms, int64_t* launches,
 int sgp_microbench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops) {
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   double t[2];
-  SGP_TRY(launch_microbench(ctx, 0, iters, 0, t));
+  SGP_TRY(launch_microbench(ctx, 7, iters, 0, t));  // v_mfma_f64_4x4x4_4b_f64 chains
   *tflops = t[0];
   return 0;
 }
