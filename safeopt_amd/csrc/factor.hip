@@ -238,25 +238,92 @@ __global__ void k_pack(const double* Li, int64_t ld, int n, int nblk,
   Apack[e] = v;
 }
 
-// t = Linv * y (lower-triangular matvec), one thread per row
-__global__ void k_trmv_lower(const double* Li, int64_t ld, int n,
-                             const double* y, double* t) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// Lower-triangular products with up to 16 right-hand sides, V and the results
+// stored one vector per row (pitch ldv / ldo).  Both read L^-1 exactly once,
+// coalesced along its rows, in a fixed summation order (every rank of a
+// multi-GPU run computes bit-identical operands).
+constexpr int kMaxRhs = 16;
+
+// T[c][i] = sum_{j <= i} Li[i][j] V[c][j]: one wave per row i.
+__global__ __launch_bounds__(256) void k_tri_mv(const double* Li, int64_t ld,
+                                                int n, const double* V,
+                                                int64_t ldv, int m, double* T,
+                                                int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
-  double s = 0.0;
-  for (int j = 0; j <= i; ++j) s = fma(Li[int64_t(i) * ld + j], y[j], s);
-  t[i] = s;
+  double acc[kMaxRhs];
+#pragma unroll
+  for (int c = 0; c < kMaxRhs; ++c) acc[c] = 0.0;
+  const double* row = Li + int64_t(i) * ld;
+  for (int j = lane; j <= i; j += 64) {
+    const double l = row[j];
+#pragma unroll
+    for (int c = 0; c < kMaxRhs; ++c)
+      if (c < m) acc[c] = fma(l, V[c * ldv + j], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < kMaxRhs; ++c) {
+    if (c < m) {
+      double v = acc[c];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) T[c * ldo + i] = v;
+    }
+  }
 }
 
-// out = Linv^T * t, one thread per column; out has n_out >= n entries (zero pad)
-__global__ void k_trmv_lower_t(const double* Li, int64_t ld, int n,
-                               const double* t, double* out, int n_out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_out) return;
-  double s = 0.0;
-  if (j < n)
-    for (int i = j; i < n; ++i) s = fma(Li[int64_t(i) * ld + j], t[i], s);
-  out[j] = s;
+// W[c][j] = sum_{i >= j} Li[i][j] T[c][i] for j < n, 0 for n <= j < n_out:
+// one workgroup per 64 columns, its 8 waves take every 8th row.
+__global__ __launch_bounds__(512) void k_tri_mtv(const double* Li, int64_t ld,
+                                                 int n, const double* T,
+                                                 int64_t ldt, int m, double* W,
+                                                 int64_t ldo, int n_out) {
+  __shared__ double sh[8][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j0 = blockIdx.x * 64, j = j0 + lane;
+  double acc[kMaxRhs];
+#pragma unroll
+  for (int c = 0; c < kMaxRhs; ++c) acc[c] = 0.0;
+  if (j < n) {
+    for (int i = j0 + wave; i < n; i += 8) {
+      const double l = (i >= j) ? Li[int64_t(i) * ld + j] : 0.0;
+#pragma unroll
+      for (int c = 0; c < kMaxRhs; ++c)
+        if (c < m) acc[c] = fma(l, T[c * ldt + i], acc[c]);
+    }
+  }
+  for (int c = 0; c < m; ++c) {           // m is uniform: barriers are safe
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < kMaxRhs; ++k) v = (k == c) ? acc[k] : v;
+    sh[wave][lane] = v;
+    __syncthreads();
+    if (wave == 0 && j < n_out) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) tot += sh[w][lane];
+      W[c * ldo + j] = (j < n) ? tot : 0.0;
+    }
+    __syncthreads();
+  }
+}
+
+int launch_tri_mv(sgp_ctx* ctx, const double* Li, int64_t ld, int n,
+                  const double* V, int64_t ldv, int m, double* T, int64_t ldo) {
+  hipLaunchKernelGGL(k_tri_mv, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, Li,
+                     ld, n, V, ldv, m, T, ldo);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_tri_mtv(sgp_ctx* ctx, const double* Li, int64_t ld, int n,
+                   const double* T, int64_t ldt, int m, double* W, int64_t ldo,
+                   int n_out) {
+  hipLaunchKernelGGL(k_tri_mtv, dim3((n_out + 63) / 64), dim3(512), 0,
+                     ctx->stream, Li, ld, n, T, ldt, m, W, ldo, n_out);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
 }
 
 // Xpad = zero-padded X; Xs = Xpad * scale0 per column (products of parts: copy)
@@ -398,13 +465,9 @@ int factor_gp(sgp_gp* gp, int* info) {
   SGP_TRY(sgp_d2h(ctx, info, info_dev, sizeof(int)));
   if (*info != 0) return 0;
 
-  hipLaunchKernelGGL(k_trmv_lower, dim3((n + 127) / 128), dim3(128), 0,
-                     ctx->stream, Li, int64_t(ld), n,
-                     static_cast<double*>(gp->Y.p), tv);
-  hipLaunchKernelGGL(k_trmv_lower_t, dim3((np + 127) / 128), dim3(128), 0,
-                     ctx->stream, Li, int64_t(ld), n, tv,
-                     static_cast<double*>(gp->alpha.p), np);
-  SGP_HIP(ctx, hipGetLastError());
+  SGP_TRY(launch_tri_mv(ctx, Li, ld, n, static_cast<double*>(gp->Y.p), 0, 1, tv, 0));
+  SGP_TRY(launch_tri_mtv(ctx, Li, ld, n, tv, 0, 1,
+                         static_cast<double*>(gp->alpha.p), 0, np));
   return publish_gp(gp);
 }
 
@@ -488,8 +551,8 @@ int append_gp(sgp_gp* gp, double y, int* info) {
   const double* xnew = X + size_t(n) * d;
   SGP_TRY(launch_kernel_matrix(ctx, gp->kern, xnew, 1, X, n, Kc, ld, 0, 0.0,
                                INT64_MAX));
-  SGP_TRY(gemm(ctx, true, 1, n, n, 1.0, Kc, ld, Li, ld, 0.0, Tt, ld));
-  SGP_TRY(gemm(ctx, false, 1, n, n, 1.0, Tt, ld, Li, ld, 0.0, Wt, ld));
+  SGP_TRY(launch_tri_mv(ctx, Li, ld, n, Kc, ld, 1, Tt, ld));
+  SGP_TRY(launch_tri_mtv(ctx, Li, ld, n, Tt, ld, 1, Wt, ld, n));
   const int np_new = (n + 1 + 15) / 16 * 16;
   const double prior = gp->kern.kdiag + gp->noise_var + 1e-8 + gp->jitter;
   hipLaunchKernelGGL(k_append_finish, dim3(1), dim3(1024), 0, ctx->stream, Li,
@@ -518,13 +581,9 @@ int pop_gp(sgp_gp* gp) {
   gp->n_pad = (n + 15) / 16 * 16;
   gp->n_f = (n + 31) / 32 * 32;
   gp->upd_valid = false;
-  hipLaunchKernelGGL(k_trmv_lower, dim3((n + 127) / 128), dim3(128), 0,
-                     ctx->stream, Li, int64_t(ld), n,
-                     static_cast<double*>(gp->Y.p), tv);
-  hipLaunchKernelGGL(k_trmv_lower_t, dim3((gp->n_pad + 127) / 128), dim3(128),
-                     0, ctx->stream, Li, int64_t(ld), n, tv,
-                     static_cast<double*>(gp->alpha.p), gp->n_pad);
-  SGP_HIP(ctx, hipGetLastError());
+  SGP_TRY(launch_tri_mv(ctx, Li, ld, n, static_cast<double*>(gp->Y.p), 0, 1, tv, 0));
+  SGP_TRY(launch_tri_mtv(ctx, Li, ld, n, tv, 0, 1,
+                         static_cast<double*>(gp->alpha.p), 0, gp->n_pad));
   return publish_gp(gp);
 }
 
@@ -546,8 +605,8 @@ int expander_operands(sgp_gp* gp, const double* xc_dev, int m,
                                static_cast<double*>(gp->X.p), n, Kc, nf, 0,
                                0.0, INT64_MAX));
   // T^T[c][i] = sum_j Kc[c][j] Li[i][j] ; W^T[c][j] = sum_i T^T[c][i] Li[i][j]
-  SGP_TRY(gemm(ctx, true, m, n, n, 1.0, Kc, nf, Li, nf, 0.0, Tt, nf));
-  SGP_TRY(gemm(ctx, false, m, n, n, 1.0, Tt, nf, Li, nf, 0.0, Wt, nf));
+  SGP_TRY(launch_tri_mv(ctx, Li, nf, n, Kc, nf, m, Tt, nf));
+  SGP_TRY(launch_tri_mtv(ctx, Li, nf, n, Tt, nf, m, Wt, nf, n));
   const double prior = gp->kern.kdiag + gp->noise_var + 1e-8 + gp->jitter;
   hipLaunchKernelGGL(k_s2, dim3(m), dim3(256), 0, ctx->stream, Tt, int64_t(nf),
                      n, m, prior, resid_dev, delta, inv_s2, tn2);
