@@ -197,6 +197,16 @@ int sgp_swarm_fitness(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
                       const double* fmin, const double* scaling,
                       double best_lower_bound, double* values, uint8_t* safe);
 
+/* ---- SafeOptSwarm safe-set growth (gp_opt.py:1089-1111) ---------------------
+ * After a maximizer / expander swarm run the reference appends, in order, every
+ * best position B_j (n,d row-major) whose prior correlation
+ * gp.kern.K(B_j, p) / scaling[0]^2 is <= thr (0.95) with every point p of the
+ * safe set S (m,d row-major) and with every B_i accepted before it.
+ * scale2 = scaling[0]^2; accept (n) u8 = 1 for the rows to append.            */
+int sgp_swarm_grow(sgp_ctx* ctx, sgp_gp* gp0, const double* S, int64_t m,
+                   const double* B, int64_t n, double scale2, double thr,
+                   uint8_t* accept);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -------------------------
  * The only cross-rank traffic of the path is a handful of scalars per
  * iteration (max / any / arg-max / top-k merge).                             */

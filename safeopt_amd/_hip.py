@@ -87,6 +87,8 @@ PROTOTYPES = {
                                     C.c_int64, C.c_double, c_double_p,
                                     c_double_p, C.c_double, c_double_p,
                                     c_u8_p]),
+    "sgp_swarm_grow": (C.c_int, [vp, vp, c_double_p, C.c_int64, c_double_p,
+                                 C.c_int64, C.c_double, C.c_double, c_u8_p]),
     "sgp_comm_unique_id": (C.c_int, [vp]),
     "sgp_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "sgp_comm_allreduce_max": (C.c_int, [vp, c_double_p, C.c_int]),
@@ -555,6 +557,19 @@ class DeviceGrid(object):
             np.copyto(out, buf)
             return out
         return buf
+
+
+def swarm_grow(ctx, gp, S, B, scale2, thr=0.95):
+    """Rows of ``B`` to append to the safe set ``S`` (bool mask, in order)."""
+    d = gp.d
+    S = f64(S).reshape(-1, d)
+    B = f64(B).reshape(-1, d)
+    accept = np.zeros(B.shape[0], dtype=np.uint8)
+    if B.shape[0]:
+        ctx.check(lib().sgp_swarm_grow(
+            ctx.h, gp.h, dptr(S), S.shape[0], dptr(B), B.shape[0],
+            float(scale2), float(thr), accept.ctypes.data_as(c_u8_p)))
+    return accept.view(np.bool_)
 
 
 def swarm_fitness(ctx, gps, swarm_type, particles, beta, fmin, scaling,

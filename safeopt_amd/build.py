@@ -17,7 +17,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libsafeopt_hip.so")
-SOURCES = ["api.hip", "sweep.hip", "factor.hip", "sets.hip"]
+SOURCES = ["api.hip", "sweep.hip", "factor.hip", "sets.hip", "swarm.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kern_eval.h"),
            os.path.join(REPO, "include", "safeopt_hip.h")]
 BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

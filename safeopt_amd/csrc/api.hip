@@ -919,6 +919,35 @@ int sgp_swarm_fitness(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
   return 0;
 }
 
+// SafeOptSwarm safe-set growth, gp_opt.py:1089-1111 (kernels in swarm.hip).
+int sgp_swarm_grow(sgp_ctx* ctx, sgp_gp* gp0, const double* S, int64_t m,
+                   const double* B, int64_t n, double scale2, double thr,
+                   uint8_t* accept) {
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, gp0 != nullptr, "no GP");
+  SGP_CHECK(ctx, m >= 0 && n >= 0 && n <= INT32_MAX, "bad sizes m=%lld n=%lld",
+            (long long)m, (long long)n);
+  if (n == 0) return 0;
+  const int d = gp0->kern.d;
+  const int nchunks = swarm_grow_chunks(m);
+  const size_t bs = size_t(m) * d * 8, bb = size_t(n) * d * 8;
+  const size_t bp = size_t(n) * size_t(nchunks > 0 ? nchunks : 1) * 8;
+  const size_t bl = size_t(n) * 4, ba = size_t(n);
+  char* buf = static_cast<char*>(
+      sgp_scratch(ctx, 4, bs + bb + bp + bl + ba + 64));
+  SGP_CHECK(ctx, buf, "device allocation failed: %s", ctx->err.c_str());
+  double* dS = reinterpret_cast<double*>(buf);
+  double* dB = reinterpret_cast<double*>(buf + bs);
+  double* part = reinterpret_cast<double*>(buf + bs + bb);
+  int* list = reinterpret_cast<int*>(buf + bs + bb + bp);
+  uint8_t* dacc = reinterpret_cast<uint8_t*>(buf + bs + bb + bp + bl);
+  SGP_TRY(sgp_h2d(ctx, dS, S, bs));
+  SGP_TRY(sgp_h2d(ctx, dB, B, bb));
+  SGP_TRY(launch_swarm_grow(ctx, gp0->kern, dS, m, dB, int(n), scale2, thr, part,
+                            list, dacc));
+  return sgp_d2h(ctx, accept, dacc, ba);
+}
+
 // ---- timing ---------------------------------------------------------------------
 int sgp_timer_start(sgp_ctx* ctx) {
   SGP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));

@@ -797,20 +797,15 @@ class SafeOptSwarm(GaussianProcessOptimization):
         swarm.run_swarm(self.max_iters)
 
         if swarm_type != 'greedy':
-            num_added = 0
-            covariance = self.gp.kern.K(swarm.best_positions,
-                                        np.vstack((self.S,
-                                                   swarm.best_positions)))
-            covariance /= self.scaling[0] ** 2
-            initial_safe = len(self.S)
-            n, m = np.shape(covariance)
-            mask = np.zeros(m, dtype=bool)
-            mask[:initial_safe] = True
-            for j in range(n):
-                if np.all(covariance[j, mask] <= 0.95):
-                    self.S = np.vstack((self.S, swarm.best_positions[[j], :]))
-                    num_added += 1
-                    mask[initial_safe + j] = True
+            # correlation filter of gp_opt.py:1089-1111 on the device: the
+            # n x (m + n) covariance matrix is never formed
+            gp0 = self.gp._fitted()
+            accept = _hip.swarm_grow(gp0.ctx, gp0, self.S,
+                                     swarm.best_positions,
+                                     self.scaling[0] ** 2, 0.95)
+            num_added = int(np.count_nonzero(accept))
+            if num_added:
+                self.S = np.vstack((self.S, swarm.best_positions[accept]))
             logging.debug("At the end of swarm {}, {} points were appended to"
                           " the safeset".format(swarm_type, num_added))
         else:

@@ -321,6 +321,54 @@ def test_swarm_optimize_golden(mods):
     assert_allclose(opt.best_lower_bound, z["opt0_best_lower_bound"], atol=1e-7)
 
 
+def _grow_reference(K, m, scale2, thr=0.95):
+    """The host loop of gp_opt.py:1089-1111 on a covariance matrix K (n, m + n)."""
+    cov = K / scale2
+    n = cov.shape[0]
+    mask = np.zeros(m + n, dtype=bool)
+    mask[:m] = True
+    acc = np.zeros(n, dtype=bool)
+    for j in range(n):
+        if np.all(cov[j, mask] <= thr):
+            acc[j] = True
+            mask[m + j] = True
+    return acc, cov
+
+
+@pytest.mark.parametrize("kind,d,m,n", [("RBF", 2, 300, 40), ("Matern52", 3, 9000, 64),
+                                         ("Matern32", 1, 5, 30), ("RBF", 4, 0, 25),
+                                         ("prod", 3, 700, 50)])
+def test_swarm_grow_matches_reference_loop(mods, kind, d, m, n):
+    """the correlation filter that grows SafeOptSwarm's safe
+    set (gp_opt.py:1089-1111), device kernels vs the reference's host loop."""
+    _, gpy, gpn, _ = mods
+    from safeopt_amd import _hip
+    rng = np.random.default_rng(m + n)
+
+    def kern(ns):
+        if kind == "prod":
+            return (ns.RBF(2, variance=1.5, lengthscale=[0.7, 1.1], ARD=True, active_dims=[0, 1]) *
+                    ns.Matern52(1, variance=1.2, lengthscale=0.9, active_dims=[2], name="context"))
+        return getattr(ns, kind)(d, variance=2.0, lengthscale=list(0.5 + 0.2 * np.arange(d)), ARD=True)
+    X0 = rng.normal(size=(5, d))
+    gp = gpy.models.GPRegression(X0, rng.normal(size=(5, 1)), kern(gpy.kern), noise_var=0.01)
+    ko = kern(gpn)
+    S = rng.uniform(-2, 2, size=(m, d))
+    # candidates: some close to S / to each other (rejected), some far (accepted)
+    B = rng.uniform(-3, 3, size=(n, d))
+    if m:
+        B[::5] = S[rng.integers(0, m, size=B[::5].shape[0])] + 0.02 * rng.normal(size=B[::5].shape)
+    B[1::7] = B[:1] + 0.03 * rng.normal(size=B[1::7].shape)
+    scale2 = float(ko.Kdiag(np.zeros((1, d)))[0])
+    ref, cov = _grow_reference(ko.K(B, np.vstack((S, B))), m, scale2)
+    off = cov[~np.eye(n, m + n, k=m, dtype=bool)]
+    assert np.min(np.abs(off - 0.95)) > 1e-9          # no knife-edge decisions
+    dev = gp._fitted()
+    got = _hip.swarm_grow(dev.ctx, dev, S, B, scale2, 0.95)
+    assert_array_equal(got, ref)
+    assert 0 < ref.sum() < n
+
+
 def test_swarm_empty_safe_set_raises(mods):
     """safeopt/tests/test_swarm.py:13-22"""
     safeopt_amd, gpy, _, _ = mods
