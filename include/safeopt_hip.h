@@ -207,6 +207,26 @@ int sgp_swarm_grow(sgp_ctx* ctx, sgp_gp* gp0, const double* S, int64_t m,
                    const double* B, int64_t n, double scale2, double thr,
                    uint8_t* accept);
 
+/* ---- SwarmOptimization on the device (swarm.py:61-146) -----------------------
+ * init_swarm (init != 0: velocities = rand * velocity_scale, personal bests :=
+ * positions / their fitness, global best := arg-max, unmasked as in the
+ * reference) followed by `iters` iterations of run_swarm (inertia0, += step per
+ * iteration; velocity clip 10 * velocity_scale; positions clipped to bounds
+ * (d,2) when given), the fitness being the fused posterior kernel of
+ * sgp_swarm_fitness.  State arrays are row-major (P,d) / (P) / (d), in and out
+ * (with init only `positions` is read).
+ * rand != NULL: the uniform numbers in the order the reference draws them --
+ * P*d for init, then 2*P*d per iteration (np.random.rand(2*P, d): r1 rows, r2
+ * rows) -- the run is then bit-identical to the host implementation.
+ * rand == NULL: counter-based device generator (Philox4x32-10) keyed by seed. */
+int sgp_swarm_run(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
+                  double beta, const double* fmin, const double* scaling,
+                  double best_lower_bound, int64_t P, double* positions,
+                  double* velocities, double* best_positions, double* best_values,
+                  double* global_best, const double* velocity_scale,
+                  const double* bounds, int init, int iters, double inertia0,
+                  double step, const double* rand, uint64_t seed);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -------------------------
  * The only cross-rank traffic of the path is a handful of scalars per
  * iteration (max / any / arg-max / top-k merge).                             */

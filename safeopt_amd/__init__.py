@@ -17,11 +17,12 @@ in hand-written HIP kernels for gfx950 behind the C ABI of
 ``python -m safeopt_amd.build``.
 """
 from .utilities import linearly_spaced_combinations, sample_gp_function
-from .swarm import SwarmOptimization
+from .swarm import SwarmOptimization, DeviceSwarmOptimization
 from .gp_opt import SafeOpt, SafeOptSwarm, GaussianProcessOptimization
 from . import gpy
 from . import dist
 
 __all__ = ['SafeOpt', 'SafeOptSwarm', 'linearly_spaced_combinations',
-           'sample_gp_function', 'SwarmOptimization', 'gpy', 'dist']
+           'sample_gp_function', 'SwarmOptimization', 'DeviceSwarmOptimization',
+           'gpy', 'dist']
 __version__ = "0.1.0"

@@ -89,6 +89,12 @@ PROTOTYPES = {
                                     c_u8_p]),
     "sgp_swarm_grow": (C.c_int, [vp, vp, c_double_p, C.c_int64, c_double_p,
                                  C.c_int64, C.c_double, C.c_double, c_u8_p]),
+    "sgp_swarm_run": (C.c_int, [vp, vpp, C.c_int, C.c_int, C.c_double,
+                                c_double_p, c_double_p, C.c_double, C.c_int64,
+                                c_double_p, c_double_p, c_double_p, c_double_p,
+                                c_double_p, c_double_p, c_double_p, C.c_int,
+                                C.c_int, C.c_double, C.c_double, c_double_p,
+                                C.c_uint64]),
     "sgp_comm_unique_id": (C.c_int, [vp]),
     "sgp_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "sgp_comm_allreduce_max": (C.c_int, [vp, c_double_p, C.c_int]),
@@ -570,6 +576,25 @@ def swarm_grow(ctx, gp, S, B, scale2, thr=0.95):
             ctx.h, gp.h, dptr(S), S.shape[0], dptr(B), B.shape[0],
             float(scale2), float(thr), accept.ctypes.data_as(c_u8_p)))
     return accept.view(np.bool_)
+
+
+def swarm_run(ctx, gps, swarm_type, beta, fmin, scaling, best_lower_bound,
+              positions, velocities, best_positions, best_values, global_best,
+              velocity_scale, bounds, init, iters, inertia0, step, rand, seed=0):
+    """Whole PSO run on the device; the state arrays are updated in place."""
+    P = positions.shape[0]
+    for a in (positions, velocities, best_positions, best_values, global_best):
+        assert a.dtype == np.float64 and a.flags.c_contiguous
+    bnd = None if bounds is None else f64(bounds)
+    rnd = None if rand is None else f64(rand).ravel()
+    ctx.check(lib().sgp_swarm_run(
+        ctx.h, _gp_array(gps), len(gps), SWARM_TYPES[swarm_type], float(beta),
+        dptr(f64(fmin)), dptr(f64(scaling)), float(best_lower_bound), P,
+        dptr(positions), dptr(velocities), dptr(best_positions),
+        dptr(best_values), dptr(global_best), dptr(f64(velocity_scale)),
+        None if bnd is None else dptr(bnd), int(bool(init)), int(iters),
+        float(inertia0), float(step), None if rnd is None else dptr(rnd),
+        int(seed)))
 
 
 def swarm_fitness(ctx, gps, swarm_type, particles, beta, fmin, scaling,

@@ -23,7 +23,7 @@ HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kern_eval.h"),
 BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
         "-I", os.path.join(REPO, "include"), "-I", CSRC, "-Wall",
         "-Wno-unused-function"]
-EXTRA = {"sets.hip": ["-ffp-contract=off"]}
+EXTRA = {"sets.hip": ["-ffp-contract=off"], "swarm.hip": ["-ffp-contract=off"]}
 # e.g. SGP_HIPCC_FLAGS=-DSGP_INSTRUMENT for scripts/ablate.py (use --force)
 USER = os.environ.get("SGP_HIPCC_FLAGS", "").split()
 

@@ -919,6 +919,88 @@ int sgp_swarm_fitness(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
   return 0;
 }
 
+// SwarmOptimization.init_swarm / run_swarm (swarm.py:61-146) with the state in
+// HBM and the fitness fused in: one call = the whole run, one host round trip.
+int sgp_swarm_run(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
+                  double beta, const double* fmin, const double* scaling,
+                  double best_lower_bound, int64_t P, double* positions,
+                  double* velocities, double* best_positions, double* best_values,
+                  double* global_best, const double* velocity_scale,
+                  const double* bounds, int init, int iters, double inertia0,
+                  double step, const double* rand, uint64_t seed) {
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, swarm_type >= SGP_SWARM_GREEDY && swarm_type <= SGP_SWARM_SAFE_SET,
+            "Invalid swarm type %d", swarm_type);
+  SGP_CHECK(ctx, G >= 1 && gps[0], "no GP");
+  SGP_CHECK(ctx, P >= 1 && iters >= 0, "bad swarm size %lld / iterations %d",
+            (long long)P, iters);
+  const int d = gps[0]->kern.d;
+  GpDev host[SGP_MAX_GPS];
+  SGP_TRY(collect_gps(ctx, gps, G, d, host));
+  const size_t nd = size_t(P) * d * 8, nv = size_t(P) * 8;
+  const size_t nrand = rand ? (size_t(init ? 1 : 0) + 2 * size_t(iters)) * nd : 0;
+  // pos | vel | best | best_values | values | gbest | vscale | bounds | gpdev | safe
+  const size_t small = size_t(d) * 8 * 4 + sizeof(GpDev) * SGP_MAX_GPS + 64;
+  char* buf = static_cast<char*>(sgp_scratch(ctx, 4, 3 * nd + 2 * nv + small + size_t(P)));
+  double* drand = rand ? static_cast<double*>(sgp_scratch(ctx, 3, nrand)) : nullptr;
+  SGP_CHECK(ctx, buf && (!rand || drand), "device allocation failed: %s",
+            ctx->err.c_str());
+  double* dpos = reinterpret_cast<double*>(buf);
+  double* dvel = reinterpret_cast<double*>(buf + nd);
+  double* dbest = reinterpret_cast<double*>(buf + 2 * nd);
+  double* dbv = reinterpret_cast<double*>(buf + 3 * nd);
+  double* dval = reinterpret_cast<double*>(buf + 3 * nd + nv);
+  double* dgb = reinterpret_cast<double*>(buf + 3 * nd + 2 * nv);
+  double* dvs = dgb + d;
+  double* dbd = dvs + d;                       // 2 d entries
+  GpDev* gdev = reinterpret_cast<GpDev*>(dbd + 2 * d);
+  uint8_t* dsafe = reinterpret_cast<uint8_t*>(gdev + SGP_MAX_GPS);
+  SGP_TRY(sgp_h2d(ctx, dpos, positions, nd));
+  if (!init) {
+    SGP_TRY(sgp_h2d(ctx, dvel, velocities, nd));
+    SGP_TRY(sgp_h2d(ctx, dbest, best_positions, nd));
+    SGP_TRY(sgp_h2d(ctx, dbv, best_values, nv));
+    SGP_TRY(sgp_h2d(ctx, dgb, global_best, size_t(d) * 8));
+  }
+  SGP_TRY(sgp_h2d(ctx, dvs, velocity_scale, size_t(d) * 8));
+  if (bounds) SGP_TRY(sgp_h2d(ctx, dbd, bounds, size_t(d) * 16));
+  if (rand) SGP_TRY(sgp_h2d(ctx, drand, rand, nrand));
+  SGP_TRY(sgp_h2d(ctx, gdev, host, sizeof(GpDev) * G));
+  FitnessArgs fa{};
+  fa.swarm_type = swarm_type;
+  fa.beta = beta;
+  fa.best_lower_bound = best_lower_bound;
+  for (int i = 0; i < SGP_MAX_GPS; ++i) {
+    fa.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
+    fa.scaling[i] = (i < G) ? scaling[i] : 1.0;
+  }
+  fa.values = dval;
+  fa.safe = dsafe;
+  const SweepPoints sp{dpos, P, d, 1};          // row-major (P, d) in place
+  const double* r = drand;
+  if (init) {
+    SGP_TRY(launch_pso_init_vel(ctx, P, d, dvel, dvs, r, seed));
+    if (r) r += size_t(P) * d;
+    SGP_TRY(launch_sweep_fitness(ctx, gdev, host, G, d, sp, fa));
+    SGP_TRY(launch_pso_best(ctx, P, d, dval, dsafe, dpos, dbest, dbv, dgb, 1));
+  }
+  double inertia = inertia0;
+  for (int it = 0; it < iters; ++it) {
+    SGP_TRY(launch_pso_move(ctx, P, d, dpos, dvel, dbest, dgb, dvs,
+                            bounds ? dbd : nullptr, inertia, r, seed,
+                            uint32_t(it + 1)));
+    if (r) r += 2 * size_t(P) * d;
+    inertia += step;
+    SGP_TRY(launch_sweep_fitness(ctx, gdev, host, G, d, sp, fa));
+    SGP_TRY(launch_pso_best(ctx, P, d, dval, dsafe, dpos, dbest, dbv, dgb, 0));
+  }
+  SGP_TRY(sgp_d2h(ctx, positions, dpos, nd));
+  SGP_TRY(sgp_d2h(ctx, velocities, dvel, nd));
+  SGP_TRY(sgp_d2h(ctx, best_positions, dbest, nd));
+  SGP_TRY(sgp_d2h(ctx, best_values, dbv, nv));
+  return sgp_d2h(ctx, global_best, dgb, size_t(d) * 8);
+}
+
 // SafeOptSwarm safe-set growth, gp_opt.py:1089-1111 (kernels in swarm.hip).
 int sgp_swarm_grow(sgp_ctx* ctx, sgp_gp* gp0, const double* S, int64_t m,
                    const double* B, int64_t n, double scale2, double thr,

@@ -256,5 +256,14 @@ int launch_swarm_grow(sgp_ctx* ctx, const KernDesc& kd, const double* S, int64_t
                       const double* B, int n, double scale2, double thr,
                       double* part, int* list, uint8_t* accept);
 int swarm_grow_chunks(int64_t m);
+int launch_pso_init_vel(sgp_ctx* ctx, int64_t P, int d, double* vel,
+                        const double* vscale, const double* rand, uint64_t seed);
+int launch_pso_move(sgp_ctx* ctx, int64_t P, int d, double* pos, double* vel,
+                    const double* best, const double* gbest, const double* vscale,
+                    const double* bounds, double inertia, const double* rand,
+                    uint64_t seed, uint32_t draw);
+int launch_pso_best(sgp_ctx* ctx, int64_t P, int d, const double* values,
+                    const uint8_t* safe, const double* pos, double* best,
+                    double* best_values, double* gbest, int init);
 int launch_import_points(sgp_ctx* ctx, const double* src, int64_t N, int d,
                          int64_t stride_row, int64_t stride_col, double* dst);

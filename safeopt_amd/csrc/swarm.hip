@@ -115,3 +115,163 @@ int launch_swarm_grow(sgp_ctx* ctx, const KernDesc& kd, const double* S, int64_t
 }
 
 int swarm_grow_chunks(int64_t m) { return int((m + kGrowChunk - 1) / kGrowChunk); }
+
+// ---- particle swarm on the device ---------------------------------------------------
+// SwarmOptimization.init_swarm / run_swarm (safeopt/swarm.py:61-146) with the
+// swarm state resident in HBM for the whole run; the fitness is the fused
+// posterior sweep (k_sweep, MODE_FITNESS) on the same buffers.  This file is
+// built with -ffp-contract=off and the update below mirrors NumPy's evaluation
+// order, so that with the reference's own random numbers (rand != nullptr,
+// drawn by np.random.rand on the host in the reference's order) the run is
+// bit-identical to the host implementation.
+namespace {
+
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, no state to keep.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0,
+                                             uint32_t k1) {
+  const uint64_t p0 = uint64_t(0xD2511F53u) * c[0];
+  const uint64_t p1 = uint64_t(0xCD9E8D57u) * c[2];
+  const uint32_t n0 = uint32_t(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n2 = uint32_t(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = uint32_t(p1);
+  c[3] = uint32_t(p0);
+  c[0] = n0;
+  c[2] = n2;
+}
+
+// e-th uniform double in [0, 1) of stream (seed, draw): 53 random bits.
+__device__ __forceinline__ double philox_uniform(uint64_t seed, uint32_t draw,
+                                                 uint64_t e) {
+  uint32_t c[4] = {uint32_t(e >> 1), uint32_t(e >> 33), draw, 0x5afe0b7u};
+  uint32_t k0 = uint32_t(seed), k1 = uint32_t(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const uint64_t bits = (e & 1) ? ((uint64_t(c[2]) << 32) | c[3])
+                                : ((uint64_t(c[0]) << 32) | c[1]);
+  return double(bits >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// velocities = rand(P, d) * velocity_scale          (swarm.py:75-76)
+__global__ void k_pso_init_vel(int64_t P, int d, double* vel,
+                               const double* vscale, const double* rand,
+                               uint64_t seed) {
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= P * d) return;
+  const double r = rand ? rand[e] : philox_uniform(seed, 0u, uint64_t(e));
+  vel[e] = r * vscale[e % d];
+}
+
+// one velocity / position update                     (swarm.py:98-123)
+__global__ void k_pso_move(int64_t P, int d, double* pos, double* vel,
+                           const double* best, const double* gbest,
+                           const double* vscale, const double* bounds,
+                           double inertia, const double* rand, uint64_t seed,
+                           uint32_t draw) {
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= P * d) return;
+  const int k = int(e % d);
+  const double x = pos[e];
+  const double to_global = gbest[k] - x;
+  const double to_own = best[e] - x;
+  // r = rand(2 P, d); r1 = r[:P], r2 = r[P:]
+  const double r1 = rand ? rand[e] : philox_uniform(seed, draw, uint64_t(e));
+  const double r2 = rand ? rand[P * d + e]
+                         : philox_uniform(seed, draw, uint64_t(P * d + e));
+  double v = vel[e] * inertia;
+  v = v + (r1 * to_own + r2 * to_global) / vscale[k];
+  const double vmax = 10.0 * vscale[k];
+  v = fmin(fmax(v, -vmax), vmax);
+  vel[e] = v;
+  double xn = x + v;
+  if (bounds) xn = fmin(fmax(xn, bounds[2 * k]), bounds[2 * k + 1]);
+  pos[e] = xn;
+}
+
+// personal bests                                     (swarm.py:77-79, 138-143)
+__global__ void k_pso_best(int64_t P, int d, const double* values,
+                           const uint8_t* safe, const double* pos, double* best,
+                           double* best_values, int init) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const bool better = init || (values[i] > best_values[i] && safe[i]);
+  if (better) {
+    best_values[i] = values[i];
+    for (int k = 0; k < d; ++k) best[i * d + k] = pos[i * d + k];
+  }
+}
+
+// global_best = best_positions[argmax(best_values)], first index on ties
+__global__ __launch_bounds__(1024) void k_pso_gbest(int64_t P, int d,
+                                                    const double* best_values,
+                                                    const double* best,
+                                                    double* gbest) {
+  __shared__ double sv[1024 / 64];
+  __shared__ long long si[1024 / 64];
+  double v = -INFINITY;
+  long long idx = -1;
+  for (int64_t i = threadIdx.x; i < P; i += 1024) {
+    const double x = best_values[i];
+    if (idx < 0 || x > v) {      // strided scan keeps the lowest index per thread
+      v = x;
+      idx = i;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double ov = __shfl_xor(v, o, 64);
+    const long long oi = __shfl_xor(idx, o, 64);
+    if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) {
+      v = ov;
+      idx = oi;
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sv[threadIdx.x >> 6] = v;
+    si[threadIdx.x >> 6] = idx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 1024 / 64; ++w)
+      if (si[w] >= 0 && (idx < 0 || sv[w] > v || (sv[w] == v && si[w] < idx))) {
+        v = sv[w];
+        idx = si[w];
+      }
+    for (int k = 0; k < d; ++k) gbest[k] = best[idx * d + k];
+  }
+}
+
+}  // namespace
+
+int launch_pso_init_vel(sgp_ctx* ctx, int64_t P, int d, double* vel,
+                        const double* vscale, const double* rand, uint64_t seed) {
+  hipLaunchKernelGGL(k_pso_init_vel, dim3(unsigned((P * d + 255) / 256)),
+                     dim3(256), 0, ctx->stream, P, d, vel, vscale, rand, seed);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_pso_move(sgp_ctx* ctx, int64_t P, int d, double* pos, double* vel,
+                    const double* best, const double* gbest, const double* vscale,
+                    const double* bounds, double inertia, const double* rand,
+                    uint64_t seed, uint32_t draw) {
+  hipLaunchKernelGGL(k_pso_move, dim3(unsigned((P * d + 255) / 256)), dim3(256), 0,
+                     ctx->stream, P, d, pos, vel, best, gbest, vscale, bounds,
+                     inertia, rand, seed, draw);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_pso_best(sgp_ctx* ctx, int64_t P, int d, const double* values,
+                    const uint8_t* safe, const double* pos, double* best,
+                    double* best_values, double* gbest, int init) {
+  hipLaunchKernelGGL(k_pso_best, dim3(unsigned((P + 255) / 256)), dim3(256), 0,
+                     ctx->stream, P, d, values, safe, pos, best, best_values, init);
+  hipLaunchKernelGGL(k_pso_gbest, dim3(1), dim3(1024), 0, ctx->stream, P, d,
+                     best_values, best, gbest);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}

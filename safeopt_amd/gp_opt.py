@@ -29,7 +29,7 @@ import numpy as np
 
 from . import _hip
 from .dist import LocalComm, merge_argmax, merge_topk, shard_range
-from .swarm import SwarmOptimization
+from .swarm import SwarmOptimization, DeviceSwarmOptimization
 
 __all__ = ['SafeOpt', 'SafeOptSwarm']
 
@@ -682,7 +682,9 @@ class SafeOptSwarm(GaussianProcessOptimization):
     """
 
     def __init__(self, gp, fmin, bounds, beta=2, scaling='auto', threshold=0,
-                 swarm_size=20):
+                 swarm_size=20, pso='device'):
+        if pso not in ('device', 'device-rng', 'host'):
+            raise ValueError("pso must be 'device', 'device-rng' or 'host'")
         super(SafeOptSwarm, self).__init__(gp, fmin=fmin, beta=beta,
                                            num_contexts=0,
                                            threshold=threshold,
@@ -700,12 +702,24 @@ class SafeOptSwarm(GaussianProcessOptimization):
         self.greedy_point = self.S[0, :]
         self.optimal_velocities = self.optimize_particle_velocity()
 
-        self.swarms = {
-            swarm_type: SwarmOptimization(
-                swarm_size, self.optimal_velocities,
-                partial(self._compute_particle_fitness, swarm_type),
-                bounds=self.bounds)
-            for swarm_type in ['greedy', 'maximizers', 'expanders']}
+        # pso='device' (default): whole swarm runs on the GPU with NumPy's
+        # random stream (bit-identical to the host loop); 'device-rng': GPU
+        # generator, no per-run random upload; 'host': the reference's loop
+        # with one fitness call per iteration.
+        if pso == 'host':
+            self.swarms = {
+                swarm_type: SwarmOptimization(
+                    swarm_size, self.optimal_velocities,
+                    partial(self._compute_particle_fitness, swarm_type),
+                    bounds=self.bounds)
+                for swarm_type in ['greedy', 'maximizers', 'expanders']}
+        else:
+            self.swarms = {
+                swarm_type: DeviceSwarmOptimization(
+                    swarm_size, self.optimal_velocities, self, swarm_type,
+                    bounds=self.bounds,
+                    rng='numpy' if pso == 'device' else 'device')
+                for swarm_type in ['greedy', 'maximizers', 'expanders']}
 
     def optimize_particle_velocity(self):
         """Velocity per dimension at which the prior correlation drops to

@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ['SwarmOptimization']
+__all__ = ['SwarmOptimization', 'DeviceSwarmOptimization']
 
 
 class SwarmOptimization(object):
@@ -96,3 +96,69 @@ class SwarmOptimization(object):
 
             self.global_best = self.best_positions[
                 np.argmax(self.best_values), :]
+
+
+class DeviceSwarmOptimization(SwarmOptimization):
+    """The same swarm with its state in HBM: ``init_swarm`` and ``run_swarm``
+    are one C-ABI call each (``sgp_swarm_run``) -- velocity / position update,
+    fused posterior fitness, personal and global bests all run on the GPU and
+    nothing crosses PCIe between iterations.
+
+    ``rng='numpy'`` (default): the uniform numbers are drawn with
+    ``np.random.rand`` on the host exactly where and in the order the reference
+    draws them (``swarm.py:75, 104``) and shipped with the call, so the run --
+    and the state of NumPy's global generator afterwards -- is bit-identical to
+    :class:`SwarmOptimization`.  ``rng='device'``: a counter-based generator
+    on the GPU (Philox4x32-10); nothing but the swarm state is transferred,
+    results are reproducible per ``seed`` but differ from ``np.random``.
+
+    ``owner`` is the :class:`SafeOptSwarm` whose GPs / beta / fmin / scaling /
+    best lower bound define the fitness of ``swarm_type``.
+    """
+
+    def __init__(self, swarm_size, velocity, owner, swarm_type, bounds=None,
+                 rng='numpy', seed=0):
+        super(DeviceSwarmOptimization, self).__init__(
+            swarm_size, velocity, None, bounds=bounds)
+        if rng not in ('numpy', 'device'):
+            raise ValueError("rng must be 'numpy' or 'device'")
+        self._owner = owner
+        self._type = swarm_type
+        self._rng = rng
+        self._seed = int(seed)
+        self._calls = 0
+        self.global_best = np.zeros(self.ndim)
+
+    def fitness(self, positions):                 # kept for API parity
+        return self._owner._compute_particle_fitness(self._type, positions)
+
+    def _device_run(self, init, iters, inertia0, step):
+        from . import _hip
+        o = self._owner
+        devs = [g._fitted() for g in o.gps]
+        P, d = self.positions.shape
+        if self._rng == 'numpy':
+            rand = np.random.rand((P * d if init else 0) + 2 * P * d * iters)
+        else:
+            rand = None
+        self._calls += 1
+        _hip.swarm_run(
+            devs[0].ctx, devs, self._type, o.beta(o.t), o.fmin, o.scaling,
+            o.best_lower_bound, self.positions, self.velocities,
+            self.best_positions, self.best_values, self.global_best,
+            np.broadcast_to(self.velocity_scale, (d,)), self.bounds, init,
+            iters, inertia0, step, rand,
+            seed=(self._seed << 20) + self._calls)
+
+    def init_swarm(self, positions):
+        self.positions = np.ascontiguousarray(positions, dtype=float)
+        shape = self.positions.shape
+        self.velocities = np.empty(shape)
+        self.best_positions = np.empty(shape)
+        self.best_values = np.empty(shape[0])
+        self.global_best = np.empty(shape[1])
+        self._device_run(True, 0, self.initial_inertia, 0.0)
+
+    def run_swarm(self, max_iter):
+        step = (self.final_inertia - self.initial_inertia) / max_iter
+        self._device_run(False, max_iter, self.initial_inertia, step)

@@ -305,20 +305,88 @@ def test_swarm_fitness_golden(mods):
         assert_array_equal(s, z["fit_%s_safe" % st])
 
 
-def test_swarm_optimize_golden(mods):
+@pytest.mark.parametrize("pso", ["device", "host"])
+def test_swarm_optimize_golden(mods, pso):
     """Whole SafeOptSwarm.optimize() iterations against the reference run with
-    the same NumPy global RNG seed (host RNG order is part of the contract)."""
+    the same NumPy global RNG seed (host RNG order is part of the contract) --
+    with the swarm loop on the GPU (default) and with the host loop."""
     safeopt_amd, gpy, _, _ = mods
     z, meta = load("swarm_2d_g2")
     gps = [gpy.models.GPRegression(z["X0"], z["Y0"][:, [i]], make_kernel(gpy.kern, meta["kernels"][i]),
                                    noise_var=meta["noise_vars"][i]) for i in range(2)]
     opt = safeopt_amd.SafeOptSwarm(gps, meta["fmin"], bounds=[tuple(b) for b in meta["bounds"]],
-                                   threshold=meta["threshold"])
+                                   threshold=meta["threshold"], pso=pso)
     np.random.seed(meta["seed"])
     x = opt.optimize()
     assert_allclose(x, z["opt_x"][0], rtol=0, atol=1e-6)
     assert_allclose(opt.S, z["opt0_S"], rtol=0, atol=1e-6)
     assert_allclose(opt.best_lower_bound, z["opt0_best_lower_bound"], atol=1e-7)
+
+
+def _swarm_problem(mods, pso, swarm_size=40):
+    safeopt_amd, gpy, _, _ = mods
+    z, meta = load("swarm_2d_g2")
+    gps = [gpy.models.GPRegression(z["X0"], z["Y0"][:, [i]], make_kernel(gpy.kern, meta["kernels"][i]),
+                                   noise_var=meta["noise_vars"][i]) for i in range(2)]
+    return safeopt_amd.SafeOptSwarm(gps, meta["fmin"], bounds=[tuple(b) for b in meta["bounds"]],
+                                    threshold=meta["threshold"], swarm_size=swarm_size, pso=pso)
+
+
+@pytest.mark.parametrize("swarm_type", ["greedy", "maximizers", "expanders"])
+def test_device_pso_bit_identical_to_host_loop(mods, swarm_type):
+    """SwarmOptimization with its state in HBM
+    (sgp_swarm_run) against the host loop of swarm.py:61-146, same np.random
+    stream: every state array bit-identical, generator left in the same state."""
+    host = _swarm_problem(mods, "host")
+    dev = _swarm_problem(mods, "device")
+    for o in (host, dev):
+        o.best_lower_bound = 0.3
+    start = np.random.default_rng(3).uniform(-0.5, 0.5, size=(40, 2))
+    out = []
+    for o in (host, dev):
+        np.random.seed(11)
+        sw = o.swarms[swarm_type]
+        sw.init_swarm(start.copy())
+        sw.run_swarm(25)
+        out.append((sw.positions.copy(), sw.velocities.copy(), sw.best_positions.copy(),
+                    np.array(sw.best_values), np.array(sw.global_best), np.random.rand()))
+    for a, b in zip(out[0], out[1]):
+        assert_array_equal(a, b)
+
+
+def test_device_pso_device_rng(mods):
+    """rng on the GPU: not NumPy-reproducible by design; check the invariants of
+    the algorithm, determinism per seed and that NumPy's stream is untouched."""
+    from safeopt_amd import DeviceSwarmOptimization
+    o = _swarm_problem(mods, "device-rng", swarm_size=500)
+    o.best_lower_bound = 0.3
+    sw = o.swarms["maximizers"]
+    assert isinstance(sw, DeviceSwarmOptimization)
+    start = np.random.default_rng(5).uniform(-0.5, 0.5, size=(500, 2))
+    np.random.seed(1)
+    sw.init_swarm(start.copy())
+    v0, _ = o._compute_particle_fitness("maximizers", start)
+    assert_allclose(sw.best_values, v0, rtol=1e-12)
+    assert np.all((sw.velocities >= 0) & (sw.velocities <= o.optimal_velocities))
+    assert len(np.unique(sw.velocities)) > 900            # really random
+    sw.run_swarm(20)
+    assert np.random.rand() == np.random.RandomState(1).rand()
+    lo, hi = np.asarray(o.bounds).T
+    assert np.all((sw.positions >= lo) & (sw.positions <= hi))
+    assert np.all(np.abs(sw.velocities) <= 10 * o.optimal_velocities + 1e-15)
+    assert np.all(sw.best_values >= v0)                   # personal bests never get worse
+    vb, sb = o._compute_particle_fitness("maximizers", sw.best_positions)
+    assert_allclose(vb, sw.best_values, rtol=1e-9, atol=1e-12)
+    moved = sw.best_values > v0
+    assert moved.any() and np.all(sb[moved])              # improvements are safe points
+    assert_array_equal(sw.global_best, sw.best_positions[np.argmax(sw.best_values)])
+    # same seed, same call sequence -> same run
+    o2 = _swarm_problem(mods, "device-rng", swarm_size=500)
+    o2.best_lower_bound = 0.3
+    sw2 = o2.swarms["maximizers"]
+    sw2.init_swarm(start.copy())
+    sw2.run_swarm(20)
+    assert_array_equal(sw2.best_positions, sw.best_positions)
 
 
 def _grow_reference(K, m, scale2, thr=0.95):
