@@ -179,6 +179,16 @@ int sgp_grid_sets_back(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                        const double* u_c, double near_frac, int64_t gidx_c,
                        int mark, const double* scaling, int32_t* flags,
                        double* value, int64_t* gidx);
+/* Both halves in one call and ONE stream sync (single GPU): the first candidate
+ * stays on the device, the probe scan (near_frac) runs on it, G is marked if
+ * every active GP certifies it, and the M|G arg-max follows.  Outputs as in
+ * sgp_grid_sets_front + sgp_grid_sets_back; flags are void when out5 reports
+ * no candidate or no unsafe row (G is then left untouched).                  */
+int sgp_grid_sets_fused(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
+                        const double* fmin, double max_l, const double* scaling,
+                        const double* thr_beta, double near_frac, double* out5,
+                        double* x_top, double* mean_top, double* q_top,
+                        int32_t* flags, double* value, int64_t* gidx);
 /* gp_opt.py:615: G[idx] = True for owned global indices                      */
 int sgp_grid_mark_expanders(sgp_grid* grid, const int64_t* gidx, int m);
 /* get_new_query_point / get_maximum arg-max (gp_opt.py:635, 642-644,

@@ -74,6 +74,11 @@ PROTOTYPES = {
     "sgp_grid_sets_front": (C.c_int, [vp, C.c_double, C.c_int, C.c_double,
                                       c_double_p, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_double_p]),
+    "sgp_grid_sets_fused": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p,
+                                      C.c_double, c_double_p, c_double_p,
+                                      C.c_double, c_double_p, c_double_p,
+                                      c_double_p, c_double_p, c_i32_p,
+                                      c_double_p, c_i64_p]),
     "sgp_grid_sets_back": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p,
                                      c_double_p, c_double_p, c_double_p,
                                      C.c_double, C.c_int64, C.c_int,
@@ -532,6 +537,22 @@ class DeviceGrid(object):
             int(bool(mark)), dptr(scaling), flags.ctypes.data_as(c_i32_p),
             C.byref(v), C.byref(i)))
         return flags, v.value, i.value
+
+    def sets_fused(self, gps, beta, fmin, max_l, scaling, thr_beta, near_frac):
+        fmin, scaling, thr_beta = f64(fmin), f64(scaling), f64(thr_beta)
+        out5 = np.empty(5)
+        x = np.empty(self.d)
+        mean = np.empty(self.G)
+        q = np.empty(2 * self.G)
+        flags = np.zeros(self.G, dtype=np.int32)
+        v = C.c_double(0)
+        i = C.c_int64(0)
+        self.ctx.check(lib().sgp_grid_sets_fused(
+            self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin),
+            float(max_l), dptr(scaling), dptr(thr_beta), float(near_frac),
+            dptr(out5), dptr(x), dptr(mean), dptr(q),
+            flags.ctypes.data_as(c_i32_p), C.byref(v), C.byref(i)))
+        return out5, x, mean, q, flags, v.value, i.value
 
     def mark_expanders(self, gidx):
         gidx = np.ascontiguousarray(gidx, dtype=np.int64)

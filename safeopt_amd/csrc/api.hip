@@ -709,10 +709,13 @@ int sgp_grid_download(sgp_grid* g, int what, void* out) {
 }
 
 // Enqueue the expander test (operands + scan); flags stay on the device.
+// `top` != nullptr: the single candidate is already on the device (result
+// block of the front half: x | mean | q) and xc / mu_c / u_c are ignored.
 static int enqueue_expander(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
                             const double* fmin, int m, const double* xc,
                             const double* mu_c, const double* u_c,
-                            double near_frac, int32_t** flags_dev) {
+                            double near_frac, int32_t** flags_dev,
+                            const double* top = nullptr) {
   sgp_ctx* ctx = g->ctx;
   SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
   SGP_CHECK(ctx, m >= 1 && m <= SGP_TOPK, "m = %d not in 1..%d", m, SGP_TOPK);
@@ -739,15 +742,21 @@ static int enqueue_expander(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   const size_t hb = bx + bv + sizeof(GpDev) * SGP_MAX_GPS;
   SGP_CHECK(ctx, hb <= ctx->pinned_cap / 2, "staging buffer too small");
   char* stage = static_cast<char*>(ctx->pinned) + ctx->pinned_cap / 2;
-  memset(stage, 0, bx + bv);
-  memcpy(stage, xc, size_t(m) * d * 8);
-  double* resid = reinterpret_cast<double*>(stage + bx);
-  for (int c = 0; c < m; ++c)
-    for (int i = 0; i < G; ++i) resid[size_t(i) * 16 + c] = u_c[c * G + i] - mu_c[c * G + i];
   memcpy(stage + bx + bv, host, sizeof(GpDev) * G);
   // previous users of the staging block have completed (every call syncs)
-  SGP_HIP(ctx, hipMemcpyAsync(dxc, stage, bx + bv, hipMemcpyHostToDevice,
-                              ctx->stream));
+  if (top) {
+    SGP_HIP(ctx, hipMemsetAsync(dxc, 0, bx + bv, ctx->stream));
+    SGP_TRY(launch_stage_top(g, top, top + d, top + d + G, dxc, dres));
+  } else {
+    memset(stage, 0, bx + bv);
+    memcpy(stage, xc, size_t(m) * d * 8);
+    double* resid = reinterpret_cast<double*>(stage + bx);
+    for (int c = 0; c < m; ++c)
+      for (int i = 0; i < G; ++i)
+        resid[size_t(i) * 16 + c] = u_c[c * G + i] - mu_c[c * G + i];
+    SGP_HIP(ctx, hipMemcpyAsync(dxc, stage, bx + bv, hipMemcpyHostToDevice,
+                                ctx->stream));
+  }
   SGP_HIP(ctx, hipMemcpyAsync(g->gpdev, stage + bx + bv, sizeof(GpDev) * G,
                               hipMemcpyHostToDevice, ctx->stream));
   SGP_HIP(ctx, hipMemsetAsync(dfl, 0, bf, ctx->stream));
@@ -874,6 +883,69 @@ int sgp_grid_sets_back(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   memcpy(flags, host.data(), size_t(G) * 4);
   memcpy(value, host.data() + (span - 16), 8);
   memcpy(gidx, host.data() + (span - 8), 8);
+  return 0;
+}
+
+// Single-rank fast path, both halves with ONE stream sync: the front half
+// leaves the first candidate on the device, the probe scan runs on it right
+// away, G is marked if it is certified and the M|G arg-max follows.  The host
+// decides afterwards which of the results apply (no candidate / nothing unsafe:
+// the back results are void except the arg-max; candidate not certified: the
+// exact scan and the general loop take over).
+int sgp_grid_sets_fused(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
+                        const double* fmin, double max_l, const double* scaling,
+                        const double* thr_beta, double near_frac, double* out5,
+                        double* x_top, double* mean_top, double* q_top,
+                        int32_t* flags, double* value, int64_t* gidx) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  const int d = g->d;
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  // result block: [0] max width | [1..2] counts (u64) | [3] w_top | [4] idx_top
+  //   (i64) | [5] n_found (int) | x[d] | mean[G] | q[2G] | flags[G] (i32, padded
+  //   to 8 B) | value | index (i64)
+  const size_t nfront = 6 + size_t(d) + 3 * size_t(G);
+  const size_t nfl = (size_t(G) + 1) / 2;
+  const size_t nres = nfront + nfl + 2;
+  double* res = static_cast<double*>(sgp_scratch(ctx, 1, (nres + 8) * 8));
+  SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
+  SGP_TRY(launch_maximizers(g, max_l));
+  SGP_TRY(launch_reduce_max(ctx, g->partial, (g->N + 255) / 256, res));
+  SGP_TRY(launch_candidates(g, 0.0, res, scaling, thr_beta, 0,
+                            reinterpret_cast<unsigned long long*>(res + 1)));
+  SGP_TRY(launch_topk(g, 0, INFINITY, INT64_MAX, 1, res + 3,
+                      reinterpret_cast<int64_t*>(res + 4),
+                      reinterpret_cast<int*>(res + 5)));
+  SGP_TRY(launch_gather_top(g, reinterpret_cast<int64_t*>(res + 4), res + 6,
+                            res + 6 + d, res + 6 + d + G));
+  int32_t* dfl = nullptr;
+  SGP_TRY(enqueue_expander(g, gps, G, beta, fmin, 1, nullptr, nullptr, nullptr,
+                           near_frac, &dfl, res + 6));
+  SGP_TRY(launch_mark_top_if(g, reinterpret_cast<int64_t*>(res + 4),
+                             reinterpret_cast<int*>(res + 5), dfl, fmin));
+  SGP_HIP(ctx, hipMemcpyAsync(res + nfront, dfl, size_t(G) * 4,
+                              hipMemcpyDeviceToDevice, ctx->stream));
+  SGP_TRY(launch_argmax(g, SGP_ARGMAX_MG_WIDTH, scaling, res + nfront + nfl,
+                        reinterpret_cast<int64_t*>(res + nfront + nfl + 1)));
+  std::vector<double> host(nres);
+  SGP_TRY(sgp_d2h(ctx, host.data(), res, nres * 8));
+  unsigned long long cnt[2];
+  int64_t idx;
+  int nfound;
+  memcpy(cnt, &host[1], 16);
+  memcpy(&idx, &host[4], 8);
+  memcpy(&nfound, &host[5], 4);
+  out5[0] = host[0];
+  out5[1] = double(cnt[0]);
+  out5[2] = double(cnt[1]);
+  out5[3] = host[3];
+  out5[4] = (nfound > 0) ? double(idx) : -1.0;
+  memcpy(x_top, &host[6], size_t(d) * 8);
+  memcpy(mean_top, &host[6 + d], size_t(G) * 8);
+  memcpy(q_top, &host[6 + d + G], size_t(2 * G) * 8);
+  memcpy(flags, &host[nfront], size_t(G) * 4);
+  *value = host[nfront + nfl];
+  memcpy(gidx, &host[nfront + nfl + 1], 8);
   return 0;
 }
 

@@ -369,6 +369,33 @@ __global__ void k_mark_if(uint8_t* Gm, int64_t li, const int32_t* flags, int G,
   if (ok && any) Gm[li] = 1;
 }
 
+// Fused single-GPU path: the first candidate (found by k_topk / k_gather_top
+// into the result block) becomes the operand of the expander test without a
+// host round trip.  xc[d] = its row, resid[g * 16] = u_g(x_c) - mu_g(x_c).
+__global__ void k_stage_top(const double* x_top, const double* mean_top,
+                            const double* q_top, int d, int G, double* xc,
+                            double* resid) {
+  const int t = threadIdx.x;
+  if (t < d) xc[t] = x_top[t];
+  if (t < G) resid[t * 16] = q_top[2 * t + 1] - mean_top[t];
+}
+
+// ... and G[that row] = 1 when a candidate was found and every active GP
+// certified it.
+__global__ void k_mark_top_if(uint8_t* Gm, const int64_t* gidx, const int* nfound,
+                              int64_t goff, const int32_t* flags, int G,
+                              Vec8 fmin) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (*nfound <= 0) return;
+  bool ok = true, any = false;
+  for (int g = 0; g < G; ++g) {
+    if (fmin.v[g] == -INFINITY) continue;
+    any = true;
+    ok = ok && (flags[g] != 0);
+  }
+  if (ok && any) Gm[gidx[0] - goff] = 1;
+}
+
 __global__ void k_mark(uint8_t* Gm, const int64_t* lidx, int m) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < m) Gm[lidx[j]] = 1;
@@ -515,6 +542,25 @@ int launch_mark_if(sgp_grid* g, int64_t li, const int32_t* flags_dev,
   sgp_ctx* ctx = g->ctx;
   hipLaunchKernelGGL(k_mark_if, dim3(1), dim3(64), 0, ctx->stream, g->Gm, li,
                      flags_dev, g->G, vec8(fmin, g->G, -INFINITY));
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_stage_top(sgp_grid* g, const double* x_top, const double* mean_top,
+                     const double* q_top, double* xc, double* resid) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_stage_top, dim3(1), dim3(64), 0, ctx->stream, x_top,
+                     mean_top, q_top, g->d, g->G, xc, resid);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_mark_top_if(sgp_grid* g, const int64_t* gidx_dev, const int* nfound_dev,
+                       const int32_t* flags_dev, const double* fmin) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_mark_top_if, dim3(1), dim3(64), 0, ctx->stream, g->Gm,
+                     gidx_dev, nfound_dev, g->goff, flags_dev, g->G,
+                     vec8(fmin, g->G, -INFINITY));
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -235,6 +235,10 @@ class _HipGridBackend(object):
     def sets_front(self, max_l, max_var, scaling, thr_beta):
         return self.grid.sets_front(max_l, max_var, scaling, thr_beta)
 
+    def sets_fused(self, beta, fmin, max_l, scaling, thr_beta, near_frac):
+        return self.grid.sets_fused(self._dev(), beta, fmin, max_l, scaling,
+                                    thr_beta, near_frac)
+
     def sets_back(self, beta, fmin, xc, mu_c, u_c, near_frac, gidx_c, scaling,
                   mark):
         return self.grid.sets_back(self._dev(), beta, fmin, xc, mu_c, u_c,
@@ -482,7 +486,15 @@ class SafeOpt(GaussianProcessOptimization):
             # trips + 3 scalar collectives (max_var; every rank's first
             # candidate with its rows; probe flags + local arg-max).
             d = self.inputs.shape[1]
-            if world == 1:
+            fused = None
+            if world == 1 and np.any(active) and hasattr(be, 'sets_fused'):
+                # both halves in one device round trip
+                out5, x_c, mu_c, q_c, f_flags, f_val, f_idx = be.sets_fused(
+                    beta, self.fmin, self._max_l, self.scaling, thr_beta, 0.5)
+                n_cand, n_unsafe, w_c, idx_c = (out5[1], out5[2],
+                                                float(out5[3]), int(out5[4]))
+                fused = (f_flags, f_val, f_idx)
+            elif world == 1:
                 out5, x_c, mu_c, q_c = be.sets_front(self._max_l, None,
                                                      self.scaling, thr_beta)
                 n_cand, n_unsafe, w_c, idx_c = (out5[1], out5[2],
@@ -505,10 +517,15 @@ class SafeOpt(GaussianProcessOptimization):
                                   pk[r, 4 + d + G:])
             self._stale.update(M=True, G=True)
             if n_cand == 0 or n_unsafe == 0 or not np.any(active) or idx_c < 0:
+                if fused is not None:       # G untouched: the arg-max over M holds
+                    self._argmax_cache = (fused[1], int(fused[2]))
                 return
-            flags, val, idx = be.sets_back(beta, self.fmin, x_c, mu_c,
-                                           q_c[1::2], 0.5, idx_c, self.scaling,
-                                           world == 1)
+            if fused is not None:
+                flags, val, idx = fused
+            else:
+                flags, val, idx = be.sets_back(beta, self.fmin, x_c, mu_c,
+                                               q_c[1::2], 0.5, idx_c,
+                                               self.scaling, world == 1)
             if world > 1:
                 pk = self._comm.allgather(np.concatenate(
                     [flags.astype(np.float64), [val, float(idx)]]))
