@@ -105,7 +105,9 @@ int sgp_grid_set_context(sgp_grid* grid, const double* c, int nc);
 /* update_confidence_intervals + compute_safe_set (gp_opt.py:453-481), fused:
  * for every GP mean/var over all rows, Q[:,2i] = mean - beta*std,
  * Q[:,2i+1] = mean + beta*std, S = all(Q[:, ::2] > fmin).
- * out2 = { max(l0[S]) or -inf, any(S) }  (local rows).                       */
+ * out2 = { max(l0[S]) or -inf, any(S) }  (local rows); out2 == NULL: no read-
+ * back and no stream sync, the value stays on the device for
+ * sgp_grid_sets_fused.                                                        */
 int sgp_grid_confidence(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                         const double* fmin, double* out2);
 /* update_confidence_intervals after ONE sgp_gp_append on the GPs flagged in
@@ -183,12 +185,16 @@ int sgp_grid_sets_back(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
  * stays on the device, the probe scan (near_frac) runs on it, G is marked if
  * every active GP certifies it, and the M|G arg-max follows.  Outputs as in
  * sgp_grid_sets_front + sgp_grid_sets_back; flags are void when out5 reports
- * no candidate or no unsafe row (G is then left untouched).                  */
+ * no candidate or no unsafe row (G is then left untouched).  max_l = NaN: use
+ * the value a preceding sgp_grid_confidence / _rank1_update call with
+ * out2 == NULL left on the device, and report it in *max_l_out (-inf = no safe
+ * point) -- a whole SafeOpt.optimize() is then one device round trip.        */
 int sgp_grid_sets_fused(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                         const double* fmin, double max_l, const double* scaling,
                         const double* thr_beta, double near_frac, double* out5,
                         double* x_top, double* mean_top, double* q_top,
-                        int32_t* flags, double* value, int64_t* gidx);
+                        int32_t* flags, double* value, int64_t* gidx,
+                        double* max_l_out);
 /* gp_opt.py:615: G[idx] = True for owned global indices                      */
 int sgp_grid_mark_expanders(sgp_grid* grid, const int64_t* gidx, int m);
 /* get_new_query_point / get_maximum arg-max (gp_opt.py:635, 642-644,

@@ -78,7 +78,7 @@ PROTOTYPES = {
                                       C.c_double, c_double_p, c_double_p,
                                       C.c_double, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_i32_p,
-                                      c_double_p, c_i64_p]),
+                                      c_double_p, c_i64_p, c_double_p]),
     "sgp_grid_sets_back": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p,
                                      c_double_p, c_double_p, c_double_p,
                                      C.c_double, C.c_int64, C.c_int,
@@ -423,22 +423,24 @@ class DeviceGrid(object):
         c = f64(c).reshape(-1)
         self.ctx.check(lib().sgp_grid_set_context(self.h, dptr(c), c.size))
 
-    def confidence(self, gps, beta, fmin):
+    def confidence(self, gps, beta, fmin, defer=False):
+        """``defer``: enqueue only; ``max l0[S]`` stays on the device and comes
+        back with the next ``sets_fused`` call (returns ``(None, None)``)."""
         fmin = f64(fmin)
         out = np.empty(2)
         self.ctx.check(lib().sgp_grid_confidence(
             self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin),
-            dptr(out)))
-        return out[0], bool(out[1])
+            None if defer else dptr(out)))
+        return (None, None) if defer else (out[0], bool(out[1]))
 
-    def rank1_update(self, gps, which, beta, fmin):
+    def rank1_update(self, gps, which, beta, fmin, defer=False):
         fmin = f64(fmin)
         w = np.ascontiguousarray(which, dtype=np.int32)
         out = np.empty(2)
         self.ctx.check(lib().sgp_grid_rank1_update(
             self.h, _gp_array(gps), len(gps), w.ctypes.data_as(c_int_p),
-            float(beta), dptr(fmin), dptr(out)))
-        return out[0], bool(out[1])
+            float(beta), dptr(fmin), None if defer else dptr(out)))
+        return (None, None) if defer else (out[0], bool(out[1]))
 
     def upload_Q(self, Qh, fmin):
         Qh = f64(Qh).reshape(self.N, 2 * self.G)
@@ -547,12 +549,14 @@ class DeviceGrid(object):
         flags = np.zeros(self.G, dtype=np.int32)
         v = C.c_double(0)
         i = C.c_int64(0)
+        ml = C.c_double(0)
         self.ctx.check(lib().sgp_grid_sets_fused(
             self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin),
-            float(max_l), dptr(scaling), dptr(thr_beta), float(near_frac),
-            dptr(out5), dptr(x), dptr(mean), dptr(q),
-            flags.ctypes.data_as(c_i32_p), C.byref(v), C.byref(i)))
-        return out5, x, mean, q, flags, v.value, i.value
+            float('nan') if max_l is None else float(max_l), dptr(scaling),
+            dptr(thr_beta), float(near_frac), dptr(out5), dptr(x), dptr(mean),
+            dptr(q), flags.ctypes.data_as(c_i32_p), C.byref(v), C.byref(i),
+            C.byref(ml)))
+        return out5, x, mean, q, flags, v.value, i.value, ml.value
 
     def mark_expanders(self, gidx):
         gidx = np.ascontiguousarray(gidx, dtype=np.int64)

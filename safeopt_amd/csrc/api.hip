@@ -432,7 +432,8 @@ int sgp_grid_create(sgp_ctx* ctx, const double* base, int64_t N, int d,
                 {(void**)&g->Gm, size_t(N)},    {(void**)&g->cand, size_t(N)},
                 {(void**)&g->w, nd},
                 {(void**)&g->partial, size_t(g->partial_cap) * sizeof(double)},
-                {(void**)&g->gpdev, sizeof(GpDev) * SGP_MAX_GPS}};
+                {(void**)&g->gpdev, sizeof(GpDev) * SGP_MAX_GPS},
+                {(void**)&g->scal, 64}};
   for (auto& a : allocs) {
     hipError_t e = hipMalloc(a.p, a.bytes);
     if (e != hipSuccess) {
@@ -472,7 +473,7 @@ void sgp_grid_destroy(sgp_grid* g) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {g->pts, g->Q,    g->mean, g->var,     g->S,    g->M,
-                  g->Gm,  g->cand, g->w,    g->partial, g->gpdev};
+                  g->Gm,  g->cand, g->w,    g->partial, g->gpdev, g->scal};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
@@ -487,15 +488,29 @@ int sgp_grid_set_context(sgp_grid* g, const double* c, int nc) {
   return launch_fill_cols(g, c, nc);
 }
 
+// max l0 over S ends up in g->scal[0]; out2 == nullptr defers the read-back
+// (sgp_grid_sets_fused picks the value up on the device and reports it).
 static int finish_safe_partials(sgp_grid* g, int nblocks, double* out2) {
   sgp_ctx* ctx = g->ctx;
-  double* red = static_cast<double*>(sgp_scratch(ctx, 1, 64));
-  SGP_CHECK(ctx, red, "device allocation failed: %s", ctx->err.c_str());
-  SGP_TRY(launch_reduce_max(ctx, g->partial, nblocks, red));
+  SGP_TRY(launch_reduce_max(ctx, g->partial, nblocks, g->scal));
+  if (!out2) return 0;
   double m = 0.0;
-  SGP_TRY(sgp_d2h(ctx, &m, red, sizeof(double)));
+  SGP_TRY(sgp_d2h(ctx, &m, g->scal, sizeof(double)));
   out2[0] = m;
   out2[1] = (m > -INFINITY) ? 1.0 : 0.0;
+  return 0;
+}
+
+// GP descriptors -> g->gpdev through a fixed slot of the pinned staging block
+// (no stream sync: the slot always holds the descriptors of this very call or
+// of an identical earlier one that may still be in flight).
+static int stage_gpdev(sgp_grid* g, const GpDev* host, int G) {
+  sgp_ctx* ctx = g->ctx;
+  char* slot = static_cast<char*>(ctx->pinned) + ctx->pinned_cap -
+               sizeof(GpDev) * SGP_MAX_GPS;
+  memcpy(slot, host, sizeof(GpDev) * G);
+  SGP_HIP(ctx, hipMemcpyAsync(g->gpdev, slot, sizeof(GpDev) * G,
+                              hipMemcpyHostToDevice, ctx->stream));
   return 0;
 }
 
@@ -506,9 +521,7 @@ int sgp_grid_confidence(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
   GpDev host[SGP_MAX_GPS];
   SGP_TRY(collect_gps(ctx, gps, G, g->d, host));
-  SGP_HIP(ctx, hipMemcpyAsync(g->gpdev, host, sizeof(GpDev) * G,
-                              hipMemcpyHostToDevice, ctx->stream));
-  SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host[] is on the stack
+  SGP_TRY(stage_gpdev(g, host, G));
   SweepPoints sp{g->pts, g->N, 1, g->N};
   ConfOut co{};
   co.Q = g->Q;
@@ -538,9 +551,7 @@ int sgp_grid_rank1_update(sgp_grid* g, sgp_gp* const* gps, int G,
       SGP_CHECK(ctx, gps[i]->upd_valid,
                 "GP %d has no append record for a rank-1 update", i);
   }
-  SGP_HIP(ctx, hipMemcpyAsync(g->gpdev, host, sizeof(GpDev) * G,
-                              hipMemcpyHostToDevice, ctx->stream));
-  SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host[] is on the stack
+  SGP_TRY(stage_gpdev(g, host, G));
   ra.Q = g->Q;
   ra.mean = g->mean;
   ra.var = g->var;
@@ -738,12 +749,12 @@ static int enqueue_expander(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   double* dtn2 = reinterpret_cast<double*>(buf + bx + 3 * bv);
   int32_t* dfl = reinterpret_cast<int32_t*>(buf + bx + 4 * bv);
   double* dW = reinterpret_cast<double*>(buf + bx + 4 * bv + bf);
-  // one pinned staging block: xc | resid | gp descriptors
+  // pinned staging block: xc | resid (descriptors have their own slot)
   const size_t hb = bx + bv + sizeof(GpDev) * SGP_MAX_GPS;
   SGP_CHECK(ctx, hb <= ctx->pinned_cap / 2, "staging buffer too small");
   char* stage = static_cast<char*>(ctx->pinned) + ctx->pinned_cap / 2;
-  memcpy(stage + bx + bv, host, sizeof(GpDev) * G);
-  // previous users of the staging block have completed (every call syncs)
+  // previous users of this block have completed (every call that writes it
+  // syncs before returning)
   if (top) {
     SGP_HIP(ctx, hipMemsetAsync(dxc, 0, bx + bv, ctx->stream));
     SGP_TRY(launch_stage_top(g, top, top + d, top + d + G, dxc, dres));
@@ -757,8 +768,7 @@ static int enqueue_expander(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
     SGP_HIP(ctx, hipMemcpyAsync(dxc, stage, bx + bv, hipMemcpyHostToDevice,
                                 ctx->stream));
   }
-  SGP_HIP(ctx, hipMemcpyAsync(g->gpdev, stage + bx + bv, sizeof(GpDev) * G,
-                              hipMemcpyHostToDevice, ctx->stream));
+  SGP_TRY(stage_gpdev(g, host, G));
   SGP_HIP(ctx, hipMemsetAsync(dfl, 0, bf, ctx->stream));
   ExpanderArgs ea{};
   for (int i = 0; i < SGP_MAX_GPS; ++i) {
@@ -896,20 +906,26 @@ int sgp_grid_sets_fused(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
                         const double* fmin, double max_l, const double* scaling,
                         const double* thr_beta, double near_frac, double* out5,
                         double* x_top, double* mean_top, double* q_top,
-                        int32_t* flags, double* value, int64_t* gidx) {
+                        int32_t* flags, double* value, int64_t* gidx,
+                        double* max_l_out) {
   sgp_ctx* ctx = g->ctx;
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   const int d = g->d;
   SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
   // result block: [0] max width | [1..2] counts (u64) | [3] w_top | [4] idx_top
   //   (i64) | [5] n_found (int) | x[d] | mean[G] | q[2G] | flags[G] (i32, padded
-  //   to 8 B) | value | index (i64)
+  //   to 8 B) | value | index (i64) | max_l (when it was resident)
   const size_t nfront = 6 + size_t(d) + 3 * size_t(G);
   const size_t nfl = (size_t(G) + 1) / 2;
-  const size_t nres = nfront + nfl + 2;
+  const size_t nres = nfront + nfl + 3;
   double* res = static_cast<double*>(sgp_scratch(ctx, 1, (nres + 8) * 8));
   SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
-  SGP_TRY(launch_maximizers(g, max_l));
+  // max_l = NaN: the confidence pass was issued without read-back, the value
+  // is in g->scal[0]
+  const bool resident = max_l != max_l;
+  SGP_HIP(ctx, hipMemcpyAsync(res + nfront + nfl + 2, g->scal, 8,
+                              hipMemcpyDeviceToDevice, ctx->stream));
+  SGP_TRY(launch_maximizers(g, max_l, resident ? g->scal : nullptr));
   SGP_TRY(launch_reduce_max(ctx, g->partial, (g->N + 255) / 256, res));
   SGP_TRY(launch_candidates(g, 0.0, res, scaling, thr_beta, 0,
                             reinterpret_cast<unsigned long long*>(res + 1)));
@@ -946,6 +962,7 @@ int sgp_grid_sets_fused(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   memcpy(flags, &host[nfront], size_t(G) * 4);
   *value = host[nfront + nfl];
   memcpy(gidx, &host[nfront + nfl + 1], 8);
+  if (max_l_out) *max_l_out = resident ? host[nfront + nfl + 2] : max_l;
   return 0;
 }
 

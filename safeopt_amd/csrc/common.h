@@ -139,6 +139,7 @@ struct sgp_grid {
   double* partial = nullptr; // block partials
   int64_t partial_cap = 0;
   GpDev* gpdev = nullptr;    // [SGP_MAX_GPS] device copy of descriptors
+  double* scal = nullptr;    // [8] resident scalars: [0] = max l0 over S
 };
 
 // ---- helpers (api.hip) ------------------------------------------------------
@@ -233,7 +234,8 @@ int launch_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
 // sets.hip
 int launch_reduce_max(sgp_ctx* ctx, const double* in, int64_t n, double* out);
 int launch_safe_set(sgp_grid* g, const double* fmin);  // from Q -> S, partial
-int launch_maximizers(sgp_grid* g, double max_l);
+int launch_maximizers(sgp_grid* g, double max_l,
+                      const double* max_l_dev = nullptr);  // device value wins
 int launch_candidates(sgp_grid* g, double max_var, const double* max_width_dev,
                       const double* scaling, const double* thr_beta,
                       int full_sets, unsigned long long* counts_dev);

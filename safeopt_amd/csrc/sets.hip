@@ -87,8 +87,10 @@ __global__ __launch_bounds__(T) void k_safe_set(const double* Q, int64_t N,
 __global__ __launch_bounds__(T) void k_maximizers(const double* Q,
                                                   const uint8_t* S, int64_t N,
                                                   int G, double max_l,
+                                                  const double* max_l_dev,
                                                   uint8_t* M, double* partial) {
   __shared__ double sh[T / 64];
+  if (max_l_dev) max_l = max_l_dev[0];   // still on the device (deferred sync)
   const int64_t i = int64_t(blockIdx.x) * T + threadIdx.x;
   double v = -INFINITY;
   if (i < N) {
@@ -436,10 +438,10 @@ int launch_safe_set(sgp_grid* g, const double* fmin) {
   return 0;
 }
 
-int launch_maximizers(sgp_grid* g, double max_l) {
+int launch_maximizers(sgp_grid* g, double max_l, const double* max_l_dev) {
   sgp_ctx* ctx = g->ctx;
   hipLaunchKernelGGL(k_maximizers, dim3(nblk(g->N, T)), dim3(T), 0, ctx->stream,
-                     g->Q, g->S, g->N, g->G, max_l, g->M, g->partial);
+                     g->Q, g->S, g->N, g->G, max_l, max_l_dev, g->M, g->partial);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -185,7 +185,7 @@ class _HipGridBackend(object):
         self.grid.set_context(c)
         self._seen = [None] * len(self.gps)      # rows changed: full sweep
 
-    def confidence(self, beta, fmin):
+    def confidence(self, beta, fmin, defer=False):
         devs = self._dev()
         tags = [(id(dv), dv.version) for dv in devs]
         which = [0] * len(devs)
@@ -201,9 +201,9 @@ class _HipGridBackend(object):
         self._seen = tags
         if rank1 and any(which):
             self._rank1_streak += 1
-            return self.grid.rank1_update(devs, which, beta, fmin)
+            return self.grid.rank1_update(devs, which, beta, fmin, defer)
         self._rank1_streak = 0
-        return self.grid.confidence(devs, beta, fmin)
+        return self.grid.confidence(devs, beta, fmin, defer)
 
     def upload_Q(self, Q, fmin):
         self._seen = [None] * len(self.gps)      # mean/var no longer match Q
@@ -434,17 +434,25 @@ class SafeOpt(GaussianProcessOptimization):
             self._ci_fresh = False
 
     # -- the hot path -------------------------------------------------------------
-    def update_confidence_intervals(self, context=None):
+    def update_confidence_intervals(self, context=None, _defer=False):
         """Posterior sweep of every GP over all candidates -> ``Q`` (and ``S``).
 
         One fused kernel per rank; the only values that come back are
-        ``max(l_0[S])`` and ``any(S)``.
+        ``max(l_0[S])`` and ``any(S)``.  (``_defer``: internal to
+        :meth:`optimize` -- the sweep is only enqueued and the two scalars
+        arrive with the set passes, one device round trip for the whole step.)
         """
         beta = self.beta(self.t)
         self.context = context
-        m, a = self._backend.confidence(beta, self.fmin)
-        red = self._comm.allreduce_max(np.array([m, float(a)]))
-        self._max_l, self._any_safe = red[0], bool(red[1] > 0)
+        if _defer:
+            m, a = self._backend.confidence(beta, self.fmin, defer=True)
+        else:
+            m, a = self._backend.confidence(beta, self.fmin)
+        if m is None:
+            self._max_l, self._any_safe = None, None      # known after the sets
+        else:
+            red = self._comm.allreduce_max(np.array([m, float(a)]))
+            self._max_l, self._any_safe = red[0], bool(red[1] > 0)
         self._stale.update(Q=True, S=True)
         self._ci_fresh = True
         self._argmax_cache = None
@@ -472,7 +480,7 @@ class SafeOpt(GaussianProcessOptimization):
             np.asarray(self.threshold, dtype=float) * beta, (G,)).copy()
 
         self._argmax_cache = None
-        if not self._any_safe:
+        if self._max_l is not None and not self._any_safe:
             # M = G = False everywhere
             be.maximizers(np.inf)
             be.candidates(np.inf, self.scaling, thr_beta, False)
@@ -489,8 +497,15 @@ class SafeOpt(GaussianProcessOptimization):
             fused = None
             if world == 1 and np.any(active) and hasattr(be, 'sets_fused'):
                 # both halves in one device round trip
-                out5, x_c, mu_c, q_c, f_flags, f_val, f_idx = be.sets_fused(
-                    beta, self.fmin, self._max_l, self.scaling, thr_beta, 0.5)
+                (out5, x_c, mu_c, q_c, f_flags, f_val, f_idx,
+                 max_l) = be.sets_fused(beta, self.fmin, self._max_l,
+                                        self.scaling, thr_beta, 0.5)
+                if self._max_l is None:         # deferred confidence pass
+                    self._max_l, self._any_safe = max_l, bool(max_l > -np.inf)
+                    if not self._any_safe:
+                        # the passes ran with max_l = -inf: M = G = False
+                        self._stale.update(M=True, G=True)
+                        return
                 n_cand, n_unsafe, w_c, idx_c = (out5[1], out5[2],
                                                 float(out5[3]), int(out5[4]))
                 fused = (f_flags, f_val, f_idx)
@@ -670,7 +685,13 @@ class SafeOpt(GaussianProcessOptimization):
 
     def optimize(self, context=None, ucb=False):
         """One SafeOpt step: intervals -> sets -> next query point."""
-        self.update_confidence_intervals(context=context)
+        # common case on one GPU: sweep, set passes, probe of the first
+        # candidate and arg-max are enqueued back to back, one read-back
+        one_trip = (not ucb and self._comm.world == 1
+                    and not self.use_lipschitz
+                    and hasattr(self._backend, 'sets_fused')
+                    and bool(np.any(self.fmin != -np.inf)))
+        self.update_confidence_intervals(context=context, _defer=one_trip)
         if ucb:
             self.compute_safe_set()
         else:
