@@ -290,6 +290,37 @@ def test_topk_order_and_ties(mods):
     assert got == ref[:80].tolist()
 
 
+def test_optimize_one_round_trip_paths(mods):
+    """SafeOpt.optimize() enqueues sweep + set passes + probe + arg-max with one
+    read-back; same answer as the step-by-step methods, and the reference's
+    EnvironmentError when nothing is safe (gp_opt.py:631-632)."""
+    safeopt_amd, gpy, _, _ = mods
+    rng = np.random.default_rng(4)
+    X = rng.uniform(-1, 1, size=(12, 2))
+    Y = 1.0 + 0.3 * np.sin(3 * X[:, :1]) + 0.2 * X[:, 1:]
+    grid = safeopt_amd.linearly_spaced_combinations([(-3, 3)] * 2, 60)
+
+    def make(y):
+        gp = gpy.models.GPRegression(X, y, gpy.kern.RBF(2, variance=2., lengthscale=1., ARD=True),
+                                     noise_var=0.05 ** 2)
+        return safeopt_amd.SafeOpt(gp, grid, 0., threshold=0.2)
+    a, b = make(Y), make(Y)
+    xa = a.optimize()
+    b.update_confidence_intervals()
+    b.compute_sets()
+    xb = b.get_new_query_point()
+    assert_array_equal(xa, xb)
+    for name in "QSMG":
+        assert_array_equal(getattr(a, name), getattr(b, name))
+    assert a.S.any() and a.M.any()
+    # nothing safe: every observation far below fmin
+    c = make(Y - 5.0)
+    with pytest.raises(EnvironmentError):
+        c.optimize()
+    assert not c.S.any() and not c.M.any() and not c.G.any()
+    assert c.get_maximum() is None
+
+
 def test_swarm_fitness_golden(mods):
     safeopt_amd, gpy, _, _ = mods
     z, meta = load("swarm_2d_g2")
