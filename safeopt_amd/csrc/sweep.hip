@@ -126,22 +126,30 @@ __device__ __forceinline__ void stage_dma(const GpView& gp, double* buf, int b0,
   }
 }
 
-// X rows / alpha entries of j-block jb: one double per thread through VGPRs.
-__device__ __forceinline__ double stage_x_load(const GpView& gp, int D, int jb,
-                                               int tid) {
-  const int j0 = jb * kJC;
-  const bool isx = tid < kJC * D;
-  const bool isa = tid >= 128 && tid < 128 + kJC;
-  gptr_t src = isx ? gp.Xs + (j0 * D + tid) : gp.alpha + (j0 + (tid - 128));
-  return (isx || isa) ? *src : 0.0;
-}
-
-__device__ __forceinline__ void stage_x_store(double v, double* buf, int D,
-                                              int tid) {
-  if (tid < kJC * D) {
-    buf[kATile + tid] = v;
-  } else if (tid >= 128 && tid < 128 + kJC) {
-    buf[kATile + kXTile + (tid - 128)] = v;
+// Training rows (pre-scaled) and alpha entries of j-block jb: contiguous runs of
+// 16 D and 16 doubles in GpDev::Xs / alpha, copied by LDS-DMA as well -- wave 0
+// moves the rows (8 D lanes x 16 B), wave 1 the alpha run (8 lanes x 16 B); the
+// other lanes are masked off and write nothing.
+template <int D>
+__device__ __forceinline__ void stage_x_dma(const GpView& gp, double* buf, int jb,
+                                            int tid) {
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  if (wave == 0) {
+    if (lane < 8 * D) {
+      gptr_t src = gp.Xs + (jb * kJC * D + lane * 2);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)(buf + kATile), 16, 0, 0);
+    }
+  } else if (wave == 1) {
+    if (lane < 8) {
+      gptr_t src = gp.alpha + (jb * kJC + lane * 2);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)(buf + kATile + kXTile), 16,
+          0, 0);
+    }
   }
 }
 
@@ -266,13 +274,12 @@ __device__ __forceinline__ bool stage_next(StagePos& sp, const GpDev* gps,
   return true;
 }
 
-template <int NW>
+template <int D, int NW>
 __device__ __forceinline__ void stage_issue(const StagePos& sp, const GpView& gp,
-                                            double* buf, int D, int tid,
-                                            double& xstage) {
+                                            double* buf, int tid) {
   const int lo = sp.shift + max(0, sp.jb - sp.b0);
   stage_dma<NW>(gp, buf, sp.b0, sp.shift, sp.jb, lo, tid);
-  xstage = stage_x_load(gp, D, sp.jb, tid);
+  stage_x_dma<D>(gp, buf, sp.jb, tid);
 }
 
 template <int D, int NW, int MODE>
@@ -315,11 +322,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   gv_next.load(p.gps[0]);
   KernFast<D> kf(p.gps[0].kern);
   double kdiag = p.gps[0].kern.kdiag;
-  {
-    double xs0;
-    stage_issue<NW>(cur, gv_next, lds, D, tid, xs0);
-    stage_x_store(xs0, lds, D, tid);
-  }
+  stage_issue<D, NW>(cur, gv_next, lds, tid);
   __syncthreads();
 
   // per-GP state
@@ -344,12 +347,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     // prefetch the next stage (and the rows of the next tile)
     StagePos nxt = cur;
     more = stage_next(nxt, p.gps, Geff, ntiles, gridDim.x);
-    double xstage = 0.0;
     const bool tile_ends = !more || nxt.tile != cur.tile;
     const bool gp_ends = tile_ends || nxt.g != cur.g;
     if (more) {
       if (gp_ends && Geff > 1) gv_next.load(p.gps[nxt.g]);
-      if (!SGP_ABL(2)) stage_issue<NW>(nxt, gv_next, nbuf, D, tid, xstage);
+      if (!SGP_ABL(2)) stage_issue<D, NW>(nxt, gv_next, nbuf, tid);
     }
     const bool chunk_ends = gp_ends || nxt.c != cur.c;
     if (more && tile_ends) load_x(nxt.tile, xnext);
@@ -493,7 +495,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       kf = KernFast<D>(p.gps[nxt.g].kern);
       kdiag = p.gps[nxt.g].kern.kdiag;
     }
-    if (more) stage_x_store(xstage, nbuf, D, tid);
     if (!SGP_ABL(1)) __syncthreads();
     bufsel ^= 1;
     cur = nxt;
