@@ -101,12 +101,25 @@ def build_gps(cfg, ns, **kw):
             for g in range(cfg["G"])]
 
 
+CPU_BASELINE_SECONDS = 12.0      # target CPU work of the default sample
+
+
 def cpu_baseline(cfg, sample_rows, dev_Q=None):
     """The oracle (NumPy restatement of the reference path, all host cores via
-    the BLAS thread pool) on a bounded sample of the same workload."""
+    the BLAS thread pool) on a bounded sample of the same workload.
+    ``sample_rows=None``: as many rows (a centred block of the grid) as a 20k-row
+    pilot predicts for ~CPU_BASELINE_SECONDS of work."""
     from oracle import gp_numpy as gpn
     from oracle import safeopt_numpy as son
     gps = build_gps(cfg, gpn)
+    if sample_rows is None:
+        N = cfg["grid"].shape[0]
+        pilot = np.ascontiguousarray(cfg["grid"][(N - 20000) // 2:(N + 20000) // 2])
+        son.confidence_intervals(gps, pilot[:8192], cfg["beta"])
+        t0 = time.perf_counter()
+        son.confidence_intervals(gps, pilot, cfg["beta"])
+        rate = pilot.shape[0] / (time.perf_counter() - t0)
+        sample_rows = int(min(N, max(20000, rate * CPU_BASELINE_SECONDS)))
     # a contiguous block of rows from the middle of the grid (the block around
     # the training data, so the sample contains safe, maximiser and unsafe rows)
     N = cfg["grid"].shape[0]
@@ -154,7 +167,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
     ap.add_argument("--side", type=int, default=None,
                     help="grid points per dimension (default: the config's)")
-    ap.add_argument("--cpu-rows", type=int, default=100000)
+    ap.add_argument("--cpu-rows", type=int, default=None,
+                    help="rows of the CPU-baseline sample (default: ~12 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -261,7 +275,7 @@ def main():
     if world == 1:
         res["mfma_f64_microbench_tflops"] = ctx.microbench_mfma_f64(20000)
     if world == 1 and not args.no_cpu_baseline and args.config != 5:
-        rows = min(args.cpu_rows, units)
+        rows = None if args.cpu_rows is None else min(args.cpu_rows, units)
         base, parity = cpu_baseline(cfg, rows, dev_Q=opt.Q)
         res["cpu_baseline"] = base
         res["parity"] = parity

@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd $R
 python bench.py --steps 20 --warmup 3 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
-python bench.py --config 3 --steps 5 --warmup 2 --cpu-rows 20000 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
+python bench.py --config 3 --steps 5 --warmup 2 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
 python bench.py --config 4 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg4_1gpu.json 2> $OUT/bench_cfg4.err
 python bench.py --config 5 --steps 5 --warmup 1 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
 python scripts/microbench.py > $OUT/microbench.txt 2>&1
