@@ -793,6 +793,13 @@ static int enqueue_expander(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   ea.flags = dfl;
   ea.wstride = wstride;
   ea.near_frac = near_frac;
+  // single candidate: pre-filter + listed contraction; the group counter sits
+  // in the slack behind the flags (zeroed with them), the list in scratch
+  ea.count = reinterpret_cast<int*>(reinterpret_cast<char*>(dfl) +
+                                    size_t(SGP_TOPK) * G * 4 + 32);
+  ea.list = (m == 1) ? static_cast<int*>(sgp_scratch(
+                           ctx, 0, (size_t(g->N) / 16 + 2) * sizeof(int)))
+                     : nullptr;
   SweepPoints sp{g->pts, g->N, 1, g->N};
   SGP_TRY(launch_expander_check(ctx, g->gpdev, host, G, d, sp, ea));
   *flags_dev = dfl;

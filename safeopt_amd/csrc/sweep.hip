@@ -503,23 +503,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
 
 // ---- expander check ---------------------------------------------------------
 // One MFMA row block = up to 16 candidates: acc[cand, pt] = sum_j w_c[j] K[j,pt].
+// The 16 rows of a wave are row0 + (lane & 15); lane >> 4 selects the candidate
+// quad.  `unsafe` marks the lanes whose row takes part.
 template <int D>
-__global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
-                                                  SweepPoints pts,
-                                                  ExpanderArgs ea) {
-  __shared__ double tab[kExpTabSize];
-  exp_tab_init(tab);
-  __syncthreads();
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int64_t row = int64_t(blockIdx.x) * 64 + wave * 16 + (lane & 15);
-  const bool valid = row < pts.N;
-  const int64_t rrow = valid ? row : pts.N - 1;
-  const bool unsafe = valid && (ea.S[rrow] == 0);
-  // skip waves with no unsafe row (wave-uniform)
-  if (__ballot(unsafe) == 0ull) return;
-
+__device__ __forceinline__ void expander_rows(const GpDev* gps, int G,
+                                              const SweepPoints& pts,
+                                              const ExpanderArgs& ea,
+                                              int64_t rrow, bool unsafe,
+                                              const double* tab, int lane) {
   double x[D];
 #pragma unroll
   for (int k = 0; k < D; ++k)
@@ -598,6 +589,101 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
         }
       }
     }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
+                                                  SweepPoints pts,
+                                                  ExpanderArgs ea) {
+  __shared__ double tab[kExpTabSize];
+  exp_tab_init(tab);
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t row = int64_t(blockIdx.x) * 64 + wave * 16 + (lane & 15);
+  const bool valid = row < pts.N;
+  const int64_t rrow = valid ? row : pts.N - 1;
+  const bool unsafe = valid && (ea.S[rrow] == 0);
+  // skip waves with no unsafe row (wave-uniform)
+  if (__ballot(unsafe) == 0ull) return;
+  expander_rows<D>(gps, G, pts, ea, rrow, unsafe, tab, lane);
+}
+
+// Single candidate (the probe of the first candidate and its exact re-scan):
+// the pre-filter runs with one row per lane over the whole shard and appends
+// the 16-row groups that contain a row which could be lifted above fmin to a
+// list; k_expander_list then does the n-term contraction for those groups only
+// (a few per cent of the unsafe set).  Same arithmetic as k_expander.
+template <int D>
+__global__ __launch_bounds__(256) void k_expander_filter(const GpDev* gps, int G,
+                                                         SweepPoints pts,
+                                                         ExpanderArgs ea,
+                                                         int* count, int* list) {
+  __shared__ double tab[kExpTabSize];
+  exp_tab_init(tab);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const bool valid = row < pts.N;
+  const int64_t rrow = valid ? row : pts.N - 1;
+  const bool unsafe = valid && (ea.S[rrow] == 0);
+  if (__ballot(unsafe) == 0ull) return;
+  double x[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+    x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
+  bool possible = false;
+  if (unsafe) {
+    for (int g = 0; g < G; ++g) {
+      if (!ea.active[g]) continue;
+      const GpDev& gp = gps[g];
+      const KernFast<D> kf(gp.kern);
+      const double mu = ea.mean[int64_t(g) * pts.N + rrow];
+      const double var = ea.var[int64_t(g) * pts.N + rrow];
+      const double kdiag = gp.kern.kdiag;
+      const double qx = fmax(kdiag - var, 0.0);
+      const double kxc = kf.raw(x, ea.xc, tab);
+      const double cmax =
+          (fabs(kxc) + sqrt(qx * ea.tn2[g * 16])) * (1.0 + 1e-9);
+      const double mu2 = mu + fabs(ea.delta[g * 16]) * cmax;
+      const double var2 = fmax(var - cmax * cmax * ea.inv_s2[g * 16], 1e-15);
+      const double l2max = mu2 - ea.beta * sqrt(var2);
+      possible = possible ||
+                 ((l2max + 1e-9 * (fabs(mu2) + 1.0) >= ea.fmin[g]) &&
+                  (kxc >= ea.near_frac * kdiag));
+    }
+  }
+  const unsigned long long b = __ballot(possible);
+  if (b == 0ull) return;
+  if (lane == 0) {
+    int k = 0, grp[4];
+    for (int q = 0; q < 4; ++q)
+      if ((b >> (16 * q)) & 0xffffull) grp[k++] = int(row >> 4) + q;
+    const int at = atomicAdd(count, k);
+    for (int q = 0; q < k; ++q) list[at + q] = grp[q];
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_expander_list(const GpDev* gps, int G,
+                                                       SweepPoints pts,
+                                                       ExpanderArgs ea,
+                                                       const int* count,
+                                                       const int* list) {
+  __shared__ double tab[kExpTabSize];
+  exp_tab_init(tab);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int n = *count;
+  const int nwaves = gridDim.x * 4;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += nwaves) {
+    const int64_t row = int64_t(list[i]) * 16 + (lane & 15);
+    const bool valid = row < pts.N;
+    const int64_t rrow = valid ? row : pts.N - 1;
+    const bool unsafe = valid && (ea.S[rrow] == 0);
+    expander_rows<D>(gps, G, pts, ea, rrow, unsafe, tab, lane);
   }
 }
 
@@ -938,10 +1024,19 @@ int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
   (void)gps_host;
   if (pts.N <= 0) return 0;
   const int nblocks = int((pts.N + 63) / 64);
+  const bool listed = ea.m == 1 && ea.count && ea.list;
+  const int nfilter = int((pts.N + 255) / 256), nlist = ctx->num_cu * 2;
 #define EXP_CASE(DD)                                                          \
   case DD:                                                                    \
-    hipLaunchKernelGGL(k_expander<DD>, dim3(nblocks), dim3(256), 0,           \
-                       ctx->stream, gps_dev, G, pts, ea);                     \
+    if (listed) {                                                             \
+      hipLaunchKernelGGL(k_expander_filter<DD>, dim3(nfilter), dim3(256), 0,  \
+                         ctx->stream, gps_dev, G, pts, ea, ea.count, ea.list);\
+      hipLaunchKernelGGL(k_expander_list<DD>, dim3(nlist), dim3(256), 0,      \
+                         ctx->stream, gps_dev, G, pts, ea, ea.count, ea.list);\
+    } else {                                                                  \
+      hipLaunchKernelGGL(k_expander<DD>, dim3(nblocks), dim3(256), 0,         \
+                         ctx->stream, gps_dev, G, pts, ea);                   \
+    }                                                                         \
     break;
   switch (d) {
     EXP_CASE(1) EXP_CASE(2) EXP_CASE(3) EXP_CASE(4)
