@@ -551,21 +551,38 @@ __device__ __forceinline__ void expander_rows(const GpDev* gps, int G,
     }
     if (__ballot(possible) == 0ull) continue;  // wave-uniform
 
-    const double* W = ea.Wpack + int64_t(g) * ea.wstride + lane;
-    const double* Xj = gp.Xs + (lane >> 4) * D;
+    gptr_t W = (gptr_t)ea.Wpack + int64_t(g) * ea.wstride + lane;
+    gptr_t Xj = (gptr_t)gp.Xs + (lane >> 4) * D;
     double xs[D];
     kf.prep(x, xs);
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
     const int nsteps = gp.n_pad >> 2;  // multiple of 4 (n_pad is 16-aligned)
+    // operands of 16 training points per iteration, fetched one iteration ahead
+    // (the loop is otherwise a chain of exposed global-memory latencies)
+    double a[4], xr[4][D], an[4], xn[4][D];
+    auto fetch = [&](int s0, double (&ao)[4], double (&xo)[4][D]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ao[q] = W[(s0 + q) * 64];
+#pragma unroll
+        for (int k = 0; k < D; ++k) xo[q][k] = Xj[(s0 + q) * 4 * D + k];
+      }
+    };
+    fetch(0, a, xr);
 #pragma unroll 1
     for (int s0 = 0; s0 < nsteps; s0 += 4) {
-      double a[4], kv[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) a[q] = W[(s0 + q) * 64];
-      kf.template many<4>(xs, Xj + s0 * 4 * D, 4 * D, tab, kv);
+      if (s0 + 4 < nsteps) fetch(s0 + 4, an, xn);
+      double kv[4];
+      kf.template many<4>(xs, &xr[0][0], D, tab, kv);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], kv[q], acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[q] = an[q];
+#pragma unroll
+        for (int k = 0; k < D; ++k) xr[q][k] = xn[q][k];
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
