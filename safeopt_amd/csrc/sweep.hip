@@ -710,11 +710,14 @@ __global__ __launch_bounds__(256) void k_expander_list(const GpDev* gps, int G,
 // GP this is n covariance evaluations and n FMAs on the VALU -- no n^2 term.
 // Lane (r, q) = (lane & 15, lane >> 4) handles row r and training points
 // j = q (mod 4); the four partial dot products are folded with two shuffles.
+constexpr int kRank1Lds = 6144;   // doubles of staged training data (48 KB)
+
 template <int D>
 __global__ __launch_bounds__(256) void k_rank1(const GpDev* gps, int G,
                                                SweepPoints pts, Rank1Args ra) {
   __shared__ double tab[kExpTabSize];
   __shared__ double red[4];
+  __shared__ double stage[kRank1Lds];   // [n_pad][D] scaled rows | [n_pad] w
   exp_tab_init(tab);
   __syncthreads();
   const int tid = threadIdx.x;
@@ -740,10 +743,22 @@ __global__ __launch_bounds__(256) void k_rank1(const GpDev* gps, int G,
       const KernFast<D> kf(gp.kern);
       double xs[D];
       kf.prep(x, xs);
+      // training rows and the update vector: through LDS when they fit (one
+      // coalesced pass per workgroup instead of a global round trip per step)
+      const int np = gp.n_pad;
+      const bool staged = np * (D + 1) <= kRank1Lds;      // block-uniform
       const double* Xj = gp.Xs + (lane >> 4) * D;
       const double* w = gp.upd_w + (lane >> 4);
+      if (staged) {
+        __syncthreads();                                   // previous GP's readers
+        for (int e = tid; e < np * D; e += 256) stage[e] = gp.Xs[e];
+        for (int e = tid; e < np; e += 256) stage[np * D + e] = gp.upd_w[e];
+        __syncthreads();
+        Xj = stage + (lane >> 4) * D;
+        w = stage + np * D + (lane >> 4);
+      }
       double dot = 0.0;
-      const int nsteps = gp.n_pad >> 2;
+      const int nsteps = np >> 2;
 #pragma unroll 1
       for (int s = 0; s < nsteps; s += 4) {   // n_pad is a multiple of 16
         double kq[4];

@@ -13,6 +13,8 @@ python bench.py --steps 20 --warmup 3 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.
 python bench.py --config 3 --steps 5 --warmup 2 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
 python bench.py --config 4 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg4_1gpu.json 2> $OUT/bench_cfg4.err
 python bench.py --config 5 --steps 5 --warmup 1 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
+python scripts/bench_bo_loop.py --config 2 > $OUT/bo_loop.json 2> /dev/null
+python scripts/bench_bo_loop.py --config 3 >> $OUT/bo_loop.json 2> /dev/null
 python scripts/microbench.py > $OUT/microbench.txt 2>&1
 python scripts/stagebench.py > $OUT/stagebench.txt 2>&1
 bash scripts/ablate.sh 2 3 4 5 > $OUT/ablation.txt 2>&1

@@ -23,7 +23,7 @@ def main(tag):
     os.makedirs(dst, exist_ok=True)
     for name in ("SUMMARY.txt", "microbench.txt", "stagebench.txt", "ablation.txt",
                  "bench_cfg2.json", "bench_cfg3.json", "bench_cfg4_1gpu.json",
-                 "bench_cfg5.json"):
+                 "bench_cfg5.json", "bo_loop.json"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, name))
     for c in (2, 3):
