@@ -53,50 +53,59 @@ class SwarmOptimization(object):
         return 10 * self.velocity_scale
 
     def init_swarm(self, positions):
-        """Start a run from ``positions`` (kept by reference)."""
+        """Start a run from ``positions`` (kept by reference).
+
+        One ``np.random.rand(swarm_size, ndim)`` draw for the velocities; the
+        global best is the arg-max of the raw fitness (the safety mask is not
+        applied here, as in the reference)."""
         self.positions = positions
-        self.velocities = (np.random.rand(*self.velocities.shape) *
-                           self.velocity_scale)
-        values, _safe = self.fitness(self.positions)
-        self.best_positions[:] = self.positions
-        self.best_values = values
-        self.global_best = self.best_positions[np.argmax(values), :]
+        draw = np.random.rand(*self.velocities.shape)
+        self.velocities = draw * self.velocity_scale
+        fit, _mask = self.fitness(self.positions)
+        np.copyto(self.best_positions, self.positions)
+        self.best_values = fit
+        self._pick_global_best()
+
+    def _pick_global_best(self):
+        # a view into best_positions, first index among equal values
+        self.global_best = self.best_positions[int(np.argmax(self.best_values)), :]
+
+    def _move(self, inertia):
+        """Velocity and position update of one iteration (one draw of
+        ``np.random.rand(2 * swarm_size, ndim)``: own pull first, then global).
+        The expression order is part of the contract -- bit-identical runs."""
+        pull_global = self.global_best - self.positions
+        pull_own = self.best_positions - self.positions
+        u = np.random.rand(2 * self.swarm_size, self.ndim)
+        u_own, u_global = u[:self.swarm_size], u[self.swarm_size:]
+        v = self.velocities
+        v *= inertia
+        v += (self.c1 * u_own * pull_own +
+              self.c2 * u_global * pull_global) / self.velocity_scale
+        limit = self.max_velocity
+        np.clip(v, -limit, limit, out=v)
+        x = self.positions
+        x += v
+        if self.bounds is not None:
+            np.clip(x, self.bounds[:, 0], self.bounds[:, 1], out=x)
+
+    def _keep_improvements(self):
+        """Personal bests move only to safe points with a higher fitness."""
+        fit, mask = self.fitness(self.positions)
+        take = (fit > self.best_values) & mask
+        self.best_values[take] = fit[take]
+        self.best_positions[take] = self.positions[take]
+        self._pick_global_best()
 
     def run_swarm(self, max_iter):
-        """Iterate the swarm ``max_iter`` times."""
-        inertia = self.initial_inertia
+        """Iterate the swarm ``max_iter`` times, inertia going linearly from
+        ``initial_inertia`` towards ``final_inertia``."""
         step = (self.final_inertia - self.initial_inertia) / max_iter
-
+        inertia = self.initial_inertia
         for _ in range(max_iter):
-            to_global = self.global_best - self.positions
-            to_own = self.best_positions - self.positions
-
-            r = np.random.rand(2 * self.swarm_size, self.ndim)
-            r1, r2 = r[:self.swarm_size], r[self.swarm_size:]
-
-            self.velocities *= inertia
-            self.velocities += ((self.c1 * r1 * to_own +
-                                 self.c2 * r2 * to_global) /
-                                self.velocity_scale)
+            self._move(inertia)
             inertia += step
-
-            np.clip(self.velocities, -self.max_velocity, self.max_velocity,
-                    out=self.velocities)
-            self.positions += self.velocities
-            if self.bounds is not None:
-                np.clip(self.positions, self.bounds[:, 0], self.bounds[:, 1],
-                        out=self.positions)
-
-            values, safe = self.fitness(self.positions)
-
-            better = values > self.best_values
-            better &= safe
-            self.best_values[better] = values[better]
-            self.best_positions[better] = self.positions[better]
-
-            self.global_best = self.best_positions[
-                np.argmax(self.best_values), :]
-
+            self._keep_improvements()
 
 class DeviceSwarmOptimization(SwarmOptimization):
     """The same swarm with its state in HBM: ``init_swarm`` and ``run_swarm``
