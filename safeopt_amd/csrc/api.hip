@@ -1213,13 +1213,26 @@ int sgp_comm_init(sgp_ctx* ctx, const void* id128, int rank, int world) {
   return 0;
 }
 
+// Small host -> device copy through the pinned staging half (no stream sync:
+// the collective and the read-back that follow are ordered behind it and the
+// read-back's sync completes all three); large payloads take the synchronous
+// path.
+static int stage_h2d(sgp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes > ctx->pinned_cap / 4) return sgp_h2d(ctx, dst, src, bytes);
+  char* slot = static_cast<char*>(ctx->pinned) + ctx->pinned_cap / 2;
+  memcpy(slot, src, bytes);
+  SGP_HIP(ctx, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice,
+                              ctx->stream));
+  return 0;
+}
+
 int sgp_comm_allreduce_max(sgp_ctx* ctx, double* buf, int n) {
   if ((ctx->world <= 1 && !ctx->comm) || n <= 0) return 0;
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   SGP_CHECK(ctx, ctx->comm, "sgp_comm_init was not called");
   double* d = static_cast<double*>(sgp_scratch(ctx, 6, size_t(n) * 8));
   SGP_CHECK(ctx, d, "device allocation failed: %s", ctx->err.c_str());
-  SGP_TRY(sgp_h2d(ctx, d, buf, size_t(n) * 8));
+  SGP_TRY(stage_h2d(ctx, d, buf, size_t(n) * 8));
   SGP_NCCL(ctx, g_rccl.AllReduce(d, d, size_t(n), ncclFloat64, ncclMax,
                                  static_cast<ncclComm_t>(ctx->comm),
                                  ctx->stream));
@@ -1239,7 +1252,7 @@ int sgp_comm_allgather(sgp_ctx* ctx, const void* send, void* recv,
       sgp_scratch(ctx, 6, size_t(nbytes) * (size_t(ctx->world) + 1)));
   SGP_CHECK(ctx, d, "device allocation failed: %s", ctx->err.c_str());
   char* r = d + nbytes;
-  SGP_TRY(sgp_h2d(ctx, d, send, size_t(nbytes)));
+  SGP_TRY(stage_h2d(ctx, d, send, size_t(nbytes)));
   SGP_NCCL(ctx, g_rccl.AllGather(d, r, size_t(nbytes), ncclInt8,
                                  static_cast<ncclComm_t>(ctx->comm),
                                  ctx->stream));
