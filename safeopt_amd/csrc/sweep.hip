@@ -6,9 +6,10 @@
 // per-candidate re-prediction of the expander loop (:579-606).
 //
 // For a tile of candidate rows the kernel forms the covariance tile
-// K[j, pt] = k(X_j, x_pt) ON THE FLY in registers, directly in the B-operand
-// layout of v_mfma_f64_16x16x4_f64, and contracts it with A = L^-1 (lower
-// triangular, pre-packed in A-operand order) on the fp64 matrix cores:
+// K[j, pt] = k(X_j, x_pt) ON THE FLY in registers, in the (k-step, point) lane
+// order of the fp64 matrix instructions, and contracts it with A = L^-1 (lower
+// triangular, pre-packed in A-operand order) on the fp64 matrix cores
+// (v_mfma_f64_4x4x4_4b_f64, see "matrix part" below):
 //     var(pt)  = k(x,x) - || A K[:, pt] ||^2          (n^2 flops / row)
 //     mean(pt) = alpha . K[:, pt]                      (2n flops / row)
 // K (n x N doubles, 1.6 GB at n=200, N=1e6) is never written to memory.
@@ -155,7 +156,7 @@ __device__ __forceinline__ void stage_x_dma(const GpView& gp, double* buf, int j
 
 // ---- matrix part ------------------------------------------------------------------
 // v_mfma_f64_4x4x4_4b_f64 is the fp64 matrix instruction that reaches the chip's
-// peak on gfx950 (74.6 TFLOP/s measured vs 49 for v_mfma_f64_16x16x4_f64,
+// peak on gfx950 (74-77 TFLOP/s measured vs 49 for v_mfma_f64_16x16x4_f64,
 // scripts/microbench.py).  Its operand maps (scripts/probe_mfma_layout.py):
 //   A[blk][i][k] <- lane 16k + 4blk + i     B[blk][k][j] <- lane 16k + 4blk + j
 //   D[blk][i][j] -> lane 16i + 4blk + j
