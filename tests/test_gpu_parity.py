@@ -520,6 +520,70 @@ def test_full_size_config2(mods):
     assert_array_equal(opt.optimize(), x)
 
 
+@pytest.mark.parametrize("k", [3, 4])
+def test_full_size_configs_3_and_4(mods, k):
+    """BASELINE.json configs[2] (Matern-5/2, 3 GPs, n=500, 1e6 rows) and one
+    rank's share of configs[3] (3-D RBF, n=1000, 1e6 rows) at FULL size: spot
+    rows against the oracle + the size-independent properties of the path."""
+    safeopt_amd, gpy, gpn, son = mods
+    from bench import make_config, build_gps
+    cfg = make_config(k)
+    G = cfg["G"]
+    gps, gos = build_gps(cfg, gpy), build_gps(cfg, gpn)
+    grid = cfg["grid"]
+    fmin = np.asarray(cfg["fmin"], dtype=float)
+    opt = safeopt_amd.SafeOpt(gps if G > 1 else gps[0], grid, cfg["fmin"] if G > 1 else 0.,
+                              threshold=cfg["threshold"])
+    x = opt.optimize()
+    Q = opt.Q
+    rows = np.random.default_rng(k).choice(grid.shape[0], 3000, replace=False)
+    for g in range(G):
+        mo, vo = gos[g].predict_noiseless(grid[rows])
+        sd = np.sqrt(vo.ravel())
+        assert_allclose(Q[rows, 2 * g], mo.ravel() - 2 * sd, atol=1e-8)
+        assert_allclose(Q[rows, 2 * g + 1], mo.ravel() + 2 * sd, atol=1e-8)
+    lo, up = Q[:, ::2], Q[:, 1::2]
+    assert np.all(up >= lo)
+    S = np.all(lo > fmin, axis=1)
+    assert_array_equal(opt.S, S)
+    assert S.any() and not S.all()
+    assert_array_equal(opt.M, S & (up[:, 0] >= lo[S, 0].max()))
+    assert np.all(opt.G <= opt.S) and opt.G.sum() <= 1
+    MG = opt.M | opt.G
+    val = np.max((up - lo) / opt.scaling, axis=1)
+    assert_array_equal(x, grid[np.flatnonzero(MG)[np.argmax(val[MG])]])
+    assert_array_equal(opt.optimize(), x)                 # idempotent
+    lmax = opt.get_maximum()
+    assert lmax is not None and lmax[1] == lo[S, 0].max()
+
+
+def test_full_size_config5_fitness(mods):
+    """BASELINE.json configs[4] at FULL size (4-D RBF, 2 GPs, n=2000, 1e5
+    particles): oracle on a 2000-particle sample for every swarm type + the
+    relations between the swarm types on all particles."""
+    safeopt_amd, gpy, gpn, son = mods
+    from bench import make_config, build_gps
+    cfg = make_config(5)
+    gps, gos = build_gps(cfg, gpy), build_gps(cfg, gpn)
+    P = cfg["particles"]
+    opt = safeopt_amd.SafeOptSwarm(gps, cfg["fmin"], bounds=[(-5., 5.)] * 4,
+                                   threshold=cfg["threshold"])
+    opt.best_lower_bound = 0.4
+    out = {st: opt._compute_particle_fitness(st, P)
+           for st in ["greedy", "maximizers", "expanders", "safe_set"]}
+    pick = np.random.default_rng(5).choice(P.shape[0], 2000, replace=False)
+    for st, (v, s) in out.items():
+        vo, so = son.swarm_fitness(gos, P[pick], st, 2., cfg["fmin"], opt.scaling, 0.4)
+        assert_array_equal(s[pick], so)
+        assert_allclose(v[pick], vo, rtol=1e-7, atol=1e-8)
+    # greedy ignores safety (gp_opt.py:938-940)
+    assert out["greedy"][1].all()
+    # the safety mask is the same for every constrained swarm type
+    assert_array_equal(out["maximizers"][1], out["expanders"][1])
+    assert_array_equal(out["maximizers"][1], out["safe_set"][1])
+    assert out["safe_set"][1].any() and not out["safe_set"][1].all()
+
+
 @pytest.mark.parametrize("k,side", [(2, 250), (3, 120), (4, 30)])
 def test_reduced_configs_against_oracle(mods, k, side):
     """configs[1..3] at reduced grid size, full run of the oracle beside it:
