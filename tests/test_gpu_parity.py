@@ -95,7 +95,11 @@ def test_factor_matches_lapack(mods, n):
 
 @pytest.mark.parametrize("kind", ["RBF", "Matern32", "Matern52"])
 @pytest.mark.parametrize("n,d", [(1, 1), (7, 1), (16, 2), (17, 2), (200, 2),
-                                 (300, 3), (520, 4), (40, 6)])
+                                 (300, 3), (520, 4), (40, 6),
+                                 # accumulator-chunk boundaries (256 rows), many
+                                 # chunks, and every input dimension up to 8
+                                 (256, 2), (257, 2), (1040, 3), (100, 5),
+                                 (100, 7), (33, 8)])
 def test_predict_noiseless(mods, kind, n, d):
     _, gpy, gpn, _ = mods
     rng = np.random.default_rng(100 * n + d)
