@@ -161,6 +161,15 @@ int sgp_grid_expander_check(sgp_grid* grid, sgp_gp* const* gps, int G,
 int sgp_grid_lipschitz_check(sgp_grid* grid, int G, const double* fmin,
                              const double* lipschitz, int m, const double* xc,
                              const double* u_c, int32_t* flags);
+/* N-rank variant of sgp_grid_sets_front after sgp_grid_confidence(out2 = NULL):
+ * max(l0[S]) and the maximiser width are all-reduced in stream (RCCL on the
+ * context's stream, device-resident operands), so the front half of
+ * compute_sets costs one device round trip per rank instead of three.
+ * out5[0] = GLOBAL max(u0[M]-l0[M]); *max_l_out = GLOBAL max(l0[S]) (-inf: no
+ * safe point on any rank); the other outputs describe this rank's shard.      */
+int sgp_grid_sets_front_comm(sgp_grid* grid, const double* scaling,
+                             const double* thr_beta, double* out5, double* x_top,
+                             double* mean_top, double* q_top, double* max_l_out);
 /* Fused passes (one stream sync each; results identical to the step-by-step
  * calls above):
  * front = gp_opt.py:511-552: M and max_var (have_max_var = 0; with

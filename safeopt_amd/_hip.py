@@ -74,6 +74,9 @@ PROTOTYPES = {
     "sgp_grid_sets_front": (C.c_int, [vp, C.c_double, C.c_int, C.c_double,
                                       c_double_p, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_double_p]),
+    "sgp_grid_sets_front_comm": (C.c_int, [vp, c_double_p, c_double_p,
+                                           c_double_p, c_double_p, c_double_p,
+                                           c_double_p, c_double_p]),
     "sgp_grid_sets_fused": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p,
                                       C.c_double, c_double_p, c_double_p,
                                       C.c_double, c_double_p, c_double_p,
@@ -524,6 +527,18 @@ class DeviceGrid(object):
             0.0 if max_var is None else float(max_var), dptr(scaling),
             dptr(thr_beta), dptr(out5), dptr(x), dptr(mean), dptr(q)))
         return out5, x, mean, q
+
+    def sets_front_comm(self, scaling, thr_beta):
+        scaling, thr_beta = f64(scaling), f64(thr_beta)
+        out5 = np.empty(5)
+        x = np.empty(self.d)
+        mean = np.empty(self.G)
+        q = np.empty(2 * self.G)
+        ml = C.c_double(0)
+        self.ctx.check(lib().sgp_grid_sets_front_comm(
+            self.h, dptr(scaling), dptr(thr_beta), dptr(out5), dptr(x),
+            dptr(mean), dptr(q), C.byref(ml)))
+        return out5, x, mean, q, ml.value
 
     def sets_back(self, gps, beta, fmin, xc, mu_c, u_c, near_frac, gidx_c,
                   scaling, mark=True):

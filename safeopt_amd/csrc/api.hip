@@ -872,6 +872,59 @@ int sgp_grid_sets_front(sgp_grid* g, double max_l, int have_max_var,
   return 0;
 }
 
+// N-rank front half with the cross-rank scalars kept on the device: max l0[S]
+// (left in g->scal[0] by a confidence pass without read-back) and the maximiser
+// width are all-reduced IN STREAM (RCCL on the context's stream), the kernels
+// read them from device memory, and one read-back returns this rank's counts,
+// its first candidate and the global max l0.  Without a communicator (one
+// rank) the all-reduces are skipped.
+int sgp_grid_sets_front_comm(sgp_grid* g, const double* scaling,
+                             const double* thr_beta, double* out5, double* x_top,
+                             double* mean_top, double* q_top, double* max_l_out) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  const int d = g->d, G = g->G;
+  const size_t nres = 7 + size_t(d) + 3 * size_t(G);   // front block + max_l
+  double* res = static_cast<double*>(sgp_scratch(ctx, 1, (nres + 8) * 8));
+  SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
+  ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+  if (comm)
+    SGP_NCCL(ctx, g_rccl.AllReduce(g->scal, g->scal, 1, ncclFloat64, ncclMax,
+                                   comm, ctx->stream));
+  SGP_TRY(launch_maximizers(g, 0.0, g->scal));
+  SGP_TRY(launch_reduce_max(ctx, g->partial, (g->N + 255) / 256, res));
+  if (comm)
+    SGP_NCCL(ctx, g_rccl.AllReduce(res, res, 1, ncclFloat64, ncclMax, comm,
+                                   ctx->stream));
+  SGP_TRY(launch_candidates(g, 0.0, res, scaling, thr_beta, 0,
+                            reinterpret_cast<unsigned long long*>(res + 1)));
+  SGP_TRY(launch_topk(g, 0, INFINITY, INT64_MAX, 1, res + 3,
+                      reinterpret_cast<int64_t*>(res + 4),
+                      reinterpret_cast<int*>(res + 5)));
+  SGP_TRY(launch_gather_top(g, reinterpret_cast<int64_t*>(res + 4), res + 6,
+                            res + 6 + d, res + 6 + d + G));
+  SGP_HIP(ctx, hipMemcpyAsync(res + nres - 1, g->scal, 8,
+                              hipMemcpyDeviceToDevice, ctx->stream));
+  std::vector<double> host(nres);
+  SGP_TRY(sgp_d2h(ctx, host.data(), res, nres * 8));
+  unsigned long long cnt[2];
+  int64_t idx;
+  int nfound;
+  memcpy(cnt, &host[1], 16);
+  memcpy(&idx, &host[4], 8);
+  memcpy(&nfound, &host[5], 4);
+  out5[0] = host[0];
+  out5[1] = double(cnt[0]);
+  out5[2] = double(cnt[1]);
+  out5[3] = host[3];
+  out5[4] = (nfound > 0) ? double(idx) : -1.0;
+  memcpy(x_top, &host[6], size_t(d) * 8);
+  memcpy(mean_top, &host[6 + d], size_t(G) * 8);
+  memcpy(q_top, &host[6 + d + G], size_t(2 * G) * 8);
+  *max_l_out = host[nres - 1];
+  return 0;
+}
+
 // Back half for ONE candidate (the common case: the first candidate is the
 // expander): probe scan, conditional G mark and the M|G arg-max with one sync.
 int sgp_grid_sets_back(sgp_grid* g, sgp_gp* const* gps, int G, double beta,

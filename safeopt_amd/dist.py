@@ -53,7 +53,11 @@ class LocalComm(object):
 
 
 class RcclComm(object):
-    """RCCL collectives (through libsafeopt_hip.so) on small host arrays."""
+    """RCCL collectives (through libsafeopt_hip.so) on small host arrays.
+
+    ``in_stream``: the library may also run scalar all-reduces on device-
+    resident operands inside a fused call (``sgp_grid_sets_front_comm``)."""
+    in_stream = True
 
     def __init__(self, ctx):
         self.ctx = ctx

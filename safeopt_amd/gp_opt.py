@@ -235,6 +235,9 @@ class _HipGridBackend(object):
     def sets_front(self, max_l, max_var, scaling, thr_beta):
         return self.grid.sets_front(max_l, max_var, scaling, thr_beta)
 
+    def sets_front_comm(self, scaling, thr_beta):
+        return self.grid.sets_front_comm(scaling, thr_beta)
+
     def sets_fused(self, beta, fmin, max_l, scaling, thr_beta, near_frac):
         return self.grid.sets_fused(self._dev(), beta, fmin, max_l, scaling,
                                     thr_beta, near_frac)
@@ -515,11 +518,21 @@ class SafeOpt(GaussianProcessOptimization):
                 n_cand, n_unsafe, w_c, idx_c = (out5[1], out5[2],
                                                 float(out5[3]), int(out5[4]))
             else:
-                width = self._comm.allreduce_max(
-                    np.array([be.maximizers(self._max_l)]))[0]
-                out5, x_l, mu_l, q_l = be.sets_front(
-                    self._max_l, width / self.scaling[0], self.scaling,
-                    thr_beta)
+                if self._max_l is None:
+                    # deferred confidence pass: max l0 and the maximiser width
+                    # are all-reduced in stream, one round trip for this half
+                    out5, x_l, mu_l, q_l, max_l = be.sets_front_comm(
+                        self.scaling, thr_beta)
+                    self._max_l, self._any_safe = max_l, bool(max_l > -np.inf)
+                    if not self._any_safe:
+                        self._stale.update(M=True, G=True)
+                        return
+                else:
+                    width = self._comm.allreduce_max(
+                        np.array([be.maximizers(self._max_l)]))[0]
+                    out5, x_l, mu_l, q_l = be.sets_front(
+                        self._max_l, width / self.scaling[0], self.scaling,
+                        thr_beta)
                 pk = self._comm.allgather(
                     np.concatenate([out5[1:5], x_l, mu_l, q_l]))
                 n_cand, n_unsafe = pk[:, 0].sum(), pk[:, 1].sum()
@@ -687,10 +700,12 @@ class SafeOpt(GaussianProcessOptimization):
         """One SafeOpt step: intervals -> sets -> next query point."""
         # common case on one GPU: sweep, set passes, probe of the first
         # candidate and arg-max are enqueued back to back, one read-back
-        one_trip = (not ucb and self._comm.world == 1
-                    and not self.use_lipschitz
+        # (N ranks: the same deferral with the two scalar all-reduces in stream)
+        one_trip = (not ucb and not self.use_lipschitz
                     and hasattr(self._backend, 'sets_fused')
-                    and bool(np.any(self.fmin != -np.inf)))
+                    and bool(np.any(self.fmin != -np.inf))
+                    and (self._comm.world == 1
+                         or getattr(self._comm, 'in_stream', False)))
         self.update_confidence_intervals(context=context, _defer=one_trip)
         if ucb:
             self.compute_safe_set()

@@ -14,8 +14,8 @@ ctx, comm = dist.init_from_env()
 class Pretend(object):
     rank = 0
 
-    def __init__(self, c, world):
-        self.c, self.world = c, world
+    def __init__(self, c, world, in_stream):
+        self.c, self.world, self.in_stream = c, world, in_stream
 
     def allreduce_max(self, a):
         return self.c.allreduce_max(a)
@@ -28,14 +28,15 @@ class Pretend(object):
 
 
 cfg = bench.make_config(2)
-for world in (1, 2):
+for world, in_stream in ((1, False), (2, False), (2, True)):
     gps = bench.build_gps(cfg, gpy)
     opt = safeopt_amd.SafeOpt(gps[0], cfg["grid"], 0., threshold=cfg["threshold"],
-                              comm=Pretend(comm, world))
+                              comm=Pretend(comm, world, in_stream))
     for _ in range(3):
         x = opt.optimize()
     ctx.sync(); t0 = time.perf_counter()
     for _ in range(20):
         x = opt.optimize()
     ctx.sync(); dt = (time.perf_counter() - t0) / 20
-    print("control flow of world=%d: %.3f ms/step, x=%s" % (world, dt * 1e3, x))
+    print("control flow of world=%d (in-stream scalars: %s): %.3f ms/step, x=%s"
+          % (world, in_stream, dt * 1e3, x))

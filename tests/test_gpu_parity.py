@@ -630,6 +630,57 @@ def kernels_from(cfg, ns):
     return [make_kernel(ns, spec) for spec in cfg["kernels"]]
 
 
+class _PretendWorld(object):
+    """A one-rank RCCL communicator that claims ``world`` ranks towards the host
+    driver: SafeOpt takes every N-rank branch (sharding, packed all-gathers,
+    in-stream all-reduces) while the collectives themselves run for real."""
+    rank, in_stream = 0, True
+
+    def __init__(self, comm, world):
+        self._c, self.world = comm, world
+
+    def allreduce_max(self, a):
+        return self._c.allreduce_max(a)
+
+    def allgather(self, a):
+        return self._c.allgather(a)
+
+    def barrier(self):
+        self._c.barrier()
+
+
+def test_multirank_control_flow_on_one_gpu(mods):
+    """The N-rank host driver with in-stream RCCL scalars on ONE GPU: rank 0 of
+    a pretended world of 2 owns the first half of the grid, so every iteration
+    must equal a plain single-GPU SafeOpt on that half."""
+    safeopt_amd, gpy, _, _ = mods
+    from safeopt_amd import _hip, dist
+    from bench import make_config, build_gps, _bumps
+    ctx = _hip.Context.default()
+    if not getattr(ctx, "_one_rank_comm", False):
+        ctx.comm_init(_hip.Context.comm_unique_id(), 0, 1)
+        ctx._one_rank_comm = True
+    comm = _PretendWorld(dist.RcclComm(ctx), 2)
+    cfg = make_config(3, side=90)                 # 3 GPs, Matern-5/2
+    half = cfg["grid"][:cfg["grid"].shape[0] // 2]
+
+    def make(grid, comm):
+        gps = build_gps(cfg, gpy)
+        return safeopt_amd.SafeOpt(gps, grid, cfg["fmin"], threshold=cfg["threshold"], comm=comm)
+    a, b = make(cfg["grid"], comm), make(half, None)
+    assert a._shard == (0, half.shape[0])
+    for it in range(4):
+        xa, xb = a.optimize(), b.optimize()
+        assert_array_equal(xa, xb)
+        n = half.shape[0]
+        assert_array_equal(a._backend.download(_hip.Q), b.Q)
+        for what, ref in ((_hip.S, b.S), (_hip.M, b.M), (_hip.G, b.G)):
+            assert_array_equal(a._backend.download(what)[:n], ref)
+        y = np.array([[_bumps(np.atleast_2d(xa), 102 + g)[0] + 1.0 for g in range(3)]])
+        a.add_new_data_point(xa, y)
+        b.add_new_data_point(xb, y)
+
+
 def test_torchrun_launch_with_rccl(mods, tmp_path):
     """The driver's launch line (torch.distributed.run, one rank) with the RCCL
     communicator forced on: rendezvous file, comm init, collectives, bench JSON."""
