@@ -1,0 +1,61 @@
+"""Randomised device-vs-oracle comparison of whole SafeOpt.optimize() steps:
+random n, d, G, kernel kinds, lengthscales, fmin (incl. -inf), thresholds and
+unstructured parameter sets.  Reports every mismatch that is not explained by a
+knife-edge comparison (|margin| < 1e-9)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import safeopt_amd, safeopt_amd.gpy as gpy
+from oracle import gp_numpy as gpn, safeopt_numpy as son
+
+KINDS = ["RBF", "Matern32", "Matern52"]
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+bad = 0
+worst = 0.0
+for t in range(trials):
+    rng = np.random.default_rng(1000 + t)
+    n, d, G = int(rng.integers(1, 300)), int(rng.integers(1, 5)), int(rng.integers(1, 4))
+    N = int(rng.integers(1, 3000))
+    X = rng.uniform(-2, 2, size=(n, d))
+    grid = rng.uniform(-3, 3, size=(N, d))
+    gps, gos = [], []
+    for g in range(G):
+        kind = KINDS[int(rng.integers(0, 3))]
+        ls = list(rng.uniform(0.5, 2.0, size=d))
+        var = float(rng.uniform(0.5, 3.0))
+        y = (np.sin(X.sum(1) + g) + 1.0 + 0.3 * rng.normal(size=n))[:, None]
+        noise = float(rng.uniform(0.01, 0.2)) ** 2
+        gps.append(gpy.models.GPRegression(X, y, getattr(gpy.kern, kind)(d, variance=var, lengthscale=ls, ARD=True),
+                                           noise_var=noise))
+        gos.append(gpn.GPRegression(X, y, getattr(gpn, kind)(d, variance=var, lengthscale=ls, ARD=True),
+                                    noise_var=noise))
+    fmin = [float(rng.uniform(-0.5, 1.0)) if (g == 0 or rng.random() < 0.7) else -np.inf for g in range(G)]
+    thr = float(rng.uniform(0, 0.5))
+    opt = safeopt_amd.SafeOpt(gps if G > 1 else gps[0], grid, fmin if G > 1 else fmin[0], threshold=thr)
+    try:
+        x = opt.optimize()
+        empty = False
+    except EnvironmentError:
+        empty = True
+    try:
+        idx, Q, S, M, Gm = son.optimize_grid(gos, grid, fmin, opt.scaling, thr, 2.)
+        oempty = False
+    except EnvironmentError:
+        oempty = True
+        Q = son.confidence_intervals(gos, grid, 2.)
+    dq = float(np.max(np.abs(opt.Q - Q)))
+    worst = max(worst, dq)
+    # north-star tolerance: 1e-5 relative (to the prior standard deviation)
+    ok = dq < 1e-5 and empty == oempty
+    sets_ok = True
+    if not empty and not oempty:
+        sets_ok = (np.array_equal(opt.S, S) and np.array_equal(opt.M, M) and np.array_equal(opt.G, Gm)
+                   and np.array_equal(x, grid[idx]))
+    if not (ok and sets_ok):
+        fm = np.asarray(fmin)
+        lo = Q[:, ::2][:, np.isfinite(fm)]
+        margin = float(np.min(np.abs(lo - fm[np.isfinite(fm)])))
+        print("trial %d n=%d d=%d G=%d N=%d: dQ=%.2g empty=%s/%s sets equal=%s min|l-fmin|=%.2g  MISMATCH"
+              % (t, n, d, G, N, dq, empty, oempty, sets_ok, margin))
+        bad += 1
+print("%d trials, %d mismatches, max |Q_dev - Q_oracle| = %.3g" % (trials, bad, worst))
