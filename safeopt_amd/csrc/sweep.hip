@@ -24,6 +24,7 @@
 // (tile, GP, chunk, j-block) loop nest is flattened into one stage sequence so
 // that the LDS-DMA of stage s+1 always runs under the MFMAs of stage s.
 #include <stdio.h>
+#include <algorithm>
 #include <stdlib.h>
 
 #include "kern_eval.h"
@@ -63,6 +64,12 @@ struct SweepParams {
   SweepPoints pts;
   ConfOut conf;
   FitnessArgs fit;
+  // Covariance cache (n > 256 only): the values a lane evaluates in the
+  // triangular part of chunk c are needed again by every later chunk; they are
+  // parked in global memory, [workgroup][wave][j-block][lane][4], and read back
+  // (one stage ahead) instead of being re-evaluated.  nullptr: re-evaluate.
+  double* kvc;
+  int kvc_blocks;   // j-blocks per (workgroup, wave) slab
 };
 
 // The descriptor fields the stage pipeline touches every iteration, hoisted out
@@ -283,7 +290,7 @@ __device__ __forceinline__ void stage_issue(const StagePos& sp, const GpView& gp
   stage_x_dma<D>(gp, buf, sp.jb, tid);
 }
 
-template <int D, int NW, int MODE>
+template <int D, int NW, int MODE, bool CACHE>
 __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   constexpr int kWaves = NW;
   constexpr int kTilePts = 16 * NW;
@@ -336,6 +343,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   bool safe = true;
   double l0 = 0.0, values = 0.0, interest = 1.0, total_pen = 0.0, lower = 0.0;
 
+  // this lane's slab of the covariance cache
+  typedef double double2_t __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) double2_t* g2ptr_t;
+  // (CACHE is a template parameter: the single-chunk kernel, n <= 256, carries
+  // none of this)
+  g2ptr_t kslab = nullptr;
+  if (CACHE)
+    kslab = (g2ptr_t)(p.kvc + ((int64_t(blockIdx.x) * kWaves + wave) *
+                               int64_t(p.kvc_blocks)) * 256 + lane * 4);
+  double kvn[4] = {0.0, 0.0, 0.0, 0.0};   // values fetched for the next stage
+  bool cached = false;                     // ... which is a re-visited j-block
+
   int bufsel = 0;
   bool more = true;
 #pragma unroll 1
@@ -356,13 +375,34 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     }
     const bool chunk_ends = gp_ends || nxt.c != cur.c;
     if (more && tile_ends) load_x(nxt.tile, xnext);
+    // a j-block below the diagonal part of its chunk was evaluated (and parked)
+    // while an earlier chunk of this (tile, GP) pass was processed
+    const bool was_cached = CACHE && cached;
+    double kvc_cur[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kvc_cur[q] = kvn[q];
+    cached = CACHE && more && nxt.jb < nxt.b0;
+    if (cached) {
+      const double2_t a = __builtin_nontemporal_load(kslab + nxt.jb * 128);
+      const double2_t b = __builtin_nontemporal_load(kslab + nxt.jb * 128 + 1);
+      kvn[0] = a.x; kvn[1] = a.y; kvn[2] = b.x; kvn[3] = b.y;
+    }
 
     // this stage: 16 training points against the active row blocks
     const double* xT = cbuf + kATile;
     const double* alT = cbuf + kATile + kXTile;
     double kv[4];
-    if (!SGP_ABL(4)) {
+    if (was_cached) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) kv[q] = kvc_cur[q];
+    } else if (!SGP_ABL(4)) {
       kf.template many<4>(xs, xT + (lane >> 4) * D, 4 * D, tab, kv);
+      if (CACHE && cur.c + 1 < cur.nchunks) {       // needed again by later chunks
+        double2_t a, b;
+        a.x = kv[0]; a.y = kv[1]; b.x = kv[2]; b.y = kv[3];
+        __builtin_nontemporal_store(a, kslab + cur.jb * 128);
+        __builtin_nontemporal_store(b, kslab + cur.jb * 128 + 1);
+      }
     } else {
       kv[0] = xs[0]; kv[1] = xs[0] + 1.0; kv[2] = xs[0] + 2.0; kv[3] = xs[0] + 3.0;
     }
@@ -946,12 +986,12 @@ __global__ __launch_bounds__(256, 2) void k_stage_bench(const double* src,
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int D, int NW, int MODE>
+template <int D, int NW, int MODE, bool CACHE>
 int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep<D, NW, MODE>),
+                     reinterpret_cast<const void*>(&k_sweep<D, NW, MODE, CACHE>),
                      hipFuncAttributeMaxDynamicSharedMemorySize,
                      int(kLdsBytes)));
     attr_set = true;
@@ -982,7 +1022,7 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
   pp.ablate = ablate;
 #endif
-  hipLaunchKernelGGL((k_sweep<D, NW, MODE>), dim3(nblocks), dim3(64 * NW),
+  hipLaunchKernelGGL((k_sweep<D, NW, MODE, CACHE>), dim3(nblocks), dim3(64 * NW),
                      kLdsBytes, ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
   if (e1) SGP_HIP(ctx, hipEventRecord(e1, ctx->stream));
@@ -992,8 +1032,10 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
 template <int D>
 int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
   if (p.mode == MODE_CONF)
-    return launch_sweep_v<D, kSweepWaves, MODE_CONF>(ctx, p, flops);
-  return launch_sweep_v<D, kSweepWaves, MODE_FITNESS>(ctx, p, flops);
+    return p.kvc ? launch_sweep_v<D, kSweepWaves, MODE_CONF, true>(ctx, p, flops)
+                 : launch_sweep_v<D, kSweepWaves, MODE_CONF, false>(ctx, p, flops);
+  return p.kvc ? launch_sweep_v<D, kSweepWaves, MODE_FITNESS, true>(ctx, p, flops)
+               : launch_sweep_v<D, kSweepWaves, MODE_FITNESS, false>(ctx, p, flops);
 }
 
 int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
@@ -1005,15 +1047,31 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
   for (int g = 0; g < Geff; ++g)
     flops += (double(gh[g].n) * gh[g].n + 2.0 * gh[g].n) * double(p.pts.N);
   if (p.pts.N <= 0) return 0;
+  // covariance cache: j-blocks of all but the last chunk, per resident wave
+  SweepParams q = p;
+  q.kvc = nullptr;
+  q.kvc_blocks = 0;
+  for (int g = 0; g < Geff; ++g) {
+    const int nchunks = (gh[g].nblk + kIB - 1) / kIB;
+    q.kvc_blocks = std::max(q.kvc_blocks, (nchunks - 1) * kIB);
+  }
+  if (q.kvc_blocks > 0 && !getenv("SGP_NO_KVCACHE")) {
+    const int64_t tiles = (p.pts.N + 16 * kSweepWaves - 1) / (16 * kSweepWaves);
+    const int64_t wgs = std::min<int64_t>(tiles, int64_t(ctx->num_cu) *
+                                                     (kMaxWaves / kSweepWaves));
+    q.kvc = static_cast<double*>(sgp_scratch(
+        ctx, 0, size_t(wgs) * kSweepWaves * q.kvc_blocks * 256 * sizeof(double)));
+    if (!q.kvc) return -1;
+  }
   switch (d) {
-    case 1: return launch_sweep_d<1>(ctx, p, flops);
-    case 2: return launch_sweep_d<2>(ctx, p, flops);
-    case 3: return launch_sweep_d<3>(ctx, p, flops);
-    case 4: return launch_sweep_d<4>(ctx, p, flops);
-    case 5: return launch_sweep_d<5>(ctx, p, flops);
-    case 6: return launch_sweep_d<6>(ctx, p, flops);
-    case 7: return launch_sweep_d<7>(ctx, p, flops);
-    case 8: return launch_sweep_d<8>(ctx, p, flops);
+    case 1: return launch_sweep_d<1>(ctx, q, flops);
+    case 2: return launch_sweep_d<2>(ctx, q, flops);
+    case 3: return launch_sweep_d<3>(ctx, q, flops);
+    case 4: return launch_sweep_d<4>(ctx, q, flops);
+    case 5: return launch_sweep_d<5>(ctx, q, flops);
+    case 6: return launch_sweep_d<6>(ctx, q, flops);
+    case 7: return launch_sweep_d<7>(ctx, q, flops);
+    case 8: return launch_sweep_d<8>(ctx, q, flops);
   }
   sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
   return -2;
