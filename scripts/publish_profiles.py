@@ -39,7 +39,7 @@ def main(tag):
             continue
         agg = collections.defaultdict(list)
         for x in csv.DictReader(open(max(f, key=os.path.getmtime))):
-            m = re.search(r"(k_\w+(<[\d, ]+>)?|__amd\w+)", x["Kernel_Name"])
+            m = re.search(r"(k_\w+(<[\w, ]+>)?|__amd\w+)", x["Kernel_Name"])
             k = m.group(1) if m else x["Kernel_Name"][:40]
             agg[(k, x["Counter_Name"])].append(
                 (float(x["Counter_Value"]), int(x["End_Timestamp"]) - int(x["Start_Timestamp"])))

@@ -10,7 +10,7 @@ import sys
 
 
 def key(n):
-    m = re.search(r"(k_\w+(<[\d, ]+>)?|__amd\w+)", n)
+    m = re.search(r"(k_\w+(<[\w, ]+>)?|__amd\w+)", n)
     return m.group(1) if m else n[:40]
 
 
