@@ -798,7 +798,7 @@ static int enqueue_expander(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   ea.count = reinterpret_cast<int*>(reinterpret_cast<char*>(dfl) +
                                     size_t(SGP_TOPK) * G * 4 + 32);
   ea.list = (m == 1) ? static_cast<int*>(sgp_scratch(
-                           ctx, 0, (size_t(g->N) / 16 + 2) * sizeof(int)))
+                           ctx, 0, (size_t(g->N) + 64) * sizeof(int)))
                      : nullptr;
   SweepPoints sp{g->pts, g->N, 1, g->N};
   SGP_TRY(launch_expander_check(ctx, g->gpdev, host, G, d, sp, ea));

@@ -209,8 +209,8 @@ struct ExpanderArgs {
   int32_t* flags;        // [16][G] device
   int64_t wstride;       // doubles between consecutive GPs in Wpack
   double near_frac;      // >0: only rows with k(x,x_c) >= near_frac * k(x,x)
-  int* count;            // m == 1: number of 16-row groups that passed the
-  int* list;             //         pre-filter (zeroed by the caller) / the groups
+  int* count;            // m == 1: number of rows that passed the pre-filter
+  int* list;             //         (zeroed by the caller) / their local indices
 };
 int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
                           const GpDev* gps_host, int G, int d, SweepPoints pts,

@@ -671,9 +671,11 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
 
 // Single candidate (the probe of the first candidate and its exact re-scan):
 // the pre-filter runs with one row per lane over the whole shard and appends
-// the 16-row groups that contain a row which could be lifted above fmin to a
-// list; k_expander_list then does the n-term contraction for those groups only
-// (a few per cent of the unsafe set).  Same arithmetic as k_expander.
+// the rows that could be lifted above fmin to a list (a few per cent of the
+// unsafe set); k_expander_list then computes c(x) = k(x,x_c) - w . k(X,x) for
+// those rows only, one row per lane and the training rows / w through LDS --
+// with a single candidate the contraction is a dot product, not a matrix
+// product.  Same pre-filter and the same update formulas as k_expander.
 template <int D>
 __global__ __launch_bounds__(256) void k_expander_filter(const GpDev* gps, int G,
                                                          SweepPoints pts,
@@ -715,14 +717,13 @@ __global__ __launch_bounds__(256) void k_expander_filter(const GpDev* gps, int G
   }
   const unsigned long long b = __ballot(possible);
   if (b == 0ull) return;
-  if (lane == 0) {
-    int k = 0, grp[4];
-    for (int q = 0; q < 4; ++q)
-      if ((b >> (16 * q)) & 0xffffull) grp[k++] = int(row >> 4) + q;
-    const int at = atomicAdd(count, k);
-    for (int q = 0; q < k; ++q) list[at + q] = grp[q];
-  }
+  int at = 0;
+  if (lane == 0) at = atomicAdd(count, __popcll(b));
+  at = __builtin_amdgcn_readfirstlane(at);
+  if (possible) list[at + __popcll(b & ((1ull << lane) - 1ull))] = int(row);
 }
+
+constexpr int kExpLds = 6144;     // doubles of staged training data (48 KB)
 
 template <int D>
 __global__ __launch_bounds__(256) void k_expander_list(const GpDev* gps, int G,
@@ -731,17 +732,67 @@ __global__ __launch_bounds__(256) void k_expander_list(const GpDev* gps, int G,
                                                        const int* count,
                                                        const int* list) {
   __shared__ double tab[kExpTabSize];
+  __shared__ double stage[kExpLds];      // [n_pad][D] scaled rows | [n_pad] w
   exp_tab_init(tab);
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int n = *count;
-  const int nwaves = gridDim.x * 4;
-  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += nwaves) {
-    const int64_t row = int64_t(list[i]) * 16 + (lane & 15);
-    const bool valid = row < pts.N;
-    const int64_t rrow = valid ? row : pts.N - 1;
-    const bool unsafe = valid && (ea.S[rrow] == 0);
-    expander_rows<D>(gps, G, pts, ea, rrow, unsafe, tab, lane);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nrows = *count;
+  // 16 rows per wave (lane & 15); the four 16-lane groups split the training
+  // points (j = 4 s + (lane >> 4)) and fold their partial dot products at the end
+  const int first = (blockIdx.x * 4 + (tid >> 6)) * 16, stride = gridDim.x * 64;
+  for (int g = 0; g < G; ++g) {
+    if (!ea.active[g]) continue;
+    const GpDev& gp = gps[g];
+    const KernFast<D> kf(gp.kern);
+    const int np = gp.n_pad;
+    // w_j of the single candidate sits in lane 16 (j & 3) of k-step j >> 2 of
+    // the packed operand
+    const double* Wp = ea.Wpack + int64_t(g) * ea.wstride;
+    const bool staged = np * (D + 1) <= kExpLds;        // block-uniform
+    const double* Xj = gp.Xs;
+    if (staged) {
+      __syncthreads();                                   // previous GP's readers
+      for (int e = tid; e < np * D; e += 256) stage[e] = gp.Xs[e];
+      for (int j = tid; j < np; j += 256)
+        stage[np * D + j] = Wp[(j >> 2) * 64 + (j & 3) * 16];
+      __syncthreads();
+      Xj = stage;
+    }
+    const double kdiag = gp.kern.kdiag;
+    for (int i0 = first; i0 < nrows; i0 += stride) {
+      const bool valid = i0 + (lane & 15) < nrows;
+      const int64_t rrow = list[valid ? i0 + (lane & 15) : i0];
+      double x[D], xs[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
+      kf.prep(x, xs);
+      const double mu = ea.mean[int64_t(g) * pts.N + rrow];
+      const double var = ea.var[int64_t(g) * pts.N + rrow];
+      double dot = 0.0;
+      const int ph = lane >> 4;
+#pragma unroll 1
+      for (int s0 = 0; s0 < (np >> 2); s0 += 4) {   // 16 training points / step
+        double kq[4], wq[4];
+        kf.template many<4>(xs, Xj + (s0 * 4 + ph) * D, 4 * D, tab, kq);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          wq[q] = staged ? stage[np * D + (s0 + q) * 4 + ph]
+                         : Wp[(s0 + q) * 64 + ph * 16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dot = fma(wq[q], kq[q], dot);
+      }
+      dot = sum_lane_groups(dot);
+      const double kxc = kf.raw(x, ea.xc, tab);
+      bool hit = false;
+      if (valid && kxc >= ea.near_frac * kdiag) {
+        const double cx = kxc - dot;
+        const double mu2 = mu + cx * ea.delta[g * 16];
+        const double var2 = fmax(var - cx * cx * ea.inv_s2[g * 16], 1e-15);
+        hit = mu2 - ea.beta * sqrt(var2) >= ea.fmin[g];
+      }
+      if (__ballot(hit) != 0ull && lane == 0) atomicOr(&ea.flags[g], 1);
+    }
   }
 }
 
