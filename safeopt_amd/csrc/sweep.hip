@@ -1106,6 +1106,8 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
     const int nchunks = (gh[g].nblk + kIB - 1) / kIB;
     q.kvc_blocks = std::max(q.kvc_blocks, (nchunks - 1) * kIB);
   }
+  // (SGP_NO_KVCACHE=1 re-evaluates instead -- the A/B switch behind the numbers
+  // in profiles/README.md)
   if (q.kvc_blocks > 0 && !getenv("SGP_NO_KVCACHE")) {
     const int64_t tiles = (p.pts.N + 16 * kSweepWaves - 1) / (16 * kSweepWaves);
     const int64_t wgs = std::min<int64_t>(tiles, int64_t(ctx->num_cu) *
