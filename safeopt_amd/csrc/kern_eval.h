@@ -100,11 +100,14 @@ __device__ __forceinline__ void exp2_32x4(const double (&u)[4], const double* ta
 }
 
 // Four square roots, step-major: v_rsq_f64 seed (relative error 5e-8 on
-// gfx950), one Goldschmidt step and a final correction -- bit-identical to the
-// correctly rounded sqrt on 4M random inputs (scripts/dev/sqrt_accuracy.hip).
+// gfx950, scripts/dev/sqrt_accuracy.hip) and ONE Newton step
+//   g = x y,  out = g + (x - g^2) (y / 2)
+// which leaves a relative error of ~1.3e-15 -- far below what the covariance
+// needs (it enters 2^(u/32) as an absolute error of |u| 1.3e-15 ln2/32 < 1e-13
+// wherever the covariance is not already below 1e-16 of its variance).
 // 0 maps to ~1e-150, which is 0 for the Matern factors.
 __device__ __forceinline__ void sqrt4(const double (&xin)[4], double (&out)[4]) {
-  double x[4], y[4], g[4], h[4], r[4];
+  double x[4], y[4], g[4], r[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) x[q] = fmax(xin[q], 1e-300);
   SGP_FENCE();
@@ -114,23 +117,14 @@ __device__ __forceinline__ void sqrt4(const double (&xin)[4], double (&out)[4]) 
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     g[q] = x[q] * y[q];
-    h[q] = 0.5 * y[q];
-  }
-  SGP_FENCE();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) r[q] = fma(-h[q], g[q], 0.5);
-  SGP_FENCE();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    g[q] = fma(g[q], r[q], g[q]);
-    h[q] = fma(h[q], r[q], h[q]);
+    y[q] = 0.5 * y[q];
   }
   SGP_FENCE();
 #pragma unroll
   for (int q = 0; q < 4; ++q) r[q] = fma(-g[q], g[q], x[q]);
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) out[q] = fma(r[q], h[q], g[q]);
+  for (int q = 0; q < 4; ++q) out[q] = fma(r[q], y[q], g[q]);
   SGP_FENCE();
 }
 
