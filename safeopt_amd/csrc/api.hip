@@ -334,6 +334,18 @@ int sgp_gp_predict(sgp_gp* gp, const double* Xnew, int64_t N,
   GpDev* gdev = static_cast<GpDev*>(sgp_scratch(ctx, 5, sizeof(GpDev)));
   SGP_CHECK(ctx, stage && pts && gdev, "device allocation failed: %s",
             ctx->err.c_str());
+  if (small_path_pays(gp, N)) {
+    // a few points: triangular multi-RHS products instead of one sweep tile
+    std::vector<double> tmp(size_t(N) * d);
+    for (int64_t r = 0; r < N; ++r)
+      for (int k = 0; k < d; ++k)
+        tmp[size_t(r) * d + k] = Xnew[r * stride_row + k * stride_col];
+    SGP_TRY(sgp_h2d(ctx, stage, tmp.data(), tmp.size() * sizeof(double)));
+    double* mvs = pts;                        // [mean N | var N]
+    SGP_TRY(posterior_small(gp, stage, int(N), mvs, mvs + N));
+    SGP_TRY(sgp_d2h(ctx, mean, mvs, size_t(N) * sizeof(double)));
+    return sgp_d2h(ctx, var, mvs + N, size_t(N) * sizeof(double));
+  }
   if (stride_col == 1 && stride_row == d) {
     SGP_TRY(sgp_h2d(ctx, stage, Xnew, size_t(N) * d * sizeof(double)));
     SGP_TRY(launch_import_points(ctx, stage, N, d, d, 1, pts));
@@ -1026,6 +1038,29 @@ int sgp_grid_sets_fused(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   return 0;
 }
 
+// Fitness of P <= kSmallPoints particles (row-major, device) through the
+// small-point posterior path: mean / var per GP, then the shaping kernel.
+static int fitness_small(sgp_ctx* ctx, sgp_gp* const* gps, int G,
+                         const double* pts_rowmajor, int64_t P,
+                         const FitnessArgs& fa) {
+  const int Geff = (fa.swarm_type == SGP_SWARM_GREEDY) ? 1 : G;
+  double* mv = static_cast<double*>(
+      sgp_scratch(ctx, 2, size_t(2) * SGP_MAX_GPS * kSmallPoints * sizeof(double)));
+  SGP_CHECK(ctx, mv, "device allocation failed: %s", ctx->err.c_str());
+  double* mean = mv;
+  double* var = mv + size_t(SGP_MAX_GPS) * kSmallPoints;
+  for (int g = 0; g < Geff; ++g)
+    SGP_TRY(posterior_small(gps[g], pts_rowmajor, int(P), mean + size_t(g) * P,
+                            var + size_t(g) * P));
+  return launch_fitness_small(ctx, G, P, mean, var, fa);
+}
+
+static bool small_path_pays_all(sgp_gp* const* gps, int G, int64_t P) {
+  for (int g = 0; g < G; ++g)
+    if (!small_path_pays(gps[g], P)) return false;
+  return true;
+}
+
 // ---- swarm ----------------------------------------------------------------------
 int sgp_swarm_fitness(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
                       const double* particles, int64_t P, double beta,
@@ -1061,8 +1096,12 @@ int sgp_swarm_fitness(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
   }
   fa.values = dval;
   fa.safe = dsafe;
-  SweepPoints sp{pts, P, 1, P};
-  SGP_TRY(launch_sweep_fitness(ctx, gdev, host, G, d, sp, fa));
+  if (small_path_pays_all(gps, G, P)) {
+    SGP_TRY(fitness_small(ctx, gps, G, stage, P, fa));
+  } else {
+    SweepPoints sp{pts, P, 1, P};
+    SGP_TRY(launch_sweep_fitness(ctx, gdev, host, G, d, sp, fa));
+  }
   SGP_TRY(sgp_d2h(ctx, values, dval, nd));
   SGP_TRY(sgp_d2h(ctx, safe, dsafe, size_t(P)));
   return 0;
@@ -1126,11 +1165,16 @@ int sgp_swarm_run(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
   fa.values = dval;
   fa.safe = dsafe;
   const SweepPoints sp{dpos, P, d, 1};          // row-major (P, d) in place
+  const bool few = small_path_pays_all(gps, G, P);
+  auto fitness = [&]() -> int {
+    return few ? fitness_small(ctx, gps, G, dpos, P, fa)
+                 : launch_sweep_fitness(ctx, gdev, host, G, d, sp, fa);
+  };
   const double* r = drand;
   if (init) {
     SGP_TRY(launch_pso_init_vel(ctx, P, d, dvel, dvs, r, seed));
     if (r) r += size_t(P) * d;
-    SGP_TRY(launch_sweep_fitness(ctx, gdev, host, G, d, sp, fa));
+    SGP_TRY(fitness());
     SGP_TRY(launch_pso_best(ctx, P, d, dval, dsafe, dpos, dbest, dbv, dgb, 1));
   }
   double inertia = inertia0;
@@ -1140,7 +1184,7 @@ int sgp_swarm_run(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
                             uint32_t(it + 1)));
     if (r) r += 2 * size_t(P) * d;
     inertia += step;
-    SGP_TRY(launch_sweep_fitness(ctx, gdev, host, G, d, sp, fa));
+    SGP_TRY(fitness());
     SGP_TRY(launch_pso_best(ctx, P, d, dval, dsafe, dpos, dbest, dbv, dgb, 0));
   }
   SGP_TRY(sgp_d2h(ctx, positions, dpos, nd));

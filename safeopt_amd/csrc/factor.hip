@@ -10,6 +10,8 @@
 //   factor(A[0:s]):  s == 32 -> leaf (potf2 + triangular inverse in LDS)
 //     else split h:  factor(A11); L21 = A21 Linv11^T; A22 -= L21 L21^T;
 //                    factor(A22); Linv21 = -Linv22 (L21 Linv11)
+#include <algorithm>
+
 #include "kern_eval.h"
 
 namespace {
@@ -587,6 +589,46 @@ int pop_gp(sgp_gp* gp) {
   return publish_gp(gp);
 }
 
+// ---- posterior of a FEW points -------------------------------------------------------
+// SafeOptSwarm's default swarm has 20 particles and SafeOpt asks for the
+// posterior of single points (gp_opt.py:1117, 1132): one 64-row tile of the
+// sweep kernel would walk through all n^2/512 block products on ONE compute
+// unit.  For P <= kSmallPoints the same quantities come out of
+//   Kc = k(pts, X)            (P x n)
+//   T  = Kc L^-T              (k_tri_mv, 16 right-hand sides per launch, one
+//                              wave per row of L^-1: the whole chip reads L^-1 once)
+//   var = k(x,x) - |T_p|^2,  mean = alpha . Kc_p
+// in a handful of launches whose time does not depend on n^2 / CU.
+__global__ __launch_bounds__(256) void k_post_small(const double* Kc,
+                                                    const double* T, int64_t ld,
+                                                    int n, const double* alpha,
+                                                    double kdiag, double* mean,
+                                                    double* var) {
+  __shared__ double sh[2][4];
+  const int p = blockIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double t = T[int64_t(p) * ld + i];
+    a = fma(t, t, a);
+    b = fma(alpha[i], Kc[int64_t(p) * ld + i], b);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = a;
+    sh[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double ss = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    mean[p] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    var[p] = fmax(kdiag - ss, 1e-15);      // GPy clip
+  }
+}
+
 // For m <= 16 candidates xc (m x d, device) and residuals u_c - mu_c (device):
 // w_c = Ky^-1 k(X, x_c) packed as an MFMA A operand, delta_c, 1/s2_c.
 int expander_operands(sgp_gp* gp, const double* xc_dev, int m,
@@ -613,6 +655,38 @@ int expander_operands(sgp_gp* gp, const double* xc_dev, int m,
   const int nsteps = np / 4;
   hipLaunchKernelGGL(k_pack_w, dim3((nsteps * 64 + 255) / 256), dim3(256), 0,
                      ctx->stream, Wt, int64_t(nf), n, m, nsteps, Wpack);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+bool small_path_pays(const sgp_gp* gp, int64_t P) {
+  // sweep: ~3 us per 16 x 256 stage on one CU (n = 200: 13 stages, n = 2000:
+  // 573); small path: four launches + one pass over L^-1 per 16 points.
+  // Measured crossover (scripts/dev/swarm_small.py): between n = 200 and 1000.
+  return P >= 1 && P <= kSmallPoints && gp->n >= 384;
+}
+
+int posterior_small(sgp_gp* gp, const double* pts_rowmajor, int P, double* mean,
+                    double* var) {
+  sgp_ctx* ctx = gp->ctx;
+  const int n = int(gp->n), nf = gp->ld;
+  double* buf = static_cast<double*>(
+      sgp_scratch(ctx, 6, size_t(2) * kSmallPoints * nf * sizeof(double)));
+  if (!buf) return -1;
+  double* Kc = buf;
+  double* T = buf + size_t(kSmallPoints) * nf;
+  const double* Li = static_cast<double*>(gp->Linv.p);
+  SGP_TRY(launch_kernel_matrix(ctx, gp->kern, pts_rowmajor, P,
+                               static_cast<double*>(gp->X.p), n, Kc, nf, 0, 0.0,
+                               INT64_MAX));
+  for (int p0 = 0; p0 < P; p0 += kMaxRhs) {
+    const int m = std::min(kMaxRhs, P - p0);
+    SGP_TRY(launch_tri_mv(ctx, Li, nf, n, Kc + size_t(p0) * nf, nf, m,
+                          T + size_t(p0) * nf, nf));
+  }
+  hipLaunchKernelGGL(k_post_small, dim3(P), dim3(256), 0, ctx->stream, Kc, T,
+                     int64_t(nf), n, static_cast<double*>(gp->alpha.p),
+                     gp->kern.kdiag, mean, var);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -240,6 +240,61 @@ __device__ __forceinline__ double swarm_penalty(double slack) {
   return pen;
 }
 
+// The fitness shaping of SafeOptSwarm._compute_particle_fitness
+// (gp_opt.py:925-1013) on resident mean / var ([G][P]) -- the epilogue of
+// k_sweep<.., MODE_FITNESS> as a kernel of its own, for the small-swarm path
+// (posterior_small in factor.hip) where the posterior does not come out of the
+// sweep.  One thread per particle; same formulas, same order as the epilogue.
+__global__ void k_fitness_small(int G, int64_t P, const double* mean,
+                                const double* var, FitnessArgs f) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int st = f.swarm_type;
+  const int Geff = (st == SGP_SWARM_GREEDY) ? 1 : G;
+  bool safe = true;
+  double values = 0.0, interest = 1.0, total_pen = 0.0, lower = 0.0;
+  for (int g = 0; g < Geff; ++g) {
+    const double mu = mean[int64_t(g) * P + i];
+    const double sd = sqrt(var[int64_t(g) * P + i]);
+    lower = mu - f.beta * sd;
+    if (g == 0) {
+      values = sd / f.scaling[0];
+      if (st == SGP_SWARM_EXPANDERS) interest = double(G);
+      if (st == SGP_SWARM_MAXIMIZERS) {
+        const double upper = mu + f.beta * sd;
+        const double z = 10.0 * (upper - f.best_lower_bound) / f.scaling[0];
+        interest = 1.0 / (1.0 + exp(-z));  // scipy.special.expit
+      }
+    } else {
+      values = fmax(values, sd / f.scaling[g]);
+    }
+    if (f.fmin[g] != -INFINITY) {
+      double slack = lower - f.fmin[g];
+      safe = safe && (slack >= 0.0);
+      if (st != SGP_SWARM_SAFE_SET) {
+        slack = slack / f.scaling[g];
+        total_pen += swarm_penalty(slack);
+        if (st == SGP_SWARM_EXPANDERS) {
+          const double z = slack / 0.2;   // scipy.stats.norm.pdf(slack, scale=0.2)
+          interest *= exp(-0.5 * z * z) / 2.5066282746310002 / 0.2;
+        }
+      }
+    }
+  }
+  double out;
+  bool ok = safe;
+  if (st == SGP_SWARM_GREEDY) {
+    out = lower;
+    ok = true;
+  } else if (st == SGP_SWARM_SAFE_SET) {
+    out = lower;
+  } else {
+    out = (values + total_pen) * interest;
+  }
+  f.values[i] = out;
+  f.safe[i] = ok ? 1 : 0;
+}
+
 // Position in the flattened stage sequence of one workgroup:
 //   for tile: for gp: for chunk (16 row blocks of L^-1): for jb (16 columns)
 // A stage's LDS image (A chunk, X rows, alpha) depends on (gp, chunk, jb) only,
@@ -1160,6 +1215,14 @@ int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,
   p.conf = ConfOut{};
   p.fit = fa;
   return launch_sweep(ctx, p, gps_host, d);
+}
+
+int launch_fitness_small(sgp_ctx* ctx, int G, int64_t P, const double* mean,
+                         const double* var, FitnessArgs fa) {
+  hipLaunchKernelGGL(k_fitness_small, dim3(unsigned((P + 255) / 256)), dim3(256),
+                     0, ctx->stream, G, P, mean, var, fa);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
 }
 
 int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,

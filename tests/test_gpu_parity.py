@@ -626,6 +626,55 @@ def test_swarm_fitness_config5_reduced(mods):
         assert_allclose(v, vo, rtol=1e-7, atol=1e-8)
 
 
+@pytest.mark.parametrize("n,P", [(400, 1), (500, 20), (2000, 64), (2000, 17)])
+def test_few_points_path(mods, n, P):
+    """P <= 64 points at n >= 384: posterior and swarm fitness come out of the
+    triangular multi-RHS path (posterior_small) instead of one sweep tile --
+    SafeOptSwarm's default swarm (20 particles) and the single-point predictions
+    of gp_opt.py:1117, 1132.  Same oracle, same tolerances."""
+    safeopt_amd, gpy, gpn, son = mods
+    from bench import make_config, build_gps
+    cfg = make_config(5)
+    cfg["X"], cfg["Y"], cfg["n"] = cfg["X"][:n], cfg["Y"][:n], n
+    gps, gos = build_gps(cfg, gpy), build_gps(cfg, gpn)
+    parts = np.random.default_rng(n + P).uniform(-3, 3, size=(P, 4))
+    for g in range(2):
+        m, v = gps[g].predict_noiseless(parts)
+        mo, vo = gos[g].predict_noiseless(parts)
+        check_posterior(m, v, mo, vo, 2.0)
+    opt = safeopt_amd.SafeOptSwarm(gps, cfg["fmin"], bounds=[(-5., 5.)] * 4,
+                                   threshold=cfg["threshold"])
+    opt.best_lower_bound = 0.4
+    for st in ["greedy", "maximizers", "expanders", "safe_set"]:
+        v, s = opt._compute_particle_fitness(st, parts)
+        vo, so = son.swarm_fitness(gos, parts, st, 2., cfg["fmin"], opt.scaling, 0.4)
+        assert_array_equal(s, so)
+        assert_allclose(v, vo, rtol=1e-7, atol=1e-8)
+
+
+def test_device_pso_few_points_path_bit_identical(mods):
+    """Device PSO == host loop also when the fitness takes the few-points path
+    (n = 600 observations, 30 particles)."""
+    safeopt_amd, gpy, _, _ = mods
+    from bench import make_config, build_gps
+    cfg = make_config(5)
+    cfg["X"], cfg["Y"], cfg["n"] = cfg["X"][:600], cfg["Y"][:600], 600
+    out = []
+    for pso in ("host", "device"):
+        gps = build_gps(cfg, gpy)
+        o = safeopt_amd.SafeOptSwarm(gps, cfg["fmin"], bounds=[(-5., 5.)] * 4,
+                                     threshold=cfg["threshold"], swarm_size=30, pso=pso)
+        o.best_lower_bound = 0.4
+        np.random.seed(3)
+        sw = o.swarms["expanders"]
+        sw.init_swarm(np.random.default_rng(1).uniform(-1, 1, size=(30, 4)))
+        sw.run_swarm(15)
+        out.append((sw.positions.copy(), sw.velocities.copy(), sw.best_positions.copy(),
+                    np.array(sw.best_values), np.array(sw.global_best)))
+    for a, b in zip(out[0], out[1]):
+        assert_array_equal(a, b)
+
+
 def kernels_from(cfg, ns):
     return [make_kernel(ns, spec) for spec in cfg["kernels"]]
 
