@@ -593,40 +593,87 @@ int pop_gp(sgp_gp* gp) {
 // SafeOptSwarm's default swarm has 20 particles and SafeOpt asks for the
 // posterior of single points (gp_opt.py:1117, 1132): one 64-row tile of the
 // sweep kernel would walk through all n^2/512 block products on ONE compute
-// unit.  For P <= kSmallPoints the same quantities come out of
-//   Kc = k(pts, X)            (P x n)
-//   T  = Kc L^-T              (k_tri_mv, 16 right-hand sides per launch, one
-//                              wave per row of L^-1: the whole chip reads L^-1 once)
-//   var = k(x,x) - |T_p|^2,  mean = alpha . Kc_p
-// in a handful of launches whose time does not depend on n^2 / CU.
-__global__ __launch_bounds__(256) void k_post_small(const double* Kc,
-                                                    const double* T, int64_t ld,
-                                                    int n, const double* alpha,
-                                                    double kdiag, double* mean,
-                                                    double* var) {
-  __shared__ double sh[2][4];
-  const int p = blockIdx.x;
-  double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const double t = T[int64_t(p) * ld + i];
-    a = fma(t, t, a);
-    b = fma(alpha[i], Kc[int64_t(p) * ld + i], b);
-  }
+// unit.  For P <= kSmallPoints the work is spread over the chip the other way
+// round -- one workgroup per 16-row block of L^-1, 16 points per pass:
+//   k_small_kb   : Kb = k(X, pts) in MFMA B-operand order, zero padded
+//   k_small_mfma : |L^-1 Kb|^2 per (row block, point) on the matrix cores (the
+//                  packed A operands of the sweep), its four waves splitting
+//                  the k-steps; the last row block also forms alpha . Kb
+//   k_small_post : var = k(x,x) - sum over row blocks, GPy clip
+// Three launches whose time does not depend on n^2 per compute unit.
+template <int D>
+__global__ void k_small_kb(KernDesc kd, const double* pts, int P, const double* X,
+                           int n, int nsteps, double* Kb) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pass = blockIdx.y;
+  if (e >= nsteps * 64) return;
+  const int lane = e & 63, s = e >> 6;
+  const int pt = pass * 16 + (lane & 15), j = 4 * s + (lane >> 4);
+  double v = 0.0;
+  if (pt < P && j < n) {
+    double a[D], b[D];
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    a += __shfl_xor(a, o, 64);
-    b += __shfl_xor(b, o, 64);
+    for (int k = 0; k < D; ++k) {
+      a[k] = pts[int64_t(pt) * D + k];
+      b[k] = X[int64_t(j) * D + k];
+    }
+    v = kern_eval<D>(kd, a, b);
   }
-  if ((threadIdx.x & 63) == 0) {
-    sh[0][threadIdx.x >> 6] = a;
-    sh[1][threadIdx.x >> 6] = b;
+  Kb[int64_t(pass) * nsteps * 64 + e] = v;
+}
+
+__global__ __launch_bounds__(256) void k_small_mfma(const double* Apack,
+                                                    const double* Kb,
+                                                    const double* alpha,
+                                                    int nsteps, int nblk,
+                                                    double* part, double* mean) {
+  __shared__ double4_t sh[4][64];
+  __shared__ double shm[4][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x, pass = blockIdx.y;
+  const double* A = Apack + int64_t(blk) * nsteps * 64 + lane;
+  const double* B = Kb + int64_t(pass) * nsteps * 64 + lane;
+  const bool last = blk == nblk - 1;            // covers every k-step: the mean
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  double m = 0.0;
+  const int send = (blk + 1) * 4;               // up to the diagonal block
+#pragma unroll 4
+  for (int s = wave; s < send; s += 4) {
+    const double b = B[s * 64];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[s * 64], b, acc, 0, 0, 0);
+    if (last) m = fma(alpha[4 * s + (lane >> 4)], b, m);
+  }
+  sh[wave][lane] = acc;
+  if (last) {
+    m += __shfl_xor(m, 16, 64);
+    m += __shfl_xor(m, 32, 64);
+    if (lane < 16) shm[wave][lane] = m;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const double ss = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
-    mean[p] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
-    var[p] = fmax(kdiag - ss, 1e-15);      // GPy clip
+  if (wave == 0) {
+    // D layout: column (point) = lane & 15, rows (lane >> 4) + 4 r
+    const double4_t t = sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane];
+    double ss = (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (lane < 16) {
+      part[(int64_t(pass) * nblk + blk) * 16 + lane] = ss;
+      if (last)
+        mean[pass * 16 + lane] =
+            (shm[0][lane] + shm[1][lane]) + (shm[2][lane] + shm[3][lane]);
+    }
   }
+}
+
+__global__ void k_small_post(const double* part, int nblk, int P, double kdiag,
+                             const double* mean_in, double* mean, double* var) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int pass = p >> 4, c = p & 15;
+  double ss = 0.0;
+  for (int b = 0; b < nblk; ++b) ss += part[(int64_t(pass) * nblk + b) * 16 + c];
+  mean[p] = mean_in[p];
+  var[p] = fmax(kdiag - ss, 1e-15);      // GPy clip
 }
 
 // For m <= 16 candidates xc (m x d, device) and residuals u_c - mu_c (device):
@@ -669,24 +716,34 @@ bool small_path_pays(const sgp_gp* gp, int64_t P) {
 int posterior_small(sgp_gp* gp, const double* pts_rowmajor, int P, double* mean,
                     double* var) {
   sgp_ctx* ctx = gp->ctx;
-  const int n = int(gp->n), nf = gp->ld;
+  const int n = int(gp->n), np = gp->n_pad, nblk = np / 16, nsteps = np / 4;
+  const int passes = (P + 15) / 16;
+  const size_t nkb = size_t(passes) * nsteps * 64, npart = size_t(passes) * nblk * 16;
   double* buf = static_cast<double*>(
-      sgp_scratch(ctx, 6, size_t(2) * kSmallPoints * nf * sizeof(double)));
+      sgp_scratch(ctx, 6, (nkb + npart + kSmallPoints) * sizeof(double)));
   if (!buf) return -1;
-  double* Kc = buf;
-  double* T = buf + size_t(kSmallPoints) * nf;
-  const double* Li = static_cast<double*>(gp->Linv.p);
-  SGP_TRY(launch_kernel_matrix(ctx, gp->kern, pts_rowmajor, P,
-                               static_cast<double*>(gp->X.p), n, Kc, nf, 0, 0.0,
-                               INT64_MAX));
-  for (int p0 = 0; p0 < P; p0 += kMaxRhs) {
-    const int m = std::min(kMaxRhs, P - p0);
-    SGP_TRY(launch_tri_mv(ctx, Li, nf, n, Kc + size_t(p0) * nf, nf, m,
-                          T + size_t(p0) * nf, nf));
+  double* Kb = buf;
+  double* part = buf + nkb;
+  double* mtmp = part + npart;
+#define SMALL_CASE(DD)                                                         \
+  case DD:                                                                     \
+    hipLaunchKernelGGL(k_small_kb<DD>, dim3((nsteps * 64 + 255) / 256, passes),\
+                       dim3(256), 0, ctx->stream, gp->kern, pts_rowmajor, P,   \
+                       static_cast<double*>(gp->X.p), n, nsteps, Kb);          \
+    break;
+  switch (gp->kern.d) {
+    SMALL_CASE(1) SMALL_CASE(2) SMALL_CASE(3) SMALL_CASE(4)
+    SMALL_CASE(5) SMALL_CASE(6) SMALL_CASE(7) SMALL_CASE(8)
+    default:
+      sgp_set_error(ctx, "input dimension %d not in 1..%d", gp->kern.d, SGP_MAX_D);
+      return -2;
   }
-  hipLaunchKernelGGL(k_post_small, dim3(P), dim3(256), 0, ctx->stream, Kc, T,
-                     int64_t(nf), n, static_cast<double*>(gp->alpha.p),
-                     gp->kern.kdiag, mean, var);
+#undef SMALL_CASE
+  hipLaunchKernelGGL(k_small_mfma, dim3(nblk, passes), dim3(256), 0, ctx->stream,
+                     static_cast<double*>(gp->Apack.p), Kb,
+                     static_cast<double*>(gp->alpha.p), nsteps, nblk, part, mtmp);
+  hipLaunchKernelGGL(k_small_post, dim3((P + 63) / 64), dim3(64), 0, ctx->stream,
+                     part, nblk, P, gp->kern.kdiag, mtmp, mean, var);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }
