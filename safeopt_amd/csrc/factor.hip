@@ -708,9 +708,9 @@ int expander_operands(sgp_gp* gp, const double* xc_dev, int m,
 
 bool small_path_pays(const sgp_gp* gp, int64_t P) {
   // sweep: ~3 us per 16 x 256 stage on one CU (n = 200: 13 stages, n = 2000:
-  // 573); small path: four launches + one pass over L^-1 per 16 points.
-  // Measured crossover (scripts/dev/swarm_small.py): between n = 200 and 1000.
-  return P >= 1 && P <= kSmallPoints && gp->n >= 384;
+  // 573); few-points path: three launches per GP.  Measured crossover
+  // (scripts/dev/swarm_small.py): between n = 50 and n = 200.
+  return P >= 1 && P <= kSmallPoints && gp->n >= 128;
 }
 
 int posterior_small(sgp_gp* gp, const double* pts_rowmajor, int P, double* mean,

@@ -626,9 +626,9 @@ def test_swarm_fitness_config5_reduced(mods):
         assert_allclose(v, vo, rtol=1e-7, atol=1e-8)
 
 
-@pytest.mark.parametrize("n,P", [(400, 1), (500, 20), (2000, 64), (2000, 17)])
+@pytest.mark.parametrize("n,P", [(130, 5), (400, 1), (500, 20), (2000, 64), (2000, 17)])
 def test_few_points_path(mods, n, P):
-    """P <= 64 points at n >= 384: posterior and swarm fitness come out of the
+    """P <= 64 points at n >= 128: posterior and swarm fitness come out of the
     triangular multi-RHS path (posterior_small) instead of one sweep tile --
     SafeOptSwarm's default swarm (20 particles) and the single-point predictions
     of gp_opt.py:1117, 1132.  Same oracle, same tolerances."""
