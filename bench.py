@@ -7,9 +7,19 @@ A "step" is one ``SafeOpt.optimize()`` = ``update_confidence_intervals`` +
 ``compute_sets`` + ``get_new_query_point`` over the whole resident candidate
 grid (config 5: one ``SafeOptSwarm._compute_particle_fitness`` call for every
 swarm type's GP set).  Inputs are synthetic and already
-resident in HBM when the timed region starts.  For N > 1 the driver launches
-one process per GPU (torchrun env: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*);
-each rank holds 1e6 rows (weak scaling), the scalar reductions go over RCCL.
+resident in HBM when the timed region starts.
+
+Default workload = BASELINE.json configs[2] ("config 3", the north-star target):
+2-D Matern-5/2, 3 GPs, 500 training observations, 1e6-point grid.
+
+Multi-GPU: one process per GPU.  Under ``torch.distributed.run`` the ranks come
+from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; a bare
+``python bench.py --gpus N`` spawns the N ranks itself (same environment
+variables, rank 0's JSON line is passed through).  Configs 2 and 3 scale weakly
+(1e6 rows per rank: the grid gets ``N`` times as many rows in its last
+dimension); config 4 is BASELINE.json's fixed 200^3 grid, row-sharded in
+contiguous blocks of the flat index (strong scaling).  The only cross-rank
+traffic is a handful of scalars per step over RCCL.
 
 Rank 0 prints ONE JSON line.  No torch anywhere: device memory, streams,
 events and RCCL all come from libsafeopt_hip.so.
@@ -19,6 +29,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -55,7 +66,7 @@ def make_config(k, side=None, rows_y_mult=1):
         1: dict(d=1, kind="RBF", G=1, n=20, side=1000, box=10., xr=4.0, seed=0),
         2: dict(d=2, kind="RBF", G=1, n=200, side=1000, box=5., xr=2.0, seed=1),
         3: dict(d=2, kind="Matern52", G=3, n=500, side=1000, box=5., xr=2.0, seed=2),
-        4: dict(d=3, kind="RBF", G=1, n=1000, side=100, box=5., xr=2.5, seed=5),
+        4: dict(d=3, kind="RBF", G=1, n=1000, side=200, box=5., xr=2.5, seed=5),
         5: dict(d=4, kind="RBF", G=2, n=2000, side=None, box=5., xr=3.0, seed=6),
     }[k]
     d, G, n = spec["d"], spec["G"], spec["n"]
@@ -101,52 +112,88 @@ def build_gps(cfg, ns, **kw):
             for g in range(cfg["G"])]
 
 
-CPU_BASELINE_SECONDS = 12.0      # target CPU work of the default sample
+CPU_BASELINE_SECONDS = 2.5       # target CPU work of ONE timed run of the sample
+CPU_BASELINE_REPEATS = 5         # median of this many runs (after one warm-up)
 
 
-def cpu_baseline(cfg, sample_rows, dev_Q=None):
-    """The oracle (NumPy restatement of the reference path, all host cores via
-    the BLAS thread pool) on a bounded sample of the same workload.
-    ``sample_rows=None``: as many rows (a centred block of the grid) as a 20k-row
-    pilot predicts for ~CPU_BASELINE_SECONDS of work."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _time_oracle(son, gps, grid, cfg, scaling, repeats):
+    """Median wall time of the oracle's optimize() over `grid` (one warm-up)."""
+    def once():
+        t0 = time.perf_counter()
+        try:
+            out = son.optimize_grid(gps, grid, cfg["fmin"], scaling,
+                                    cfg["threshold"], cfg["beta"])
+        except EnvironmentError:      # sample without a safe row: sweep only
+            out = (None, son.confidence_intervals(gps, grid, cfg["beta"]))
+        return time.perf_counter() - t0, out
+    once()
+    runs = [once() for _ in range(repeats)]
+    times = sorted(r[0] for r in runs)
+    return times[len(times) // 2], times, runs[-1][1]
+
+
+def cpu_baseline(cfg, sample_rows, dev_Q=None, row_offset=0):
+    """The oracle (NumPy restatement of the reference path) on the host cores,
+    on a bounded sample of the same workload: a centred block of the grid.
+
+    Protocol: buffers pre-faulted by a warm-up run,
+    median of CPU_BASELINE_REPEATS runs with every BLAS thread, and the same on
+    ONE thread (smaller block).  ``sample_rows=None`` sizes the blocks from a
+    pilot so that one run is ~CPU_BASELINE_SECONDS of host work."""
     from oracle import gp_numpy as gpn
     from oracle import safeopt_numpy as son
+    from threadpoolctl import threadpool_info, threadpool_limits
     gps = build_gps(cfg, gpn)
-    if sample_rows is None:
-        N = cfg["grid"].shape[0]
-        pilot = np.ascontiguousarray(cfg["grid"][(N - 20000) // 2:(N + 20000) // 2])
-        son.confidence_intervals(gps, pilot[:8192], cfg["beta"])
-        t0 = time.perf_counter()
-        son.confidence_intervals(gps, pilot, cfg["beta"])
-        rate = pilot.shape[0] / (time.perf_counter() - t0)
-        sample_rows = int(min(N, max(20000, rate * CPU_BASELINE_SECONDS)))
-    # a contiguous block of rows from the middle of the grid (the block around
-    # the training data, so the sample contains safe, maximiser and unsafe rows)
     N = cfg["grid"].shape[0]
-    start = max(0, (N - sample_rows) // 2)
-    grid = np.ascontiguousarray(cfg["grid"][start:start + sample_rows])
     scaling = np.sqrt([2.0] * cfg["G"])
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    son.confidence_intervals(gps, grid[:8192], cfg["beta"])    # warm-up
-    t0 = time.perf_counter()
-    try:
-        idx, Q, S, M, G = son.optimize_grid(gps, grid, cfg["fmin"], scaling,
-                                            cfg["threshold"], cfg["beta"])
-    except EnvironmentError:          # sample without a safe row: sweep only
-        Q = son.confidence_intervals(gps, grid, cfg["beta"])
-    dt = time.perf_counter() - t0
-    out = dict(value=sample_rows / dt, unit="candidates/s", cores=int(cores),
-               kind="port",
+    cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+
+    def block(rows):
+        start = max(0, (N - rows) // 2)
+        return start, np.ascontiguousarray(cfg["grid"][start:start + rows])
+
+    def pilot_rate():
+        _, pg = block(min(N, 20000))
+        son.confidence_intervals(gps, pg[:8192], cfg["beta"])
+        t0 = time.perf_counter()
+        son.confidence_intervals(gps, pg, cfg["beta"])
+        return pg.shape[0] / (time.perf_counter() - t0)
+
+    rows_all = sample_rows or int(min(N, max(20000, pilot_rate() * CPU_BASELINE_SECONDS)))
+    start, grid = block(rows_all)
+    t_all, times_all, (idx, *rest) = _time_oracle(son, gps, grid, cfg, scaling,
+                                                  CPU_BASELINE_REPEATS)
+    Q = rest[0]
+    with threadpool_limits(limits=1):
+        rows_one = sample_rows or int(min(N, max(5000, pilot_rate() * CPU_BASELINE_SECONDS * 0.6)))
+        _, grid1 = block(rows_one)
+        t_one, times_one, _ = _time_oracle(son, gps, grid1, cfg, scaling,
+                                           CPU_BASELINE_REPEATS)
+    out = dict(value=rows_all / t_all, unit="candidates/s", cores=int(cores),
+               kind="port", cpu=_cpu_model(),
+               runs=CPU_BASELINE_REPEATS, spread=[rows_all / max(times_all), rows_all / min(times_all)],
+               single_thread=dict(value=rows_one / t_one, rows=int(rows_one),
+                                  spread=[rows_one / max(times_one), rows_one / min(times_one)]),
                sample="oracle optimize_grid (NumPy/OpenBLAS restatement of "
-                      "gp_opt.py:453-649 + GPy predict) on rows [%d, %d) of "
-                      "the same grid, %.1f s" % (start, start + sample_rows, dt))
+                      "gp_opt.py:453-649 + GPy predict) on rows [%d, %d) of the "
+                      "same grid: warm-up + median of %d runs, %.2f s each on %d "
+                      "threads; single thread: %d rows, %.2f s each"
+                      % (start, start + rows_all, CPU_BASELINE_REPEATS, t_all,
+                         cores, rows_one, t_one))
     parity = None
     if dev_Q is not None:
-        dq = dev_Q[start:start + sample_rows]
+        dq = dev_Q[start - row_offset:start - row_offset + rows_all]
         lo, up = Q[:, ::2], Q[:, 1::2]
         mean_o, mean_d = 0.5 * (lo + up), 0.5 * (dq[:, ::2] + dq[:, 1::2])
         var_o = ((up - lo) / (2 * cfg["beta"])) ** 2
@@ -155,43 +202,87 @@ def cpu_baseline(cfg, sample_rows, dev_Q=None):
             mean_linf_rel=float(np.max(np.abs(mean_d - mean_o)) /
                                 np.max(np.abs(mean_o))),
             var_linf_over_prior=float(np.max(np.abs(var_d - var_o)) / 2.0),
-            rows=int(sample_rows))
+            rows=int(rows_all))
     return out, parity
+
+
+def spawn_ranks(n, argv):
+    """``python bench.py --gpus N`` from a bare shell: start the N ranks (one
+    process per GPU, torchrun-style environment) and pass rank 0's line on."""
+    import socket
+    with socket.socket() as sk:                  # a free port for the launch
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    nonce = "%d-%x" % (os.getpid(), int(time.time() * 1e6))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SAFEOPT_RDZV_NONCE=nonce)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + argv, env=env,
+            stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("rank exit codes: %s" % rcs)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5])
     ap.add_argument("--side", type=int, default=None,
                     help="grid points per dimension (default: the config's)")
     ap.add_argument("--cpu-rows", type=int, default=None,
-                    help="rows of the CPU-baseline sample (default: ~12 s of CPU work)")
+                    help="rows of the CPU-baseline sample (default: ~2.5 s per run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=10,
+                    help="steps of the separate (untimed) per-launch hipEvent pass")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only rendezvous the ranks (no device): launcher self-test")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])
+    if args.launch_check:
+        from safeopt_amd import dist
+        rank, world, ok = dist.launch_check()
+        if not ok:
+            raise SystemExit("rank %d: rendezvous token mismatch" % rank)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world,
+                              "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}))
+        return
 
     import safeopt_amd
     import safeopt_amd.gpy as gpy
-    from safeopt_amd import _hip, dist
+    from safeopt_amd import dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run "
-                         "(one process per GPU)")
     ctx, comm = dist.init_from_env()
 
-    cfg = make_config(args.config, side=args.side, rows_y_mult=world)
+    # configs 2/3: weak scaling (1e6 rows per rank); config 4: the fixed 200^3
+    # grid of BASELINE.json, row-sharded by SafeOpt (strong scaling)
+    weak = args.config != 4
+    cfg = make_config(args.config, side=args.side,
+                      rows_y_mult=world if weak else 1)
     gps = build_gps(cfg, gpy)
     ctx.sync()
 
+    last = {}
     if args.config == 5:
         parts = cfg["particles"]
         opt = safeopt_amd.SafeOptSwarm(gps, cfg["fmin"], bounds=[(-5., 5.)] * cfg["d"],
                                        threshold=cfg["threshold"])
         units = parts.shape[0]
+        rows_rank = units
 
         def step():
             for st in ("greedy", "maximizers", "expanders"):
@@ -204,19 +295,21 @@ def main():
                                   cfg["fmin"] if cfg["G"] > 1 else 0.0,
                                   threshold=cfg["threshold"], comm=comm)
         units = grid.shape[0]
-        last = {}
+        lo, hi = dist.shard_range(units, rank, world)
+        rows_rank = hi - lo
 
         def step():
             last["x"] = opt.optimize()
         workload = ("config%d: %d-D %s, G=%d, n=%d, grid %s = %d rows "
-                    "(%d per GPU), one SafeOpt.optimize()" %
+                    "(%d per GPU, contiguous blocks of the flat index), one "
+                    "SafeOpt.optimize()" %
                     (args.config, cfg["d"], cfg["kernels"][0][0]["kind"],
                      cfg["G"], cfg["n"], "x".join(map(str, cfg["sides"])),
-                     units, units // world))
+                     units, rows_rank))
 
     for _ in range(args.warmup):
         step()
-    ctx.profile_enable(True)
+    # ---- the timed region: K steps, nothing but the path
     comm.barrier()
     ctx.sync()
     ctx.timer_start()
@@ -227,9 +320,17 @@ def main():
     comm.barrier()
     dt = time.perf_counter() - t0
     ev_ms = ctx.timer_stop()
+    dt = float(comm.allreduce_max(np.array([dt]))[0])       # MAX over ranks
+
+    # ---- separate, untimed pass: a hipEvent pair around every sweep launch on
+    # the library's stream (roofline.achieved); rocprofv3 --kernel-trace of the
+    # same command must agree (profiles/)
+    ctx.profile_enable(True)
+    for _ in range(max(1, args.profile_steps)):
+        step()
+    ctx.sync()
     prof_ms, launches, flops = ctx.profile_read()
     ctx.profile_enable(False)
-    dt = float(comm.allreduce_max(np.array([dt]))[0])       # MAX over ranks
 
     if rank != 0:
         return
@@ -242,10 +343,11 @@ def main():
         "unit": "candidates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic",
+        "scaling": "weak" if weak else "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload, "n_train": cfg["n"], "G": G, "d": d,
-                   "rows": int(units)},
+                   "rows": int(units), "rows_per_gpu": int(rows_rank),
+                   "sharding": "contiguous row blocks (dist.shard_range)"},
         "roofline": {
             "bound": "mfma", "kernel": "k_sweep (posterior_sweep)",
             "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
@@ -254,11 +356,13 @@ def main():
             "kernel_ms_avg": prof_ms / max(launches, 1),
             "launches": int(launches),
             "algorithmic_flops_per_launch": flops / max(launches, 1),
-            "algorithmic_hbm_frac": ((8 * d + 16 * G + 3) * (units / world) /
+            "algorithmic_hbm_bytes_per_launch": (8 * d + 16 * G + 3) * rows_rank,
+            "algorithmic_hbm_frac": ((8 * d + 16 * G + 3) * rows_rank /
                                      (prof_ms / max(launches, 1) * 1e-3) /
                                      1e9 / HBM_PEAK_GBS) if prof_ms > 0 else 0.0,
         },
         "hip_event_ms_per_step": ev_ms / args.steps,
+        "timed_region_s": dt,
     }
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc
     # passes (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process)
@@ -271,9 +375,10 @@ def main():
     except (OSError, ValueError):
         pass
     if args.config != 5:
-        res["chosen_x"] = [float(v) for v in np.atleast_1d(last["x"])]
-    if world == 1:
-        res["mfma_f64_microbench_tflops"] = ctx.microbench_mfma_f64(20000)
+        x = np.atleast_1d(last["x"])
+        res["chosen_x"] = [float(v) for v in x]
+        hit = np.flatnonzero(np.all(cfg["grid"] == x, axis=1))
+        res["chosen_index"] = int(hit[0]) if hit.size else None
     if world == 1 and not args.no_cpu_baseline and args.config != 5:
         rows = None if args.cpu_rows is None else min(args.cpu_rows, units)
         base, parity = cpu_baseline(cfg, rows, dev_Q=opt.Q)

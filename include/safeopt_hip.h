@@ -110,6 +110,12 @@ int sgp_grid_set_context(sgp_grid* grid, const double* c, int nc);
  * sgp_grid_sets_fused.                                                        */
 int sgp_grid_confidence(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                         const double* fmin, double* out2);
+/* gp.predict_noiseless(self.inputs) for every GP (gp_opt.py:469, and the
+ * re-predictions of the expander loop, :585-602): refreshes the resident
+ * mean / var only -- Q, S, M, G are not touched.  Needed when the intervals
+ * were assigned by hand (opt.Q = ...) or the data changed without an interval
+ * update before compute_sets().                                              */
+int sgp_grid_posterior(sgp_grid* grid, sgp_gp* const* gps, int G);
 /* update_confidence_intervals after ONE sgp_gp_append on the GPs flagged in
  * which[]: closed-form rank-1 update of the resident mean/var,
  *   c(x) = k(x,x*) - k(X,x)^T Ky^-1 k(X,x*),  mean += c r / s2,

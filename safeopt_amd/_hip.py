@@ -6,6 +6,7 @@ through this module, and a missing library or a missing GPU raises.
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import os
 
 import numpy as np
@@ -54,6 +55,7 @@ PROTOTYPES = {
     "sgp_grid_set_context": (C.c_int, [vp, c_double_p, C.c_int]),
     "sgp_grid_confidence": (C.c_int, [vp, vpp, C.c_int, C.c_double,
                                       c_double_p, c_double_p]),
+    "sgp_grid_posterior": (C.c_int, [vp, vpp, C.c_int]),
     "sgp_grid_rank1_update": (C.c_int, [vp, vpp, C.c_int, c_int_p, C.c_double,
                                         c_double_p, c_double_p]),
     "sgp_grid_upload_Q": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
@@ -312,6 +314,8 @@ def _gp_array(gps):
 class DeviceGP(object):
     """Device-resident GP state (training data, packed L^-1, alpha)."""
 
+    _serials = itertools.count(1)      # process-wide, never reused
+
     def __init__(self, ctx, kdesc, noise_var):
         d, kinds, variances, inv_ls = kdesc
         self.ctx = ctx
@@ -327,6 +331,7 @@ class DeviceGP(object):
         # was a one-row append whose rank-1 record is on the device
         self.version = 0
         self.appended = False
+        self.serial = next(DeviceGP._serials)
 
     def __del__(self):
         try:
@@ -435,6 +440,10 @@ class DeviceGrid(object):
             self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin),
             None if defer else dptr(out)))
         return (None, None) if defer else (out[0], bool(out[1]))
+
+    def posterior(self, gps):
+        """Resident mean / var of every GP from a full sweep; Q, S untouched."""
+        self.ctx.check(lib().sgp_grid_posterior(self.h, _gp_array(gps), len(gps)))
 
     def rank1_update(self, gps, which, beta, fmin, defer=False):
         fmin = f64(fmin)

@@ -96,6 +96,10 @@ int collect_gps(sgp_ctx* ctx, sgp_gp* const* gps, int G, int d, GpDev* host) {
             SGP_MAX_GPS);
   for (int g = 0; g < G; ++g) {
     SGP_CHECK(ctx, gps[g] && gps[g]->n > 0, "GP %d has no data", g);
+    SGP_CHECK(ctx, gps[g]->ctx == ctx,
+              "GP %d lives in another context (device %d) than the grid "
+              "(device %d): no stream ordering, foreign device pointers",
+              g, gps[g]->ctx ? gps[g]->ctx->device : -1, ctx->device);
     SGP_CHECK(ctx, gps[g]->kern.d == d, "GP %d input_dim %d != %d", g,
               gps[g]->kern.d, d);
     host[g] = gps[g]->dev;
@@ -458,6 +462,10 @@ int sgp_grid_create(sgp_ctx* ctx, const double* base, int64_t N, int d,
   SGP_HIP(ctx, hipMemsetAsync(g->M, 0, N, ctx->stream));
   SGP_HIP(ctx, hipMemsetAsync(g->Gm, 0, N, ctx->stream));
   SGP_HIP(ctx, hipMemsetAsync(g->cand, 0, N, ctx->stream));
+  // defined contents before the first sweep (zero mean, zero variance, Q = 0)
+  SGP_HIP(ctx, hipMemsetAsync(g->mean, 0, nd * G, ctx->stream));
+  SGP_HIP(ctx, hipMemsetAsync(g->var, 0, nd * G, ctx->stream));
+  SGP_HIP(ctx, hipMemsetAsync(g->Q, 0, nd * 2 * G, ctx->stream));
   // upload the rows; the resident layout is SoA [d][N] (= the F-ordered array
   // linearly_spaced_combinations returns, so the common case is one memcpy)
   const int64_t sr = stride_row_B / 8, sc = stride_col_B / 8;
@@ -545,6 +553,22 @@ int sgp_grid_confidence(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   for (int i = 0; i < SGP_MAX_GPS; ++i) co.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
   SGP_TRY(launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co));
   return finish_safe_partials(g, sweep_num_blocks(g->N), out2);
+}
+
+int sgp_grid_posterior(sgp_grid* g, sgp_gp* const* gps, int G) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  GpDev host[SGP_MAX_GPS];
+  SGP_TRY(collect_gps(ctx, gps, G, g->d, host));
+  SGP_TRY(stage_gpdev(g, host, G));
+  SweepPoints sp{g->pts, g->N, 1, g->N};
+  ConfOut co{};            // Q, S, partial stay null: mean / var only
+  co.mean = g->mean;
+  co.var = g->var;
+  co.beta = 0.0;
+  for (int i = 0; i < SGP_MAX_GPS; ++i) co.fmin[i] = -INFINITY;
+  return launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co);
 }
 
 int sgp_grid_rank1_update(sgp_grid* g, sgp_gp* const* gps, int G,
@@ -900,6 +924,10 @@ int sgp_grid_sets_front_comm(sgp_grid* g, const double* scaling,
   double* res = static_cast<double*>(sgp_scratch(ctx, 1, (nres + 8) * 8));
   SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
   ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+  SGP_CHECK(ctx, comm || ctx->world <= 1,
+            "rank %d of %d has no communicator in the grid's context: the "
+            "in-stream all-reduces cannot run (sgp_comm_init on THIS context)",
+            ctx->rank, ctx->world);
   if (comm)
     SGP_NCCL(ctx, g_rccl.AllReduce(g->scal, g->scal, 1, ncclFloat64, ncclMax,
                                    comm, ctx->stream));

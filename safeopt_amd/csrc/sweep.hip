@@ -50,8 +50,16 @@ enum { MODE_CONF = 0, MODE_FITNESS = 1 };
 // evaluation, 8 no MFMA, 16 no mean/var/Q stores, 32 no per-GP epilogue at all.  profiles/r01/ablation.txt holds the numbers.
 #ifdef SGP_INSTRUMENT
 #define SGP_ABL(mask) (p.ablate & (mask))
+// cycle stamps of one wave's stage phases (s_memtime; waits for lgkmcnt(0))
+#define SGP_STAMP(k)                                              \
+  if (p.stamps) {                                                 \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+    stamp_acc[k] += t_ - stamp_last;                              \
+    stamp_last = t_;                                              \
+  }
 #else
 #define SGP_ABL(mask) false
+#define SGP_STAMP(k)
 #endif
 
 struct SweepParams {
@@ -60,6 +68,9 @@ struct SweepParams {
   int mode;
 #ifdef SGP_INSTRUMENT
   int ablate;      // timing experiments (scripts/ablate.py), see SGP_ABL
+  int skew;        // SGP_SKEW: the second workgroup of a CU starts 64*skew cycles late
+  int* cu_count;   // [8 XCC][256] arrival order per compute unit
+  unsigned long long* stamps;   // SGP_STAMPS: [workgroup][wave][8] cycle totals
 #endif
   SweepPoints pts;
   ConfOut conf;
@@ -366,6 +377,21 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   cur.tile = blockIdx.x;
   cur.g = cur.c = cur.jb = 0;
   if (cur.tile >= ntiles) return;
+#ifdef SGP_INSTRUMENT
+  if (p.skew > 0) {   // phase experiment: delay the second workgroup of every CU
+    int* flag = reinterpret_cast<int*>(lds + 2 * kBuf);
+    if (threadIdx.x == 0) {
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // XCC_ID
+      *flag = atomicAdd(p.cu_count + (((xcc & 7) << 8) | ((hw >> 8) & 0xff)), 1);
+    }
+    __syncthreads();
+    const int order = *flag;
+    __syncthreads();
+    if (order & 1)
+      for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(1);
+  }
+#endif
   stage_derive(cur, p.gps);
 
   // candidate rows of the current tile (and, prefetched, of the next one)
@@ -412,8 +438,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
 
   int bufsel = 0;
   bool more = true;
+#ifdef SGP_INSTRUMENT
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long stamp_first = stamp_last;
+#endif
 #pragma unroll 1
   while (more) {
+    SGP_STAMP(0)   // loop back edge
     if (cur.c == 0 && cur.jb == 0) kf.prep(x, xs);
 
     double* cbuf = lds + bufsel * kBuf;
@@ -443,6 +475,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       kvn[0] = a.x; kvn[1] = a.y; kvn[2] = b.x; kvn[3] = b.y;
     }
 
+    SGP_STAMP(1)   // bookkeeping + DMA issue + cache traffic
     // this stage: 16 training points against the active row blocks
     const double* xT = cbuf + kATile;
     const double* alT = cbuf + kATile + kXTile;
@@ -466,8 +499,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       for (int q = 0; q < 4; ++q)
         mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
     }
+    SGP_STAMP(2)   // covariance evaluation + mean
     if (!SGP_ABL(8))
       mfma_jblock(cur.shift + max(0, cur.jb - cur.b0), acc, cbuf + lane, kv);
+    SGP_STAMP(3)   // swizzles + MFMAs
 
     if (chunk_ends) {
 #pragma unroll
@@ -591,10 +626,20 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       kf = KernFast<D>(p.gps[nxt.g].kern);
       kdiag = p.gps[nxt.g].kern.kdiag;
     }
+    SGP_STAMP(4)   // chunk fold + epilogue
     if (!SGP_ABL(1)) __syncthreads();
+    SGP_STAMP(5)   // barrier
     bufsel ^= 1;
     cur = nxt;
   }
+#ifdef SGP_INSTRUMENT
+  if (p.stamps && lane == 0) {
+    unsigned long long* o = p.stamps + (int64_t(blockIdx.x) * kWaves + wave) * 8;
+    for (int k = 0; k < 6; ++k) o[k] = stamp_acc[k];
+    o[6] = stamp_last - stamp_first;
+    o[7] = stamp_first;
+  }
+#endif
 }
 
 // ---- expander check ---------------------------------------------------------
@@ -1127,11 +1172,43 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
 #ifdef SGP_INSTRUMENT
   static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
   pp.ablate = ablate;
+  static const int skew = getenv("SGP_SKEW") ? atoi(getenv("SGP_SKEW")) : 0;
+  static int* cu_count = nullptr;
+  pp.skew = skew;
+  if (skew > 0) {
+    if (!cu_count) SGP_HIP(ctx, hipMalloc(&cu_count, 2048 * sizeof(int)));
+    SGP_HIP(ctx, hipMemsetAsync(cu_count, 0, 2048 * sizeof(int), ctx->stream));
+  }
+  pp.cu_count = cu_count;
+  static const bool want_stamps = getenv("SGP_STAMPS") != nullptr;
+  static unsigned long long* stamps = nullptr;
+  if (want_stamps && !stamps)
+    SGP_HIP(ctx, hipMalloc(&stamps, size_t(nblocks) * NW * 8 * 8));
+  pp.stamps = stamps;
 #endif
   hipLaunchKernelGGL((k_sweep<D, NW, MODE, CACHE>), dim3(nblocks), dim3(64 * NW),
                      kLdsBytes, ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
   if (e1) SGP_HIP(ctx, hipEventRecord(e1, ctx->stream));
+#ifdef SGP_INSTRUMENT
+  if (pp.stamps) {   // per-phase cycle totals, averaged over all waves
+    std::vector<unsigned long long> h(size_t(nblocks) * NW * 8);
+    SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SGP_HIP(ctx, hipMemcpy(h.data(), pp.stamps, h.size() * 8, hipMemcpyDeviceToHost));
+    double tot[8] = {0};
+    unsigned long long first = ~0ull, last = 0;
+    for (size_t w = 0; w < h.size() / 8; ++w) {
+      for (int k = 0; k < 7; ++k) tot[k] += double(h[w * 8 + k]);
+      first = std::min(first, h[w * 8 + 7]);
+      last = std::max(last, h[w * 8 + 7] + h[w * 8 + 6]);
+    }
+    const double nw = double(h.size() / 8);
+    fprintf(stderr, "stamps (cycles/wave): back %.0f  book+dma %.0f  eval %.0f  "
+            "mfma %.0f  epilogue %.0f  barrier %.0f  | loop %.0f  span %.0f\n",
+            tot[0] / nw, tot[1] / nw, tot[2] / nw, tot[3] / nw, tot[4] / nw,
+            tot[5] / nw, tot[6] / nw, double(last - first));
+  }
+#endif
   return 0;
 }
 

@@ -23,7 +23,7 @@ import time
 import numpy as np
 
 __all__ = ["shard_range", "LocalComm", "RcclComm", "init_from_env",
-           "merge_topk", "merge_argmax"]
+           "merge_topk", "merge_argmax", "launch_check"]
 
 
 def shard_range(N, rank, world):
@@ -109,7 +109,10 @@ def _fetch_uid(addr, port, timeout):
         s.settimeout(timeout)
         hdr = b""
         while len(hdr) < 4:
-            hdr += s.recv(4 - len(hdr))
+            chunk = s.recv(4 - len(hdr))
+            if not chunk:
+                raise RuntimeError("rendezvous connection closed early")
+            hdr += chunk
         n = struct.unpack("<I", hdr)[0]
         buf = b""
         while len(buf) < n:
@@ -120,29 +123,71 @@ def _fetch_uid(addr, port, timeout):
     return buf
 
 
-def _file_rendezvous(rank, world, port, timeout):
-    """Single-node exchange of the ncclUniqueId through /tmp.
+def _launch_tag(port):
+    """16 bytes naming THIS launch: every rank of one launch derives the same
+    tag (launcher pid, MASTER_PORT, the launcher's run id / nonce), a file left
+    behind by another launch does not carry it."""
+    import hashlib
+    nonce = os.environ.get("SAFEOPT_RDZV_NONCE",
+                           os.environ.get("TORCHELASTIC_RUN_ID", ""))
+    return hashlib.md5(("%d:%d:%s" % (os.getppid(), port, nonce)).encode()).digest()
 
-    All workers of one ``torch.distributed.run`` launch share the agent as
-    parent process, so (parent pid, MASTER_PORT) names the launch.
+
+def _rdzv_dir():
+    """A directory only this user can write (0700, ownership checked)."""
+    d = os.environ.get("SAFEOPT_RDZV_DIR")
+    if d is None:
+        d = os.path.join("/tmp", "safeopt-rdzv-%d" % os.geteuid())
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.geteuid() or (st.st_mode & 0o022):
+        raise RuntimeError("rendezvous directory %s is not private to this user" % d)
+    return d
+
+
+def _launcher_start():
+    """Start time of the launching process (0 if /proc does not tell)."""
+    try:
+        return os.stat("/proc/%d" % os.getppid()).st_mtime
+    except OSError:
+        return 0.0
+
+
+def _file_rendezvous(rank, world, port, timeout):
+    """Single-node exchange of the ncclUniqueId through a private directory.
+
+    All workers of one launch (``torch.distributed.run`` or
+    ``bench.py --gpus N``) share the launcher as parent process, so
+    (parent pid, MASTER_PORT, run id) names the launch.  Rank 0 removes any
+    left-over file first and publishes ``uid + tag`` atomically (O_EXCL
+    temporary, 0600, rename); readers only accept a file that carries this
+    launch's tag and is not older than the launcher itself.
     """
     from . import _hip
-    path = os.path.join(os.environ.get("SAFEOPT_RDZV_DIR", "/tmp"),
-                        "safeopt_rdzv_%d_%d.bin" % (os.getppid(), port))
+    tag = _launch_tag(port)
+    path = os.path.join(_rdzv_dir(),
+                        "rdzv_%d_%d_%s.bin" % (os.getppid(), port, tag.hex()[:8]))
     if rank == 0:
+        try:
+            os.unlink(path)                    # a crashed launch's left-over
+        except OSError:
+            pass
         uid = _hip.Context.comm_unique_id()
         tmp = path + ".tmp%d" % os.getpid()
-        with open(tmp, "wb") as f:
-            f.write(uid)
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(uid + tag)
         os.replace(tmp, path)                  # atomic publish
         return uid, path
     deadline = time.time() + timeout
+    born = _launcher_start() - 1.0
     while True:
         try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == 128:
-                return uid, None
+            if os.stat(path).st_mtime >= born:
+                with open(path, "rb") as f:
+                    blob = f.read()
+                if len(blob) == 144 and blob[128:] == tag:
+                    return blob[:128], None
         except OSError:
             pass
         if time.time() > deadline:
@@ -195,6 +240,25 @@ def init_from_env(ctx=None, timeout=300.0):
         except OSError:
             pass
     return ctx, comm
+
+
+def launch_check(timeout=60.0):
+    """Rendezvous of a launch WITHOUT a device (``bench.py --launch-check``):
+    rank 0 serves a 128-byte token over the TCP rendezvous, every other rank
+    fetches it; returns ``(rank, world, token_ok)``.  Exercises the launcher's
+    environment (RANK / WORLD_SIZE / MASTER_*) and the socket path on a CPU box.
+    """
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 17
+    token = _launch_tag(port) * 8
+    if world <= 1:
+        return rank, world, True
+    if rank == 0:
+        _serve_uid(addr, port, token, world, timeout)
+        return rank, world, True
+    return rank, world, _fetch_uid(addr, port, timeout) == token
 
 
 # ---------------------------------------------------------------------------

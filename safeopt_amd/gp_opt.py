@@ -36,56 +36,76 @@ __all__ = ['SafeOpt', 'SafeOptSwarm']
 _I64_MAX = np.iinfo(np.int64).max
 
 
-class GaussianProcessOptimization(object):
-    """Base class: GP list, ``fmin``, ``beta``, ``scaling``, data plumbing.
+def _one_per_gp(value, count):
+    """``value`` as a 1-d array with one entry per GP: a list is taken as it
+    is, anything else is repeated for every GP (``fmin``, ``lipschitz``)."""
+    items = value if isinstance(value, list) else [value] * count
+    return np.atleast_1d(np.asarray(items).squeeze())
 
-    Parameters follow ``gp_opt.py:30-99`` of the reference.
+
+def _prior_std(gps):
+    """``sqrt(k(x, x))`` of every GP (stationary kernels: taken at the origin);
+    this is what ``scaling='auto'`` means in the reference (gp_opt.py:80-83)."""
+    origin = np.zeros((1, gps[0].input_dim))
+    return np.sqrt(np.array([g.kern.Kdiag(origin)[0] for g in gps]))
+
+
+def _with_context(x, context):
+    """``x`` (m, d) with the context columns appended to every row."""
+    context = np.atleast_2d(context)
+    out = np.empty((x.shape[0], x.shape[1] + context.shape[1]), dtype=float)
+    out[:, :x.shape[1]] = x
+    out[:, x.shape[1]:] = context
+    return out
+
+
+class GaussianProcessOptimization(object):
+    """What SafeOpt and SafeOptSwarm share: the GP handles, ``fmin``,
+    ``beta(t)``, ``scaling``, ``threshold`` and the measurement log.
+
+    Same constructor, attributes and methods as the base class of the
+    reference (``gp_opt.py:30-278``): ``gps`` / ``gp``, ``fmin`` (one per GP),
+    ``beta`` (always callable), ``scaling``, ``x`` / ``y`` / ``data`` / ``t``,
+    ``add_new_data_point`` / ``remove_last_data_point``.
     """
 
     def __init__(self, gp, fmin, beta=2, num_contexts=0, threshold=0,
                  scaling='auto'):
         self.gps = gp if isinstance(gp, list) else [gp]
-        self.gp = self.gps[0]
         if len(self.gps) > _hip.MAX_GPS:
             raise ValueError("at most %d GPs are supported" % _hip.MAX_GPS)
+        self.gp = self.gps[0]                    # GP 0 = the objective
+        n_gps = len(self.gps)
 
-        self.fmin = fmin
-        if not isinstance(self.fmin, list):
-            self.fmin = [self.fmin] * len(self.gps)
-        self.fmin = np.atleast_1d(np.asarray(self.fmin).squeeze())
-
-        if hasattr(beta, '__call__'):
-            self.beta = beta
-        else:
-            self.beta = lambda t: beta
+        self.fmin = _one_per_gp(fmin, n_gps)
+        self.beta = beta if callable(beta) else (lambda t: beta)
+        self.threshold = threshold
+        self.num_contexts = num_contexts
 
         if isinstance(scaling, str) and scaling == 'auto':
-            dummy = np.zeros((1, self.gps[0].input_dim))
-            self.scaling = np.sqrt(np.asarray(
-                [g.kern.Kdiag(dummy)[0] for g in self.gps]))
+            self.scaling = _prior_std(self.gps)
         else:
             self.scaling = np.asarray(scaling)
-            if self.scaling.shape[0] != len(self.gps):
+            if self.scaling.shape[0] != n_gps:
                 raise ValueError("The number of scaling values should be "
                                  "equal to the number of GPs")
 
-        self.threshold = threshold
+        # filled in by the subclasses that discretise the domain
         self._parameter_set = None
         self.bounds = None
         self.num_samples = 0
-        self.num_contexts = num_contexts
 
-        self._x = None
-        self._y = None
-        self._get_initial_xy()
+        # measurement log: every GP must start from the same inputs
+        for other in self.gps[1:]:
+            if not np.allclose(self.gp.X, other.X):
+                raise NotImplementedError('The GPs have different '
+                                          'measurements.')
+        self._x = self.gp.X
+        self._y = np.concatenate([g.Y for g in self.gps], axis=1)
 
-    @property
-    def x(self):
-        return self._x
-
-    @property
-    def y(self):
-        return self._y
+    # -- measurement log ----------------------------------------------------------
+    x = property(lambda self: self._x)
+    y = property(lambda self: self._y)
 
     @property
     def data(self):
@@ -97,17 +117,6 @@ class GaussianProcessOptimization(object):
         """Time step = number of measurements."""
         return self._x.shape[0]
 
-    def _get_initial_xy(self):
-        self._x = self.gp.X
-        ys = [self.gp.Y]
-        for gp in self.gps[1:]:
-            if np.allclose(self._x, gp.X):
-                ys.append(gp.Y)
-            else:
-                raise NotImplementedError('The GPs have different '
-                                          'measurements.')
-        self._y = np.concatenate(ys, axis=1)
-
     def plot(self, *args, **kwargs):
         raise NotImplementedError(
             "plotting is outside the accelerated path (SURVEY.md section 2, "
@@ -115,43 +124,39 @@ class GaussianProcessOptimization(object):
             "matplotlib directly")
 
     def _add_context(self, x, context):
-        context = np.atleast_2d(context)
-        nc = context.shape[1]
-        x2 = np.empty((x.shape[0], x.shape[1] + nc), dtype=float)
-        x2[:, :x.shape[1]] = x
-        x2[:, x.shape[1]:] = context
-        return x2
+        return _with_context(x, context)
 
     def _add_data_point(self, gp, x, y, context=None):
-        """Append ``(x, y)`` to one GP only (does not touch ``self.x/y``)."""
-        if context is not None:
-            x = self._add_context(x, context)
-        gp.set_XY(np.vstack([gp.X, x]), np.vstack([gp.Y, y]))
+        """Append ``(x, y)`` to one GP only (``self.x`` / ``self.y`` untouched).
+        One more row than before: the handle turns this ``set_XY`` into a
+        bordered update of the factor (``sgp_gp_append``)."""
+        rows = x if context is None else _with_context(x, context)
+        gp.set_XY(np.vstack([gp.X, rows]), np.vstack([gp.Y, y]))
 
     def add_new_data_point(self, x, y, context=None):
-        """Add a measurement; ``nan`` entries of ``y`` skip that GP."""
-        x = np.atleast_2d(x)
-        y = np.atleast_2d(y)
+        """Log a measurement and hand it to the GPs; a ``nan`` in column ``i``
+        of ``y`` means GP ``i`` did not observe it."""
+        x, y = np.atleast_2d(x), np.atleast_2d(y)
         if self.num_contexts:
-            x = self._add_context(x, context)
+            x = _with_context(x, context)
         for i, gp in enumerate(self.gps):
-            ok = ~np.isnan(y[:, i])
-            if np.any(ok):
-                self._add_data_point(gp, x[ok, :], y[ok, [i]])
+            seen = ~np.isnan(y[:, i])
+            if seen.any():
+                self._add_data_point(gp, x[seen, :], y[seen, [i]])
         self._x = np.concatenate((self._x, x), axis=0)
         self._y = np.concatenate((self._y, y), axis=0)
 
     def _remove_last_data_point(self, gp):
+        """Drop the newest row of one GP (a one-row ``sgp_gp_pop``)."""
         gp.set_XY(gp.X[:-1, :], gp.Y[:-1, :])
 
     def remove_last_data_point(self):
-        """Undo the last ``add_new_data_point``."""
-        last_y = self._y[-1]
-        for gp, yi in zip(self.gps, last_y):
-            if not np.isnan(yi):
-                gp.set_XY(gp.X[:-1, :], gp.Y[:-1, :])
-        self._x = self._x[:-1, :]
-        self._y = self._y[:-1, :]
+        """Undo the last ``add_new_data_point``: every GP that observed the
+        newest measurement forgets it, then the log is shortened."""
+        for gp, value in zip(self.gps, self._y[-1]):
+            if not np.isnan(value):
+                self._remove_last_data_point(gp)
+        self._x, self._y = self._x[:-1, :], self._y[:-1, :]
 
 
 class _HipGridBackend(object):
@@ -160,7 +165,14 @@ class _HipGridBackend(object):
     NumPy stand-in to exercise the sharded host logic without a GPU.)"""
 
     def __init__(self, gps, inputs_shard, global_offset, ctx=None):
-        self.ctx = ctx if ctx is not None else _hip.Context.default()
+        # the grid must live in the context of its GPs (stream ordering, device
+        # pointers) and of the communicator (in-stream collectives)
+        gp_ctx = getattr(gps[0], '_ctx', None)
+        self.ctx = ctx or gp_ctx or _hip.Context.default()
+        if gp_ctx is not None and gp_ctx is not self.ctx:
+            raise ValueError("the GPs live on HIP device %d but the communicator"
+                             " / grid context is device %d"
+                             % (gp_ctx.device, self.ctx.device))
         self.gps = gps
         self.grid = _hip.DeviceGrid(self.ctx, inputs_shard, len(gps),
                                     global_offset)
@@ -178,6 +190,24 @@ class _HipGridBackend(object):
     def _dev(self):
         return [g._fitted() for g in self.gps]
 
+    def _tags(self, devs):
+        # (serial number of the device GP, its data version): serials are never
+        # reused, unlike id(), so a re-created handle cannot alias an old tag
+        return [(dv.serial, dv.version) for dv in devs]
+
+    def posterior_is_current(self):
+        """Do the resident mean / var describe the GPs as they are now?"""
+        return self._seen == self._tags(self._dev())
+
+    def refresh_posterior(self):
+        """Resident mean / var of every GP from a fresh sweep, ``Q`` and ``S``
+        untouched (after ``opt.Q = ...`` or a data change without an interval
+        update: the GP expander test reads mean / var, gp_opt.py:585-602)."""
+        devs = self._dev()
+        self.grid.posterior(devs)
+        self._seen = self._tags(devs)
+        self._rank1_streak = 0
+
     def owns(self, gidx):
         return self.lo <= gidx < self.hi
 
@@ -187,23 +217,26 @@ class _HipGridBackend(object):
 
     def confidence(self, beta, fmin, defer=False):
         devs = self._dev()
-        tags = [(id(dv), dv.version) for dv in devs]
+        tags = self._tags(devs)
         which = [0] * len(devs)
         rank1 = self.incremental and self._rank1_streak < self.refresh_every
         for i, dv in enumerate(devs):
             if self._seen[i] == tags[i]:
                 continue                                  # up to date
             if (rank1 and dv.appended and self._seen[i] is not None
-                    and self._seen[i] == (id(dv), dv.version - 1)):
+                    and self._seen[i] == (dv.serial, dv.version - 1)):
                 which[i] = 1                              # one append behind
             else:
                 rank1 = False
-        self._seen = tags
+        self._seen = [None] * len(devs)          # unknown until the call is through
         if rank1 and any(which):
+            out = self.grid.rank1_update(devs, which, beta, fmin, defer)
             self._rank1_streak += 1
-            return self.grid.rank1_update(devs, which, beta, fmin, defer)
-        self._rank1_streak = 0
-        return self.grid.confidence(devs, beta, fmin, defer)
+        else:
+            out = self.grid.confidence(devs, beta, fmin, defer)
+            self._rank1_streak = 0
+        self._seen = tags
+        return out
 
     def upload_Q(self, Q, fmin):
         self._seen = [None] * len(self.gps)      # mean/var no longer match Q
@@ -292,38 +325,38 @@ class SafeOpt(GaussianProcessOptimization):
         super(SafeOpt, self).__init__(gp, fmin=fmin, beta=beta,
                                       num_contexts=num_contexts,
                                       threshold=threshold, scaling=scaling)
-        parameter_set = np.asarray(parameter_set)
-        if self.num_contexts > 0:
-            ctx_shape = (parameter_set.shape[0], self.num_contexts)
-            self.inputs = np.hstack((parameter_set,
-                                     np.zeros(ctx_shape,
-                                              dtype=parameter_set.dtype)))
-            self.parameter_set = self.inputs[:, :-self.num_contexts]
+        # candidate rows = parameters (+ zeroed context columns that the context
+        # setter fills); `parameter_set` stays a view of the parameter columns
+        params = np.asarray(parameter_set)
+        if self.num_contexts:
+            self.inputs = np.hstack(
+                (params, np.zeros((params.shape[0], self.num_contexts),
+                                  dtype=params.dtype)))
+            self.parameter_set = self.inputs[:, :params.shape[1]]
         else:
-            self.inputs = self.parameter_set = parameter_set
+            self.inputs = self.parameter_set = params
 
-        self.liptschitz = lipschitz
-        if self.liptschitz is not None:
-            if not isinstance(self.liptschitz, list):
-                self.liptschitz = [self.liptschitz] * len(self.gps)
-            self.liptschitz = np.atleast_1d(
-                np.asarray(self.liptschitz).squeeze())
+        # attribute name as spelled by the reference (gp_opt.py:366)
+        self.liptschitz = (None if lipschitz is None
+                           else _one_per_gp(lipschitz, len(self.gps)))
         self._use_lipschitz = lipschitz is not None
 
+        # host mirrors of the resident arrays, with the reference's dtypes and
+        # shapes (gp_opt.py:374-390); refreshed from HBM only when read
         N = self.inputs.shape[0]
-        # host mirrors of the resident arrays (same dtypes / shapes as the
-        # reference: gp_opt.py:374-390)
         self._Q = np.empty((N, 2 * len(self.gps)), dtype=float)
-        self._S = np.zeros(N, dtype=bool)
-        self._G = self._S.copy()
-        self._M = self._S.copy()
+        self._S, self._M, self._G = (np.zeros(N, dtype=bool) for _ in range(3))
         self._stale = dict(Q=False, S=False, M=False, G=False)
 
+        # this rank's contiguous block of rows, resident on its GPU
         self._comm = comm if comm is not None else LocalComm()
-        lo, hi = shard_range(N, self._comm.rank, self._comm.world)
-        self._shard = (lo, hi)
-        factory = _backend_factory or _HipGridBackend
-        self._backend = factory(self.gps, self.inputs[lo:hi], lo)
+        self._shard = shard_range(N, self._comm.rank, self._comm.world)
+        lo, hi = self._shard
+        if _backend_factory is not None:          # tests: NumPy stand-in
+            self._backend = _backend_factory(self.gps, self.inputs[lo:hi], lo)
+        else:
+            self._backend = _HipGridBackend(self.gps, self.inputs[lo:hi], lo,
+                                            ctx=getattr(self._comm, 'ctx', None))
         self._any_safe = False
         self._max_l = -np.inf
         self._ci_fresh = False
@@ -388,8 +421,8 @@ class SafeOpt(GaussianProcessOptimization):
     # -- reference properties ---------------------------------------------------
     @property
     def use_lipschitz(self):
-        """Whether the Lipschitz constant (instead of the GP confidence
-        intervals) certifies expanders."""
+        """True: expanders are certified with the Lipschitz constant, False:
+        with the GP confidence intervals."""
         return self._use_lipschitz
 
     @use_lipschitz.setter
@@ -400,41 +433,42 @@ class SafeOpt(GaussianProcessOptimization):
 
     @property
     def parameter_set(self):
-        """Discrete parameter samples."""
+        """Discrete parameter samples (without context columns)."""
         return self._parameter_set
 
     @parameter_set.setter
     def parameter_set(self, parameter_set):
+        cols = parameter_set.T
         self._parameter_set = parameter_set
-        self.bounds = list(zip(np.min(self._parameter_set, axis=0),
-                               np.max(self._parameter_set, axis=0)))
-        self.num_samples = [len(np.unique(self._parameter_set[:, i]))
-                            for i in range(self._parameter_set.shape[1])]
+        self.bounds = [(c.min(), c.max()) for c in cols]
+        self.num_samples = [np.unique(c).size for c in cols]
+
+    def _context_columns(self):
+        return self.inputs[0, self.inputs.shape[1] - self.num_contexts:]
 
     @property
     def context_fixed_inputs(self):
-        """Fixed inputs (column, value) of the current context."""
-        n = self.gp.input_dim - 1
-        nc = self.num_contexts
-        if nc > 0:
-            contexts = self.inputs[0, -self.num_contexts:]
-            return list(zip(range(n, n - nc, -1), contexts))
+        """``[(column, value), ...]`` of the inputs the current context fixes
+        (counted down from the last GP input, as the reference's plots expect)."""
+        if self.num_contexts > 0:
+            last = self.gp.input_dim - 1
+            return [(last - k, v) for k, v in enumerate(self._context_columns())]
 
     @property
     def context(self):
         """Current context variables."""
         if self.num_contexts:
-            return self.inputs[0, -self.num_contexts:]
+            return self._context_columns()
 
     @context.setter
     def context(self, context):
-        if self.num_contexts:
-            if context is None:
-                raise ValueError('Need to provide value for context.')
-            self.inputs[:, -self.num_contexts:] = context
-            self._backend.set_context(
-                np.asarray(self.inputs[0, -self.num_contexts:], dtype=float))
-            self._ci_fresh = False
+        if not self.num_contexts:
+            return
+        if context is None:
+            raise ValueError('Need to provide value for context.')
+        self.inputs[:, self.inputs.shape[1] - self.num_contexts:] = context
+        self._backend.set_context(np.asarray(self._context_columns(), dtype=float))
+        self._ci_fresh = False
 
     # -- the hot path -------------------------------------------------------------
     def update_confidence_intervals(self, context=None, _defer=False):
@@ -479,6 +513,12 @@ class SafeOpt(GaussianProcessOptimization):
         self.compute_safe_set()
         be = self._backend
         G = len(self.gps)
+        # the GP expander test updates the RESIDENT posterior in closed form
+        # (the reference re-predicts from the GP, gp_opt.py:585-602): bring it
+        # up to date if the intervals were assigned by hand or the data changed
+        if (not self.use_lipschitz and hasattr(be, 'posterior_is_current')
+                and not be.posterior_is_current()):
+            be.refresh_posterior()
         thr_beta = np.broadcast_to(
             np.asarray(self.threshold, dtype=float) * beta, (G,)).copy()
 
@@ -827,91 +867,102 @@ class SafeOptSwarm(GaussianProcessOptimization):
             self.scaling, self.best_lower_bound)
         return values, safe
 
+    # -- one swarm run, in the steps of gp_opt.py:1015-1134 -------------------------
+    def _recheck_safe_set(self):
+        """The stored safe points under the CURRENT posterior: raise if none is
+        safe any more, drop the unsafe ones unless that would leave fewer than
+        one swarm's worth of points."""
+        _, still_safe = self._compute_particle_fitness('safe_set', self.S)
+        kept = int(still_safe.sum())
+        if kept == 0:
+            raise RuntimeError('The safe set is empty.')
+        if self.swarm_size <= kept < len(still_safe):
+            logging.warning("Warning: {} unsafe points removed. "
+                            "Model might be violated"
+                            .format(np.count_nonzero(~still_safe)))
+            self.S = self.S[still_safe]
+
+    def _initial_particles(self, swarm_type):
+        """Start positions: uniform draws (with replacement, NumPy's global
+        stream -- one ``randint`` call, as in the reference) from the safe set;
+        the greedy swarm swaps three of them for the previous greedy point, the
+        newest observation and the best observation."""
+        fixed = []
+        if swarm_type == 'greedy':
+            fixed = [self.greedy_point, self.gp.X[-1, :],
+                     self.gp.X[np.argmax(self.gp.Y)]]
+        picks = np.random.randint(self.S.shape[0],
+                                  size=self.swarm_size - len(fixed))
+        return np.vstack([self.S[picks, :]] + fixed)
+
+    def _grow_safe_set(self, swarm, swarm_type):
+        """Append the swarm's personal bests that are at most 0.95-correlated
+        (prior correlation of GP 0) with everything already in the safe set,
+        in order.  The correlation filter runs on the device (``sgp_swarm_grow``);
+        the m x (|S| + m) covariance matrix of gp_opt.py:1093 is never formed."""
+        gp0 = self.gp._fitted()
+        keep = _hip.swarm_grow(gp0.ctx, gp0, self.S, swarm.best_positions,
+                               self.scaling[0] ** 2, 0.95)
+        added = int(np.count_nonzero(keep))
+        if added:
+            self.S = np.vstack((self.S, swarm.best_positions[keep]))
+        logging.debug("At the end of swarm {}, {} points were appended to"
+                      " the safeset".format(swarm_type, added))
+
+    def _lower_bound_at(self, x, beta):
+        mean, var = self.gp.predict_noiseless(x[None, :])
+        return mean.squeeze() - beta * np.sqrt(var.squeeze())
+
     def get_new_query_point(self, swarm_type):
         """Run one swarm (``'greedy' | 'maximizers' | 'expanders'``).
 
         Returns ``(global_best, value)`` for the greedy swarm and
-        ``(global_best, std_devs)`` otherwise.
+        ``(global_best, std_devs)`` -- one posterior standard deviation per GP
+        at the chosen point -- otherwise.
         """
         beta = self.beta(self.t)
-        safe_size, input_dim = self.S.shape
-
-        _, safe = self._compute_particle_fitness('safe_set', self.S)
-        num_safe = safe.sum()
-        if num_safe == 0:
-            raise RuntimeError('The safe set is empty.')
-
-        if num_safe >= self.swarm_size and num_safe != len(safe):
-            logging.warning("Warning: {} unsafe points removed. "
-                            "Model might be violated"
-                            .format(np.count_nonzero(~safe)))
-            self.S = self.S[safe]
-            safe_size = self.S.shape[0]
-
-        if swarm_type == 'greedy':
-            random_id = np.random.randint(safe_size, size=self.swarm_size - 3)
-            best_sampled_point = np.argmax(self.gp.Y)
-            particles = np.vstack((self.S[random_id, :],
-                                   self.greedy_point,
-                                   self.gp.X[-1, :],
-                                   self.gp.X[best_sampled_point]))
-        else:
-            random_id = np.random.randint(safe_size, size=self.swarm_size)
-            particles = self.S[random_id, :]
+        self._recheck_safe_set()
 
         swarm = self.swarms[swarm_type]
-        swarm.init_swarm(particles)
+        swarm.init_swarm(self._initial_particles(swarm_type))
         swarm.run_swarm(self.max_iters)
 
-        if swarm_type != 'greedy':
-            # correlation filter of gp_opt.py:1089-1111 on the device: the
-            # n x (m + n) covariance matrix is never formed
-            gp0 = self.gp._fitted()
-            accept = _hip.swarm_grow(gp0.ctx, gp0, self.S,
-                                     swarm.best_positions,
-                                     self.scaling[0] ** 2, 0.95)
-            num_added = int(np.count_nonzero(accept))
-            if num_added:
-                self.S = np.vstack((self.S, swarm.best_positions[accept]))
-            logging.debug("At the end of swarm {}, {} points were appended to"
-                          " the safeset".format(swarm_type, num_added))
-        else:
-            mean, var = self.gp.predict_noiseless(self.greedy_point[None, :])
-            lower_bound = mean.squeeze() - beta * np.sqrt(var.squeeze())
-            if lower_bound < np.max(swarm.best_values):
-                self.greedy_point = swarm.global_best.copy()
-
         if swarm_type == 'greedy':
-            return swarm.global_best.copy(), np.max(swarm.best_values)
+            # keep the better of the old and the new estimate of the optimum
+            best_value = np.max(swarm.best_values)
+            if self._lower_bound_at(self.greedy_point, beta) < best_value:
+                self.greedy_point = swarm.global_best.copy()
+            return swarm.global_best.copy(), best_value
 
-        var = np.empty(len(self.gps), dtype=float)
-        for i, gp in enumerate(self.gps):
-            var[i] = gp.predict_noiseless(swarm.global_best[None, :])[1].item()
-        return swarm.global_best, np.sqrt(var)
+        self._grow_safe_set(swarm, swarm_type)
+        point = swarm.global_best
+        std = np.sqrt([gp.predict_noiseless(point[None, :])[1].item()
+                       for gp in self.gps])
+        return point, std
 
     def optimize(self, ucb=False):
-        """One SafeOptSwarm step; returns the next parameters to evaluate."""
+        """One SafeOptSwarm step; returns the next parameters to evaluate:
+        the best maximiser, or the best expander when that one is at least as
+        uncertain (``ucb=True``: always the maximiser)."""
         self.greedy, self.best_lower_bound = self.get_new_query_point('greedy')
 
         x_maxi, std_maxi = self.get_new_query_point('maximizers')
         if ucb:
             logging.info('Using ucb criterion.')
             return x_maxi
-
         x_exp, std_exp = self.get_new_query_point('expanders')
-        std_exp[(std_exp < self.threshold) | (self.fmin == -np.inf)] = 0
-        std_exp /= self.scaling
-        std_exp = np.max(std_exp)
+
+        # expander uncertainty: only GPs that carry a constraint and are above
+        # the threshold count, each in units of its prior std
+        counts = (std_exp >= self.threshold) & (self.fmin != -np.inf)
+        std_exp = np.max(np.where(counts, std_exp, 0.) / self.scaling)
         std_maxi = std_maxi[0] / self.scaling[0]
 
         logging.info("The best maximizer has std. dev. %f" % std_maxi)
         logging.info("The best expander has std. dev. %f" % std_exp)
         logging.info("The greedy estimate of lower bound has value %f" %
                      self.best_lower_bound)
-
-        if std_maxi > std_exp:
-            return x_maxi
-        return x_exp
+        return x_maxi if std_maxi > std_exp else x_exp
 
     def get_maximum(self):
         """Best observed point ``(x, y)``."""

@@ -251,6 +251,6 @@ class GPRegression(object):
         return mean, var
 
 
-kern = _types.SimpleNamespace(RBF=RBF, Matern32=Matern32, Matern52=Matern52,
+kern = _types.SimpleNamespace(Kern=_Kern, RBF=RBF, Matern32=Matern32, Matern52=Matern52,
                               Prod=Prod)
 models = _types.SimpleNamespace(GPRegression=GPRegression)

@@ -168,3 +168,55 @@ def test_three_way_shard_single_process():
         x, S, M, G = out[r]
         assert np.array_equal(x, z["x_next"]) and np.array_equal(S, z["S"])
         assert np.array_equal(M, z["M"]) and np.array_equal(G, z["G"])
+
+
+# ---------------------------------------------------------------------------
+# the launcher: `python bench.py --gpus N` from a bare shell
+def test_bench_spawns_its_own_ranks():
+    """bench.py --gpus 2 with no torchrun environment starts two ranks itself
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), they rendezvous over the
+    product's TCP helpers and rank 0 alone prints the JSON line."""
+    import json, subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2",
+                          "--launch-check"], capture_output=True, text=True, env=env,
+                         timeout=120, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j == {"launch_check": True, "n_gpus": 2, "local_rank": 0}
+
+
+def test_file_rendezvous_rejects_foreign_and_stale_files(tmp_path, monkeypatch):
+    """Readers of the single-node rendezvous only accept a file that carries
+    this launch's tag; rank 0 replaces a left-over file."""
+    sys.path.insert(0, REPO)
+    from safeopt_amd import dist
+    monkeypatch.setenv("SAFEOPT_RDZV_DIR", str(tmp_path))
+    os.chmod(str(tmp_path), 0o700)
+    monkeypatch.setenv("SAFEOPT_RDZV_NONCE", "launch-A")
+    tag_a = dist._launch_tag(4711)
+    path = os.path.join(str(tmp_path), "rdzv_%d_%d_%s.bin" % (os.getppid(), 4711, tag_a.hex()[:8]))
+    monkeypatch.setenv("SAFEOPT_RDZV_NONCE", "launch-B")
+    assert dist._launch_tag(4711) != tag_a
+    # a file of another launch under the name a reader of launch A polls
+    with open(path, "wb") as f:
+        f.write(b"x" * 128 + dist._launch_tag(4711))
+    monkeypatch.setenv("SAFEOPT_RDZV_NONCE", "launch-A")
+    with pytest.raises(RuntimeError, match="did not appear"):
+        dist._file_rendezvous(1, 2, 4711, timeout=0.3)
+    # the right tag is accepted
+    with open(path, "wb") as f:
+        f.write(b"u" * 128 + tag_a)
+    uid, _ = dist._file_rendezvous(1, 2, 4711, timeout=2.0)
+    assert uid == b"u" * 128
+    # truncated connection on the TCP path is an error, not a spin
+    import socket, threading
+    srv = socket.socket(); srv.bind(("127.0.0.1", 0)); srv.listen(1)
+    port = srv.getsockname()[1]
+    t = threading.Thread(target=lambda: srv.accept()[0].close()); t.start()
+    with pytest.raises(RuntimeError, match="closed early"):
+        dist._fetch_uid("127.0.0.1", port, timeout=5.0)
+    t.join(); srv.close()

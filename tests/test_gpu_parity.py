@@ -524,21 +524,31 @@ def test_full_size_config2(mods):
     assert_array_equal(opt.optimize(), x)
 
 
-@pytest.mark.parametrize("k", [3, 4])
-def test_full_size_configs_3_and_4(mods, k):
-    """BASELINE.json configs[2] (Matern-5/2, 3 GPs, n=500, 1e6 rows) and one
-    rank's share of configs[3] (3-D RBF, n=1000, 1e6 rows) at FULL size: spot
-    rows against the oracle + the size-independent properties of the path."""
+@pytest.mark.parametrize("k,shard", [(3, None), (4, 4), (4, 0)])
+def test_full_size_configs_3_and_4(mods, k, shard):
+    """BASELINE.json configs[2] (Matern-5/2, 3 GPs, n=500, 1e6 rows) and TRUE
+    shards of configs[3] (3-D RBF, n=1000, the 200^3 grid row-sharded over 8
+    ranks in contiguous blocks of the flat index: rank 4's rows [4e6, 5e6),
+    which cut through the data, and rank 0's rows [0, 1e6) at its edge) at
+    FULL size: spot rows against the oracle + the size-independent properties."""
     safeopt_amd, gpy, gpn, son = mods
     from bench import make_config, build_gps
+    from safeopt_amd.dist import shard_range
     cfg = make_config(k)
     G = cfg["G"]
     gps, gos = build_gps(cfg, gpy), build_gps(cfg, gpn)
     grid = cfg["grid"]
+    if shard is not None:
+        lo, hi = shard_range(grid.shape[0], shard, 8)
+        assert (lo, hi) == (shard * 1000000, (shard + 1) * 1000000)
+        grid = grid[lo:hi]
     fmin = np.asarray(cfg["fmin"], dtype=float)
     opt = safeopt_amd.SafeOpt(gps if G > 1 else gps[0], grid, cfg["fmin"] if G > 1 else 0.,
                               threshold=cfg["threshold"])
-    x = opt.optimize()
+    try:
+        x = opt.optimize()
+    except EnvironmentError:          # a block without a safe row (gp_opt.py:632)
+        x = None
     Q = opt.Q
     rows = np.random.default_rng(k).choice(grid.shape[0], 3000, replace=False)
     for g in range(G):
@@ -550,7 +560,11 @@ def test_full_size_configs_3_and_4(mods, k):
     assert np.all(up >= lo)
     S = np.all(lo > fmin, axis=1)
     assert_array_equal(opt.S, S)
-    assert S.any() and not S.all()
+    assert (x is None) == (not S.any())
+    if x is None:
+        assert not opt.M.any() and not opt.G.any() and opt.get_maximum() is None
+        return
+    assert not S.all() and (shard != 4 or S.sum() > 1000)
     assert_array_equal(opt.M, S & (up[:, 0] >= lo[S, 0].max()))
     assert np.all(opt.G <= opt.S) and opt.G.sum() <= 1
     MG = opt.M | opt.G
