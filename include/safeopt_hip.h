@@ -277,24 +277,6 @@ int sgp_timer_stop(sgp_ctx* ctx, float* ms);
 int sgp_profile_enable(sgp_ctx* ctx, int on);
 int sgp_profile_read(sgp_ctx* ctx, double* total_ms, int64_t* launches,
                      double* flops);
-/* fp64 MFMA issue-rate microbenchmark (v_mfma_f64_4x4x4_4b_f64), TFLOP/s     */
-int sgp_microbench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops);
-/* issue-rate probes (scripts/microbench.py, scripts/stagebench.py):
- *   mode 0/1/5 = 8/4/16 chains of v_mfma_f64_16x16x4_f64, 2/4 = that + 8/2
- *   v_fma_f64 per MFMA, 3 = v_fma_f64 only, 6/7/8 = 16/4/2 chains of
- *   v_mfma_f64_4x4x4_4b_f64, 9 = the sweep's operand pattern; lds_bytes of
- *   dynamic LDS only limit residency; tflops2 = {MFMA, VALU-FMA} TFLOP/s.
- *   mode 20..24 = one stage of the sweep's inner loop in isolation (MFMAs; +
- *   barrier; + LDS-DMA; + covariance evaluation; evaluation + MFMAs), with
- *   lds_bytes = first active accumulator slot; tflops2 = {MFMA TFLOP/s,
- *   ns per stage}.                                                           */
-int sgp_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
-                   double* tflops2);
-/* operand-layout probe (test hook): ONE v_mfma_f64_16x16x4_f64 (which = 0;
- * c, d hold 4 values per lane) or v_mfma_f64_4x4x4_4b_f64 (which = 1; 1 value
- * per lane) with the given per-lane operands                                  */
-int sgp_probe_mfma(sgp_ctx* ctx, int which, const double* a64, const double* b64,
-                   const double* c, double* d);
 
 #ifdef __cplusplus
 }

@@ -114,10 +114,7 @@ PROTOTYPES = {
     "sgp_timer_stop": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "sgp_profile_enable": (C.c_int, [vp, C.c_int]),
     "sgp_profile_read": (C.c_int, [vp, c_double_p, c_i64_p, c_double_p]),
-    "sgp_microbench_mfma_f64": (C.c_int, [vp, C.c_int, c_double_p]),
-    "sgp_microbench": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_double_p]),
-    "sgp_probe_mfma": (C.c_int, [vp, C.c_int, c_double_p, c_double_p,
-                                 c_double_p, c_double_p]),
+
 }
 
 _lib = None
@@ -242,25 +239,6 @@ class Context(object):
         self.check(lib().sgp_profile_read(self.h, C.byref(ms), C.byref(n),
                                           C.byref(fl)))
         return ms.value, n.value, fl.value
-
-    def microbench_mfma_f64(self, iters=20000):
-        t = C.c_double(0)
-        self.check(lib().sgp_microbench_mfma_f64(self.h, iters, C.byref(t)))
-        return t.value
-
-    def probe_mfma(self, which, a, b, c=None):
-        a, b = f64(a).reshape(64), f64(b).reshape(64)
-        nc = 256 if which == 0 else 64
-        c = np.zeros(nc) if c is None else f64(c).reshape(nc)
-        d = np.empty(nc)
-        self.check(lib().sgp_probe_mfma(self.h, which, dptr(a), dptr(b),
-                                        dptr(c), dptr(d)))
-        return d
-
-    def microbench(self, mode, iters=20000, lds_bytes=0):
-        t = np.zeros(2)
-        self.check(lib().sgp_microbench(self.h, mode, iters, lds_bytes, dptr(t)))
-        return float(t[0]), float(t[1])
 
     # -- RCCL
     @staticmethod

@@ -214,6 +214,7 @@ void sgp_destroy(sgp_ctx* ctx) {
     g_rccl.CommDestroy(static_cast<ncclComm_t>(ctx->comm));
   for (auto& b : ctx->scratch)
     if (b.p) (void)hipFree(b.p);
+  if (ctx->stage_tab.p) (void)hipFree(ctx->stage_tab.p);
   for (auto e : ctx->prof_events) (void)hipEventDestroy(e);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -438,7 +439,7 @@ int sgp_grid_create(sgp_ctx* ctx, const double* base, int64_t N, int d,
   g->G = G;
   g->goff = global_offset;
   const size_t nd = size_t(N) * sizeof(double);
-  g->partial_cap = N / 64 + 2;
+  g->partial_cap = N / 16 + 32;
   struct {
     void** p;
     size_t bytes;
@@ -1285,33 +1286,6 @@ int sgp_profile_read(sgp_ctx* ctx, double* total_ms, int64_t* launches,
   *launches = int64_t(ctx->prof_used / 2);
   *flops = ctx->prof_flops;
   return 0;
-}
-
-int sgp_microbench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops) {
-  SGP_HIP(ctx, hipSetDevice(ctx->device));
-  double t[2];
-  SGP_TRY(launch_microbench(ctx, 7, iters, 0, t));  // v_mfma_f64_4x4x4_4b_f64 chains
-  *tflops = t[0];
-  return 0;
-}
-
-int sgp_probe_mfma(sgp_ctx* ctx, int which, const double* a64, const double* b64,
-                   const double* c, double* d) {
-  SGP_HIP(ctx, hipSetDevice(ctx->device));
-  const int nc = which == 0 ? 256 : 64;
-  double* buf = static_cast<double*>(sgp_scratch(ctx, 0, (128 + 2 * 256) * 8));
-  SGP_CHECK(ctx, buf, "device allocation failed: %s", ctx->err.c_str());
-  SGP_TRY(sgp_h2d(ctx, buf, a64, 64 * 8));
-  SGP_TRY(sgp_h2d(ctx, buf + 64, b64, 64 * 8));
-  SGP_TRY(sgp_h2d(ctx, buf + 128, c, size_t(nc) * 8));
-  SGP_TRY(launch_probe_mfma(ctx, which, buf, buf + 64, buf + 128, buf + 384));
-  return sgp_d2h(ctx, d, buf + 384, size_t(nc) * 8);
-}
-
-int sgp_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
-                   double* tflops2) {
-  SGP_HIP(ctx, hipSetDevice(ctx->device));
-  return launch_microbench(ctx, mode, iters, lds_bytes, tflops2);
 }
 
 // ---- RCCL -----------------------------------------------------------------------

@@ -101,6 +101,10 @@ struct sgp_ctx {
   std::vector<hipEvent_t> prof_events;  // start/stop pairs of sweep launches
   size_t prof_used = 0;
   double prof_flops = 0.0;
+  // stage table of the posterior sweep (sweep.hip: stage_table)
+  DevBuf stage_tab;
+  std::vector<int> stage_sig;
+  int stage_count = 0;
   // RCCL
   void* comm = nullptr;  // ncclComm_t
   int rank = 0, world = 1;
@@ -233,13 +237,9 @@ struct Rank1Args {
   double fmin[SGP_MAX_GPS];
   int which[SGP_MAX_GPS];
 };
-int launch_probe_mfma(sgp_ctx* ctx, int which, const double* a, const double* b,
-                      const double* c, double* d);
 int rank1_num_blocks(int64_t N);
 int launch_rank1(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d,
                  SweepPoints pts, Rank1Args ra);
-int launch_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
-                      double* tflops);
 
 // sets.hip
 int launch_reduce_max(sgp_ctx* ctx, const double* in, int64_t n, double* out);

@@ -128,6 +128,26 @@ __device__ __forceinline__ void sqrt4(const double (&xin)[4], double (&out)[4]) 
   SGP_FENCE();
 }
 
+// The same for strictly positive arguments (no clamp).
+__device__ __forceinline__ void sqrt4_pos(const double (&x)[4], double (&out)[4]) {
+  double y[4], g[4], r[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) y[q] = __builtin_amdgcn_rsq(x[q]);
+  SGP_FENCE();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    g[q] = x[q] * y[q];
+    y[q] = 0.5 * y[q];
+  }
+  SGP_FENCE();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) r[q] = fma(-g[q], g[q], x[q]);
+  SGP_FENCE();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) out[q] = fma(r[q], y[q], g[q]);
+  SGP_FENCE();
+}
+
 __device__ __forceinline__ double k_of_r2(int kind, double r2) {
   if (kind == SGP_RBF) return exp(-0.5 * r2);
   const double r = sqrt(r2);
@@ -259,6 +279,59 @@ struct KernFast {
 #pragma unroll
       for (int q = 0; q < NV; ++q)
         out[q] = kern_eval<D>(*kd, xs, ys + q * stride);
+    }
+  }
+
+  // The sweep's variants with the single-part test resolved at compile time
+  // (no generic product-kernel code, registers or branches in that instance).
+  template <bool SINGLE>
+  __device__ __forceinline__ void prep_t(const double* x, double* xs) const {
+#pragma unroll
+    for (int i = 0; i < D; ++i) xs[i] = SINGLE ? x[i] * sc[i] : x[i];
+  }
+
+  template <bool SINGLE>
+  __device__ __forceinline__ void many4_t(const double* xs, const double* ys,
+                                          int stride, const double* tab,
+                                          double (&out)[4]) const {
+    if (SINGLE) {
+      double r2[4], u[4], e[4], y[4][D];
+      // all the training rows first (one LDS round trip, not four)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < D; ++i) y[q][i] = ys[q * stride + i];
+      SGP_FENCE();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // 1e-300 instead of 0: the square root below needs no clamp, and it is
+        // far below the last bit of any distance that matters
+        r2[q] = 1e-300;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          const double t = xs[i] - y[q][i];
+          r2[q] = fma(t, t, r2[q]);
+        }
+      }
+      if (kind0 == SGP_RBF) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u[q] = -r2[q];
+        exp2_32x4(u, tab, e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q] = var0 * e[q];
+      } else {
+        double rr[4];
+        sqrt4_pos(r2, rr);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u[q] = -rr[q];
+        exp2_32x4(u, tab, e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          out[q] = fma(u[q], fma(u[q], m2, m1), var0) * e[q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[q] = kern_eval<D>(*kd, xs, ys + q * stride);
     }
   }
 

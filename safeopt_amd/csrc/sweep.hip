@@ -6,60 +6,89 @@
 // per-candidate re-prediction of the expander loop (:579-606).
 //
 // For a tile of candidate rows the kernel forms the covariance tile
-// K[j, pt] = k(X_j, x_pt) ON THE FLY in registers, in the (k-step, point) lane
-// order of the fp64 matrix instructions, and contracts it with A = L^-1 (lower
-// triangular, pre-packed in A-operand order) on the fp64 matrix cores
-// (v_mfma_f64_4x4x4_4b_f64, see "matrix part" below):
+// K[j, pt] = k(X_j, x_pt) ON THE FLY in registers and contracts it with
+// A = L^-1 (lower triangular, pre-packed in MFMA operand order) on the fp64
+// matrix cores (v_mfma_f64_4x4x4_4b_f64, see "matrix part" below):
 //     var(pt)  = k(x,x) - || A K[:, pt] ||^2          (n^2 flops / row)
 //     mean(pt) = alpha . K[:, pt]                      (2n flops / row)
-// K (n x N doubles, 1.6 GB at n=200, N=1e6) is never written to memory.
+// K (n x N doubles, 4 GB per GP at n = 500, N = 1e6) is never written to memory.
 //
-// Work split: workgroup = 4 waves = 64 rows, two workgroups per CU (each SIMD
-// hosts one wave of either); wave w owns 16 rows (the MFMA N dimension); the
-// waves of a workgroup share the staged A chunk through LDS.  The rows of A are
-// processed in chunks of 16 MFMA row blocks (256 rows) held in 16 accumulator
-// slots per wave; the triangular structure is exploited at 16x16 block
-// granularity (a j-block only feeds row blocks >= its own index).  The kernel
-// is persistent: 2 x num_CU workgroups walk over the row tiles, and the
-// (tile, GP, chunk, j-block) loop nest is flattened into one stage sequence so
-// that the LDS-DMA of stage s+1 always runs under the MFMAs of stage s.
+// Work split: workgroup = NW waves, wave w owns 16 rows (the MFMA N dimension);
+// the waves of a workgroup share the staged A chunk through LDS (LDS-DMA,
+// double buffered, one barrier per stage).  The rows of A are processed in
+// chunks of 16 MFMA row blocks (256 rows) held in 16 accumulator slots per wave;
+// the triangular structure is exploited at 16x16 block granularity.  The kernel
+// is persistent; the (tile, GP, chunk, j-block) loop nest is flattened into one
+// stage sequence described by a small table the HOST builds (StageEnt), so the
+// per-stage bookkeeping is one scalar load and a few scalar ALU instructions.
+//
+// What sets the speed (profiles/r02/probes.txt): the fp64 MFMA occupies its SIMD
+// for 16 cycles and a co-resident wave gets ONE issue slot per MFMA of its
+// partner, of any instruction type.  Everything that is not an MFMA therefore
+// costs wall time roughly in proportion to its instruction COUNT; the stage loop
+// below is written for few instructions per MFMA:
+//   * accumulator slots are ordered so that the active ones are a prefix
+//     (slot s <-> row block bend-1-s): one compare + branch per executed slot;
+//   * the covariance operand is broadcast to the four column quads through a
+//     wave-private LDS transpose (2 stores + 8 16-byte loads instead of 32
+//     swizzles);
+//   * covariances needed again by a later accumulator chunk are re-evaluated,
+//     not parked in global memory (a slab of 64-459 MB and ~12 GB of traffic per
+//     launch in round 1 for 3-5 %).
 #include <stdio.h>
-#include <algorithm>
 #include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
 
 #include "kern_eval.h"
 
 namespace {
 
-constexpr int kMaxWaves = 8;         // waves per CU at 256 VGPRs
-constexpr int kSweepWaves = 4;       // waves per workgroup (two workgroups per CU)
 constexpr int kIB = 16;                // accumulator slots = 256 rows of L^-1
-constexpr int kJC = 16;                // training points per staged chunk
-constexpr int kSteps = kJC / 4;        // MFMA k-steps per chunk (one j-block)
+constexpr int kJC = 16;                // training points per stage (one j-block)
+constexpr int kSteps = kJC / 4;        // MFMA k-steps per stage
 constexpr int kATile = kIB * kSteps * 64;           // doubles (32 KB)
 constexpr int kXTile = kJC * SGP_MAX_D;             // doubles
 constexpr int kBuf = kATile + kXTile + kJC;         // + alpha chunk
-constexpr int kTabOff = 2 * kBuf + kMaxWaves;           // exp table (32 doubles)
-constexpr size_t kLdsBytes = (size_t(kTabOff) + kExpTabSize) * sizeof(double);
+constexpr int kTabOff = 2 * kBuf;                   // exp table (32 doubles)
+constexpr int kKbRow = 80;     // doubles between the 4 k-rows of a wave's
+                               // broadcast buffer (64 + 16: k-rows on disjoint banks)
+constexpr int kKbBuf = 4 * kKbRow;
+constexpr int kKbOff = kTabOff + kExpTabSize;
+constexpr size_t sweep_lds_bytes(int nw) {
+  return (size_t(kKbOff) + size_t(nw) * kKbBuf) * sizeof(double);
+}
 
 enum { MODE_CONF = 0, MODE_FITNESS = 1 };
+
+// One stage of the flattened (GP, chunk, j-block) sequence of a tile, built on
+// the host (build_stage_table).  Slot s of the staged A chunk holds row block
+// bend-1-s of the chunk, k-steps 4 jb .. 4 jb + 3; its source is
+// Apack + (a_off - s * row_stride) * 64 doubles.
+struct StageEnt {
+  uint32_t a_off;       // (bend - 1) * nsteps_total + 4 jb       [units of 64 doubles]
+  uint32_t row_stride;  // nsteps_total = n_pad / 4               [units of 64 doubles]
+  uint32_t jb;          // j-block: training points 16 jb .. 16 jb + 15
+  uint32_t word;        // see SW_*
+};
+enum : uint32_t {
+  SW_NACT_MASK = 31u,       // active slots 0 .. nact-1 (1..16)
+  SW_CHUNK_END = 1u << 5,   // last j-block of an accumulator chunk: fold
+  SW_GP_END = 1u << 6,      // last stage of a GP: row epilogue
+  SW_TILE_END = 1u << 7,    // last stage of the tile
+  SW_MEAN = 1u << 8,        // stage of the LAST chunk: accumulate alpha . k
+  SW_G_SHIFT = 12           // GP index (3 bits)
+};
 
 // Timing experiments ("what does the kernel cost without X"; results are wrong
 // with any bit set): built only with -DSGP_INSTRUMENT, selected at run time by
 // SGP_ABLATE=<mask>: 1 no stage barrier, 2 no LDS-DMA, 4 no covariance
-// evaluation, 8 no MFMA, 16 no mean/var/Q stores, 32 no per-GP epilogue at all.  profiles/r01/ablation.txt holds the numbers.
+// evaluation, 8 no MFMA, 16 no mean/var/Q stores, 32 no per-GP epilogue at all.
 #ifdef SGP_INSTRUMENT
 #define SGP_ABL(mask) (p.ablate & (mask))
-// cycle stamps of one wave's stage phases (s_memtime; waits for lgkmcnt(0))
-#define SGP_STAMP(k)                                              \
-  if (p.stamps) {                                                 \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
-    stamp_acc[k] += t_ - stamp_last;                              \
-    stamp_last = t_;                                              \
-  }
 #else
 #define SGP_ABL(mask) false
-#define SGP_STAMP(k)
 #endif
 
 struct SweepParams {
@@ -68,35 +97,39 @@ struct SweepParams {
   int mode;
 #ifdef SGP_INSTRUMENT
   int ablate;      // timing experiments (scripts/ablate.py), see SGP_ABL
-  int skew;        // SGP_SKEW: the second workgroup of a CU starts 64*skew cycles late
-  int* cu_count;   // [8 XCC][256] arrival order per compute unit
-  unsigned long long* stamps;   // SGP_STAMPS: [workgroup][wave][8] cycle totals
 #endif
   SweepPoints pts;
   ConfOut conf;
   FitnessArgs fit;
-  // Covariance cache (n > 256 only): the values a lane evaluates in the
-  // triangular part of chunk c are needed again by every later chunk; they are
-  // parked in global memory, [workgroup][wave][j-block][lane][4], and read back
-  // (one stage ahead) instead of being re-evaluated.  nullptr: re-evaluate.
-  double* kvc;
-  int kvc_blocks;   // j-blocks per (workgroup, wave) slab
+  const StageEnt* stages;   // [nstages] one tile's stage sequence (all GPs)
+  int nstages;
+  int single;               // every GP has a one-part kernel (pre-scaled inputs)
 };
 
-// The descriptor fields the stage pipeline touches every iteration, hoisted out
-// of the device array once per GP (they live in SGPRs across the stage loop).
-// (The pointers come out of a descriptor in memory, so the compiler would emit
-// FLAT loads for them; a FLAT load also counts on lgkmcnt, and every LDS wait
-// of the stage would then sit out a global-memory latency.  Hence the explicit
-// global address space.)
 typedef const __attribute__((address_space(1))) double* gptr_t;
+typedef double double2_t __attribute__((ext_vector_type(2)));
+// the stage table is read-only for the whole launch: constant address space, so
+// that an entry is ONE scalar load (a plain global pointer becomes a vector load
+// with a full memory wait, since the kernel also stores to global memory)
+typedef const __attribute__((address_space(4))) StageEnt* stage_ptr_t;
+__device__ __forceinline__ StageEnt load_stage(stage_ptr_t t, int i) {
+  StageEnt e;      // member-wise: one s_load_dwordx4
+  e.a_off = t[i].a_off;
+  e.row_stride = t[i].row_stride;
+  e.jb = t[i].jb;
+  e.word = t[i].word;
+  return e;
+}
+
+// Wave-uniform view of one GP's operands: SGPR-resident base pointers.  (They
+// come out of a descriptor in memory, so the compiler would emit FLAT loads for
+// them; a FLAT load also counts on lgkmcnt, and every LDS wait of the stage
+// would then sit out a global-memory latency.  Hence the explicit global
+// address space.)
 struct GpView {
   gptr_t Apack;
   gptr_t Xs;
   gptr_t alpha;
-  int nsteps_total;
-  // wave-uniform values, pinned to SGPRs (they are loaded through VGPRs and
-  // would otherwise stay there -- or get spilled to scratch at 256 VGPRs)
   static __device__ __forceinline__ gptr_t uniform(const double* q) {
     const uint64_t v = reinterpret_cast<uint64_t>(q);
     const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v));
@@ -107,99 +140,103 @@ struct GpView {
     Apack = uniform(gp.Apack);
     Xs = uniform(gp.Xs);
     alpha = uniform(gp.alpha);
-    nsteps_total = __builtin_amdgcn_readfirstlane(gp.n_pad >> 2);
   }
 };
 
-// Asynchronous global -> LDS copy of one A chunk (LDS-DMA, no VGPR round trip).
-// LDS image: slot-major A[slot][step][lane]; slot = row block - b0 + shift so
-// that the last row block of the chunk always sits in slot 15.  A slot is 2 KB
-// = two 1 KB instructions (k-steps {0,1} and {2,3}, the second through the
-// instruction offset, which applies to the global and the LDS address alike);
-// wave w copies slots w, w + NW, ...  Only the slots the j-block reads are
-// fetched (`lo` = its first active slot).  Everything but the per-lane offset
-// is scalar, and the address of the next slot is one 64-bit add away: the
-// wave's issue slots are the scarce resource of this loop (scripts/
-// stagebench.py), so the bookkeeping per copy is kept to a handful of SALU ops.
-template <int NW>
-__device__ __forceinline__ void stage_dma(const GpView& gp, double* buf, int b0,
-                                          int shift, int jb, int lo, int tid) {
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63;
-  const int64_t row_stride = int64_t(gp.nsteps_total) * 64;   // doubles / row block
-  gptr_t src = gp.Apack + (int64_t(b0 - shift + wave) * gp.nsteps_total +
-                           jb * kSteps) * 64 + lane * 2;
-  double* dst = buf + wave * (2 * 128);                       // wave-uniform
-#pragma unroll
-  for (int k = 0; k < kIB / NW; ++k) {
-    if (wave + NW * k >= lo) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)src,
-          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)src,
-          (__attribute__((address_space(3))) void*)dst, 16, 1024, 0);
+__device__ __forceinline__ void lds_dma16(gptr_t src, double* dst, int off) {
+  // global -> LDS, 16 bytes per lane, no VGPR round trip; `off` (an immediate)
+  // applies to the global and the LDS address alike
+  if (off == 0)
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)src,
+        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  else
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)src,
+        (__attribute__((address_space(3))) void*)dst, 16, 1024, 0);
+}
+
+// (src is wave-uniform and stays in SGPRs; the lane offset is added at the call
+// so every copy is "scalar base + 32-bit lane offset", no 64-bit VALU adds)
+template <int NW, int K>
+__device__ __forceinline__ void dma_slots(gptr_t src, double* dst, int64_t rs,
+                                          int left, unsigned lane2) {
+  if constexpr (K < kIB / NW) {
+    if (left > NW * K) {          // slot wave + NW K is active (prefix: nested)
+      lds_dma16(src + lane2, dst, 0);
+      lds_dma16(src + lane2, dst, 1024);
+      dma_slots<NW, K + 1>(src - NW * rs, dst + NW * (kSteps * 64), rs, left,
+                           lane2);
     }
-    src += NW * row_stride;
-    dst += NW * (2 * 128);
   }
 }
 
-// Training rows (pre-scaled) and alpha entries of j-block jb: contiguous runs of
-// 16 D and 16 doubles in GpDev::Xs / alpha, copied by LDS-DMA as well -- wave 0
-// moves the rows (8 D lanes x 16 B), wave 1 the alpha run (8 lanes x 16 B); the
-// other lanes are masked off and write nothing.
-template <int D>
-__device__ __forceinline__ void stage_x_dma(const GpView& gp, double* buf, int jb,
-                                            int tid) {
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63;
+// Asynchronous global -> LDS copy of the active slots of one stage.  LDS image:
+// slot-major A[slot][k-step][lane] (2 KB per slot = two 1 KB instructions);
+// wave w copies slots w, w + NW, ... below nact.
+template <int NW>
+__device__ __forceinline__ void stage_dma(const GpView& gp, const StageEnt& e,
+                                          double* buf, int wave, int lane) {
+  const int nact = int(e.word & SW_NACT_MASK);
+  const int64_t rs = int64_t(e.row_stride) * 64;            // doubles / row block
+  gptr_t src = gp.Apack + (int64_t(e.a_off) * 64 - wave * rs);   // wave-uniform
+  double* dst = buf + wave * (kSteps * 64);                       // wave-uniform
+  dma_slots<NW, 0>(src, dst, rs, nact - wave, unsigned(lane) * 2u);
+}
+
+// Training rows (pre-scaled) and alpha entries of the stage's j-block: runs of
+// 16 D and 16 doubles in GpDev::Xs / alpha -- wave 0 moves the rows (8 D lanes x
+// 16 B), the last wave the alpha run (8 lanes x 16 B); the other lanes are
+// masked off and write nothing.
+template <int D, int NW>
+__device__ __forceinline__ void stage_x_dma(const GpView& gp, const StageEnt& e,
+                                            double* buf, int wave, int lane) {
   if (wave == 0) {
-    if (lane < 8 * D) {
-      gptr_t src = gp.Xs + (jb * kJC * D + lane * 2);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)src,
-          (__attribute__((address_space(3))) void*)(buf + kATile), 16, 0, 0);
-    }
-  } else if (wave == 1) {
-    if (lane < 8) {
-      gptr_t src = gp.alpha + (jb * kJC + lane * 2);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)src,
-          (__attribute__((address_space(3))) void*)(buf + kATile + kXTile), 16,
-          0, 0);
-    }
+    if (lane < 8 * D)
+      lds_dma16(gp.Xs + int64_t(e.jb) * (kJC * D) + unsigned(lane) * 2u,
+                buf + kATile, 0);
+  } else if (wave == NW - 1) {
+    if (lane < 8)
+      lds_dma16(gp.alpha + int64_t(e.jb) * kJC + unsigned(lane) * 2u,
+                buf + kATile + kXTile, 0);
   }
 }
 
 // ---- matrix part ------------------------------------------------------------------
 // v_mfma_f64_4x4x4_4b_f64 is the fp64 matrix instruction that reaches the chip's
-// peak on gfx950 (74-77 TFLOP/s measured vs 49 for v_mfma_f64_16x16x4_f64,
-// scripts/microbench.py).  Its operand maps (scripts/probe_mfma_layout.py):
+// peak on gfx950 (74-77 TFLOP/s measured vs 49 for v_mfma_f64_16x16x4_f64).  Its
+// operand maps (probed):
 //   A[blk][i][k] <- lane 16k + 4blk + i     B[blk][k][j] <- lane 16k + 4blk + j
 //   D[blk][i][j] -> lane 16i + 4blk + j
 // Used with blk = 4-row group: the A operand is then the SAME register the
 // 16x16x4 form takes (lane = 16k + row, row = 4blk + i), one instruction is a
 // 16-row x 4-column x 4-deep product, and a 16-column slab needs four of them
 // (m = 0..3) whose B operands are the covariance register with column quad m
-// broadcast to all four quads of each 16-lane row -- two ds_swizzle_b32 per
-// operand, done once per k-step and reused by every row block.  Accumulator
-// component m of a slot holds rows 4((l>>2)&3) + (l>>4), column 4m + (l&3).
-__device__ __forceinline__ double quad_bcast(double v, int m) {
-  // src lane = (lane & 0b110011) | (m << 2)   (BITMASK_PERM: and 0x13, or m<<2)
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  int slo, shi;
-  switch (m) {
-    case 0: slo = __builtin_amdgcn_ds_swizzle(lo, 0x13 | (0 << 5));
-            shi = __builtin_amdgcn_ds_swizzle(hi, 0x13 | (0 << 5)); break;
-    case 1: slo = __builtin_amdgcn_ds_swizzle(lo, 0x13 | (4 << 5));
-            shi = __builtin_amdgcn_ds_swizzle(hi, 0x13 | (4 << 5)); break;
-    case 2: slo = __builtin_amdgcn_ds_swizzle(lo, 0x13 | (8 << 5));
-            shi = __builtin_amdgcn_ds_swizzle(hi, 0x13 | (8 << 5)); break;
-    default: slo = __builtin_amdgcn_ds_swizzle(lo, 0x13 | (12 << 5));
-             shi = __builtin_amdgcn_ds_swizzle(hi, 0x13 | (12 << 5)); break;
+// broadcast to all four quads of each 16-lane row.  (cbsz / abid do NOT
+// broadcast for this opcode on gfx950 -- probed, scripts/dev/probe_cbsz.hip.)
+// Accumulator component m of a slot holds rows 4((l>>2)&3) + (l>>4), column
+// 4m + (l&3).
+
+// Covariance values of a stage -> B operands.  Lane (k, c) = (l >> 4, l & 15)
+// holds kv[q] = k(X_{4q+k}, x_c); operand (q, m) of lane (k, a, j) is kv[q] of
+// lane (k, m, j).  Through a wave-private LDS buffer laid out [k][c][q]: two
+// 16-byte stores and eight 16-byte loads per lane (LDS instructions of one wave
+// execute in order; no barrier).
+__device__ __forceinline__ void broadcast_quads(const double (&kv)[4], double* kbw,
+                                                int lane, double (&kb)[4][4]) {
+  double2_t* w = reinterpret_cast<double2_t*>(kbw + (lane >> 4) * kKbRow +
+                                              (lane & 15) * 4);
+  w[0] = double2_t{kv[0], kv[1]};
+  w[1] = double2_t{kv[2], kv[3]};
+  __builtin_amdgcn_wave_barrier();
+  const double2_t* r = reinterpret_cast<const double2_t*>(
+      kbw + (lane >> 4) * kKbRow + (lane & 3) * 4);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const double2_t a = r[m * 8], b = r[m * 8 + 1];
+    kb[m][0] = a.x; kb[m][1] = a.y; kb[m][2] = b.x; kb[m][3] = b.y;
   }
-  return __hiloint2double(shi, slo);
+  __builtin_amdgcn_wave_barrier();
 }
 
 // A operands of one slot: the 4 k-steps of the staged j-block.
@@ -209,36 +246,43 @@ __device__ __forceinline__ void load_slot(double (&ops)[4], const double* aT,
   for (int q = 0; q < 4; ++q) ops[q] = aT[(slot * kSteps + q) * 64];
 }
 
-// One 16-wide j-block against accumulator slots lo..15.  Slots are guarded by
-// wave-uniform branches (the active set is a suffix); a slot is 16 MFMAs on
-// four independent accumulators, and the next slot's A operands are read from
-// LDS while they execute.
-__device__ __forceinline__ void mfma_jblock(int lo, double4_t (&acc)[kIB],
-                                            const double* aT,
-                                            const double (&kv)[4]) {
-  double kb[4][4];  // [k-step][column quad]
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) kb[q][m] = quad_bcast(kv[q], m);
-
-  double opsA[4], opsB[4];
-#pragma unroll
-  for (int s = 0; s < kIB; ++s) {
-    if (s >= lo) {
-      double(&cur)[4] = (s & 1) ? opsB : opsA;
-      double(&nxt)[4] = (s & 1) ? opsA : opsB;
-      if (s == lo) load_slot(cur, aT, s);
-      if (s + 1 < kIB) load_slot(nxt, aT, s + 1);
+// One 16-wide j-block against accumulator slots 0..nact-1: a slot is 16 MFMAs on
+// four independent accumulators; the next slot's A operands are read from LDS
+// while they execute (the read of slot nact is harmless: it stays inside the
+// stage buffer).  The active slots are a prefix, so the guards nest: the first
+// inactive slot leaves the whole sequence with one branch.
+template <int S>
+__device__ __forceinline__ void mfma_slots(int nact, double4_t (&acc)[kIB],
+                                           const double* aT,
+                                           const double (&kb)[4][4],
+                                           double (&cur)[4], double (&nxt)[4]) {
+  if constexpr (S < kIB) {
+    if (S < nact) {
+      // operands of the next slot: issued HERE, consumed after this slot's 16
+      // MFMAs (the empty asm keeps the compiler from sinking the reads into
+      // the next slot's block, where their latency would be exposed)
+      if (S + 1 < kIB) load_slot(nxt, aT, S + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-          acc[s][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(cur[q], kb[q][m],
-                                                         acc[s][m], 0, 0, 0);
+          acc[S][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(cur[q], kb[m][q],
+                                                         acc[S][m], 0, 0, 0);
       }
+      if (S + 1 < kIB)
+        asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
+      mfma_slots<S + 1>(nact, acc, aT, kb, nxt, cur);
     }
   }
+}
+
+__device__ __forceinline__ void mfma_jblock(int nact, double4_t (&acc)[kIB],
+                                            const double* aT,
+                                            const double (&kb)[4][4]) {
+  double opsA[4], opsB[4];
+  load_slot(opsA, aT, 0);
+  mfma_slots<0>(nact, acc, aT, kb, opsA, opsB);
 }
 
 // SafeOptSwarm._compute_penalty (gp_opt.py:874-899) for one value.
@@ -306,112 +350,64 @@ __global__ void k_fitness_small(int G, int64_t P, const double* mean,
   f.safe[i] = ok ? 1 : 0;
 }
 
-// Position in the flattened stage sequence of one workgroup:
-//   for tile: for gp: for chunk (16 row blocks of L^-1): for jb (16 columns)
-// A stage's LDS image (A chunk, X rows, alpha) depends on (gp, chunk, jb) only,
-// so the image of the NEXT stage is always prefetched while the current one is
-// consumed -- also across chunk, GP and tile boundaries.  The kernel is
-// persistent (one workgroup per CU walks over tiles) so that nothing but the
-// very first stage of a launch pays an exposed global -> LDS latency.
-struct StagePos {
-  int64_t tile;
-  int g, c, jb;
-  // derived, per (g, c)
-  int b0, nib, shift, njb, nchunks;
-};
 
-__device__ __forceinline__ void stage_derive(StagePos& sp, const GpDev* gps) {
-  const int nblk = gps[sp.g].nblk;
-  sp.nchunks = (nblk + kIB - 1) / kIB;
-  sp.b0 = sp.c * kIB;
-  sp.nib = min(kIB, nblk - sp.b0);
-  sp.shift = kIB - sp.nib;
-  sp.njb = sp.b0 + sp.nib;
-}
-
-// Advance to the following stage; returns false after the last stage of the
-// last tile of this workgroup.
-__device__ __forceinline__ bool stage_next(StagePos& sp, const GpDev* gps,
-                                           int Geff, int64_t ntiles,
-                                           int64_t tile_stride) {
-  if (++sp.jb < sp.njb) return true;
-  sp.jb = 0;
-  if (++sp.c >= sp.nchunks) {
-    sp.c = 0;
-    if (++sp.g >= Geff) {
-      sp.g = 0;
-      sp.tile += tile_stride;
-      if (sp.tile >= ntiles) return false;
-    }
-  }
-  stage_derive(sp, gps);
-  return true;
-}
-
-template <int D, int NW>
-__device__ __forceinline__ void stage_issue(const StagePos& sp, const GpView& gp,
-                                            double* buf, int tid) {
-  const int lo = sp.shift + max(0, sp.jb - sp.b0);
-  stage_dma<NW>(gp, buf, sp.b0, sp.shift, sp.jb, lo, tid);
-  stage_x_dma<D>(gp, buf, sp.jb, tid);
-}
-
-template <int D, int NW, int MODE, bool CACHE>
+template <int D, int NW, int MODE, bool SINGLE>
 __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
-  constexpr int kWaves = NW;
   constexpr int kTilePts = 16 * NW;
+  constexpr bool conf = MODE == MODE_CONF;   // compile-time: no dead state
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* red = lds + 2 * kBuf;  // all LDS lives in the one dynamic region
   const double* tab = lds + kTabOff;
   exp_tab_init(lds + kTabOff);   // visible after the first staging barrier
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
-  constexpr bool conf = MODE == MODE_CONF;   // compile-time: no dead state
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double* kbw = lds + kKbOff + wave * kKbBuf;
   const int st = p.fit.swarm_type;
-  const int Geff = (!conf && st == SGP_SWARM_GREEDY) ? 1 : p.G;
-  const int64_t ntiles = (p.pts.N + kTilePts - 1) / kTilePts;
+  const int ntiles = int((p.pts.N + kTilePts - 1) / kTilePts);
+  const stage_ptr_t stages = (stage_ptr_t)(p.stages);
+  const int nstages = p.nstages;
+  const int tstep = int(gridDim.x);
 
-  StagePos cur;
-  cur.tile = blockIdx.x;
-  cur.g = cur.c = cur.jb = 0;
-  if (cur.tile >= ntiles) return;
-#ifdef SGP_INSTRUMENT
-  if (p.skew > 0) {   // phase experiment: delay the second workgroup of every CU
-    int* flag = reinterpret_cast<int*>(lds + 2 * kBuf);
-    if (threadIdx.x == 0) {
-      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
-      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // XCC_ID
-      *flag = atomicAdd(p.cu_count + (((xcc & 7) << 8) | ((hw >> 8) & 0xff)), 1);
-    }
-    __syncthreads();
-    const int order = *flag;
-    __syncthreads();
-    if (order & 1)
-      for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(1);
-  }
-#endif
-  stage_derive(cur, p.gps);
+  int tile = int(blockIdx.x);
+  if (tile >= ntiles) return;
 
   // candidate rows of the current tile (and, prefetched, of the next one)
-  auto load_x = [&](int64_t tile, double (&xo)[D]) {
-    int64_t r = tile * kTilePts + wave * 16 + (lane & 15);
+  auto load_x = [&](int t, double (&xo)[D]) {
+    int64_t r = int64_t(t) * kTilePts + wave * 16 + (lane & 15);
     r = r < p.pts.N ? r : p.pts.N - 1;
 #pragma unroll
     for (int k = 0; k < D; ++k)
       xo[k] = p.pts.base[r * p.pts.stride_row + k * p.pts.stride_col];
   };
   double x[D], xnext[D];
-  load_x(cur.tile, x);
+  load_x(tile, x);
 #pragma unroll
   for (int k = 0; k < D; ++k) xnext[k] = x[k];
 
-  GpView gv_next;          // GP of the stage being prefetched
-  gv_next.load(p.gps[0]);
+  // Stage cursors: the stage being multiplied (its entry word in wcur), the
+  // stage being prefetched (entry e1, one ahead) and the stage whose entry is
+  // being loaded (two ahead: a scalar load issued a whole stage before its use).
+  auto advance = [&](int& si, int& t) {
+    if (++si == nstages) {
+      si = 0;
+      t += tstep;
+    }
+  };
+  GpView gv;               // GP of the stage being prefetched
+  int gv_g = 0;
+  gv.load(p.gps[0]);
   KernFast<D> kf(p.gps[0].kern);
   double kdiag = p.gps[0].kern.kdiag;
-  stage_issue<D, NW>(cur, gv_next, lds, tid);
+  StageEnt e1 = load_stage(stages, 0);
+  stage_dma<NW>(gv, e1, lds, wave, lane);
+  stage_x_dma<D, NW>(gv, e1, lds, wave, lane);
+  uint32_t wcur = e1.word;
+  int si1 = 0, t1 = tile;
+  advance(si1, t1);
+  bool have1 = t1 < ntiles;
+  if (have1) e1 = load_stage(stages, si1);
+  int si2 = si1, t2 = t1;
   __syncthreads();
 
   // per-GP state
@@ -423,88 +419,62 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   // per-tile state of the row epilogue (confidence sweep / swarm fitness)
   bool safe = true;
   double l0 = 0.0, values = 0.0, interest = 1.0, total_pen = 0.0, lower = 0.0;
+  bool gp_start = true;
 
-  // this lane's slab of the covariance cache
-  typedef double double2_t __attribute__((ext_vector_type(2)));
-  typedef __attribute__((address_space(1))) double2_t* g2ptr_t;
-  // (CACHE is a template parameter: the single-chunk kernel, n <= 256, carries
-  // none of this)
-  g2ptr_t kslab = nullptr;
-  if (CACHE)
-    kslab = (g2ptr_t)(p.kvc + ((int64_t(blockIdx.x) * kWaves + wave) *
-                               int64_t(p.kvc_blocks)) * 256 + lane * 4);
-  double kvn[4] = {0.0, 0.0, 0.0, 0.0};   // values fetched for the next stage
-  bool cached = false;                     // ... which is a re-visited j-block
-
-  int bufsel = 0;
-  bool more = true;
-#ifdef SGP_INSTRUMENT
-  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
-  const unsigned long long stamp_first = stamp_last;
-#endif
+  int par = 0;
 #pragma unroll 1
-  while (more) {
-    SGP_STAMP(0)   // loop back edge
-    if (cur.c == 0 && cur.jb == 0) kf.prep(x, xs);
+  while (true) {
+    double* cbuf = lds + par * kBuf;
+    double* nbuf = lds + (par ^ 1) * kBuf;
 
-    double* cbuf = lds + bufsel * kBuf;
-    double* nbuf = lds + (bufsel ^ 1) * kBuf;
-
-    // prefetch the next stage (and the rows of the next tile)
-    StagePos nxt = cur;
-    more = stage_next(nxt, p.gps, Geff, ntiles, gridDim.x);
-    const bool tile_ends = !more || nxt.tile != cur.tile;
-    const bool gp_ends = tile_ends || nxt.g != cur.g;
+    // ---- prefetch: the stage after this one (possibly of the next tile)
+    const bool more = have1;
+    const uint32_t wnext = e1.word;
+    const bool next_tile = more && si1 == 0;
     if (more) {
-      if (gp_ends && Geff > 1) gv_next.load(p.gps[nxt.g]);
-      if (!SGP_ABL(2)) stage_issue<D, NW>(nxt, gv_next, nbuf, tid);
+      const int g_n = int(wnext >> SW_G_SHIFT) & 7;
+      if (g_n != gv_g) {
+        gv.load(p.gps[g_n]);
+        gv_g = g_n;
+      }
+      if (!SGP_ABL(2)) {
+        stage_dma<NW>(gv, e1, nbuf, wave, lane);
+        stage_x_dma<D, NW>(gv, e1, nbuf, wave, lane);
+      }
+      if (next_tile) load_x(t1, xnext);
     }
-    const bool chunk_ends = gp_ends || nxt.c != cur.c;
-    if (more && tile_ends) load_x(nxt.tile, xnext);
-    // a j-block below the diagonal part of its chunk was evaluated (and parked)
-    // while an earlier chunk of this (tile, GP) pass was processed
-    const bool was_cached = CACHE && cached;
-    double kvc_cur[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) kvc_cur[q] = kvn[q];
-    cached = CACHE && more && nxt.jb < nxt.b0;
-    if (cached) {
-      const double2_t a = __builtin_nontemporal_load(kslab + nxt.jb * 128);
-      const double2_t b = __builtin_nontemporal_load(kslab + nxt.jb * 128 + 1);
-      kvn[0] = a.x; kvn[1] = a.y; kvn[2] = b.x; kvn[3] = b.y;
-    }
+    const int tile_after = t1;
+    // the entry after that: loaded now, first used at the top of the next stage
+    advance(si2, t2);
+    const bool have2 = more && t2 < ntiles;
+    StageEnt e2 = e1;
+    if (have2) e2 = load_stage(stages, si2);
 
-    SGP_STAMP(1)   // bookkeeping + DMA issue + cache traffic
-    // this stage: 16 training points against the active row blocks
+    // ---- this stage: 16 training points against the active row blocks
+    if (gp_start) {
+      kf.template prep_t<SINGLE>(x, xs);
+      gp_start = false;
+    }
     const double* xT = cbuf + kATile;
     const double* alT = cbuf + kATile + kXTile;
     double kv[4];
-    if (was_cached) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) kv[q] = kvc_cur[q];
-    } else if (!SGP_ABL(4)) {
-      kf.template many<4>(xs, xT + (lane >> 4) * D, 4 * D, tab, kv);
-      if (CACHE && cur.c + 1 < cur.nchunks) {       // needed again by later chunks
-        double2_t a, b;
-        a.x = kv[0]; a.y = kv[1]; b.x = kv[2]; b.y = kv[3];
-        __builtin_nontemporal_store(a, kslab + cur.jb * 128);
-        __builtin_nontemporal_store(b, kslab + cur.jb * 128 + 1);
-      }
+    if (!SGP_ABL(4)) {
+      kf.template many4_t<SINGLE>(xs, xT + (lane >> 4) * D, 4 * D, tab, kv);
     } else {
       kv[0] = xs[0]; kv[1] = xs[0] + 1.0; kv[2] = xs[0] + 2.0; kv[3] = xs[0] + 3.0;
     }
-    if (cur.c == cur.nchunks - 1) {
+    if (wcur & SW_MEAN) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
     }
-    SGP_STAMP(2)   // covariance evaluation + mean
-    if (!SGP_ABL(8))
-      mfma_jblock(cur.shift + max(0, cur.jb - cur.b0), acc, cbuf + lane, kv);
-    SGP_STAMP(3)   // swizzles + MFMAs
+    if (!SGP_ABL(8)) {
+      double kb[4][4];
+      broadcast_quads(kv, kbw, lane, kb);
+      mfma_jblock(int(wcur & SW_NACT_MASK), acc, cbuf + lane, kb);
+    }
 
-    if (chunk_ends) {
+    if (wcur & SW_CHUNK_END) {
 #pragma unroll
       for (int b = 0; b < kIB; ++b) {
 #pragma unroll
@@ -515,30 +485,24 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       }
     }
 
-    if (gp_ends && !SGP_ABL(32)) {
+    if ((wcur & SW_GP_END) && !SGP_ABL(32)) {
       // sq[m]: partial sums for column 4m + (lane & 3) over this lane's rows.
-      // Fold the 16 lanes that share (lane & 3), then pick the quad of this
-      // lane's own column (lane & 15) = 4 ((lane >> 2) & 3) + (lane & 3).
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        double v = sq[m];
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        sq[m] = v;
-      }
-      const int mq = (lane >> 2) & 3;
-      const double sumsq =
-          (mq == 0) ? sq[0] : (mq == 1) ? sq[1] : (mq == 2) ? sq[2] : sq[3];
+      // Transposing fold over the lanes that share (lane & 3): after the xor-4
+      // and xor-8 exchanges each lane holds the quad of its OWN column
+      // (lane & 15) = 4 ((lane >> 2) & 3) + (lane & 3); then the 4 k-rows.
+      const bool a0 = (lane & 4) != 0, a1 = (lane & 8) != 0;
+      double v0 = (a0 ? sq[1] : sq[0]) + __shfl_xor(a0 ? sq[0] : sq[1], 4, 64);
+      double v1 = (a0 ? sq[3] : sq[2]) + __shfl_xor(a0 ? sq[2] : sq[3], 4, 64);
+      double sumsq = (a1 ? v1 : v0) + __shfl_xor(a1 ? v0 : v1, 8, 64);
+      sumsq = sum_lane_groups(sumsq);
       const double mu = sum_lane_groups(mean);
       const double var = fmax(kdiag - sumsq, 1e-15);  // GPy clip
       const double sd = sqrt(var);
       sq[0] = sq[1] = sq[2] = sq[3] = 0.0;
       mean = 0.0;
 
-      const int g = cur.g;
-      const int64_t row = cur.tile * kTilePts + wave * 16 + (lane & 15);
+      const int g = int(wcur >> SW_G_SHIFT) & 7;
+      const int64_t row = int64_t(tile) * kTilePts + wave * 16 + (lane & 15);
       const bool writer = (row < p.pts.N) && (lane < 16);
       if (conf) {
         // update_confidence_intervals + compute_safe_set (gp_opt.py:453-481)
@@ -584,21 +548,15 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
         }
       }
 
-      if (tile_ends) {
+      if (wcur & SW_TILE_END) {
         if (conf) {
           if (p.conf.S) {
             if (writer) p.conf.S[row] = safe ? 1 : 0;
-            // maximum of l0 over the safe rows of the tile -> one partial
+            // maximum of l0 over the safe rows of the wave -> one partial per
+            // wave (no workgroup barrier in the epilogue)
             double v = (writer && safe) ? l0 : -INFINITY;
             v = wave_max(v);
-            if (lane == 0) red[wave] = v;
-            __syncthreads();
-            if (tid == 0) {
-              double m = red[0];
-#pragma unroll
-              for (int w = 1; w < kWaves; ++w) m = fmax(m, red[w]);
-              p.conf.partial[cur.tile] = m;
-            }
+            if (lane == 0) p.conf.partial[int64_t(tile) * NW + wave] = v;
           }
         } else if (writer) {
           double out;
@@ -619,28 +577,29 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
         interest = 1.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) x[k] = xnext[k];
+        tile = tile_after;
       }
+      if (more) {   // hyper-parameters of the next GP
+        const int g_n = int(wnext >> SW_G_SHIFT) & 7;
+        if (g_n != g) {
+          kf = KernFast<D>(p.gps[g_n].kern);
+          kdiag = p.gps[g_n].kern.kdiag;
+        }
+      }
+      gp_start = true;
     }
 
-    if (gp_ends && more && Geff > 1) {   // hyper-parameters of the next GP
-      kf = KernFast<D>(p.gps[nxt.g].kern);
-      kdiag = p.gps[nxt.g].kern.kdiag;
-    }
-    SGP_STAMP(4)   // chunk fold + epilogue
+    if (!more) break;
     if (!SGP_ABL(1)) __syncthreads();
-    SGP_STAMP(5)   // barrier
-    bufsel ^= 1;
-    cur = nxt;
+    par ^= 1;
+    wcur = wnext;
+    e1 = e2;
+    si1 = si2;
+    t1 = t2;
+    have1 = have2;
   }
-#ifdef SGP_INSTRUMENT
-  if (p.stamps && lane == 0) {
-    unsigned long long* o = p.stamps + (int64_t(blockIdx.x) * kWaves + wave) * 8;
-    for (int k = 0; k < 6; ++k) o[k] = stamp_acc[k];
-    o[6] = stamp_last - stamp_first;
-    o[7] = stamp_first;
-  }
-#endif
 }
+
 
 // ---- expander check ---------------------------------------------------------
 // One MFMA row block = up to 16 candidates: acc[cand, pt] = sum_j w_c[j] K[j,pt].
@@ -986,172 +945,79 @@ __global__ __launch_bounds__(256) void k_rank1(const GpDev* gps, int G,
     ra.partial[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
-// ---- operand-layout probe (test hook): one MFMA with caller-given lane values ------
-__global__ void k_probe_mfma(int which, const double* a, const double* b,
-                             const double* c, double* d) {
-  const int l = threadIdx.x;
-  if (which == 0) {
-    double4_t acc = {c[l * 4], c[l * 4 + 1], c[l * 4 + 2], c[l * 4 + 3]};
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[l], b[l], acc, 0, 0, 0);
-    for (int r = 0; r < 4; ++r) d[l * 4 + r] = acc[r];
-  } else {
-    d[l] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[l], b[l], c[l], 0, 0, 0);
-  }
+
+// ---- launch -----------------------------------------------------------------------
+// Waves per workgroup: 4 (two workgroups per CU).  A build with -DSGP_SWEEP_WAVES8
+// also carries the 8-wave variant (one workgroup per CU, half the L2 -> LDS
+// traffic), selected at run time by SGP_SWEEP_WAVES=8: the A/B switch of profiles/.
+int sweep_waves() {
+#ifdef SGP_SWEEP_WAVES8
+  static const int nw = (getenv("SGP_SWEEP_WAVES") && atoi(getenv("SGP_SWEEP_WAVES")) == 8) ? 8 : 4;
+  return nw;
+#else
+  return 4;
+#endif
 }
 
-// ---- fp64 issue-rate microbenchmarks ---------------------------------------------
-// MODE 6: 16 chains of v_mfma_f64_4x4x4_4b_f64 (512 flop each)
-// MODE 0: 8 independent MFMA chains   1: 4 chains   2: 8 chains + 8 v_fma_f64
-// per MFMA   3: v_fma_f64 only (16 chains)   4: 8 MFMA chains + 2 v_fma_f64 per
-// MFMA   5: 16 MFMA chains
-template <int MODE>
-__global__ __launch_bounds__(256) void k_mfma_bench(double* out, int iters) {
-  extern __shared__ double dyn_lds[];  // only limits residency
-  constexpr int NA = (MODE == 1) ? 4 : (MODE == 5 ? 16 : 8);
-  double4_t acc[NA];
-#pragma unroll
-  for (int i = 0; i < NA; ++i) acc[i] = double4_t{0, 0, 0, 0};
-  double f[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) f[i] = 1.0 + i * 1e-3 + threadIdx.x * 1e-6;
-  const double av = 1.0 + threadIdx.x * 1e-9, bv = 1.0 - threadIdx.x * 1e-9;
-  const double m = 0.999999, c = 1e-7;
-  double a4[4], b16[16];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) a4[q] = av + q * 1e-3;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) b16[j] = bv + j * 1e-3;
-  for (int it = 0; it < iters; ++it) {
-    if (MODE == 9) {
-      // the sweep's operand pattern: 4 A registers, 16 B registers, 16
-      // accumulators -- every MFMA reads a different (A, B, C) triple
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-          f[4 * q + m] = __builtin_amdgcn_mfma_f64_4x4x4f64(
-              a4[q], b16[4 * q + m], f[4 * q + m], 0, 0, 0);
-    } else if (MODE == 6 || MODE == 7 || MODE == 8) {
-      // 16 / 4 / 2 independent chains, 16 instructions per iteration
-      constexpr int NC = (MODE == 6) ? 16 : (MODE == 7 ? 4 : 2);
-#pragma unroll
-      for (int rep = 0; rep < 16 / NC; ++rep)
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-          f[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, f[j], 0, 0, 0);
-    } else if (MODE != 3) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i], 0, 0, 0);
-        if (MODE == 2) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = fma(f[j], m, c);
+// The stage sequence of one tile: for every GP, for every chunk of 16 row blocks
+// of L^-1, the j-blocks 0 .. bend-1 (only the slots at or below the diagonal are
+// active).  Depends on the block counts only, so it is rebuilt (and uploaded)
+// when a GP crosses a multiple of 16 training points, not per launch.
+int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, const StageEnt** dev,
+                int* nstages) {
+  std::vector<int> sig(1, Geff);
+  for (int g = 0; g < Geff; ++g) sig.push_back(gh[g].nblk);
+  if (sig == ctx->stage_sig && ctx->stage_tab.p) {
+    *dev = static_cast<const StageEnt*>(ctx->stage_tab.p);
+    *nstages = ctx->stage_count;
+    return 0;
+  }
+  std::vector<StageEnt> tab;
+  for (int g = 0; g < Geff; ++g) {
+    const int nblk = gh[g].nblk, nsteps = gh[g].n_pad / 4;
+    const int nchunks = (nblk + kIB - 1) / kIB;
+    for (int c = 0; c < nchunks; ++c) {
+      const int b0 = c * kIB, nib = std::min(kIB, nblk - b0), bend = b0 + nib;
+      for (int jb = 0; jb < bend; ++jb) {
+        StageEnt e;
+        e.a_off = uint32_t((bend - 1) * nsteps + 4 * jb);
+        e.row_stride = uint32_t(nsteps);
+        e.jb = uint32_t(jb);
+        e.word = uint32_t(std::min(nib, bend - jb)) | (uint32_t(g) << SW_G_SHIFT);
+        if (jb == bend - 1) e.word |= SW_CHUNK_END;
+        if (c == nchunks - 1) e.word |= SW_MEAN;
+        if (c == nchunks - 1 && jb == bend - 1) {
+          e.word |= SW_GP_END;
+          if (g == Geff - 1) e.word |= SW_TILE_END;
         }
-        if (MODE == 4) {
-          f[(2 * i) & 15] = fma(f[(2 * i) & 15], m, c);
-          f[(2 * i + 1) & 15] = fma(f[(2 * i + 1) & 15], m, c);
-        }
+        tab.push_back(e);
       }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) f[j] = fma(f[j], m, c);
     }
   }
-  double s = 0;
-#pragma unroll
-  for (int i = 0; i < NA; ++i)
-    for (int r = 0; r < 4; ++r) s += acc[i][r];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s += f[i];
-  if (iters < 0) s += dyn_lds[threadIdx.x];   // keeps the LDS allocation referenced
-  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  SGP_TRY(sgp_reserve(ctx, &ctx->stage_tab, tab.size() * sizeof(StageEnt)));
+  SGP_TRY(sgp_h2d(ctx, ctx->stage_tab.p, tab.data(), tab.size() * sizeof(StageEnt)));
+  ctx->stage_sig = sig;
+  ctx->stage_count = int(tab.size());
+  *dev = static_cast<const StageEnt*>(ctx->stage_tab.p);
+  *nstages = ctx->stage_count;
+  return 0;
 }
 
-// One stage of the sweep's inner loop in isolation (scripts/microbench.py):
-//   STAGE 0  mfma_jblock only (B-operand swizzles, slot guards, A operand reads)
-//   STAGE 1  + the stage barrier
-//   STAGE 2  + the LDS-DMA of the next A chunk (8 x 1 KB per wave) + barrier
-//   STAGE 3  + the 4 covariance evaluations per lane (RBF, d = 2)
-//   STAGE 4  covariance evaluations + mfma_jblock, no DMA, no barrier
-// `lo` = first active accumulator slot (0: all 16 slots, 9: config 2's average).
-template <int STAGE>
-__global__ __launch_bounds__(256, 2) void k_stage_bench(const double* src,
-                                                        double* out, int iters,
-                                                        int lo) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const double* tab = lds + kTabOff;
-  exp_tab_init(lds + kTabOff);
-  for (int i = tid; i < 2 * kBuf; i += 256) lds[i] = 1e-3 * (i % 97);
-  __syncthreads();
-  double4_t acc[kIB];
-#pragma unroll
-  for (int b = 0; b < kIB; ++b) acc[b] = double4_t{0.0, 0.0, 0.0, 0.0};
-  double kv[4] = {1.0 + lane * 1e-3, 1.1, 1.2 - lane * 1e-3, 1.3};
-  const double xs[2] = {lane * 0.01, 0.3 + blockIdx.x * 1e-4};
-  GpView gv;
-  gv.Apack = (gptr_t)src;
-  gv.Xs = (gptr_t)src;
-  gv.alpha = (gptr_t)src;
-  gv.nsteps_total = kSteps;
-#pragma unroll 1
-  for (int it = 0; it < iters; ++it) {
-    double* cbuf = lds + (it & 1) * kBuf;
-    double* nbuf = lds + ((it & 1) ^ 1) * kBuf;
-    if (STAGE == 2 || STAGE == 3) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int piece = wave + 4 * k;
-        if ((piece >> 1) >= lo) {
-          const double* g = src + piece * 128 + lane * 2;
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)g,
-              (__attribute__((address_space(3))) void*)(nbuf + piece * 128), 16,
-              0, 0);
-        }
-      }
-    }
-    if (STAGE >= 3) {
-      const double* xT = cbuf + kATile + (lane >> 4) * 2;
-      double r2[4], u[4], e[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double t0 = xs[0] - xT[q * 8], t1 = xs[1] - xT[q * 8 + 1];
-        r2[q] = fma(t1, t1, t0 * t0);
-        u[q] = -r2[q];
-      }
-      exp2_32x4(u, tab, e);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) kv[q] = 2.0 * e[q];
-    }
-    mfma_jblock(lo, acc, cbuf + lane, kv);
-    if (STAGE >= 1 && STAGE <= 3) __syncthreads();
-  }
-  double s = 0;
-#pragma unroll
-  for (int b = 0; b < kIB; ++b)
-    for (int r = 0; r < 4; ++r) s += acc[b][r];
-  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-
-template <int D, int NW, int MODE, bool CACHE>
+template <int D, int NW, int MODE, bool SINGLE>
 int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep<D, NW, MODE, CACHE>),
+                     reinterpret_cast<const void*>(&k_sweep<D, NW, MODE, SINGLE>),
                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                     int(kLdsBytes)));
+                     int(sweep_lds_bytes(NW))));
     attr_set = true;
   }
   const int tile = 16 * NW;
   const int64_t ntiles = (p.pts.N + tile - 1) / tile;
   // persistent: as many workgroups as are resident at once (256 VGPRs per
   // thread -> 8 waves per CU) walk over the tiles
-  const int64_t resident = int64_t(ctx->num_cu) * (kMaxWaves / NW);
+  const int64_t resident = int64_t(ctx->num_cu) * (8 / NW);
   const int nblocks = int(ntiles < resident ? ntiles : resident);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profiling) {
@@ -1172,53 +1038,29 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
 #ifdef SGP_INSTRUMENT
   static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
   pp.ablate = ablate;
-  static const int skew = getenv("SGP_SKEW") ? atoi(getenv("SGP_SKEW")) : 0;
-  static int* cu_count = nullptr;
-  pp.skew = skew;
-  if (skew > 0) {
-    if (!cu_count) SGP_HIP(ctx, hipMalloc(&cu_count, 2048 * sizeof(int)));
-    SGP_HIP(ctx, hipMemsetAsync(cu_count, 0, 2048 * sizeof(int), ctx->stream));
-  }
-  pp.cu_count = cu_count;
-  static const bool want_stamps = getenv("SGP_STAMPS") != nullptr;
-  static unsigned long long* stamps = nullptr;
-  if (want_stamps && !stamps)
-    SGP_HIP(ctx, hipMalloc(&stamps, size_t(nblocks) * NW * 8 * 8));
-  pp.stamps = stamps;
 #endif
-  hipLaunchKernelGGL((k_sweep<D, NW, MODE, CACHE>), dim3(nblocks), dim3(64 * NW),
-                     kLdsBytes, ctx->stream, pp);
+  hipLaunchKernelGGL((k_sweep<D, NW, MODE, SINGLE>), dim3(nblocks), dim3(64 * NW),
+                     sweep_lds_bytes(NW), ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
   if (e1) SGP_HIP(ctx, hipEventRecord(e1, ctx->stream));
-#ifdef SGP_INSTRUMENT
-  if (pp.stamps) {   // per-phase cycle totals, averaged over all waves
-    std::vector<unsigned long long> h(size_t(nblocks) * NW * 8);
-    SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    SGP_HIP(ctx, hipMemcpy(h.data(), pp.stamps, h.size() * 8, hipMemcpyDeviceToHost));
-    double tot[8] = {0};
-    unsigned long long first = ~0ull, last = 0;
-    for (size_t w = 0; w < h.size() / 8; ++w) {
-      for (int k = 0; k < 7; ++k) tot[k] += double(h[w * 8 + k]);
-      first = std::min(first, h[w * 8 + 7]);
-      last = std::max(last, h[w * 8 + 7] + h[w * 8 + 6]);
-    }
-    const double nw = double(h.size() / 8);
-    fprintf(stderr, "stamps (cycles/wave): back %.0f  book+dma %.0f  eval %.0f  "
-            "mfma %.0f  epilogue %.0f  barrier %.0f  | loop %.0f  span %.0f\n",
-            tot[0] / nw, tot[1] / nw, tot[2] / nw, tot[3] / nw, tot[4] / nw,
-            tot[5] / nw, tot[6] / nw, double(last - first));
-  }
-#endif
   return 0;
+}
+
+template <int D, int NW>
+int launch_sweep_w(sgp_ctx* ctx, const SweepParams& p, double flops) {
+  if (p.mode == MODE_CONF)
+    return p.single ? launch_sweep_v<D, NW, MODE_CONF, true>(ctx, p, flops)
+                    : launch_sweep_v<D, NW, MODE_CONF, false>(ctx, p, flops);
+  return p.single ? launch_sweep_v<D, NW, MODE_FITNESS, true>(ctx, p, flops)
+                  : launch_sweep_v<D, NW, MODE_FITNESS, false>(ctx, p, flops);
 }
 
 template <int D>
 int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
-  if (p.mode == MODE_CONF)
-    return p.kvc ? launch_sweep_v<D, kSweepWaves, MODE_CONF, true>(ctx, p, flops)
-                 : launch_sweep_v<D, kSweepWaves, MODE_CONF, false>(ctx, p, flops);
-  return p.kvc ? launch_sweep_v<D, kSweepWaves, MODE_FITNESS, true>(ctx, p, flops)
-               : launch_sweep_v<D, kSweepWaves, MODE_FITNESS, false>(ctx, p, flops);
+#ifdef SGP_SWEEP_WAVES8
+  if (sweep_waves() == 8) return launch_sweep_w<D, 8>(ctx, p, flops);
+#endif
+  return launch_sweep_w<D, 4>(ctx, p, flops);
 }
 
 int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
@@ -1230,24 +1072,10 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
   for (int g = 0; g < Geff; ++g)
     flops += (double(gh[g].n) * gh[g].n + 2.0 * gh[g].n) * double(p.pts.N);
   if (p.pts.N <= 0) return 0;
-  // covariance cache: j-blocks of all but the last chunk, per resident wave
   SweepParams q = p;
-  q.kvc = nullptr;
-  q.kvc_blocks = 0;
-  for (int g = 0; g < Geff; ++g) {
-    const int nchunks = (gh[g].nblk + kIB - 1) / kIB;
-    q.kvc_blocks = std::max(q.kvc_blocks, (nchunks - 1) * kIB);
-  }
-  // (SGP_NO_KVCACHE=1 re-evaluates instead -- the A/B switch behind the numbers
-  // in profiles/README.md)
-  if (q.kvc_blocks > 0 && !getenv("SGP_NO_KVCACHE")) {
-    const int64_t tiles = (p.pts.N + 16 * kSweepWaves - 1) / (16 * kSweepWaves);
-    const int64_t wgs = std::min<int64_t>(tiles, int64_t(ctx->num_cu) *
-                                                     (kMaxWaves / kSweepWaves));
-    q.kvc = static_cast<double*>(sgp_scratch(
-        ctx, 0, size_t(wgs) * kSweepWaves * q.kvc_blocks * 256 * sizeof(double)));
-    if (!q.kvc) return -1;
-  }
+  SGP_TRY(stage_table(ctx, gh, Geff, &q.stages, &q.nstages));
+  q.single = 1;
+  for (int g = 0; g < Geff; ++g) q.single = q.single && gh[g].kern.n_parts == 1;
   switch (d) {
     case 1: return launch_sweep_d<1>(ctx, q, flops);
     case 2: return launch_sweep_d<2>(ctx, q, flops);
@@ -1264,14 +1092,15 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
 
 }  // namespace
 
-int sweep_num_blocks(int64_t N) {   // = number of tiles = number of partials
-  constexpr int t = 16 * kSweepWaves;
-  return int((N + t - 1) / t);
+int sweep_num_blocks(int64_t N) {   // = number of per-wave partials of max l0[S]
+  const int nw = sweep_waves();
+  const int64_t t = 16 * nw;
+  return int((N + t - 1) / t) * nw;
 }
 
 int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
                       int G, int d, SweepPoints pts, ConfOut out) {
-  SweepParams p;
+  SweepParams p{};
   p.gps = gps_dev;
   p.G = G;
   p.mode = MODE_CONF;
@@ -1284,7 +1113,7 @@ int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
 int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,
                          const GpDev* gps_host, int G, int d, SweepPoints pts,
                          FitnessArgs fa) {
-  SweepParams p;
+  SweepParams p{};
   p.gps = gps_dev;
   p.G = G;
   p.mode = MODE_FITNESS;
@@ -1293,6 +1122,7 @@ int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,
   p.fit = fa;
   return launch_sweep(ctx, p, gps_host, d);
 }
+
 
 int launch_fitness_small(sgp_ctx* ctx, int G, int64_t P, const double* mean,
                          const double* var, FitnessArgs fa) {
@@ -1334,32 +1164,6 @@ int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
   return 0;
 }
 
-template <int MODE>
-int run_microbench(sgp_ctx* ctx, int iters, int lds_bytes, int nblocks,
-                   double* out, float* ms) {
-  if (lds_bytes > 64 * 1024)
-    SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_mfma_bench<MODE>),
-                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-  hipLaunchKernelGGL(k_mfma_bench<MODE>, dim3(nblocks), dim3(256), lds_bytes,
-                     ctx->stream, out, 16);  // warm-up
-  SGP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(k_mfma_bench<MODE>, dim3(nblocks), dim3(256), lds_bytes,
-                     ctx->stream, out, iters);
-  SGP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  SGP_HIP(ctx, hipEventSynchronize(ctx->ev1));
-  SGP_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
-  return 0;
-}
-
-// tflops[0] = MFMA flops rate, tflops[1] = VALU FMA flops rate
-int launch_probe_mfma(sgp_ctx* ctx, int which, const double* a, const double* b,
-                      const double* c, double* d) {
-  hipLaunchKernelGGL(k_probe_mfma, dim3(1), dim3(64), 0, ctx->stream, which, a,
-                     b, c, d);
-  SGP_HIP(ctx, hipGetLastError());
-  return 0;
-}
 
 int rank1_num_blocks(int64_t N) { return int((N + 63) / 64); }
 
@@ -1384,60 +1188,3 @@ int launch_rank1(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d,
   return 0;
 }
 
-int launch_microbench(sgp_ctx* ctx, int mode, int iters, int lds_bytes,
-                      double* tflops) {
-  const int nblocks = ctx->num_cu * 8;
-  double* out = static_cast<double*>(
-      sgp_scratch(ctx, 0, size_t(nblocks) * 256 * sizeof(double)));
-  if (!out) return -1;
-  float ms = 0.f;
-  int na = 8, valu_per_it = 0;
-  switch (mode) {
-    case 0: SGP_TRY(run_microbench<0>(ctx, iters, lds_bytes, nblocks, out, &ms)); break;
-    case 1: SGP_TRY(run_microbench<1>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;
-    case 2: SGP_TRY(run_microbench<2>(ctx, iters, lds_bytes, nblocks, out, &ms)); valu_per_it = 64; break;
-    case 3: SGP_TRY(run_microbench<3>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 0; valu_per_it = 64; break;
-    case 4: SGP_TRY(run_microbench<4>(ctx, iters, lds_bytes, nblocks, out, &ms)); valu_per_it = 16; break;
-    case 5: SGP_TRY(run_microbench<5>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 16; break;
-    case 6: SGP_TRY(run_microbench<6>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;  // 16 x 512 flop
-    case 7: SGP_TRY(run_microbench<7>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;
-    case 8: SGP_TRY(run_microbench<8>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;
-    case 9: SGP_TRY(run_microbench<9>(ctx, iters, lds_bytes, nblocks, out, &ms)); na = 4; break;
-    case 20: case 21: case 22: case 23: case 24: {
-      // stage probes: lds_bytes carries `lo`; two 4-wave workgroups per CU
-      const int lo = lds_bytes, nb = ctx->num_cu * 2;
-      double* src = static_cast<double*>(sgp_scratch(ctx, 1, size_t(kATile) * 8));
-      if (!src) return -1;
-      SGP_HIP(ctx, hipMemsetAsync(src, 0, size_t(kATile) * 8, ctx->stream));
-#define STAGE_RUN(S)                                                            \
-  SGP_HIP(ctx, hipFuncSetAttribute(                                             \
-                   reinterpret_cast<const void*>(&k_stage_bench<S>),            \
-                   hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsBytes)));\
-  hipLaunchKernelGGL(k_stage_bench<S>, dim3(nb), dim3(256), kLdsBytes,          \
-                     ctx->stream, src, out, 16, lo);                            \
-  SGP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));                          \
-  hipLaunchKernelGGL(k_stage_bench<S>, dim3(nb), dim3(256), kLdsBytes,          \
-                     ctx->stream, src, out, iters, lo);                         \
-  SGP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-      switch (mode) {
-        case 20: STAGE_RUN(0) break;
-        case 21: STAGE_RUN(1) break;
-        case 22: STAGE_RUN(2) break;
-        case 23: STAGE_RUN(3) break;
-        default: STAGE_RUN(4) break;
-      }
-#undef STAGE_RUN
-      SGP_HIP(ctx, hipEventSynchronize(ctx->ev1));
-      SGP_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-      tflops[0] = double(nb) * 4.0 * iters * (16 - lo) * 16 * 512.0 /
-                  (double(ms) * 1e-3) / 1e12;
-      tflops[1] = double(ms) * 1e6 / iters;     // ns per stage
-      return 0;
-    }
-    default: sgp_set_error(ctx, "unknown microbench mode %d", mode); return -2;
-  }
-  const double waves = double(nblocks) * 4.0;
-  tflops[0] = waves * iters * na * 2048.0 / (double(ms) * 1e-3) / 1e12;
-  tflops[1] = waves * iters * valu_per_it * 128.0 / (double(ms) * 1e-3) / 1e12;
-  return 0;
-}

@@ -26,6 +26,8 @@ def main():
     cfg = bench.make_config(k)
     gps = bench.build_gps(cfg, gpy)
     pts = cfg["grid"] if "grid" in cfg else cfg["particles"]
+    if k == 4:                       # one rank's share of the 200^3 grid
+        pts = pts[4000000:5000000]
     grid = _hip.DeviceGrid(ctx, pts, cfg["G"])
     devs = [g._fitted() for g in gps]
     fmin = np.zeros(cfg["G"])

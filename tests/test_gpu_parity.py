@@ -49,13 +49,6 @@ def check_posterior(m, v, m_ref, v_ref, kdiag):
 
 
 # ---------------------------------------------------------------------------
-def test_mfma_f64_microbench(mods):
-    from safeopt_amd import _hip
-    tf = _hip.Context.default().microbench_mfma_f64(20000)
-    print("fp64 MFMA issue rate: %.1f TFLOP/s" % tf)
-    assert tf > 50.0          # v_mfma_f64_4x4x4_4b_f64 sustains ~75 on an MI355X
-
-
 @pytest.mark.parametrize("kind", ["RBF", "Matern32", "Matern52"])
 def test_kern_K(mods, kind):
     _, gpy, gpn, _ = mods
