@@ -45,20 +45,31 @@
 
 namespace {
 
-constexpr int kIB = 16;                // accumulator slots = 256 rows of L^-1
 constexpr int kJC = 16;                // training points per stage (one j-block)
 constexpr int kSteps = kJC / 4;        // MFMA k-steps per stage
-constexpr int kATile = kIB * kSteps * 64;           // doubles (32 KB)
 constexpr int kXTile = kJC * SGP_MAX_D;             // doubles
-constexpr int kBuf = kATile + kXTile + kJC;         // + alpha chunk
-constexpr int kTabOff = 2 * kBuf;                   // exp table (32 doubles)
 constexpr int kKbRow = 80;     // doubles between the 4 k-rows of a wave's
                                // broadcast buffer (64 + 16: k-rows on disjoint banks)
 constexpr int kKbBuf = 4 * kKbRow;
-constexpr int kKbOff = kTabOff + kExpTabSize;
-constexpr size_t sweep_lds_bytes(int nw) {
-  return (size_t(kKbOff) + size_t(nw) * kKbBuf) * sizeof(double);
-}
+
+// LDS layout for SL accumulator slots per wave (SL x 16 rows of L^-1 per chunk):
+//   [2][A chunk | training rows | alpha]  exp table  [NW] broadcast buffers
+// SL = 16: 256 VGPRs, two waves per SIMD (two 4-wave workgroups per CU).
+// SL = 32 (experiment, -DSGP_SWEEP_SLOTS32): the accumulators take 256 registers
+//   by themselves -- one wave per SIMD with the 512-entry unified register file
+//   (AGPRs), one workgroup per CU; twice the matrix work per stage for the same
+//   evaluation / staging / bookkeeping.  Measured 1.6-1.8x slower: a lone wave
+//   exposes every latency and the compiler shuffles accumulators through AGPRs.
+template <int SL>
+struct Lay {
+  static constexpr int kATile = SL * kSteps * 64;           // doubles
+  static constexpr int kBuf = kATile + kXTile + kJC;        // + alpha chunk
+  static constexpr int kTabOff = 2 * kBuf;                  // exp table
+  static constexpr int kKbOff = kTabOff + kExpTabSize;
+  static constexpr size_t bytes(int nw) {
+    return (size_t(kKbOff) + size_t(nw) * kKbBuf) * sizeof(double);
+  }
+};
 
 enum { MODE_CONF = 0, MODE_FITNESS = 1 };
 
@@ -73,11 +84,11 @@ struct StageEnt {
   uint32_t word;        // see SW_*
 };
 enum : uint32_t {
-  SW_NACT_MASK = 31u,       // active slots 0 .. nact-1 (1..16)
-  SW_CHUNK_END = 1u << 5,   // last j-block of an accumulator chunk: fold
-  SW_GP_END = 1u << 6,      // last stage of a GP: row epilogue
-  SW_TILE_END = 1u << 7,    // last stage of the tile
-  SW_MEAN = 1u << 8,        // stage of the LAST chunk: accumulate alpha . k
+  SW_NACT_MASK = 63u,       // active slots 0 .. nact-1 (1..32)
+  SW_CHUNK_END = 1u << 6,   // last j-block of an accumulator chunk: fold
+  SW_GP_END = 1u << 7,      // last stage of a GP: row epilogue
+  SW_TILE_END = 1u << 8,    // last stage of the tile
+  SW_MEAN = 1u << 9,        // stage of the LAST chunk: accumulate alpha . k
   SW_G_SHIFT = 12           // GP index (3 bits)
 };
 
@@ -104,6 +115,7 @@ struct SweepParams {
   const StageEnt* stages;   // [nstages] one tile's stage sequence (all GPs)
   int nstages;
   int single;               // every GP has a one-part kernel (pre-scaled inputs)
+  int slots;                // accumulator slots per wave: 16 or 32 (host only)
 };
 
 typedef const __attribute__((address_space(1))) double* gptr_t;
@@ -158,15 +170,15 @@ __device__ __forceinline__ void lds_dma16(gptr_t src, double* dst, int off) {
 
 // (src is wave-uniform and stays in SGPRs; the lane offset is added at the call
 // so every copy is "scalar base + 32-bit lane offset", no 64-bit VALU adds)
-template <int NW, int K>
+template <int NW, int SL, int K>
 __device__ __forceinline__ void dma_slots(gptr_t src, double* dst, int64_t rs,
                                           int left, unsigned lane2) {
-  if constexpr (K < kIB / NW) {
+  if constexpr (K < SL / NW) {
     if (left > NW * K) {          // slot wave + NW K is active (prefix: nested)
       lds_dma16(src + lane2, dst, 0);
       lds_dma16(src + lane2, dst, 1024);
-      dma_slots<NW, K + 1>(src - NW * rs, dst + NW * (kSteps * 64), rs, left,
-                           lane2);
+      dma_slots<NW, SL, K + 1>(src - NW * rs, dst + NW * (kSteps * 64), rs, left,
+                               lane2);
     }
   }
 }
@@ -174,31 +186,31 @@ __device__ __forceinline__ void dma_slots(gptr_t src, double* dst, int64_t rs,
 // Asynchronous global -> LDS copy of the active slots of one stage.  LDS image:
 // slot-major A[slot][k-step][lane] (2 KB per slot = two 1 KB instructions);
 // wave w copies slots w, w + NW, ... below nact.
-template <int NW>
+template <int NW, int SL>
 __device__ __forceinline__ void stage_dma(const GpView& gp, const StageEnt& e,
                                           double* buf, int wave, int lane) {
   const int nact = int(e.word & SW_NACT_MASK);
   const int64_t rs = int64_t(e.row_stride) * 64;            // doubles / row block
   gptr_t src = gp.Apack + (int64_t(e.a_off) * 64 - wave * rs);   // wave-uniform
   double* dst = buf + wave * (kSteps * 64);                       // wave-uniform
-  dma_slots<NW, 0>(src, dst, rs, nact - wave, unsigned(lane) * 2u);
+  dma_slots<NW, SL, 0>(src, dst, rs, nact - wave, unsigned(lane) * 2u);
 }
 
 // Training rows (pre-scaled) and alpha entries of the stage's j-block: runs of
 // 16 D and 16 doubles in GpDev::Xs / alpha -- wave 0 moves the rows (8 D lanes x
 // 16 B), the last wave the alpha run (8 lanes x 16 B); the other lanes are
 // masked off and write nothing.
-template <int D, int NW>
+template <int D, int NW, int SL>
 __device__ __forceinline__ void stage_x_dma(const GpView& gp, const StageEnt& e,
                                             double* buf, int wave, int lane) {
   if (wave == 0) {
     if (lane < 8 * D)
       lds_dma16(gp.Xs + int64_t(e.jb) * (kJC * D) + unsigned(lane) * 2u,
-                buf + kATile, 0);
+                buf + Lay<SL>::kATile, 0);
   } else if (wave == NW - 1) {
     if (lane < 8)
       lds_dma16(gp.alpha + int64_t(e.jb) * kJC + unsigned(lane) * 2u,
-                buf + kATile + kXTile, 0);
+                buf + Lay<SL>::kATile + kXTile, 0);
   }
 }
 
@@ -247,42 +259,54 @@ __device__ __forceinline__ void load_slot(double (&ops)[4], const double* aT,
 }
 
 // One 16-wide j-block against accumulator slots 0..nact-1: a slot is 16 MFMAs on
-// four independent accumulators; the next slot's A operands are read from LDS
+// four independent accumulators (groups of four separated by one wait state --
+// measured: a dense stream without them runs 17.4 cycles per MFMA instead of
+// 16.25, profiles/r02/probes.txt); the next slot's A operands are read from LDS
 // while they execute (the read of slot nact is harmless: it stays inside the
-// stage buffer).  The active slots are a prefix, so the guards nest: the first
-// inactive slot leaves the whole sequence with one branch.
-template <int S>
-__device__ __forceinline__ void mfma_slots(int nact, double4_t (&acc)[kIB],
+// stage buffer; the empty asm keeps the compiler from sinking the reads into the
+// next slot's block, where their latency would be exposed).  The active slots are
+// a prefix, so the guards nest: the first inactive slot leaves the whole sequence
+// with one branch.
+//
+// The MFMA goes through inline asm with the accumulator tied to destination AND
+// addend: the builtin lets the register allocator rename the destination, which
+// costs v_mov_b64 copies at every join of the guarded sequence.
+__device__ __forceinline__ void mfma_acc(double& c, double a, double b) {
+  asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+template <int SL, int S>
+__device__ __forceinline__ void mfma_slots(int nact, double (&acc)[SL][4],
                                            const double* aT,
                                            const double (&kb)[4][4],
                                            double (&cur)[4], double (&nxt)[4]) {
-  if constexpr (S < kIB) {
+  if constexpr (S < SL) {
     if (S < nact) {
-      // operands of the next slot: issued HERE, consumed after this slot's 16
-      // MFMAs (the empty asm keeps the compiler from sinking the reads into
-      // the next slot's block, where their latency would be exposed)
-      if (S + 1 < kIB) load_slot(nxt, aT, S + 1);
+      if (S + 1 < SL) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nxt[q] = aT[((S + 1) * kSteps + q) * 64];
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          acc[S][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(cur[q], kb[m][q],
-                                                         acc[S][m], 0, 0, 0);
+        for (int m = 0; m < 4; ++m) mfma_acc(acc[S][m], cur[q], kb[m][q]);
       }
-      if (S + 1 < kIB)
+      if (S + 1 < SL)
         asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
-      mfma_slots<S + 1>(nact, acc, aT, kb, nxt, cur);
+      mfma_slots<SL, S + 1>(nact, acc, aT, kb, nxt, cur);
     }
   }
 }
 
-__device__ __forceinline__ void mfma_jblock(int nact, double4_t (&acc)[kIB],
+template <int SL>
+__device__ __forceinline__ void mfma_jblock(int nact, double (&acc)[SL][4],
                                             const double* aT,
                                             const double (&kb)[4][4]) {
   double opsA[4], opsB[4];
-  load_slot(opsA, aT, 0);
-  mfma_slots<0>(nact, acc, aT, kb, opsA, opsB);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) opsA[q] = aT[q * 64];
+  mfma_slots<SL, 0>(nact, acc, aT, kb, opsA, opsB);
 }
 
 // SafeOptSwarm._compute_penalty (gp_opt.py:874-899) for one value.
@@ -351,9 +375,12 @@ __global__ void k_fitness_small(int G, int64_t P, const double* mean,
 }
 
 
-template <int D, int NW, int MODE, bool SINGLE>
-__global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
+template <int D, int NW, int SL, int MODE, bool SINGLE>
+__global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams p) {
   constexpr int kTilePts = 16 * NW;
+  constexpr int kATile = Lay<SL>::kATile, kBuf = Lay<SL>::kBuf;
+  constexpr int kTabOff = Lay<SL>::kTabOff, kKbOff = Lay<SL>::kKbOff;
+  constexpr int kIB = SL;
   constexpr bool conf = MODE == MODE_CONF;   // compile-time: no dead state
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const double* tab = lds + kTabOff;
@@ -400,8 +427,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   KernFast<D> kf(p.gps[0].kern);
   double kdiag = p.gps[0].kern.kdiag;
   StageEnt e1 = load_stage(stages, 0);
-  stage_dma<NW>(gv, e1, lds, wave, lane);
-  stage_x_dma<D, NW>(gv, e1, lds, wave, lane);
+  stage_dma<NW, SL>(gv, e1, lds, wave, lane);
+  stage_x_dma<D, NW, SL>(gv, e1, lds, wave, lane);
   uint32_t wcur = e1.word;
   int si1 = 0, t1 = tile;
   advance(si1, t1);
@@ -413,9 +440,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   // per-GP state
   double xs[D];
   double sq[4] = {0.0, 0.0, 0.0, 0.0}, mean = 0.0;
-  double4_t acc[kIB];
+  double acc[kIB][4];
 #pragma unroll
-  for (int b = 0; b < kIB; ++b) acc[b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  for (int b = 0; b < kIB; ++b)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[b][m] = 0.0;
   // per-tile state of the row epilogue (confidence sweep / swarm fitness)
   bool safe = true;
   double l0 = 0.0, values = 0.0, interest = 1.0, total_pen = 0.0, lower = 0.0;
@@ -438,8 +467,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
         gv_g = g_n;
       }
       if (!SGP_ABL(2)) {
-        stage_dma<NW>(gv, e1, nbuf, wave, lane);
-        stage_x_dma<D, NW>(gv, e1, nbuf, wave, lane);
+        stage_dma<NW, SL>(gv, e1, nbuf, wave, lane);
+        stage_x_dma<D, NW, SL>(gv, e1, nbuf, wave, lane);
       }
       if (next_tile) load_x(t1, xnext);
     }
@@ -471,7 +500,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     if (!SGP_ABL(8)) {
       double kb[4][4];
       broadcast_quads(kv, kbw, lane, kb);
-      mfma_jblock(int(wcur & SW_NACT_MASK), acc, cbuf + lane, kb);
+      mfma_jblock<SL>(int(wcur & SW_NACT_MASK), acc, cbuf + lane, kb);
     }
 
     if (wcur & SW_CHUNK_END) {
@@ -963,9 +992,10 @@ int sweep_waves() {
 // of L^-1, the j-blocks 0 .. bend-1 (only the slots at or below the diagonal are
 // active).  Depends on the block counts only, so it is rebuilt (and uploaded)
 // when a GP crosses a multiple of 16 training points, not per launch.
-int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, const StageEnt** dev,
-                int* nstages) {
+int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB,
+                const StageEnt** dev, int* nstages) {
   std::vector<int> sig(1, Geff);
+  sig.push_back(kIB);
   for (int g = 0; g < Geff; ++g) sig.push_back(gh[g].nblk);
   if (sig == ctx->stage_sig && ctx->stage_tab.p) {
     *dev = static_cast<const StageEnt*>(ctx->stage_tab.p);
@@ -1003,21 +1033,21 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, const StageEnt** dev,
   return 0;
 }
 
-template <int D, int NW, int MODE, bool SINGLE>
+template <int D, int NW, int SL, int MODE, bool SINGLE>
 int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep<D, NW, MODE, SINGLE>),
+                     reinterpret_cast<const void*>(&k_sweep<D, NW, SL, MODE, SINGLE>),
                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                     int(sweep_lds_bytes(NW))));
+                     int(Lay<SL>::bytes(NW))));
     attr_set = true;
   }
   const int tile = 16 * NW;
   const int64_t ntiles = (p.pts.N + tile - 1) / tile;
   // persistent: as many workgroups as are resident at once (256 VGPRs per
   // thread -> 8 waves per CU) walk over the tiles
-  const int64_t resident = int64_t(ctx->num_cu) * (8 / NW);
+  const int64_t resident = int64_t(ctx->num_cu) * (SL == 32 ? 1 : 8 / NW);
   const int nblocks = int(ntiles < resident ? ntiles : resident);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profiling) {
@@ -1039,28 +1069,31 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
   pp.ablate = ablate;
 #endif
-  hipLaunchKernelGGL((k_sweep<D, NW, MODE, SINGLE>), dim3(nblocks), dim3(64 * NW),
-                     sweep_lds_bytes(NW), ctx->stream, pp);
+  hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE>), dim3(nblocks),
+                     dim3(64 * NW), Lay<SL>::bytes(NW), ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
   if (e1) SGP_HIP(ctx, hipEventRecord(e1, ctx->stream));
   return 0;
 }
 
-template <int D, int NW>
+template <int D, int NW, int SL>
 int launch_sweep_w(sgp_ctx* ctx, const SweepParams& p, double flops) {
   if (p.mode == MODE_CONF)
-    return p.single ? launch_sweep_v<D, NW, MODE_CONF, true>(ctx, p, flops)
-                    : launch_sweep_v<D, NW, MODE_CONF, false>(ctx, p, flops);
-  return p.single ? launch_sweep_v<D, NW, MODE_FITNESS, true>(ctx, p, flops)
-                  : launch_sweep_v<D, NW, MODE_FITNESS, false>(ctx, p, flops);
+    return p.single ? launch_sweep_v<D, NW, SL, MODE_CONF, true>(ctx, p, flops)
+                    : launch_sweep_v<D, NW, SL, MODE_CONF, false>(ctx, p, flops);
+  return p.single ? launch_sweep_v<D, NW, SL, MODE_FITNESS, true>(ctx, p, flops)
+                  : launch_sweep_v<D, NW, SL, MODE_FITNESS, false>(ctx, p, flops);
 }
 
 template <int D>
 int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
 #ifdef SGP_SWEEP_WAVES8
-  if (sweep_waves() == 8) return launch_sweep_w<D, 8>(ctx, p, flops);
+  if (sweep_waves() == 8) return launch_sweep_w<D, 8, 16>(ctx, p, flops);
 #endif
-  return launch_sweep_w<D, 4>(ctx, p, flops);
+#ifdef SGP_SWEEP_SLOTS32
+  if (p.slots == 32) return launch_sweep_w<D, 4, 32>(ctx, p, flops);
+#endif
+  return launch_sweep_w<D, 4, 16>(ctx, p, flops);
 }
 
 int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
@@ -1073,7 +1106,15 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
     flops += (double(gh[g].n) * gh[g].n + 2.0 * gh[g].n) * double(p.pts.N);
   if (p.pts.N <= 0) return 0;
   SweepParams q = p;
-  SGP_TRY(stage_table(ctx, gh, Geff, &q.stages, &q.nstages));
+  // 16 accumulator slots per wave.  (A build with -DSGP_SWEEP_SLOTS32 also
+  // carries the 32-slot / one-wave-per-SIMD variant, SGP_SWEEP_SLOTS=32 selects
+  // it: measured 1.6-1.8x SLOWER, profiles/README.md.)
+  q.slots = 16;
+#ifdef SGP_SWEEP_SLOTS32
+  static const int force = getenv("SGP_SWEEP_SLOTS") ? atoi(getenv("SGP_SWEEP_SLOTS")) : 0;
+  if (force == 32 && sweep_waves() == 4) q.slots = 32;
+#endif
+  SGP_TRY(stage_table(ctx, gh, Geff, q.slots, &q.stages, &q.nstages));
   q.single = 1;
   for (int g = 0; g < Geff; ++g) q.single = q.single && gh[g].kern.n_parts == 1;
   switch (d) {
