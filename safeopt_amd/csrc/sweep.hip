@@ -47,10 +47,6 @@ namespace {
 
 constexpr int kJC = 16;                // training points per stage (one j-block)
 constexpr int kSteps = kJC / 4;        // MFMA k-steps per stage
-constexpr int kXTile = kJC * SGP_MAX_D;             // doubles
-constexpr int kKbRow = 80;     // doubles between the 4 k-rows of a wave's
-                               // broadcast buffer (64 + 16: k-rows on disjoint banks)
-constexpr int kKbBuf = 4 * kKbRow;
 
 // LDS layout for SL accumulator slots per wave (SL x 16 rows of L^-1 per chunk):
 //   [2][A chunk | training rows | alpha]  exp table  [NW] broadcast buffers
@@ -60,14 +56,28 @@ constexpr int kKbBuf = 4 * kKbRow;
 //   (AGPRs), one workgroup per CU; twice the matrix work per stage for the same
 //   evaluation / staging / bookkeeping.  Measured 1.6-1.8x slower: a lone wave
 //   exposes every latency and the compiler shuffles accumulators through AGPRs.
-template <int SL>
+// A wave's broadcast buffer holds 4 k-rows of 64 doubles, kKbRow doubles apart
+// (an odd multiple of 16: the k-rows then sit on disjoint banks).  The padding
+// between them doubles as the staging area of the wave's Q rows (kQCap doubles):
+// 48 doubles per k-row up to d = 4 (Q rows of up to 6 GPs), 16 beyond (2 GPs) --
+// what keeps two workgroups per CU inside 160 KB of LDS.
+template <int SL, int D>
 struct Lay {
   static constexpr int kATile = SL * kSteps * 64;           // doubles
+  static constexpr int kXTile = kJC * D;
   static constexpr int kBuf = kATile + kXTile + kJC;        // + alpha chunk
   static constexpr int kTabOff = 2 * kBuf;                  // exp table
   static constexpr int kKbOff = kTabOff + kExpTabSize;
+  static constexpr int kKbRow = D <= 4 ? 112 : 80;
+  static constexpr int kKbBuf = 4 * kKbRow;
+  static constexpr int kQPad = kKbRow - 64;                 // doubles per k-row
+  static constexpr int kQMaxG = kQPad / 8;                  // 16 rows x 2 G doubles
   static constexpr size_t bytes(int nw) {
     return (size_t(kKbOff) + size_t(nw) * kKbBuf) * sizeof(double);
+  }
+  // double2 number i of a wave's staged Q block -> offset (doubles) in its buffer
+  static __device__ __forceinline__ int qoff(int i) {
+    return (i / (kQPad / 2)) * kKbRow + 64 + 2 * (i % (kQPad / 2));
   }
 };
 
@@ -200,17 +210,17 @@ __device__ __forceinline__ void stage_dma(const GpView& gp, const StageEnt& e,
 // 16 D and 16 doubles in GpDev::Xs / alpha -- wave 0 moves the rows (8 D lanes x
 // 16 B), the last wave the alpha run (8 lanes x 16 B); the other lanes are
 // masked off and write nothing.
-template <int D, int NW, int SL>
+template <int D, int NW, int SL, int WX = 0, int WA = NW - 1>
 __device__ __forceinline__ void stage_x_dma(const GpView& gp, const StageEnt& e,
                                             double* buf, int wave, int lane) {
-  if (wave == 0) {
+  if (wave == WX) {
     if (lane < 8 * D)
       lds_dma16(gp.Xs + int64_t(e.jb) * (kJC * D) + unsigned(lane) * 2u,
-                buf + Lay<SL>::kATile, 0);
-  } else if (wave == NW - 1) {
+                buf + Lay<SL, D>::kATile, 0);
+  } else if (wave == WA) {
     if (lane < 8)
       lds_dma16(gp.alpha + int64_t(e.jb) * kJC + unsigned(lane) * 2u,
-                buf + Lay<SL>::kATile + kXTile, 0);
+                buf + Lay<SL, D>::kATile + Lay<SL, D>::kXTile, 0);
   }
 }
 
@@ -234,6 +244,7 @@ __device__ __forceinline__ void stage_x_dma(const GpView& gp, const StageEnt& e,
 // lane (k, m, j).  Through a wave-private LDS buffer laid out [k][c][q]: two
 // 16-byte stores and eight 16-byte loads per lane (LDS instructions of one wave
 // execute in order; no barrier).
+template <int kKbRow>
 __device__ __forceinline__ void broadcast_quads(const double (&kv)[4], double* kbw,
                                                 int lane, double (&kb)[4][4]) {
   double2_t* w = reinterpret_cast<double2_t*>(kbw + (lane >> 4) * kKbRow +
@@ -375,11 +386,20 @@ __global__ void k_fitness_small(int G, int64_t P, const double* mean,
 }
 
 
-template <int D, int NW, int SL, int MODE, bool SINGLE>
+// PP ("ping-pong", NW = 8, one workgroup per CU): waves 0-3 and 4-7 -- the two
+// waves of every SIMD -- run half a stage apart, separated by workgroup
+// barriers: while one group streams its MFMAs the other evaluates covariances,
+// issues the LDS-DMA of the next stage and runs the row epilogues at raised
+// priority.  An fp64 MFMA occupies its SIMD for 16 cycles and the partner wave
+// gets an issue slot between two of them: the partner's scalar / LDS / DMA
+// instructions ride in those gaps, only its VALU work costs matrix time.
+template <int D, int NW, int SL, int MODE, bool SINGLE, bool PP>
 __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams p) {
+  static_assert(!PP || NW == 8, "ping-pong pairs the two waves of a SIMD");
   constexpr int kTilePts = 16 * NW;
-  constexpr int kATile = Lay<SL>::kATile, kBuf = Lay<SL>::kBuf;
-  constexpr int kTabOff = Lay<SL>::kTabOff, kKbOff = Lay<SL>::kKbOff;
+  typedef Lay<SL, D> L;
+  constexpr int kATile = L::kATile, kBuf = L::kBuf, kXTile = L::kXTile;
+  constexpr int kTabOff = L::kTabOff, kKbOff = L::kKbOff, kKbBuf = L::kKbBuf;
   constexpr int kIB = SL;
   constexpr bool conf = MODE == MODE_CONF;   // compile-time: no dead state
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -390,6 +410,8 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* kbw = lds + kKbOff + wave * kKbBuf;
+  const bool late = PP && wave >= NW / 2;     // the group that runs half a stage behind
+  constexpr int WX = PP ? NW / 2 : 0;         // waves that stage training rows / alpha
   const int st = p.fit.swarm_type;
   const int ntiles = int((p.pts.N + kTilePts - 1) / kTilePts);
   const stage_ptr_t stages = (stage_ptr_t)(p.stages);
@@ -428,7 +450,8 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
   double kdiag = p.gps[0].kern.kdiag;
   StageEnt e1 = load_stage(stages, 0);
   stage_dma<NW, SL>(gv, e1, lds, wave, lane);
-  stage_x_dma<D, NW, SL>(gv, e1, lds, wave, lane);
+  stage_x_dma<D, NW, SL, WX>(gv, e1, lds, wave, lane);
+  StageEnt e0 = e1;        // the stage being multiplied (PP: its copy is issued late)
   uint32_t wcur = e1.word;
   int si1 = 0, t1 = tile;
   advance(si1, t1);
@@ -436,6 +459,8 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
   if (have1) e1 = load_stage(stages, si1);
   int si2 = si1, t2 = t1;
   __syncthreads();
+  if (late) __builtin_amdgcn_s_barrier();
+  bool first = true;
 
   // per-GP state
   double xs[D];
@@ -460,7 +485,20 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
     const bool more = have1;
     const uint32_t wnext = e1.word;
     const bool next_tile = more && si1 == 0;
-    if (more) {
+    if (PP) __builtin_amdgcn_s_setprio(3);
+    if (PP && !late) {
+      // early group: its share of THIS stage's A chunk (the buffer was still
+      // being multiplied by the late group one interval ago)
+      if (!first) {
+        const int g_c = int(wcur >> SW_G_SHIFT) & 7;
+        if (g_c != gv_g) {
+          gv.load(p.gps[g_c]);
+          gv_g = g_c;
+        }
+        if (!SGP_ABL(2)) stage_dma<NW, SL>(gv, e0, cbuf, wave, lane);
+      }
+      if (next_tile) load_x(t1, xnext);
+    } else if (more) {
       const int g_n = int(wnext >> SW_G_SHIFT) & 7;
       if (g_n != gv_g) {
         gv.load(p.gps[g_n]);
@@ -468,7 +506,7 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
       }
       if (!SGP_ABL(2)) {
         stage_dma<NW, SL>(gv, e1, nbuf, wave, lane);
-        stage_x_dma<D, NW, SL>(gv, e1, nbuf, wave, lane);
+        stage_x_dma<D, NW, SL, WX>(gv, e1, nbuf, wave, lane);
       }
       if (next_tile) load_x(t1, xnext);
     }
@@ -497,10 +535,17 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
       for (int q = 0; q < 4; ++q)
         mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
     }
-    if (!SGP_ABL(8)) {
-      double kb[4][4];
-      broadcast_quads(kv, kbw, lane, kb);
+    double kb[4][4];
+    if (!SGP_ABL(8)) broadcast_quads<L::kKbRow>(kv, kbw, lane, kb);
+    if (PP) {
+      __builtin_amdgcn_s_setprio(0);
+      __syncthreads();          // the partner group leaves its MFMA phase here
+    }
+    if (!SGP_ABL(8))
       mfma_jblock<SL>(int(wcur & SW_NACT_MASK), acc, cbuf + lane, kb);
+    if (PP) {
+      __syncthreads();          // ... and enters it here
+      __builtin_amdgcn_s_setprio(3);
     }
 
     if (wcur & SW_CHUNK_END) {
@@ -542,10 +587,19 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
         if (writer && !SGP_ABL(16)) {
           p.conf.mean[int64_t(g) * p.pts.N + row] = mu;
           p.conf.var[int64_t(g) * p.pts.N + row] = var;
-          if (p.conf.Q) {
-            const double2 q = make_double2(lo, up);
-            *reinterpret_cast<double2*>(p.conf.Q + (row * p.G + g) * 2) = q;
-          }
+        }
+        // Q row = [l0, u0, l1, u1, ...] (gp_opt.py:375): the intervals of the G
+        // passes are collected in the padding of the wave's broadcast buffer
+        // and leave as ONE contiguous block per wave at the end of the tile --
+        // full 128-byte lines from all 64 lanes instead of 16-byte pieces of a
+        // row from 16 lanes per GP
+        if (p.conf.Q && lane < 16 && !SGP_ABL(16)) {
+          if (p.G <= L::kQMaxG)
+            *reinterpret_cast<double2_t*>(kbw + L::qoff(lane * p.G + g)) =
+                double2_t{lo, up};
+          else if (writer)
+            *reinterpret_cast<double2_t*>(p.conf.Q + (row * p.G + g) * 2) =
+                double2_t{lo, up};
         }
       } else {
         // SafeOptSwarm._compute_particle_fitness, gp_opt.py:925-1013
@@ -579,6 +633,16 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
 
       if (wcur & SW_TILE_END) {
         if (conf) {
+          if (p.conf.Q && p.G <= L::kQMaxG && !SGP_ABL(16)) {
+            const int64_t row0 = int64_t(tile) * kTilePts + wave * 16;
+            const int64_t left = p.pts.N - row0;
+            const int nq = (left >= 16 ? 16 : (left > 0 ? int(left) : 0)) * p.G;
+            __builtin_amdgcn_wave_barrier();
+            double2_t* dst = reinterpret_cast<double2_t*>(p.conf.Q) + row0 * p.G;
+            for (int i = lane; i < nq; i += 64)
+              dst[i] = *reinterpret_cast<const double2_t*>(kbw + L::qoff(i));
+            __builtin_amdgcn_wave_barrier();
+          }
           if (p.conf.S) {
             if (writer) p.conf.S[row] = safe ? 1 : 0;
             // maximum of l0 over the safe rows of the wave -> one partial per
@@ -619,13 +683,19 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
     }
 
     if (!more) break;
-    if (!SGP_ABL(1)) __syncthreads();
+    if (!PP && !SGP_ABL(1)) __syncthreads();
     par ^= 1;
+    first = false;
     wcur = wnext;
+    e0 = e1;
     e1 = e2;
     si1 = si2;
     t1 = t2;
     have1 = have2;
+  }
+  if (PP) {
+    __builtin_amdgcn_s_setprio(0);
+    if (!late) __builtin_amdgcn_s_barrier();
   }
 }
 
@@ -1033,14 +1103,14 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB,
   return 0;
 }
 
-template <int D, int NW, int SL, int MODE, bool SINGLE>
+template <int D, int NW, int SL, int MODE, bool SINGLE, bool PP = false>
 int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep<D, NW, SL, MODE, SINGLE>),
+                     reinterpret_cast<const void*>(&k_sweep<D, NW, SL, MODE, SINGLE, PP>),
                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                     int(Lay<SL>::bytes(NW))));
+                     int(Lay<SL, D>::bytes(NW))));
     attr_set = true;
   }
   const int tile = 16 * NW;
@@ -1069,8 +1139,9 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
   pp.ablate = ablate;
 #endif
-  hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE>), dim3(nblocks),
-                     dim3(64 * NW), Lay<SL>::bytes(NW), ctx->stream, pp);
+  const size_t lds_bytes = Lay<SL, D>::bytes(NW);
+  hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE, PP>), dim3(nblocks),
+                     dim3(64 * NW), lds_bytes, ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
   if (e1) SGP_HIP(ctx, hipEventRecord(e1, ctx->stream));
   return 0;
@@ -1088,7 +1159,17 @@ int launch_sweep_w(sgp_ctx* ctx, const SweepParams& p, double flops) {
 template <int D>
 int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
 #ifdef SGP_SWEEP_WAVES8
-  if (sweep_waves() == 8) return launch_sweep_w<D, 8, 16>(ctx, p, flops);
+  if (sweep_waves() == 8) {
+    static const bool pp = getenv("SGP_SWEEP_PP") != nullptr;
+    if (pp) {
+      if (p.mode == MODE_CONF)
+        return p.single ? launch_sweep_v<D, 8, 16, MODE_CONF, true, true>(ctx, p, flops)
+                        : launch_sweep_v<D, 8, 16, MODE_CONF, false, true>(ctx, p, flops);
+      return p.single ? launch_sweep_v<D, 8, 16, MODE_FITNESS, true, true>(ctx, p, flops)
+                      : launch_sweep_v<D, 8, 16, MODE_FITNESS, false, true>(ctx, p, flops);
+    }
+    return launch_sweep_w<D, 8, 16>(ctx, p, flops);
+  }
 #endif
 #ifdef SGP_SWEEP_SLOTS32
   if (p.slots == 32) return launch_sweep_w<D, 4, 32>(ctx, p, flops);
