@@ -513,12 +513,28 @@ int sgp_grid_set_context(sgp_grid* g, const double* c, int nc) {
 // (sgp_grid_sets_fused picks the value up on the device and reports it).
 static int finish_safe_partials(sgp_grid* g, int nblocks, double* out2) {
   sgp_ctx* ctx = g->ctx;
+  g->l0_pending = 0;
+  if (!out2 && nblocks <= 4096) {
+    // no read-back: the consumer (sgp_grid_sets_fused) folds the partials
+    // itself; anything else that needs scal[0] calls settle_max_l first
+    g->l0_pending = nblocks;
+    return 0;
+  }
   SGP_TRY(launch_reduce_max(ctx, g->partial, nblocks, g->scal));
   if (!out2) return 0;
   double m = 0.0;
   SGP_TRY(sgp_d2h(ctx, &m, g->scal, sizeof(double)));
   out2[0] = m;
   out2[1] = (m > -INFINITY) ? 1.0 : 0.0;
+  return 0;
+}
+
+// scal[0] = max l0[S] when a deferred confidence pass left it as partials
+static int settle_max_l(sgp_grid* g) {
+  if (g->l0_pending > 0) {
+    SGP_TRY(launch_reduce_max(g->ctx, g->partial, g->l0_pending, g->scal));
+    g->l0_pending = 0;
+  }
   return 0;
 }
 
@@ -553,7 +569,7 @@ int sgp_grid_confidence(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   co.beta = beta;
   for (int i = 0; i < SGP_MAX_GPS; ++i) co.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
   SGP_TRY(launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co));
-  return finish_safe_partials(g, sweep_num_blocks(g->N), out2);
+  return finish_safe_partials(g, sweep_num_partials(ctx, g->N), out2);
 }
 
 int sgp_grid_posterior(sgp_grid* g, sgp_gp* const* gps, int G) {
@@ -759,40 +775,63 @@ int sgp_grid_download(sgp_grid* g, int what, void* out) {
 // Enqueue the expander test (operands + scan); flags stay on the device.
 // `top` != nullptr: the single candidate is already on the device (result
 // block of the front half: x | mean | q) and xc / mu_c / u_c are ignored.
+struct ExpanderBufs {   // device layout: xc | resid[G][16] | delta | inv_s2 | tn2 | flags | W
+  double *xc, *resid, *delta, *inv_s2, *tn2, *W;
+  int32_t* flags;
+  size_t bx, bv, bf;
+  int64_t wstride;
+};
+
+static int expander_bufs(sgp_grid* g, const GpDev* host, int G, ExpanderBufs* b) {
+  sgp_ctx* ctx = g->ctx;
+  int np_max = 0;
+  for (int i = 0; i < G; ++i) np_max = host[i].n_pad > np_max ? host[i].n_pad : np_max;
+  b->wstride = int64_t(np_max / 4) * 64;
+  b->bx = size_t(SGP_TOPK) * g->d * 8;
+  b->bv = size_t(G) * 16 * 8;
+  b->bf = size_t(SGP_TOPK) * G * 4 + 64;
+  const size_t total = b->bx + 4 * b->bv + b->bf + size_t(G) * b->wstride * 8;
+  char* buf = static_cast<char*>(sgp_scratch(ctx, 7, total));
+  SGP_CHECK(ctx, buf, "device allocation failed: %s", ctx->err.c_str());
+  b->xc = reinterpret_cast<double*>(buf);
+  b->resid = reinterpret_cast<double*>(buf + b->bx);
+  b->delta = reinterpret_cast<double*>(buf + b->bx + b->bv);
+  b->inv_s2 = reinterpret_cast<double*>(buf + b->bx + 2 * b->bv);
+  b->tn2 = reinterpret_cast<double*>(buf + b->bx + 3 * b->bv);
+  b->flags = reinterpret_cast<int32_t*>(buf + b->bx + 4 * b->bv);
+  b->W = reinterpret_cast<double*>(buf + b->bx + 4 * b->bv + b->bf);
+  return 0;
+}
+
+// `staged`: xc / resid already hold the (single) candidate and the flags are
+// zeroed (k_front_final did both on the device); xc / mu_c / u_c are ignored.
 static int enqueue_expander(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
                             const double* fmin, int m, const double* xc,
                             const double* mu_c, const double* u_c,
                             double near_frac, int32_t** flags_dev,
-                            const double* top = nullptr) {
+                            const double* top = nullptr, bool staged = false) {
   sgp_ctx* ctx = g->ctx;
   SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
   SGP_CHECK(ctx, m >= 1 && m <= SGP_TOPK, "m = %d not in 1..%d", m, SGP_TOPK);
   GpDev host[SGP_MAX_GPS];
   SGP_TRY(collect_gps(ctx, gps, G, g->d, host));
   const int d = g->d;
-  int np_max = 0;
-  for (int i = 0; i < G; ++i) np_max = host[i].n_pad > np_max ? host[i].n_pad : np_max;
-  const int64_t wstride = int64_t(np_max / 4) * 64;
-  // device layout: xc | resid[G][16] | delta | inv_s2 | tn2 | flags | W
-  const size_t bx = size_t(SGP_TOPK) * d * 8, bv = size_t(G) * 16 * 8,
-               bf = size_t(SGP_TOPK) * G * 4 + 64;
-  const size_t total = bx + 4 * bv + bf + size_t(G) * wstride * 8;
-  char* buf = static_cast<char*>(sgp_scratch(ctx, 7, total));
-  SGP_CHECK(ctx, buf, "device allocation failed: %s", ctx->err.c_str());
-  double* dxc = reinterpret_cast<double*>(buf);
-  double* dres = reinterpret_cast<double*>(buf + bx);
-  double* ddel = reinterpret_cast<double*>(buf + bx + bv);
-  double* dis2 = reinterpret_cast<double*>(buf + bx + 2 * bv);
-  double* dtn2 = reinterpret_cast<double*>(buf + bx + 3 * bv);
-  int32_t* dfl = reinterpret_cast<int32_t*>(buf + bx + 4 * bv);
-  double* dW = reinterpret_cast<double*>(buf + bx + 4 * bv + bf);
+  ExpanderBufs eb;
+  SGP_TRY(expander_bufs(g, host, G, &eb));
+  const size_t bx = eb.bx, bv = eb.bv, bf = eb.bf;
+  const int64_t wstride = eb.wstride;
+  double *dxc = eb.xc, *dres = eb.resid, *ddel = eb.delta, *dis2 = eb.inv_s2,
+         *dtn2 = eb.tn2, *dW = eb.W;
+  int32_t* dfl = eb.flags;
   // pinned staging block: xc | resid (descriptors have their own slot)
   const size_t hb = bx + bv + sizeof(GpDev) * SGP_MAX_GPS;
   SGP_CHECK(ctx, hb <= ctx->pinned_cap / 2, "staging buffer too small");
   char* stage = static_cast<char*>(ctx->pinned) + ctx->pinned_cap / 2;
   // previous users of this block have completed (every call that writes it
   // syncs before returning)
-  if (top) {
+  if (staged) {
+    // nothing to stage
+  } else if (top) {
     SGP_HIP(ctx, hipMemsetAsync(dxc, 0, bx + bv, ctx->stream));
     SGP_TRY(launch_stage_top(g, top, top + d, top + d + G, dxc, dres));
   } else {
@@ -806,7 +845,7 @@ static int enqueue_expander(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
                                 ctx->stream));
   }
   SGP_TRY(stage_gpdev(g, host, G));
-  SGP_HIP(ctx, hipMemsetAsync(dfl, 0, bf, ctx->stream));
+  if (!staged) SGP_HIP(ctx, hipMemsetAsync(dfl, 0, bf, ctx->stream));
   ExpanderArgs ea{};
   for (int i = 0; i < SGP_MAX_GPS; ++i) {
     ea.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
@@ -924,6 +963,7 @@ int sgp_grid_sets_front_comm(sgp_grid* g, const double* scaling,
   const size_t nres = 7 + size_t(d) + 3 * size_t(G);   // front block + max_l
   double* res = static_cast<double*>(sgp_scratch(ctx, 1, (nres + 8) * 8));
   SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
+  SGP_TRY(settle_max_l(g));
   ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
   SGP_CHECK(ctx, comm || ctx->world <= 1,
             "rank %d of %d has no communicator in the grid's context: the "
@@ -1021,29 +1061,31 @@ int sgp_grid_sets_fused(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   const size_t nres = nfront + nfl + 3;
   double* res = static_cast<double*>(sgp_scratch(ctx, 1, (nres + 8) * 8));
   SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
-  // max_l = NaN: the confidence pass was issued without read-back, the value
-  // is in g->scal[0]
+  // max_l = NaN: the confidence pass was issued without read-back; the value
+  // is in g->scal[0] or still spread over the sweep's per-wave partials
   const bool resident = max_l != max_l;
-  SGP_HIP(ctx, hipMemcpyAsync(res + nfront + nfl + 2, g->scal, 8,
-                              hipMemcpyDeviceToDevice, ctx->stream));
-  SGP_TRY(launch_maximizers(g, max_l, resident ? g->scal : nullptr));
-  SGP_TRY(launch_reduce_max(ctx, g->partial, (g->N + 255) / 256, res));
-  SGP_TRY(launch_candidates(g, 0.0, res, scaling, thr_beta, 0,
-                            reinterpret_cast<unsigned long long*>(res + 1)));
-  SGP_TRY(launch_topk(g, 0, INFINITY, INT64_MAX, 1, res + 3,
-                      reinterpret_cast<int64_t*>(res + 4),
-                      reinterpret_cast<int*>(res + 5)));
-  SGP_TRY(launch_gather_top(g, reinterpret_cast<int64_t*>(res + 4), res + 6,
-                            res + 6 + d, res + 6 + d + G));
+  const bool pending = resident && g->l0_pending > 0;
+  GpDev ghost[SGP_MAX_GPS];
+  SGP_TRY(collect_gps(ctx, gps, G, d, ghost));
+  ExpanderBufs eb;
+  SGP_TRY(expander_bufs(g, ghost, G, &eb));
+  // maximisers -> candidates (+ the first one per workgroup) -> first candidate
+  // of the shard, staged as the operand of the expander test: three launches,
+  // the reductions in between are folded into the consumers
+  SGP_TRY(launch_sets_front_fused(
+      g, max_l, pending ? g->partial : nullptr, g->l0_pending,
+      (resident && !pending) ? g->scal : nullptr, scaling, thr_beta, res,
+      res + nfront + nfl + 2, eb.xc, int((eb.bx + eb.bv) / 8), eb.flags,
+      int(eb.bf / 4)));
+  g->l0_pending = 0;
   int32_t* dfl = nullptr;
   SGP_TRY(enqueue_expander(g, gps, G, beta, fmin, 1, nullptr, nullptr, nullptr,
-                           near_frac, &dfl, res + 6));
-  SGP_TRY(launch_mark_top_if(g, reinterpret_cast<int64_t*>(res + 4),
-                             reinterpret_cast<int*>(res + 5), dfl, fmin));
-  SGP_HIP(ctx, hipMemcpyAsync(res + nfront, dfl, size_t(G) * 4,
-                              hipMemcpyDeviceToDevice, ctx->stream));
-  SGP_TRY(launch_argmax(g, SGP_ARGMAX_MG_WIDTH, scaling, res + nfront + nfl,
-                        reinterpret_cast<int64_t*>(res + nfront + nfl + 1)));
+                           near_frac, &dfl, nullptr, true));
+  // conditional G mark + M|G arg-max + the flags into the result block
+  SGP_TRY(launch_argmax_marked(
+      g, scaling, fmin, dfl, reinterpret_cast<int64_t*>(res + 4),
+      reinterpret_cast<int*>(res + 5), reinterpret_cast<int32_t*>(res + nfront),
+      res + nfront + nfl, reinterpret_cast<int64_t*>(res + nfront + nfl + 1)));
   std::vector<double> host(nres);
   SGP_TRY(sgp_d2h(ctx, host.data(), res, nres * 8));
   unsigned long long cnt[2];

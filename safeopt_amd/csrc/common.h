@@ -144,6 +144,8 @@ struct sgp_grid {
   int64_t partial_cap = 0;
   GpDev* gpdev = nullptr;    // [SGP_MAX_GPS] device copy of descriptors
   double* scal = nullptr;    // [8] resident scalars: [0] = max l0 over S
+  int l0_pending = 0;        // > 0: scal[0] is still spread over that many
+                             // entries of `partial` (deferred confidence pass)
 };
 
 // ---- helpers (api.hip) ------------------------------------------------------
@@ -191,7 +193,7 @@ struct FitnessArgs {
   double* values;
   uint8_t* safe;
 };
-int sweep_num_blocks(int64_t N);
+int sweep_num_partials(const sgp_ctx* ctx, int64_t N);
 int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
                       int G, int d, SweepPoints pts, ConfOut out);
 int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,
@@ -264,6 +266,15 @@ int launch_lipschitz(sgp_grid* g, int G, const double* fmin,
                      const double* uc_dev, int32_t* flags_dev);
 int launch_argmax(sgp_grid* g, int mode, const double* scaling,
                   double* value_dev, int64_t* idx_dev);
+int launch_sets_front_fused(sgp_grid* g, double max_l, const double* l0_part,
+                            int n_l0, const double* max_l_dev,
+                            const double* scaling, const double* thr_beta,
+                            double* res, double* max_l_slot, double* xc,
+                            int n_xc_resid, int32_t* flags, int n_flag_words);
+int launch_argmax_marked(sgp_grid* g, const double* scaling, const double* fmin,
+                         const int32_t* flags_dev, const int64_t* cand_gidx_dev,
+                         const int* nfound_dev, int32_t* flags_out,
+                         double* value_dev, int64_t* idx_dev);
 int launch_fill_cols(sgp_grid* g, const double* c, int nc);
 int launch_gather_rows(sgp_grid* g, const int64_t* lidx_dev, int m, double* x,
                        double* mean, double* var, double* Q);

@@ -418,6 +418,231 @@ inline Vec8 vec8(const double* p, int n, double fill) {
   return v;
 }
 
+// ---- fused single-rank chain of compute_sets (gp_opt.py:511-552, 611-615, 635-649)
+// The passes below run on at most kFrontBlocks workgroups with grid-stride row
+// loops, so a pass leaves <= 1024 partial results and the NEXT pass folds them
+// itself (every workgroup re-reads 8 KB from L2) -- no reduction launches, no
+// device-to-device copies between them.
+constexpr int kFrontBlocks = 1024;
+
+// M = S & (u0 >= max l0[S]); wpart[block] = max(u0 - l0) over the block's M.
+// max l0[S] comes from (in this order) the sweep's per-wave partials, a resident
+// device value, or the host.
+__global__ __launch_bounds__(T) void k_maximizers_f(
+    const double* Q, const uint8_t* S, int64_t N, int G, double max_l,
+    const double* l0_part, int n_l0, const double* max_l_dev, uint8_t* M,
+    double* wpart, double* max_l_out, double* max_l_out2) {
+  __shared__ double sh[T / 64];
+  if (l0_part) {
+    double v = -INFINITY;
+    for (int e = threadIdx.x; e < n_l0; e += T) v = fmax(v, l0_part[e]);
+    max_l = block_max(v, sh);
+  } else if (max_l_dev) {
+    max_l = max_l_dev[0];
+  }
+  double v = -INFINITY;
+  for (int64_t i = int64_t(blockIdx.x) * T + threadIdx.x; i < N;
+       i += int64_t(gridDim.x) * T) {
+    const double l0 = Q[i * G * 2], u0 = Q[i * G * 2 + 1];
+    const bool m = S[i] && (u0 >= max_l);
+    M[i] = m ? 1 : 0;
+    if (m) v = fmax(v, u0 - l0);
+  }
+  const double mx = block_max(v, sh);
+  if (threadIdx.x == 0) {
+    wpart[blockIdx.x] = mx;
+    if (blockIdx.x == 0) {
+      if (max_l_out) *max_l_out = max_l;
+      if (max_l_out2) *max_l_out2 = max_l;
+    }
+  }
+}
+
+// Candidate mask, widths, G = 0, per-block (candidates, unsafe) counts and the
+// block's FIRST candidate in visiting order (largest width, ties: largest index).
+__global__ __launch_bounds__(T) void k_candidates_f(
+    const double* Q, const uint8_t* S, const uint8_t* M, int64_t N, int G,
+    const double* wpart, int nwpart, Vec8 scaling, Vec8 thr_beta, int64_t goff,
+    uint8_t* cand, double* w, uint8_t* Gm, unsigned* block_counts, double* best_w,
+    int64_t* best_i, double* max_width_out) {
+  __shared__ double sh[T / 64];
+  __shared__ Pair shp[T / 64];
+  __shared__ unsigned shc[2 * (T / 64)];
+  double mw = -INFINITY;
+  for (int e = threadIdx.x; e < nwpart; e += T) mw = fmax(mw, wpart[e]);
+  mw = block_max(mw, sh);
+  const double max_var = mw / scaling.v[0];
+  unsigned nc = 0, nu = 0;
+  Pair best{-INFINITY, -1};
+  for (int64_t i = int64_t(blockIdx.x) * T + threadIdx.x; i < N;
+       i += int64_t(gridDim.x) * T) {
+    const bool s = S[i] != 0;
+    double wmax = -INFINITY;
+    bool c = false;
+    if (s) {
+      double smax = -INFINITY;
+      bool above = false;
+      for (int g = 0; g < G; ++g) {
+        const double width = Q[(i * G + g) * 2 + 1] - Q[(i * G + g) * 2];
+        wmax = fmax(wmax, width);
+        smax = fmax(smax, width / scaling.v[g]);
+        above = above || (width > thr_beta.v[g]);
+      }
+      c = !M[i] && (smax > max_var) && above;
+    } else {
+      ++nu;
+    }
+    cand[i] = c ? 1 : 0;
+    w[i] = wmax;
+    Gm[i] = 0;
+    if (c) {
+      ++nc;
+      const Pair p{wmax, goff + i};
+      if (best.i < 0 || before_desc(p, best)) best = p;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    nc += __shfl_xor(nc, o, 64);
+    nu += __shfl_xor(nu, o, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    shc[2 * wave] = nc;
+    shc[2 * wave + 1] = nu;
+  }
+  const Pair win = block_best<false>(best, shp);     // (syncs)
+  if (threadIdx.x < 2) {
+    unsigned t = 0;
+    for (int wv = 0; wv < T / 64; ++wv) t += shc[2 * wv + threadIdx.x];
+    block_counts[2 * blockIdx.x + threadIdx.x] = t;
+  }
+  if (threadIdx.x == 0) {
+    best_w[blockIdx.x] = win.v;
+    best_i[blockIdx.x] = win.i;
+    if (blockIdx.x == 0 && max_width_out) *max_width_out = mw;
+  }
+}
+
+// One workgroup: total counts, the first candidate of the whole shard, its row
+// (x, mean, Q) into the result block AND as the operand of the expander test
+// (xc, resid[g * 16] = u_g - mu_g), flags / list counter zeroed.
+__global__ __launch_bounds__(T) void k_front_final(
+    const unsigned* block_counts, const double* best_w, const int64_t* best_i,
+    int nb, const double* pts, const double* mean, const double* Q, int64_t N,
+    int d, int G, int64_t goff, double* res, double* xc, int n_xc_resid,
+    int32_t* flags, int n_flag_words) {
+  __shared__ Pair shp[T / 64];
+  __shared__ unsigned long long shc[2][T / 64];
+  __shared__ int64_t top;
+  unsigned long long a = 0, b = 0;
+  Pair best{-INFINITY, -1};
+  for (int e = threadIdx.x; e < nb; e += T) {
+    a += block_counts[2 * e];
+    b += block_counts[2 * e + 1];
+    const Pair p{best_w[e], best_i[e]};
+    if (p.i >= 0 && (best.i < 0 || before_desc(p, best))) best = p;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    shc[0][threadIdx.x >> 6] = a;
+    shc[1][threadIdx.x >> 6] = b;
+  }
+  const Pair win = block_best<false>(best, shp);     // (syncs)
+  for (int e = threadIdx.x; e < n_xc_resid; e += T) xc[e] = 0.0;
+  for (int e = threadIdx.x; e < n_flag_words; e += T) flags[e] = 0;
+  if (threadIdx.x == 0) {
+    unsigned long long ta = 0, tb = 0;
+    for (int wv = 0; wv < T / 64; ++wv) {
+      ta += shc[0][wv];
+      tb += shc[1][wv];
+    }
+    reinterpret_cast<unsigned long long*>(res)[1] = ta;
+    reinterpret_cast<unsigned long long*>(res)[2] = tb;
+    res[3] = win.v;
+    reinterpret_cast<int64_t*>(res)[4] = win.i;
+    reinterpret_cast<int*>(res + 5)[0] = win.i >= 0 ? 1 : 0;
+    top = win.i;
+  }
+  __syncthreads();
+  if (top < 0) return;
+  const int64_t li = top - goff;
+  double* resid = xc + (n_xc_resid - G * 16);   // the block is xc | resid[G][16]
+  for (int k = threadIdx.x; k < d; k += T) {
+    const double v = pts[int64_t(k) * N + li];
+    res[6 + k] = v;
+    xc[k] = v;
+  }
+  for (int g = threadIdx.x; g < G; g += T) {
+    const double mu = mean[int64_t(g) * N + li];
+    const double up = Q[li * 2 * G + 2 * g + 1];
+    res[6 + d + g] = mu;
+    resid[g * 16] = up - mu;
+  }
+  for (int q = threadIdx.x; q < 2 * G; q += T) res[6 + d + G + q] = Q[li * 2 * G + q];
+}
+
+// M | G arg-max of max_i (u_i - l_i) / scaling_i with the conditional G mark of
+// the fused path folded in: when a first candidate was found and every active GP
+// certified it, the workgroup that owns its row sets G there and counts it.
+__global__ __launch_bounds__(T) void k_argmax_marked(
+    const double* Q, const uint8_t* M, uint8_t* Gm, int64_t N, int G,
+    int64_t goff, Vec8 scaling, Vec8 fmin, const int32_t* flags,
+    const int64_t* cand_gidx, const int* nfound, double* out_v, int64_t* out_i) {
+  __shared__ Pair sh[T / 64];
+  int64_t lmark = -1;
+  if (*nfound > 0) {
+    bool ok = true, any = false;
+    for (int g = 0; g < G; ++g) {
+      if (fmin.v[g] == -INFINITY) continue;
+      any = true;
+      ok = ok && (flags[g] != 0);
+    }
+    if (ok && any) lmark = cand_gidx[0] - goff;
+  }
+  Pair best{-INFINITY, -1};
+  const int64_t begin = int64_t(blockIdx.x) * (T * 4);
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = begin + r * T + threadIdx.x;
+    if (i >= N) continue;
+    const bool marked = i == lmark;
+    if (marked) Gm[i] = 1;
+    if (!(M[i] || Gm[i] || marked)) continue;
+    double v = -INFINITY;
+    for (int g = 0; g < G; ++g)
+      v = fmax(v, (Q[(i * G + g) * 2 + 1] - Q[(i * G + g) * 2]) / scaling.v[g]);
+    const Pair p{v, goff + i};
+    if (before_first(p, best)) best = p;
+  }
+  const Pair win = block_best<true>(best, sh);
+  if (threadIdx.x == 0) {
+    out_v[blockIdx.x] = win.v;
+    out_i[blockIdx.x] = win.i;
+  }
+}
+
+// ... final level, and the expander flags into the result block
+__global__ __launch_bounds__(T) void k_argmax_final_f(
+    const double* in_v, const int64_t* in_i, int64_t n, const int32_t* flags,
+    int G, int32_t* flags_out, double* out_v, int64_t* out_i) {
+  __shared__ Pair sh[T / 64];
+  Pair best{-INFINITY, -1};
+  for (int64_t e = threadIdx.x; e < n; e += T) {
+    const Pair p{in_v[e], in_i[e]};
+    if (before_first(p, best)) best = p;
+  }
+  const Pair win = block_best<true>(best, sh);
+  if (threadIdx.x == 0) {
+    out_v[0] = win.v;
+    out_i[0] = win.i;
+  }
+  if (threadIdx.x < G) flags_out[threadIdx.x] = flags[threadIdx.x];
+}
+
 inline unsigned nblk(int64_t N, int per) { return unsigned((N + per - 1) / per); }
 
 }  // namespace
@@ -579,6 +804,62 @@ int launch_import_points(sgp_ctx* ctx, const double* src, int64_t N, int d,
                          int64_t stride_row, int64_t stride_col, double* dst) {
   hipLaunchKernelGGL(k_import_points, dim3(nblk(N, T)), dim3(T), 0, ctx->stream,
                      src, N, d, stride_row, stride_col, dst);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+
+// ---- launchers of the fused single-rank chain ---------------------------------------
+static unsigned front_blocks(int64_t N) {
+  const unsigned nb = nblk(N, T);
+  return nb < unsigned(kFrontBlocks) ? nb : unsigned(kFrontBlocks);
+}
+
+int launch_sets_front_fused(sgp_grid* g, double max_l, const double* l0_part,
+                            int n_l0, const double* max_l_dev,
+                            const double* scaling, const double* thr_beta,
+                            double* res, double* max_l_slot, double* xc,
+                            int n_xc_resid, int32_t* flags, int n_flag_words) {
+  sgp_ctx* ctx = g->ctx;
+  const unsigned nb = front_blocks(g->N);
+  // scratch: width partials | block counts | block bests
+  char* sc = static_cast<char*>(sgp_scratch(
+      ctx, 2, size_t(kFrontBlocks) * (8 + 8 + 8 + 8)));
+  if (!sc) return -1;
+  double* wpart = reinterpret_cast<double*>(sc);
+  unsigned* bc = reinterpret_cast<unsigned*>(sc + size_t(kFrontBlocks) * 8);
+  double* bw = reinterpret_cast<double*>(sc + size_t(kFrontBlocks) * 16);
+  int64_t* bi = reinterpret_cast<int64_t*>(sc + size_t(kFrontBlocks) * 24);
+  hipLaunchKernelGGL(k_maximizers_f, dim3(nb), dim3(T), 0, ctx->stream, g->Q,
+                     g->S, g->N, g->G, max_l, l0_part, n_l0, max_l_dev, g->M,
+                     wpart, g->scal, max_l_slot);
+  hipLaunchKernelGGL(k_candidates_f, dim3(nb), dim3(T), 0, ctx->stream, g->Q,
+                     g->S, g->M, g->N, g->G, wpart, int(nb),
+                     vec8(scaling, g->G, 1.0), vec8(thr_beta, g->G, 0.0), g->goff,
+                     g->cand, g->w, g->Gm, bc, bw, bi, res);
+  hipLaunchKernelGGL(k_front_final, dim3(1), dim3(T), 0, ctx->stream, bc, bw, bi,
+                     int(nb), g->pts, g->mean, g->Q, g->N, g->d, g->G, g->goff,
+                     res, xc, n_xc_resid, flags, n_flag_words);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_argmax_marked(sgp_grid* g, const double* scaling, const double* fmin,
+                         const int32_t* flags_dev, const int64_t* cand_gidx_dev,
+                         const int* nfound_dev, int32_t* flags_out,
+                         double* value_dev, int64_t* idx_dev) {
+  sgp_ctx* ctx = g->ctx;
+  const unsigned nb = nblk(g->N, T * 4);
+  double* pv = static_cast<double*>(
+      sgp_scratch(ctx, 2, size_t(nb) * (sizeof(double) + sizeof(int64_t))));
+  if (!pv) return -1;
+  int64_t* pi = reinterpret_cast<int64_t*>(pv + nb);
+  hipLaunchKernelGGL(k_argmax_marked, dim3(nb), dim3(T), 0, ctx->stream, g->Q,
+                     g->M, g->Gm, g->N, g->G, g->goff, vec8(scaling, g->G, 1.0),
+                     vec8(fmin, g->G, -INFINITY), flags_dev, cand_gidx_dev,
+                     nfound_dev, pv, pi);
+  hipLaunchKernelGGL(k_argmax_final_f, dim3(1), dim3(T), 0, ctx->stream, pv, pi,
+                     int64_t(nb), flags_dev, g->G, flags_out, value_dev, idx_dev);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

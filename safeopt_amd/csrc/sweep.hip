@@ -473,6 +473,7 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
   // per-tile state of the row epilogue (confidence sweep / swarm fitness)
   bool safe = true;
   double l0 = 0.0, values = 0.0, interest = 1.0, total_pen = 0.0, lower = 0.0;
+  double lmax = -INFINITY;   // max l0 over the safe rows this wave has seen
   bool gp_start = true;
 
   int par = 0;
@@ -645,11 +646,9 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
           }
           if (p.conf.S) {
             if (writer) p.conf.S[row] = safe ? 1 : 0;
-            // maximum of l0 over the safe rows of the wave -> one partial per
-            // wave (no workgroup barrier in the epilogue)
-            double v = (writer && safe) ? l0 : -INFINITY;
-            v = wave_max(v);
-            if (lane == 0) p.conf.partial[int64_t(tile) * NW + wave] = v;
+            // running maximum of l0 over the safe rows (folded over the wave and
+            // written once, when the wave has walked all its tiles)
+            lmax = fmax(lmax, (writer && safe) ? l0 : -INFINITY);
           }
         } else if (writer) {
           double out;
@@ -696,6 +695,10 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
   if (PP) {
     __builtin_amdgcn_s_setprio(0);
     if (!late) __builtin_amdgcn_s_barrier();
+  }
+  if (conf && p.conf.S) {
+    lmax = wave_max(lmax);
+    if (lane == 0) p.conf.partial[int(blockIdx.x) * NW + wave] = lmax;
   }
 }
 
@@ -1103,6 +1106,14 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB,
   return 0;
 }
 
+// persistent: as many workgroups as are resident at once (256 VGPRs per thread
+// -> 8 waves per CU; the 32-slot experiment: 4) walk over the tiles
+int sweep_grid_blocks(int num_cu, int64_t N, int nw, int slots) {
+  const int64_t ntiles = (N + 16 * nw - 1) / (16 * nw);
+  const int64_t resident = int64_t(num_cu) * (slots == 32 ? 1 : 8 / nw);
+  return int(ntiles < resident ? ntiles : resident);
+}
+
 template <int D, int NW, int SL, int MODE, bool SINGLE, bool PP = false>
 int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static bool attr_set = false;
@@ -1113,12 +1124,7 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
                      int(Lay<SL, D>::bytes(NW))));
     attr_set = true;
   }
-  const int tile = 16 * NW;
-  const int64_t ntiles = (p.pts.N + tile - 1) / tile;
-  // persistent: as many workgroups as are resident at once (256 VGPRs per
-  // thread -> 8 waves per CU) walk over the tiles
-  const int64_t resident = int64_t(ctx->num_cu) * (SL == 32 ? 1 : 8 / NW);
-  const int nblocks = int(ntiles < resident ? ntiles : resident);
+  const int nblocks = sweep_grid_blocks(ctx->num_cu, p.pts.N, NW, SL);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profiling) {
     if (ctx->prof_used + 2 > ctx->prof_events.size()) {
@@ -1214,10 +1220,11 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
 
 }  // namespace
 
-int sweep_num_blocks(int64_t N) {   // = number of per-wave partials of max l0[S]
+// Number of partials of max l0[S] a confidence sweep leaves in ConfOut::partial:
+// one per wave of every launched workgroup.
+int sweep_num_partials(const sgp_ctx* ctx, int64_t N) {
   const int nw = sweep_waves();
-  const int64_t t = 16 * nw;
-  return int((N + t - 1) / t) * nw;
+  return sweep_grid_blocks(ctx->num_cu, N, nw, 16) * nw;
 }
 
 int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
