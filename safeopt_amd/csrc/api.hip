@@ -851,11 +851,17 @@ static int enqueue_expander(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
     ea.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
     ea.active[i] = (i < G) && (fmin[i] != -INFINITY);
   }
-  for (int i = 0; i < G; ++i) {
-    if (!ea.active[i]) continue;
-    SGP_TRY(expander_operands(gps[i], dxc, m, dres + i * 16, dW + i * wstride,
-                              ddel + i * 16, dis2 + i * 16, dtn2 + i * 16));
-  }
+  ExpanderOps ops{};
+  ops.xc = dxc;
+  ops.resid = dres;
+  ops.Wpack = dW;
+  ops.delta = ddel;
+  ops.inv_s2 = dis2;
+  ops.tn2 = dtn2;
+  ops.wstride = wstride;
+  ops.m = m;
+  for (int i = 0; i < SGP_MAX_GPS; ++i) ops.active[i] = ea.active[i];
+  SGP_TRY(expander_operands_all(ctx, g->gpdev, host, G, d, ops));
   ea.Wpack = dW;
   ea.xc = dxc;
   ea.delta = ddel;

@@ -77,6 +77,11 @@ struct GpDev {
   // upd[2..2+d) = x*
   const double* upd_w;
   const double* upd;
+  // dense L^-1 (row pitch ld) and k(x,x) + noise + 1e-8 + jitter: what the
+  // operands of the rank-1 expander test are built from (factor.hip, k_expw)
+  const double* Linv;
+  int64_t ld;
+  double prior;
   KernDesc kern;
 };
 
@@ -164,9 +169,20 @@ int factor_gp(sgp_gp* gp, int* info);  // Kmat -> Linv, Apack, alpha
 int append_gp(sgp_gp* gp, double y, int* info);  // row n already in gp->X
 int pop_gp(sgp_gp* gp);
 int publish_gp(sgp_gp* gp);  // Apack / Xpad / Xs / dev descriptor from Linv
-int expander_operands(sgp_gp* gp, const double* xc_dev, int m,
-                      const double* resid_dev, double* Wpack, double* delta,
-                      double* inv_s2, double* tn2);
+struct ExpanderOps {      // all arrays on the device; [g] blocks as noted
+  const double* xc;       // [m][d] candidates
+  const double* resid;    // [G][16]  u_c - mu_c
+  double* Wpack;          // [G][wstride]  A operands (cand x j) of Ky^-1 k_c
+  double* delta;          // [G][16]
+  double* inv_s2;         // [G][16]
+  double* tn2;            // [G][16]
+  int64_t wstride;
+  int m;
+  int active[SGP_MAX_GPS];
+};
+// operands of every active GP in three launches (all GPs per launch)
+int expander_operands_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
+                          int G, int d, const ExpanderOps& ops);
 
 // sweep.hip
 struct SweepPoints {

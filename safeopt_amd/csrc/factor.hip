@@ -339,43 +339,6 @@ __global__ void k_pad_rows(const double* X, int n, int n_pad, int d,
 }
 
 
-// ---- operands of the rank-1 expander test ---------------------------------------
-// s2_c = k(x_c,x_c) + noise + 1e-8 + jitter - |t_c|^2 ; delta = resid / s2
-__global__ void k_s2(const double* Tt, int64_t ld, int n, int m, double prior,
-                     const double* resid, double* delta, double* inv_s2,
-                     double* tn2) {
-  __shared__ double sh[256 / 64];
-  const int c = blockIdx.x;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const double t = Tt[int64_t(c) * ld + i];
-    s = fma(t, t, s);
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot = 0.0;
-    for (int w = 0; w < int(blockDim.x >> 6); ++w) tot += sh[w];
-    const double s2 = prior - tot;
-    inv_s2[c] = 1.0 / s2;
-    delta[c] = resid[c] / s2;
-    tn2[c] = tot;
-  }
-  (void)m;
-}
-
-// Wpack[s*64 + lane] = Wt[lane & 15][4 s + (lane >> 4)]  (A operand: cand x j)
-__global__ void k_pack_w(const double* Wt, int64_t ld, int n, int m, int nsteps,
-                         double* Wpack) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nsteps * 64) return;
-  const int lane = e & 63, s = e >> 6;
-  const int c = lane & 15, j = 4 * s + (lane >> 4);
-  Wpack[e] = (c < m && j < n) ? Wt[int64_t(c) * ld + j] : 0.0;
-}
-
 }  // namespace
 
 int launch_kernel_matrix(sgp_ctx* ctx, const KernDesc& kd, const double* X1,
@@ -432,6 +395,9 @@ int publish_gp(sgp_gp* gp) {
   gp->dev.n = n;
   gp->dev.n_pad = np;
   gp->dev.nblk = nblk;
+  gp->dev.Linv = Li;
+  gp->dev.ld = gp->ld;
+  gp->dev.prior = gp->kern.kdiag + gp->noise_var + 1e-8 + gp->jitter;
   gp->dev.kern = gp->kern;
   return 0;
 }
@@ -676,32 +642,159 @@ __global__ void k_small_post(const double* part, int nblk, int P, double kdiag,
   var[p] = fmax(kdiag - ss, 1e-15);      // GPy clip
 }
 
-// For m <= 16 candidates xc (m x d, device) and residuals u_c - mu_c (device):
-// w_c = Ky^-1 k(X, x_c) packed as an MFMA A operand, delta_c, 1/s2_c.
-int expander_operands(sgp_gp* gp, const double* xc_dev, int m,
-                      const double* resid_dev, double* Wpack, double* delta,
-                      double* inv_s2, double* tn2) {
-  sgp_ctx* ctx = gp->ctx;
-  const int n = int(gp->n), nf = gp->ld, np = gp->n_pad;
-  double* Li = static_cast<double*>(gp->Linv.p);
-  // rows 0..15 = Kc, rows 16..31 = T^T, rows 32..47 = W^T (pitch = ld)
-  double* buf = static_cast<double*>(sgp_scratch(ctx, 3, size_t(48) * nf * 8));
-  if (!buf) return -1;
+// ---- operands of the rank-1 expander test, all GPs per launch ----------------------
+// For candidate c and GP g:  k_c = k(X, x_c),  t = L^-1 k_c,  w = L^-T t = Ky^-1 k_c
+// (packed as an MFMA A operand: cand x j),  s2 = prior - |t|^2,  delta = resid / s2.
+namespace {
+struct ExpGpSel {
+  int active[SGP_MAX_GPS];
+};
+
+// Kc[g][c][j] = k(x_c, X_j)
+template <int D>
+__global__ __launch_bounds__(256) void k_expk(const GpDev* gps, ExpGpSel sel,
+                                              const double* xc, int m, double* Kc,
+                                              int64_t ldk) {
+  const int g = blockIdx.y;
+  if (!sel.active[g]) return;
+  const GpDev& gp = gps[g];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= gp.n) return;
+  double xj[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) xj[k] = gp.Xpad[int64_t(j) * D + k];
+  for (int c = 0; c < m; ++c)
+    Kc[(int64_t(g) * kMaxRhs + c) * ldk + j] = kern_eval<D>(gp.kern, xc + c * D, xj);
+}
+
+// T[g][c][i] = sum_{j <= i} Li[i][j] Kc[g][c][j]: one wave per row (k_tri_mv per GP)
+__global__ __launch_bounds__(256) void k_expt(const GpDev* gps, ExpGpSel sel,
+                                              const double* Kc, int m, double* Tt,
+                                              int64_t ldk) {
+  const int g = blockIdx.y;
+  if (!sel.active[g]) return;
+  const GpDev& gp = gps[g];
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= gp.n) return;
+  double acc[kMaxRhs];
+#pragma unroll
+  for (int c = 0; c < kMaxRhs; ++c) acc[c] = 0.0;
+  const double* row = gp.Linv + int64_t(i) * gp.ld;
+  const double* V = Kc + int64_t(g) * kMaxRhs * ldk;
+  for (int j = lane; j <= i; j += 64) {
+    const double l = row[j];
+#pragma unroll
+    for (int c = 0; c < kMaxRhs; ++c)
+      if (c < m) acc[c] = fma(l, V[c * ldk + j], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < kMaxRhs; ++c) {
+    if (c < m) {
+      double v = acc[c];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) Tt[(int64_t(g) * kMaxRhs + c) * ldk + i] = v;
+    }
+  }
+}
+
+// W[c][j] = sum_{i >= j} Li[i][j] T[c][i] straight into the packed operand
+// (Wpack[(j / 4) * 64 + (j % 4) * 16 + c], zero for j >= n and c >= m); the first
+// workgroup of a GP also leaves s2 / delta / |t|^2 of every candidate.
+__global__ __launch_bounds__(512) void k_expw(const GpDev* gps, ExpGpSel sel,
+                                              const double* Tt, int64_t ldk,
+                                              ExpanderOps ops) {
+  __shared__ double sh[8][64];
+  const int g = blockIdx.y;
+  if (!sel.active[g]) return;
+  const GpDev& gp = gps[g];
+  const int n = gp.n, m = ops.m;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j0 = blockIdx.x * 64, j = j0 + lane;
+  if (j0 >= gp.n_pad) return;
+  const double* T = Tt + int64_t(g) * kMaxRhs * ldk;
+  double* Wp = ops.Wpack + int64_t(g) * ops.wstride;
+  double acc[kMaxRhs];
+#pragma unroll
+  for (int c = 0; c < kMaxRhs; ++c) acc[c] = 0.0;
+  if (j < n) {
+    for (int i = j0 + wave; i < n; i += 8) {
+      const double l = (i >= j) ? gp.Linv[int64_t(i) * gp.ld + j] : 0.0;
+#pragma unroll
+      for (int c = 0; c < kMaxRhs; ++c)
+        if (c < m) acc[c] = fma(l, T[c * ldk + i], acc[c]);
+    }
+  }
+  for (int c = 0; c < kMaxRhs; ++c) {      // uniform trip count: barriers are safe
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < kMaxRhs; ++k) v = (k == c) ? acc[k] : v;
+    sh[wave][lane] = v;
+    __syncthreads();
+    if (wave == 0 && j < gp.n_pad) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) tot += sh[w][lane];
+      Wp[(j >> 2) * 64 + (j & 3) * 16 + c] = (j < n && c < m) ? tot : 0.0;
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    for (int c = wave; c < m; c += 8) {     // one wave per candidate
+      double s = 0.0;
+      for (int i = lane; i < n; i += 64) {
+        const double t = T[c * ldk + i];
+        s = fma(t, t, s);
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (lane == 0) {
+        const double s2 = gp.prior - s;
+        ops.inv_s2[g * 16 + c] = 1.0 / s2;
+        ops.delta[g * 16 + c] = ops.resid[g * 16 + c] / s2;
+        ops.tn2[g * 16 + c] = s;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int expander_operands_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
+                          int G, int d, const ExpanderOps& ops) {
+  int n_max = 0, np_max = 0;
+  ExpGpSel sel{};
+  for (int g = 0; g < G; ++g) {
+    sel.active[g] = ops.active[g];
+    if (!ops.active[g]) continue;
+    n_max = std::max(n_max, gps_host[g].n);
+    np_max = std::max(np_max, gps_host[g].n_pad);
+  }
+  if (n_max == 0) return 0;
+  const int64_t ldk = (np_max + 31) / 32 * 32;
+  double* buf = static_cast<double*>(
+      sgp_scratch(ctx, 3, size_t(2) * G * kMaxRhs * ldk * sizeof(double)));
+  SGP_CHECK(ctx, buf, "device allocation failed: %s", ctx->err.c_str());
   double* Kc = buf;
-  double* Tt = buf + size_t(16) * nf;
-  double* Wt = buf + size_t(32) * nf;
-  SGP_TRY(launch_kernel_matrix(ctx, gp->kern, xc_dev, m,
-                               static_cast<double*>(gp->X.p), n, Kc, nf, 0,
-                               0.0, INT64_MAX));
-  // T^T[c][i] = sum_j Kc[c][j] Li[i][j] ; W^T[c][j] = sum_i T^T[c][i] Li[i][j]
-  SGP_TRY(launch_tri_mv(ctx, Li, nf, n, Kc, nf, m, Tt, nf));
-  SGP_TRY(launch_tri_mtv(ctx, Li, nf, n, Tt, nf, m, Wt, nf, n));
-  const double prior = gp->kern.kdiag + gp->noise_var + 1e-8 + gp->jitter;
-  hipLaunchKernelGGL(k_s2, dim3(m), dim3(256), 0, ctx->stream, Tt, int64_t(nf),
-                     n, m, prior, resid_dev, delta, inv_s2, tn2);
-  const int nsteps = np / 4;
-  hipLaunchKernelGGL(k_pack_w, dim3((nsteps * 64 + 255) / 256), dim3(256), 0,
-                     ctx->stream, Wt, int64_t(nf), n, m, nsteps, Wpack);
+  double* Tt = buf + size_t(G) * kMaxRhs * ldk;
+#define EXPK_CASE(DD)                                                         \
+  case DD:                                                                    \
+    hipLaunchKernelGGL(k_expk<DD>, dim3((n_max + 255) / 256, G), dim3(256), 0,\
+                       ctx->stream, gps_dev, sel, ops.xc, ops.m, Kc, ldk);    \
+    break;
+  switch (d) {
+    EXPK_CASE(1) EXPK_CASE(2) EXPK_CASE(3) EXPK_CASE(4)
+    EXPK_CASE(5) EXPK_CASE(6) EXPK_CASE(7) EXPK_CASE(8)
+    default:
+      sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
+      return -2;
+  }
+#undef EXPK_CASE
+  hipLaunchKernelGGL(k_expt, dim3((n_max + 3) / 4, G), dim3(256), 0, ctx->stream,
+                     gps_dev, sel, Kc, ops.m, Tt, ldk);
+  hipLaunchKernelGGL(k_expw, dim3((np_max + 63) / 64, G), dim3(512), 0,
+                     ctx->stream, gps_dev, sel, Tt, ldk, ops);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }
