@@ -36,7 +36,8 @@ extern "C" {
 /* kernel kinds: GPy.kern.RBF / Matern32 / Matern52 (Stationary.K_of_r)        */
 enum { SGP_RBF = 0, SGP_MATERN32 = 1, SGP_MATERN52 = 2 };
 /* sgp_grid_download selectors                                                 */
-enum { SGP_Q = 0, SGP_S = 1, SGP_M = 2, SGP_G = 3, SGP_MEAN = 4, SGP_VAR = 5 };
+enum { SGP_Q = 0, SGP_S = 1, SGP_M = 2, SGP_G = 3, SGP_MEAN = 4, SGP_VAR = 5,
+       SGP_CAND = 6, SGP_WIDTH = 7 };
 /* sgp_grid_argmax modes                                                       */
 enum { SGP_ARGMAX_MG_WIDTH = 0, SGP_ARGMAX_UCB = 1, SGP_ARGMAX_LCB = 2 };
 /* sgp_swarm_fitness swarm types (gp_opt.py:901-1013)                          */
@@ -199,8 +200,11 @@ int sgp_grid_sets_back(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
 /* Both halves in one call and ONE stream sync (single GPU): the first candidate
  * stays on the device, the probe scan (near_frac) runs on it, G is marked if
  * every active GP certifies it, and the M|G arg-max follows.  Outputs as in
- * sgp_grid_sets_front + sgp_grid_sets_back; flags are void when out5 reports
- * no candidate or no unsafe row (G is then left untouched).  max_l = NaN: use
+ * sgp_grid_sets_front + sgp_grid_sets_back, plus out5[5] (SIX entries here) =
+ * number of candidates whose width equals the first one's bit for bit (> 1: the
+ * reference's argsort()[::-1] decides among them, gp_opt.py:542-552; the host
+ * settles it); flags are void when out5 reports no candidate or no unsafe row
+ * (G is then left untouched).  max_l = NaN: use
  * the value a preceding sgp_grid_confidence / _rank1_update call with
  * out2 == NULL left on the device, and report it in *max_l_out (-inf = no safe
  * point) -- a whole SafeOpt.optimize() is then one device round trip.        */
@@ -212,6 +216,10 @@ int sgp_grid_sets_fused(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                         double* max_l_out);
 /* gp_opt.py:615: G[idx] = True for owned global indices                      */
 int sgp_grid_mark_expanders(sgp_grid* grid, const int64_t* gidx, int m);
+/* ... and G[gidx] = False: when exact ties in the visiting order
+ * (gp_opt.py:542-552, argsort()[::-1]) make another candidate of the same
+ * width the first expander.                                                    */
+int sgp_grid_unmark_expanders(sgp_grid* grid, const int64_t* gidx, int m);
 /* get_new_query_point / get_maximum arg-max (gp_opt.py:635, 642-644,
  * 708-710), first (lowest) global index wins among equal values.
  * value = -inf and gidx = -1 when the masked set is empty.                   */

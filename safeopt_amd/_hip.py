@@ -23,7 +23,7 @@ vp = C.c_void_p
 vpp = C.POINTER(C.c_void_p)
 
 RBF, MATERN32, MATERN52 = 0, 1, 2
-Q, S, M, G, MEAN, VAR = 0, 1, 2, 3, 4, 5
+Q, S, M, G, MEAN, VAR, CAND, WIDTH = 0, 1, 2, 3, 4, 5, 6, 7
 ARGMAX_MG_WIDTH, ARGMAX_UCB, ARGMAX_LCB = 0, 1, 2
 SWARM_TYPES = {"greedy": 0, "maximizers": 1, "expanders": 2, "safe_set": 3}
 MAX_D, MAX_PARTS, MAX_GPS, TOPK = 8, 4, 8, 16
@@ -90,6 +90,7 @@ PROTOTYPES = {
                                      c_double_p, c_i32_p, c_double_p,
                                      c_i64_p]),
     "sgp_grid_mark_expanders": (C.c_int, [vp, c_i64_p, C.c_int]),
+    "sgp_grid_unmark_expanders": (C.c_int, [vp, c_i64_p, C.c_int]),
     "sgp_grid_argmax": (C.c_int, [vp, C.c_int, c_double_p, c_double_p,
                                   c_i64_p]),
     "sgp_grid_download": (C.c_int, [vp, C.c_int, vp]),
@@ -544,7 +545,7 @@ class DeviceGrid(object):
 
     def sets_fused(self, gps, beta, fmin, max_l, scaling, thr_beta, near_frac):
         fmin, scaling, thr_beta = f64(fmin), f64(scaling), f64(thr_beta)
-        out5 = np.empty(5)
+        out5 = np.empty(6)           # [5] = candidates tied with the first one
         x = np.empty(self.d)
         mean = np.empty(self.G)
         q = np.empty(2 * self.G)
@@ -566,6 +567,12 @@ class DeviceGrid(object):
             self.ctx.check(lib().sgp_grid_mark_expanders(
                 self.h, gidx.ctypes.data_as(c_i64_p), gidx.size))
 
+    def unmark_expanders(self, gidx):
+        gidx = np.ascontiguousarray(gidx, dtype=np.int64)
+        if gidx.size:
+            self.ctx.check(lib().sgp_grid_unmark_expanders(
+                self.h, gidx.ctypes.data_as(c_i64_p), gidx.size))
+
     def argmax(self, mode, scaling):
         scaling = f64(scaling)
         v = C.c_double(0)
@@ -577,8 +584,10 @@ class DeviceGrid(object):
     def download(self, what, out=None):
         if what == Q:
             shape, dt = (self.N, 2 * self.G), np.float64
-        elif what in (S, M, G):
+        elif what in (S, M, G, CAND):
             shape, dt = (self.N,), np.uint8
+        elif what == WIDTH:
+            shape, dt = (self.N,), np.float64
         else:
             shape, dt = (self.G, self.N), np.float64
         buf = np.empty(shape, dtype=dt)

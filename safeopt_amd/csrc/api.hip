@@ -716,7 +716,16 @@ int sgp_grid_mark_expanders(sgp_grid* g, const int64_t* gidx, int m) {
   if (m <= 0) return 0;
   int64_t* li = nullptr;
   SGP_TRY(upload_local_idx(g, gidx, m, &li));
-  return launch_mark(g, li, m);
+  return launch_mark(g, li, m, 1);
+}
+
+int sgp_grid_unmark_expanders(sgp_grid* g, const int64_t* gidx, int m) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  if (m <= 0) return 0;
+  int64_t* li = nullptr;
+  SGP_TRY(upload_local_idx(g, gidx, m, &li));
+  return launch_mark(g, li, m, 0);
 }
 
 int sgp_grid_lipschitz_check(sgp_grid* g, int G, const double* fmin,
@@ -767,6 +776,8 @@ int sgp_grid_download(sgp_grid* g, int what, void* out) {
     case SGP_G: return sgp_d2h(ctx, out, g->Gm, N);
     case SGP_MEAN: return sgp_d2h(ctx, out, g->mean, N * G * 8);
     case SGP_VAR: return sgp_d2h(ctx, out, g->var, N * G * 8);
+    case SGP_CAND: return sgp_d2h(ctx, out, g->cand, N);     // expander candidates
+    case SGP_WIDTH: return sgp_d2h(ctx, out, g->w, N * 8);   // max_i (u_i - l_i)
   }
   sgp_set_error(ctx, "unknown array selector %d", what);
   return -2;
@@ -1105,6 +1116,9 @@ int sgp_grid_sets_fused(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   out5[2] = double(cnt[1]);
   out5[3] = host[3];
   out5[4] = (nfound > 0) ? double(idx) : -1.0;
+  int ntied = 0;
+  memcpy(&ntied, reinterpret_cast<const char*>(&host[5]) + 4, 4);
+  out5[5] = double(ntied);      // candidates that share the first one's width
   memcpy(x_top, &host[6], size_t(d) * 8);
   memcpy(mean_top, &host[6 + d], size_t(G) * 8);
   memcpy(q_top, &host[6 + d + G], size_t(2 * G) * 8);

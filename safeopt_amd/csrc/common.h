@@ -294,7 +294,7 @@ int launch_argmax_marked(sgp_grid* g, const double* scaling, const double* fmin,
 int launch_fill_cols(sgp_grid* g, const double* c, int nc);
 int launch_gather_rows(sgp_grid* g, const int64_t* lidx_dev, int m, double* x,
                        double* mean, double* var, double* Q);
-int launch_mark(sgp_grid* g, const int64_t* lidx_dev, int m);
+int launch_mark(sgp_grid* g, const int64_t* lidx_dev, int m, int value = 1);
 int launch_swarm_grow(sgp_ctx* ctx, const KernDesc& kd, const double* S, int64_t m,
                       const double* B, int n, double scale2, double thr,
                       double* part, int* list, uint8_t* accept);

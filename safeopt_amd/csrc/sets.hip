@@ -398,9 +398,9 @@ __global__ void k_mark_top_if(uint8_t* Gm, const int64_t* gidx, const int* nfoun
   if (ok && any) Gm[gidx[0] - goff] = 1;
 }
 
-__global__ void k_mark(uint8_t* Gm, const int64_t* lidx, int m) {
+__global__ void k_mark(uint8_t* Gm, const int64_t* lidx, int m, int value) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < m) Gm[lidx[j]] = 1;
+  if (j < m) Gm[lidx[j]] = uint8_t(value);
 }
 
 __global__ void k_import_points(const double* src, int64_t N, int d,
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(T) void k_candidates_f(
     const double* Q, const uint8_t* S, const uint8_t* M, int64_t N, int G,
     const double* wpart, int nwpart, Vec8 scaling, Vec8 thr_beta, int64_t goff,
     uint8_t* cand, double* w, uint8_t* Gm, unsigned* block_counts, double* best_w,
-    int64_t* best_i, double* max_width_out) {
+    int64_t* best_i, unsigned* best_ties, double* max_width_out) {
   __shared__ double sh[T / 64];
   __shared__ Pair shp[T / 64];
   __shared__ unsigned shc[2 * (T / 64)];
@@ -517,7 +517,23 @@ __global__ __launch_bounds__(T) void k_candidates_f(
     for (int wv = 0; wv < T / 64; ++wv) t += shc[2 * wv + threadIdx.x];
     block_counts[2 * blockIdx.x + threadIdx.x] = t;
   }
+  // how many of this block's candidates share the width of its first one (exact
+  // ties decide the reference's visiting order, gp_opt.py:542-552): every thread
+  // re-reads the rows it wrote itself
+  unsigned nt = 0;
+  if (win.i >= 0)
+    for (int64_t i = int64_t(blockIdx.x) * T + threadIdx.x; i < N;
+         i += int64_t(gridDim.x) * T)
+      nt += (cand[i] && w[i] == win.v) ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) nt += __shfl_xor(nt, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) shc[wave] = nt;
+  __syncthreads();
   if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int wv = 0; wv < T / 64; ++wv) t += shc[wv];
+    best_ties[blockIdx.x] = t;
     best_w[blockIdx.x] = win.v;
     best_i[blockIdx.x] = win.i;
     if (blockIdx.x == 0 && max_width_out) *max_width_out = mw;
@@ -529,12 +545,14 @@ __global__ __launch_bounds__(T) void k_candidates_f(
 // (xc, resid[g * 16] = u_g - mu_g), flags / list counter zeroed.
 __global__ __launch_bounds__(T) void k_front_final(
     const unsigned* block_counts, const double* best_w, const int64_t* best_i,
-    int nb, const double* pts, const double* mean, const double* Q, int64_t N,
+    const unsigned* best_ties, int nb, const double* pts, const double* mean,
+    const double* Q, int64_t N,
     int d, int G, int64_t goff, double* res, double* xc, int n_xc_resid,
     int32_t* flags, int n_flag_words) {
   __shared__ Pair shp[T / 64];
   __shared__ unsigned long long shc[2][T / 64];
   __shared__ int64_t top;
+  __shared__ double topw;
   unsigned long long a = 0, b = 0;
   Pair best{-INFINITY, -1};
   for (int e = threadIdx.x; e < nb; e += T) {
@@ -567,9 +585,27 @@ __global__ __launch_bounds__(T) void k_front_final(
     reinterpret_cast<int64_t*>(res)[4] = win.i;
     reinterpret_cast<int*>(res + 5)[0] = win.i >= 0 ? 1 : 0;
     top = win.i;
+    topw = win.v;
   }
   __syncthreads();
-  if (top < 0) return;
+  if (top < 0) {
+    if (threadIdx.x == 0) reinterpret_cast<int*>(res + 5)[1] = 0;
+    return;
+  }
+  {   // candidates of the whole shard that share the first one's width
+    unsigned nt = 0;
+    for (int e = threadIdx.x; e < nb; e += T)
+      if (best_i[e] >= 0 && best_w[e] == topw) nt += best_ties[e];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) nt += __shfl_xor(nt, o, 64);
+    if ((threadIdx.x & 63) == 0) shc[0][threadIdx.x >> 6] = nt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned t = 0;
+      for (int wv = 0; wv < T / 64; ++wv) t += unsigned(shc[0][wv]);
+      reinterpret_cast<int*>(res + 5)[1] = int(t);
+    }
+  }
   const int64_t li = top - goff;
   double* resid = xc + (n_xc_resid - G * 16);   // the block is xc | resid[G][16]
   for (int k = threadIdx.x; k < d; k += T) {
@@ -792,10 +828,10 @@ int launch_mark_top_if(sgp_grid* g, const int64_t* gidx_dev, const int* nfound_d
   return 0;
 }
 
-int launch_mark(sgp_grid* g, const int64_t* lidx_dev, int m) {
+int launch_mark(sgp_grid* g, const int64_t* lidx_dev, int m, int value) {
   sgp_ctx* ctx = g->ctx;
   hipLaunchKernelGGL(k_mark, dim3((m + 63) / 64), dim3(64), 0, ctx->stream,
-                     g->Gm, lidx_dev, m);
+                     g->Gm, lidx_dev, m, value);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -824,21 +860,22 @@ int launch_sets_front_fused(sgp_grid* g, double max_l, const double* l0_part,
   const unsigned nb = front_blocks(g->N);
   // scratch: width partials | block counts | block bests
   char* sc = static_cast<char*>(sgp_scratch(
-      ctx, 2, size_t(kFrontBlocks) * (8 + 8 + 8 + 8)));
+      ctx, 2, size_t(kFrontBlocks) * (8 + 8 + 8 + 8 + 8)));
   if (!sc) return -1;
   double* wpart = reinterpret_cast<double*>(sc);
   unsigned* bc = reinterpret_cast<unsigned*>(sc + size_t(kFrontBlocks) * 8);
   double* bw = reinterpret_cast<double*>(sc + size_t(kFrontBlocks) * 16);
   int64_t* bi = reinterpret_cast<int64_t*>(sc + size_t(kFrontBlocks) * 24);
+  unsigned* bt = reinterpret_cast<unsigned*>(sc + size_t(kFrontBlocks) * 32);
   hipLaunchKernelGGL(k_maximizers_f, dim3(nb), dim3(T), 0, ctx->stream, g->Q,
                      g->S, g->N, g->G, max_l, l0_part, n_l0, max_l_dev, g->M,
                      wpart, g->scal, max_l_slot);
   hipLaunchKernelGGL(k_candidates_f, dim3(nb), dim3(T), 0, ctx->stream, g->Q,
                      g->S, g->M, g->N, g->G, wpart, int(nb),
                      vec8(scaling, g->G, 1.0), vec8(thr_beta, g->G, 0.0), g->goff,
-                     g->cand, g->w, g->Gm, bc, bw, bi, res);
+                     g->cand, g->w, g->Gm, bc, bw, bi, bt, res);
   hipLaunchKernelGGL(k_front_final, dim3(1), dim3(T), 0, ctx->stream, bc, bw, bi,
-                     int(nb), g->pts, g->mean, g->Q, g->N, g->d, g->G, g->goff,
+                     bt, int(nb), g->pts, g->mean, g->Q, g->N, g->d, g->G, g->goff,
                      res, xc, n_xc_resid, flags, n_flag_words);
   SGP_HIP(ctx, hipGetLastError());
   return 0;

@@ -264,6 +264,13 @@ class _HipGridBackend(object):
     def mark_expanders(self, gidx):
         self.grid.mark_expanders(gidx)
 
+    def unmark_expanders(self, gidx):
+        self.grid.unmark_expanders(gidx)
+
+    def candidate_widths(self):
+        """This shard's candidate mask and ``max_i(u_i - l_i)`` per row."""
+        return self.grid.download(_hip.CAND), self.grid.download(_hip.WIDTH)
+
     # fused passes (one stream sync each)
     def sets_front(self, max_l, max_var, scaling, thr_beta):
         return self.grid.sets_front(max_l, max_var, scaling, thr_beta)
@@ -538,6 +545,7 @@ class SafeOpt(GaussianProcessOptimization):
             # candidate with its rows; probe flags + local arg-max).
             d = self.inputs.shape[1]
             fused = None
+            n_tied = None           # candidates tied with the first one (None: unknown)
             if world == 1 and np.any(active) and hasattr(be, 'sets_fused'):
                 # both halves in one device round trip
                 (out5, x_c, mu_c, q_c, f_flags, f_val, f_idx,
@@ -552,6 +560,7 @@ class SafeOpt(GaussianProcessOptimization):
                 n_cand, n_unsafe, w_c, idx_c = (out5[1], out5[2],
                                                 float(out5[3]), int(out5[4]))
                 fused = (f_flags, f_val, f_idx)
+                n_tied = int(out5[5]) if len(out5) > 5 else None
             elif world == 1:
                 out5, x_c, mu_c, q_c = be.sets_front(self._max_l, None,
                                                      self.scaling, thr_beta)
@@ -608,6 +617,8 @@ class SafeOpt(GaussianProcessOptimization):
                         np.append(pk[:, G], v_c),
                         np.append(pk[:, G + 1].astype(np.int64), idx_c))
                 self._argmax_cache = (val, int(idx))
+                if self._settle_ties(beta, active, w_c, idx_c, n_tied) != idx_c:
+                    self._argmax_cache = None
                 return
             # not certified by the probe: exact scan, then the general loop
             hit = self._expander_flags(beta, x_c[None, :], mu_c[None, :],
@@ -615,6 +626,7 @@ class SafeOpt(GaussianProcessOptimization):
             if hit[0]:
                 if be.owns(idx_c):
                     be.mark_expanders(np.array([idx_c], dtype=np.int64))
+                self._settle_ties(beta, active, w_c, idx_c, n_tied)
                 return
             self._visit_candidates(beta, active, False, w_c, idx_c)
             return
@@ -683,11 +695,86 @@ class SafeOpt(GaussianProcessOptimization):
                 first = int(np.argmax(is_exp))
                 if own[first]:
                     be.mark_expanders(i_b[first:first + 1])
+                self._settle_ties(beta, active, float(w_b[first]), int(i_b[first]))
                 break
             if m < K:
                 break
             cut_w, cut_idx = float(w_b[-1]), int(i_b[-1])
             K = _hip.TOPK
+
+    def _gather_shards(self, part, N):
+        """Concatenate every rank's block of a per-row array."""
+        if self._comm.world == 1:
+            return part
+        counts = [np.subtract(*shard_range(N, r, self._comm.world)[::-1])
+                  for r in range(self._comm.world)]
+        buf = np.zeros((max(counts),) + part.shape[1:], dtype=part.dtype)
+        buf[:part.shape[0]] = part
+        allp = self._comm.allgather(buf)
+        return np.concatenate([allp[r][:c] for r, c in enumerate(counts)])
+
+    def _settle_ties(self, beta, active, w_star, idx_star, n_tied=None):
+        """Exact ties in the visiting order of the expander loop.
+
+        The device visits candidates by (width descending, index descending) and
+        has just found its first expander ``idx_star`` of width ``w_star``.  The
+        reference visits them in the order of ``widths.argsort()[::-1]``
+        (gp_opt.py:542-552), which is the same except among candidates whose
+        widths are EQUAL bit for bit -- NumPy's (unstable) sort decides there.
+        Only when such a tie exists: take the candidate widths to the host, run
+        the very same ``argsort()[::-1]`` on the very same values, and walk the
+        tied group in that order -- members above ``idx_star`` were already
+        rejected on the device, ``idx_star`` is an expander, the others are tested
+        now; the first expander in THAT order is the one the reference marks.
+        Returns the global index that ends up in ``G``.
+        """
+        be = self._backend
+        if not hasattr(be, 'candidate_widths'):
+            return idx_star
+        if n_tied is None:
+            # is the next candidate in the device's order tied with this one?
+            w_loc, i_loc = be.topk(0, w_star, idx_star, 1)
+            wp = np.full(1, -np.inf)
+            wp[:w_loc.size] = w_loc[:1]
+            n_tied = 2 if np.max(self._comm.allgather(wp)) == w_star else 1
+        if n_tied <= 1:
+            return idx_star
+        N = self.inputs.shape[0]
+        cand_loc, w_loc = be.candidate_widths()
+        cand = self._gather_shards(np.asarray(cand_loc, dtype=bool), N)
+        width = self._gather_shards(np.asarray(w_loc, dtype=float), N)
+        rows = np.flatnonzero(cand)
+        order = width[rows].argsort()[::-1]        # the reference's own expression
+        winner = idx_star
+        for k in order:
+            idx = int(rows[k])
+            if width[idx] != w_star or idx > idx_star:
+                continue                           # other width / rejected before
+            if idx == idx_star:
+                break
+            own = be.owns(idx)
+            xc = np.zeros((1, self.inputs.shape[1]))
+            mu_c = np.zeros((1, len(self.gps)))
+            u_c = np.zeros((1, len(self.gps)))
+            if own:
+                x_o, mean_o, _v, Q_o = be.gather_rows(np.array([idx], dtype=np.int64))
+                xc[0], mu_c[0], u_c[0] = x_o[0], mean_o[0], Q_o[0, 1::2]
+            if self._comm.world > 1:
+                packed = self._comm.allgather(
+                    np.concatenate([xc, mu_c, u_c], axis=1)).sum(axis=0)
+                d = self.inputs.shape[1]
+                xc, mu_c, u_c = (packed[:, :d], packed[:, d:d + len(self.gps)],
+                                 packed[:, d + len(self.gps):])
+            if self._expander_flags(beta, xc, mu_c, u_c, active, probe=False)[0]:
+                winner = idx
+                break
+        if winner != idx_star:
+            if be.owns(idx_star):
+                be.unmark_expanders(np.array([idx_star], dtype=np.int64))
+            if be.owns(winner):
+                be.mark_expanders(np.array([winner], dtype=np.int64))
+            self._argmax_cache = None
+        return winner
 
     def _expander_flags(self, beta, xc, mu_c, u_c, active, probe):
         """Which of the candidates are expanders (all ranks agree).

@@ -146,6 +146,12 @@ class OracleGridBackend(object):
     def mark_expanders(self, gidx):
         self.G[np.asarray(gidx, dtype=np.int64) - self.lo] = True
 
+    def unmark_expanders(self, gidx):
+        self.G[np.asarray(gidx, dtype=np.int64) - self.lo] = False
+
+    def candidate_widths(self):
+        return self.cand.copy(), self.w.copy()
+
     def argmax(self, mode, scaling):
         if mode == 0:
             mask = self.M | self.G

@@ -343,20 +343,92 @@ def case_swarm():
     opt.best_lower_bound = -np.inf
     # full optimize() iterations with a pinned global RNG
     np.random.seed(1234)
-    xs, Ss = [], []
+    xs, ys = [], []
     for t in range(4):
         x = opt.optimize()
         xs.append(np.asarray(x).copy())
         arrs["opt%d_S" % t] = opt.S.copy()
         arrs["opt%d_greedy_point" % t] = np.asarray(opt.greedy_point).copy()
         arrs["opt%d_best_lower_bound" % t] = np.array(opt.best_lower_bound)
-        opt.add_new_data_point(x, f(np.atleast_2d(x)))
+        y = f(np.atleast_2d(x))
+        ys.append(np.asarray(y).ravel().copy())
+        opt.add_new_data_point(x, y)
     arrs["opt_x"] = np.array(xs)
+    arrs["opt_y"] = np.array(ys)
     save("swarm_2d_g2", meta=dict(kernels=[kernel_spec(k1), kernel_spec(k2)],
          noise_vars=[nv, nv], fmin=[0., 0.2], bounds=bounds, threshold=0.2,
          beta=2., swarm_size=20, seed=1234,
          scaling=[float(v) for v in opt.scaling], fit_best_lower_bound=0.35),
          **arrs)
+
+
+def case_ties():
+    """Exact ties in the candidate widths (gp_opt.py:542-552): the intervals are
+    ASSIGNED (opt.Q[:] = quantised values, as a user may do) so that many
+    candidates share the largest width bit for bit; the reference's own
+    argsort()[::-1] then decides which tied candidate is visited -- and found to
+    be an expander -- first.  Recorded: the quantised Q and the resulting sets."""
+    grid = ref.linearly_spaced_combinations([(-6., 6.)], 400)
+    # (seed, quantum): chosen so that the winner is NOT always the highest tied
+    # index (what a stable sort reversed would give): 4 of the 6 discriminate
+    for tag, (seed, q) in enumerate(((0, 4.0), (1, 4.0), (11, 2.0), (11, 4.0),
+                                     (0, 2.0), (2, 2.0))):
+        rng = np.random.default_rng(100 + seed)
+        X = np.concatenate([rng.normal(0, 0.4, 6), rng.uniform(-3, 3, 5)])[:, None]
+        Y = 1.2 + 1.5 * np.exp(-X ** 2 / 3.0) + 0.05 * rng.normal(size=X.shape)
+        k = GPy.kern.RBF(1, variance=2., lengthscale=1.0, ARD=True)
+        gp = GPy.models.GPRegression(X, Y, k, noise_var=0.05 ** 2)
+        opt = ref.SafeOpt(gp, grid, 0., threshold=0.)
+        opt.update_confidence_intervals()
+        opt.Q[:] = np.round(opt.Q * q) / q           # exact ties by construction
+        calls = [0]
+        orig = gp.set_XY
+        def counted(X, Y, orig=orig):
+            calls[0] += 1
+            return orig(X, Y)
+        gp.set_XY = counted
+        opt.compute_sets()
+        x = opt.get_new_query_point()
+        s = opt.S & ~opt.M
+        widths = (opt.Q[:, 1] - opt.Q[:, 0])
+        save("ties_1d_seed%d" % tag, meta=dict(
+            kernels=[kernel_spec(k)], noise_vars=[0.05 ** 2], fmin=[0.],
+            scaling=[float(opt.scaling[0])], threshold=0., beta=2., quantum=q),
+            parameter_set=grid, X0=X, Y0=Y, Q=opt.Q.copy(), S=opt.S.copy(),
+            M=opt.M.copy(), G=opt.G.copy(), x_next=np.asarray(x).copy(),
+            n_checks=np.array(calls[0] // 2),
+            n_tied_top=np.array(int(np.sum(widths[s] == widths[s].max())) if s.any() else 0))
+
+
+def case_sample_gp_function():
+    """utilities.sample_gp_function (utilities.py:57-143) with a pinned global RNG:
+    the sampled node values (read out of the closure), noiseless and noisy
+    evaluations, kernel and linear interpolation, with and without a mean."""
+    arrs, meta = {}, {}
+    for tag, k, bounds, ns in (
+            ("rbf1", GPy.kern.RBF(1, variance=2., lengthscale=1.0), [(-5., 5.)], 40),
+            ("m52_2", GPy.kern.Matern52(2, variance=1.5, lengthscale=[1.0, 1.4], ARD=True),
+             [(-2., 2.), (-1., 3.)], [9, 11])):
+        xq = np.random.default_rng(5).uniform([b[0] for b in bounds], [b[1] for b in bounds],
+                                              size=(25, len(bounds)))
+        for interp in ("linear", "kernel"):
+            for mean in (None, "lin"):
+                mf = None if mean is None else (lambda x: 0.3 * x[:, :1] - 0.1)
+                np.random.seed(77)
+                f = ref.sample_gp_function(k, bounds, 0.05 ** 2, ns, interpolation=interp,
+                                           mean_function=mf)
+                cl = dict(zip(f.__code__.co_freevars, [c.cell_contents for c in f.__closure__]))
+                key = "%s_%s_%s" % (tag, interp, "mean" if mean else "nomean")
+                arrs[key + "_nodes"] = np.asarray(cl["inputs"]).copy()
+                if "output" in cl:           # (the kernel interpolant only keeps alpha;
+                    arrs[tag + "_output"] = np.asarray(cl["output"]).copy()   # same seed, same draw)
+                arrs[key + "_clean"] = f(xq, noise=False).copy()
+                arrs[key + "_noisy"] = f(xq).copy()          # consumes randn(25, 1)
+                arrs[key + "_noisy2"] = f(xq[:7]).copy()     # and randn(7, 1)
+        arrs[tag + "_xq"] = xq
+        meta[tag] = dict(kernel=kernel_spec(k), bounds=[list(b) for b in bounds],
+                         num_samples=ns, noise_var=0.05 ** 2, seed=77)
+    save("sample_gp_function", meta=meta, **arrs)
 
 
 def case_gp_sklearn():
@@ -387,6 +459,10 @@ def case_gp_sklearn():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:            # only the named cases
+        for name in sys.argv[1:]:
+            globals()["case_" + name]()
+        sys.exit(0)
     case_1d()
     case_2d()
     case_multi()
@@ -397,4 +473,6 @@ if __name__ == "__main__":
     case_full_sets()
     case_sets()
     case_swarm()
+    case_ties()
+    case_sample_gp_function()
     case_gp_sklearn()

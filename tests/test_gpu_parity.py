@@ -251,13 +251,45 @@ def test_sets_bit_exact_on_random_intervals(mods):
         So, Mo, Go, trace = son.compute_sets([None] * G, grid, Q, fmin, scaling, thr, 2.,
                                              lipschitz=np.asarray(lips), return_trace=True)
         assert_array_equal(opt.M, Mo)
-        if not (trial % 2 == 0):      # tie order of the sort is unpinned
-            assert_array_equal(opt.G, Go)
-            idx = son.query_index(Q, So, Mo, Go, scaling)
-            assert_array_equal(opt.get_new_query_point(), grid[idx])
+        # exact ties included: the visiting order among equal widths is the one
+        # of the reference's own argsort()[::-1] (run here by the oracle)
+        assert_array_equal(opt.G, Go)
+        idx = son.query_index(Q, So, Mo, Go, scaling)
+        assert_array_equal(opt.get_new_query_point(), grid[idx])
         assert_array_equal(opt.get_new_query_point(ucb=True),
                            grid[son.query_index(Q, So, Mo, Go, scaling, ucb=True)])
         assert opt.G.sum() <= 1
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_tied_widths_golden(mods, seed):
+    """Exact ties in the candidate widths (gp_opt.py:542-552): intervals assigned
+    by hand (quantised), GP expander test.  The reference fixture pins which of
+    the tied candidates ends up in G -- NumPy's argsort()[::-1] order, which the
+    product reproduces by running that very expression when (and only when) a tie
+    can matter.  (If this host's NumPy sorts ties differently from the one that
+    wrote the fixture, the oracle run on THIS host is the reference.)"""
+    safeopt_amd, gpy, gpn, son = mods
+    z, meta = load("ties_1d_seed%d" % seed)
+    assert int(z["n_tied_top"]) > 1
+    gp = gpy.models.GPRegression(z["X0"], z["Y0"], make_kernel(gpy.kern, meta["kernels"][0]),
+                                 noise_var=meta["noise_vars"][0])
+    go = gpn.GPRegression(z["X0"], z["Y0"], make_kernel(gpn, meta["kernels"][0]),
+                          noise_var=meta["noise_vars"][0])
+    opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"])
+    opt.Q = z["Q"]
+    opt.compute_sets()
+    x = opt.get_new_query_point()
+    So, Mo, Go = son.compute_sets([go], z["parameter_set"], z["Q"], meta["fmin"],
+                                  meta["scaling"], meta["threshold"], meta["beta"])
+    assert_array_equal(opt.S, So); assert_array_equal(opt.M, Mo)
+    assert_array_equal(opt.G, Go)
+    assert_array_equal(x, z["parameter_set"][son.query_index(z["Q"], So, Mo, Go, meta["scaling"])])
+    if np.array_equal(Go, z["G"]):             # same NumPy tie order as the fixture's host
+        assert_array_equal(opt.G, z["G"]); assert_array_equal(x, z["x_next"])
+    # the whole step in one call gives the same sets (Q is recomputed: no ties then,
+    # but the path through sets_fused with its tie count must still agree)
+    assert_array_equal(opt.S, z["S"]); assert_array_equal(opt.M, z["M"])
 
 
 def test_topk_order_and_ties(mods):
@@ -345,10 +377,49 @@ def test_swarm_optimize_golden(mods, pso):
     opt = safeopt_amd.SafeOptSwarm(gps, meta["fmin"], bounds=[tuple(b) for b in meta["bounds"]],
                                    threshold=meta["threshold"], pso=pso)
     np.random.seed(meta["seed"])
-    x = opt.optimize()
-    assert_allclose(x, z["opt_x"][0], rtol=0, atol=1e-6)
-    assert_allclose(opt.S, z["opt0_S"], rtol=0, atol=1e-6)
-    assert_allclose(opt.best_lower_bound, z["opt0_best_lower_bound"], atol=1e-7)
+    # all four recorded iterations: the measurements of the reference run are fed
+    # back, so every later iteration also checks the RNG consumption order across
+    # add_new_data_point, the safe-set growth and the greedy-point bookkeeping
+    for t in range(z["opt_x"].shape[0]):
+        x = opt.optimize()
+        assert_allclose(x, z["opt_x"][t], rtol=0, atol=1e-6, err_msg="iteration %d" % t)
+        assert_allclose(opt.S, z["opt%d_S" % t], rtol=0, atol=1e-6)
+        assert_allclose(opt.greedy_point, z["opt%d_greedy_point" % t], rtol=0, atol=1e-6)
+        assert_allclose(opt.best_lower_bound, z["opt%d_best_lower_bound" % t], atol=1e-7)
+        opt.add_new_data_point(z["opt_x"][t], z["opt_y"][t][None, :])
+
+
+def test_sample_gp_function_device_interpolant(mods, monkeypatch):
+    """with the package's kernels the RKHS interpolant of
+    sample_gp_function is the posterior mean of a device GP handle.  The prior
+    draw is pinned to the reference's (the covariance bits differ between kernel
+    implementations, and the SVD behind multivariate_normal amplifies that), the
+    evaluations are compared with the reference run."""
+    safeopt_amd, gpy, _, _ = mods
+    z, meta = load("sample_gp_function")
+    for tag in ("rbf1", "m52_2"):
+        m = meta[tag]
+        k = make_kernel(gpy.kern, m["kernel"])
+        bounds = [tuple(b) for b in m["bounds"]]
+        xq = z[tag + "_xq"]
+        monkeypatch.setattr(np.random, "multivariate_normal",
+                            lambda mean, cov, _v=z[tag + "_output"]: _v.copy())
+        for mean in (None, "mean"):
+            mf = None if mean is None else (lambda x: 0.3 * x[:, :1] - 0.1)
+            np.random.seed(m["seed"])
+            f = safeopt_amd.sample_gp_function(k, bounds, m["noise_var"], m["num_samples"],
+                                               interpolation="kernel", mean_function=mf)
+            key = "%s_kernel_%s" % (tag, "mean" if mean else "nomean")
+            assert_allclose(f.nodes, z[key + "_nodes"], rtol=0, atol=0)
+            # jitter 1e-6 on a smooth prior: the interpolation weights are ~1e5, so
+            # 1e-6 absolute is the conditioning, not the kernels
+            assert_allclose(f(xq, noise=False), z[key + "_clean"], rtol=0, atol=2e-6)
+            np.random.seed(5)
+            noisy = f(xq)                      # one randn(25, 1) call, as in the reference
+            np.random.seed(5)
+            assert_allclose(noisy - f(xq, noise=False),
+                            np.sqrt(m["noise_var"]) * np.random.randn(xq.shape[0], 1),
+                            rtol=0, atol=1e-12)
 
 
 def _swarm_problem(mods, pso, swarm_size=40):

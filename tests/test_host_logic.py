@@ -160,3 +160,66 @@ def test_swarm_optimization_reproducible():
     assert_array_equal(a, b)
     assert va == vb
     assert np.linalg.norm(a - target) < 0.05 and np.all(np.abs(a) <= 1.0)
+
+
+# ---------------------------------------------------------------------------
+# exact ties in the visiting order (gp_opt.py:542-552)
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_tie_settlement_matches_reference(seed):
+    """The product's host driver on the NumPy stand-in backend (device order =
+    width descending, index descending) must mark the candidate the REFERENCE
+    marks when widths tie exactly -- 4 of the 6 fixtures have a winner that is
+    not the highest tied index."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import safeopt_amd
+    from oracle import gp_numpy as gpn
+    from _golden import load, make_kernel
+    from _oracle_backend import OracleGridBackend
+    z, meta = load("ties_1d_seed%d" % seed)
+    gp = gpn.GPRegression(z["X0"], z["Y0"], make_kernel(gpn, meta["kernels"][0]),
+                          noise_var=meta["noise_vars"][0])
+    opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"],
+                              _backend_factory=OracleGridBackend)
+    opt.Q = z["Q"]
+    be = opt._backend
+    for i, g in enumerate(be.gps):      # the stand-in predicts from the GP; Q is assigned
+        m, v = g.predict_noiseless(be.x)
+        be.mean[:, i], be.var[:, i] = m.ravel(), v.ravel()
+    opt.compute_sets()
+    assert np.array_equal(opt.S, z["S"]) and np.array_equal(opt.M, z["M"])
+    assert np.array_equal(opt.G, z["G"])
+    assert np.array_equal(opt.get_new_query_point(), z["x_next"])
+
+
+def test_sample_gp_function_matches_reference():
+    """utilities.sample_gp_function against the reference run under the same
+    global seed: node values, noiseless and noisy evaluations (RNG call order),
+    kernel and linear interpolation, with and without a mean function.  (The
+    covariance comes from the oracle kernel here; the device-handle path of the
+    package's own kernels is covered by the GPU suite.)"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import safeopt_amd
+    from oracle import gp_numpy as gpn
+    from _golden import load, make_kernel
+    z, meta = load("sample_gp_function")
+    for tag in ("rbf1", "m52_2"):
+        m = meta[tag]
+        k = make_kernel(gpn, m["kernel"])
+        bounds = [tuple(b) for b in m["bounds"]]
+        xq = z[tag + "_xq"]
+        for interp in ("kernel", "linear"):
+            for mean in (None, "mean"):
+                mf = None if mean is None else (lambda x: 0.3 * x[:, :1] - 0.1)
+                np.random.seed(m["seed"])
+                f = safeopt_amd.sample_gp_function(k, bounds, m["noise_var"], m["num_samples"],
+                                                   interpolation=interp, mean_function=mf)
+                key = "%s_%s_%s" % (tag, interp, "mean" if mean else "nomean")
+                assert np.array_equal(f.nodes, z[key + "_nodes"])
+                np.testing.assert_allclose(f.values, z[tag + "_output"], rtol=0, atol=1e-12)
+                np.testing.assert_allclose(f(xq, noise=False), z[key + "_clean"], rtol=0, atol=1e-9)
+                np.testing.assert_allclose(f(xq), z[key + "_noisy"], rtol=0, atol=1e-9)
+                np.testing.assert_allclose(f(xq[:7]), z[key + "_noisy2"], rtol=0, atol=1e-9)
+    with pytest.raises(ValueError):
+        safeopt_amd.sample_gp_function(k, bounds, 0.1, 5, interpolation="cubic")

@@ -115,3 +115,21 @@ def test_expander_loop_golden(name):
     assert len(trace) >= 1 and G.sum() == 1
     idx = son.query_index(Q, S, M, G, meta["scaling"])
     assert_array_equal(grid[idx], z["x_next"])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_tied_widths_golden(seed):
+    """Exact ties in the candidate widths: the oracle runs the reference's own
+    ``argsort()[::-1]`` expression, so on the NumPy that wrote the fixtures it
+    reproduces which tied candidate the reference marked (gp_opt.py:542-552)."""
+    z, meta = load("ties_1d_seed%d" % seed)
+    go = gpn.GPRegression(z["X0"], z["Y0"], make_kernel(gpn, meta["kernels"][0]),
+                          noise_var=meta["noise_vars"][0])
+    S, M, G, trace = son.compute_sets([go], z["parameter_set"], z["Q"], meta["fmin"],
+                                      meta["scaling"], meta["threshold"], meta["beta"],
+                                      return_trace=True)
+    assert np.array_equal(S, z["S"]) and np.array_equal(M, z["M"])
+    assert np.array_equal(G, z["G"]) and len(trace) == int(z["n_checks"])
+    wd = z["Q"][:, 1] - z["Q"][:, 0]
+    s = S & ~M
+    assert int(np.sum(wd[s] == wd[s].max())) == int(z["n_tied_top"]) > 1
