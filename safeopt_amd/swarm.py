@@ -107,6 +107,11 @@ class SwarmOptimization(object):
             inertia += step
             self._keep_improvements()
 
+def _hip_swarm_types():
+    from . import _hip
+    return _hip.SWARM_TYPES
+
+
 class DeviceSwarmOptimization(SwarmOptimization):
     """The same swarm with its state in HBM: ``init_swarm`` and ``run_swarm``
     are one C-ABI call each (``sgp_swarm_run``) -- velocity / position update,
@@ -126,7 +131,7 @@ class DeviceSwarmOptimization(SwarmOptimization):
     """
 
     def __init__(self, swarm_size, velocity, owner, swarm_type, bounds=None,
-                 rng='numpy', seed=0):
+                 rng='numpy', seed=None):
         super(DeviceSwarmOptimization, self).__init__(
             swarm_size, velocity, None, bounds=bounds)
         if rng not in ('numpy', 'device'):
@@ -134,7 +139,13 @@ class DeviceSwarmOptimization(SwarmOptimization):
         self._owner = owner
         self._type = swarm_type
         self._rng = rng
-        self._seed = int(seed)
+        # Philox key of the device generator: `seed`, or one draw from NumPy's
+        # global stream (so np.random.seed controls it and every swarm object gets
+        # its own), mixed with the swarm type -- the greedy / maximizers /
+        # expanders swarms of one optimiser must not draw the same numbers
+        if rng == 'device' and seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
+        self._seed = (int(seed or 0) * 4 + _hip_swarm_types()[swarm_type]) & (2 ** 43 - 1)
         self._calls = 0
         self.global_best = np.zeros(self.ndim)
 
