@@ -70,7 +70,9 @@ struct GpDev {
   int n;                // training points
   int n_pad;            // n rounded up to 16
   int nblk;             // n_pad / 16
-  int pad_;
+  int narrow;           // 1: the last row block has <= 4 real rows and Apack holds
+                        // them in the "narrow" form (k_pack): the sweep then needs
+                        // one MFMA per k-step for that block instead of four
   // record of the last one-row append (sgp_gp_append), consumed by the
   // rank-1 update of the resident posterior: w = Ky_old^-1 k(X_old, x*)
   // (zero padded to n_pad), upd[0] = (y* - mu(x*)) / s2, upd[1] = 1 / s2,

@@ -224,8 +224,16 @@ int factor_rec(sgp_ctx* ctx, double* A, double* Li, double* T, int64_t ld,
 // (zero outside the n x n lower triangle): lane = 16 k + row, which is the A
 // operand map of v_mfma_f64_16x16x4_f64 AND of v_mfma_f64_4x4x4_4b_f64 when its
 // four blocks are four 4-row groups (A[blk][i][k] <- lane 16k + 4blk + i).
+//
+// Narrow last row block (n - 16 (nblk - 1) <= 4 real rows): its four 4-row
+// groups all hold the SAME real rows 16 b + (lane & 3).  With
+// v_mfma_f64_4x4x4_4b_f64 the four groups are the instruction's four blocks, so
+// B may then hold a different point quad per block -- the plain covariance
+// register, no broadcast -- and ONE instruction per k-step covers all 16 points
+// of the wave (the padding rows would otherwise cost 3 of every 4 MFMAs of the
+// row block that meets EVERY j-block).
 __global__ void k_pack(const double* Li, int64_t ld, int n, int nblk,
-                       int nsteps, double* Apack) {
+                       int nsteps, int narrow, double* Apack) {
   const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t total = int64_t(nblk) * nsteps * 64;
   if (e >= total) return;
@@ -233,7 +241,7 @@ __global__ void k_pack(const double* Li, int64_t ld, int n, int nblk,
   const int64_t bs = e >> 6;
   const int s = int(bs % nsteps);
   const int b = int(bs / nsteps);
-  const int i = 16 * b + (lane & 15);
+  const int i = 16 * b + ((narrow && b == nblk - 1) ? (lane & 3) : (lane & 15));
   const int j = 4 * s + (lane >> 4);
   double v = 0.0;
   if (i < n && j <= i) v = Li[int64_t(i) * ld + j];
@@ -375,9 +383,12 @@ int publish_gp(sgp_gp* gp) {
   double* Li = static_cast<double*>(gp->Linv.p);
   const int nblk = np / 16, nsteps = np / 4;
   const int64_t total = int64_t(nblk) * nsteps * 64;
+  // (SGP_NO_NARROW=1: the A/B switch of profiles/)
+  static const bool no_narrow = getenv("SGP_NO_NARROW") != nullptr;
+  const int narrow = (!no_narrow && n - 16 * (nblk - 1) <= 4) ? 1 : 0;
   SGP_TRY(sgp_reserve(ctx, &gp->Apack, size_t(total) * sizeof(double)));
   hipLaunchKernelGGL(k_pack, dim3(unsigned((total + 255) / 256)), dim3(256), 0,
-                     ctx->stream, Li, int64_t(gp->ld), n, nblk, nsteps,
+                     ctx->stream, Li, int64_t(gp->ld), n, nblk, nsteps, narrow,
                      static_cast<double*>(gp->Apack.p));
   SGP_TRY(sgp_reserve(ctx, &gp->Xpad, size_t(np) * d * sizeof(double)));
   SGP_TRY(sgp_reserve(ctx, &gp->Xs, size_t(np) * d * sizeof(double)));
@@ -395,6 +406,7 @@ int publish_gp(sgp_gp* gp) {
   gp->dev.n = n;
   gp->dev.n_pad = np;
   gp->dev.nblk = nblk;
+  gp->dev.narrow = narrow;
   gp->dev.Linv = Li;
   gp->dev.ld = gp->ld;
   gp->dev.prior = gp->kern.kdiag + gp->noise_var + 1e-8 + gp->jitter;
@@ -591,7 +603,7 @@ __global__ void k_small_kb(KernDesc kd, const double* pts, int P, const double* 
 __global__ __launch_bounds__(256) void k_small_mfma(const double* Apack,
                                                     const double* Kb,
                                                     const double* alpha,
-                                                    int nsteps, int nblk,
+                                                    int nsteps, int nblk, int narrow,
                                                     double* part, double* mean) {
   __shared__ double4_t sh[4][64];
   __shared__ double shm[4][16];
@@ -600,13 +612,15 @@ __global__ __launch_bounds__(256) void k_small_mfma(const double* Apack,
   const double* A = Apack + int64_t(blk) * nsteps * 64 + lane;
   const double* B = Kb + int64_t(pass) * nsteps * 64 + lane;
   const bool last = blk == nblk - 1;            // covers every k-step: the mean
+  // narrow packing of the last row block (k_pack): its rows 4..15 repeat rows 0..3
+  const bool dup = last && narrow && (lane & 15) >= 4;
   double4_t acc = {0.0, 0.0, 0.0, 0.0};
   double m = 0.0;
   const int send = (blk + 1) * 4;               // up to the diagonal block
 #pragma unroll 4
   for (int s = wave; s < send; s += 4) {
     const double b = B[s * 64];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[s * 64], b, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dup ? 0.0 : A[s * 64], b, acc, 0, 0, 0);
     if (last) m = fma(alpha[4 * s + (lane >> 4)], b, m);
   }
   sh[wave][lane] = acc;
@@ -834,7 +848,8 @@ int posterior_small(sgp_gp* gp, const double* pts_rowmajor, int P, double* mean,
 #undef SMALL_CASE
   hipLaunchKernelGGL(k_small_mfma, dim3(nblk, passes), dim3(256), 0, ctx->stream,
                      static_cast<double*>(gp->Apack.p), Kb,
-                     static_cast<double*>(gp->alpha.p), nsteps, nblk, part, mtmp);
+                     static_cast<double*>(gp->alpha.p), nsteps, nblk,
+                     gp->dev.narrow, part, mtmp);
   hipLaunchKernelGGL(k_small_post, dim3((P + 63) / 64), dim3(64), 0, ctx->stream,
                      part, nblk, P, gp->kern.kdiag, mtmp, mean, var);
   SGP_HIP(ctx, hipGetLastError());

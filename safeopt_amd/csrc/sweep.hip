@@ -99,6 +99,7 @@ enum : uint32_t {
   SW_GP_END = 1u << 7,      // last stage of a GP: row epilogue
   SW_TILE_END = 1u << 8,    // last stage of the tile
   SW_MEAN = 1u << 9,        // stage of the LAST chunk: accumulate alpha . k
+  SW_NARROW = 1u << 10,     // slot 0 holds a narrow row block (GpDev::narrow)
   SW_G_SHIFT = 12           // GP index (3 bits)
 };
 
@@ -286,10 +287,17 @@ __device__ __forceinline__ void mfma_acc(double& c, double a, double b) {
   asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
+//
+// Slot 0 of the last chunk may hold a NARROW row block (k_pack): its four MFMA
+// blocks carry the same <= 4 real rows, so the plain covariance register kv[q]
+// -- a different point quad per block -- is the B operand and one instruction
+// per k-step does the whole slot (accumulator accx: rows l >> 4, point l & 15).
 template <int SL, int S>
-__device__ __forceinline__ void mfma_slots(int nact, double (&acc)[SL][4],
+__device__ __forceinline__ void mfma_slots(int nact, bool narrow0,
+                                           double (&acc)[SL][4], double& accx,
                                            const double* aT,
                                            const double (&kb)[4][4],
+                                           const double (&kv)[4],
                                            double (&cur)[4], double (&nxt)[4]) {
   if constexpr (S < SL) {
     if (S < nact) {
@@ -298,26 +306,38 @@ __device__ __forceinline__ void mfma_slots(int nact, double (&acc)[SL][4],
         for (int q = 0; q < 4; ++q) nxt[q] = aT[((S + 1) * kSteps + q) * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (S == 0 && narrow0) {
+        // four DEPENDENT MFMAs on one accumulator: the addend must not be read
+        // before the previous result is written (4 wait states for this opcode;
+        // nothing pads inside asm)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 4; ++q)
+          asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
+                       : "+v"(accx) : "v"(cur[q]), "v"(kv[q]));
+      } else {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) mfma_acc(acc[S][m], cur[q], kb[m][q]);
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) mfma_acc(acc[S][m], cur[q], kb[m][q]);
+        }
       }
       if (S + 1 < SL)
         asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
-      mfma_slots<SL, S + 1>(nact, acc, aT, kb, nxt, cur);
+      mfma_slots<SL, S + 1>(nact, false, acc, accx, aT, kb, kv, nxt, cur);
     }
   }
 }
 
 template <int SL>
-__device__ __forceinline__ void mfma_jblock(int nact, double (&acc)[SL][4],
+__device__ __forceinline__ void mfma_jblock(int nact, bool narrow0,
+                                            double (&acc)[SL][4], double& accx,
                                             const double* aT,
-                                            const double (&kb)[4][4]) {
+                                            const double (&kb)[4][4],
+                                            const double (&kv)[4]) {
   double opsA[4], opsB[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) opsA[q] = aT[q * 64];
-  mfma_slots<SL, 0>(nact, acc, aT, kb, opsA, opsB);
+  mfma_slots<SL, 0>(nact, narrow0, acc, accx, aT, kb, kv, opsA, opsB);
 }
 
 // SafeOptSwarm._compute_penalty (gp_opt.py:874-899) for one value.
@@ -465,6 +485,7 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
   // per-GP state
   double xs[D];
   double sq[4] = {0.0, 0.0, 0.0, 0.0}, mean = 0.0;
+  double accx = 0.0, sqx = 0.0;     // narrow slot 0 (mfma_slots)
   double acc[kIB][4];
 #pragma unroll
   for (int b = 0; b < kIB; ++b)
@@ -543,7 +564,8 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
       __syncthreads();          // the partner group leaves its MFMA phase here
     }
     if (!SGP_ABL(8))
-      mfma_jblock<SL>(int(wcur & SW_NACT_MASK), acc, cbuf + lane, kb);
+      mfma_jblock<SL>(int(wcur & SW_NACT_MASK), (wcur & SW_NARROW) != 0, acc, accx,
+                      cbuf + lane, kb, kv);
     if (PP) {
       __syncthreads();          // ... and enters it here
       __builtin_amdgcn_s_setprio(3);
@@ -558,6 +580,8 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
           acc[b][m] = 0.0;
         }
       }
+      sqx = fma(accx, accx, sqx);
+      accx = 0.0;
     }
 
     if ((wcur & SW_GP_END) && !SGP_ABL(32)) {
@@ -569,11 +593,12 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
       double v0 = (a0 ? sq[1] : sq[0]) + __shfl_xor(a0 ? sq[0] : sq[1], 4, 64);
       double v1 = (a0 ? sq[3] : sq[2]) + __shfl_xor(a0 ? sq[2] : sq[3], 4, 64);
       double sumsq = (a1 ? v1 : v0) + __shfl_xor(a1 ? v0 : v1, 8, 64);
-      sumsq = sum_lane_groups(sumsq);
+      sumsq = sum_lane_groups(sumsq + sqx);   // (sqx is per point l & 15 already)
       const double mu = sum_lane_groups(mean);
       const double var = fmax(kdiag - sumsq, 1e-15);  // GPy clip
       const double sd = sqrt(var);
       sq[0] = sq[1] = sq[2] = sq[3] = 0.0;
+      sqx = 0.0;
       mean = 0.0;
 
       const int g = int(wcur >> SW_G_SHIFT) & 7;
@@ -1069,7 +1094,10 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB,
                 const StageEnt** dev, int* nstages) {
   std::vector<int> sig(1, Geff);
   sig.push_back(kIB);
-  for (int g = 0; g < Geff; ++g) sig.push_back(gh[g].nblk);
+  for (int g = 0; g < Geff; ++g) {
+    sig.push_back(gh[g].nblk);
+    sig.push_back(gh[g].narrow);
+  }
   if (sig == ctx->stage_sig && ctx->stage_tab.p) {
     *dev = static_cast<const StageEnt*>(ctx->stage_tab.p);
     *nstages = ctx->stage_count;
@@ -1089,6 +1117,8 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB,
         e.word = uint32_t(std::min(nib, bend - jb)) | (uint32_t(g) << SW_G_SHIFT);
         if (jb == bend - 1) e.word |= SW_CHUNK_END;
         if (c == nchunks - 1) e.word |= SW_MEAN;
+        // slot 0 of the last chunk = the last row block
+        if (c == nchunks - 1 && gh[g].narrow) e.word |= SW_NARROW;
         if (c == nchunks - 1 && jb == bend - 1) {
           e.word |= SW_GP_END;
           if (g == Geff - 1) e.word |= SW_TILE_END;

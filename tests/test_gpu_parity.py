@@ -457,8 +457,11 @@ def test_device_pso_device_rng(mods):
     """rng on the GPU: not NumPy-reproducible by design; check the invariants of
     the algorithm, determinism per seed and that NumPy's stream is untouched."""
     from safeopt_amd import DeviceSwarmOptimization
+    np.random.seed(7)        # the generator key is ONE draw from NumPy's stream at construction
     o = _swarm_problem(mods, "device-rng", swarm_size=500)
     o.best_lower_bound = 0.3
+    # every swarm of an optimiser (and every optimiser) has its own key
+    assert len({o.swarms[t]._seed for t in ("greedy", "maximizers", "expanders")}) == 3
     sw = o.swarms["maximizers"]
     assert isinstance(sw, DeviceSwarmOptimization)
     start = np.random.default_rng(5).uniform(-0.5, 0.5, size=(500, 2))
@@ -479,13 +482,18 @@ def test_device_pso_device_rng(mods):
     moved = sw.best_values > v0
     assert moved.any() and np.all(sb[moved])              # improvements are safe points
     assert_array_equal(sw.global_best, sw.best_positions[np.argmax(sw.best_values)])
-    # same seed, same call sequence -> same run
-    o2 = _swarm_problem(mods, "device-rng", swarm_size=500)
-    o2.best_lower_bound = 0.3
-    sw2 = o2.swarms["maximizers"]
-    sw2.init_swarm(start.copy())
-    sw2.run_swarm(20)
-    assert_array_equal(sw2.best_positions, sw.best_positions)
+    # same NumPy seed at construction, same call sequence -> same run; another seed -> another
+    runs = []
+    for seed in (7, 8):
+        np.random.seed(seed)
+        o2 = _swarm_problem(mods, "device-rng", swarm_size=500)
+        o2.best_lower_bound = 0.3
+        sw2 = o2.swarms["maximizers"]
+        sw2.init_swarm(start.copy())
+        sw2.run_swarm(20)
+        runs.append(sw2.best_positions.copy())
+    assert_array_equal(runs[0], sw.best_positions)
+    assert not np.array_equal(runs[1], sw.best_positions)
 
 
 def _grow_reference(K, m, scale2, thr=0.95):
