@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
     r = r < p.pts.N ? r : p.pts.N - 1;
 #pragma unroll
     for (int k = 0; k < D; ++k)
-      xo[k] = p.pts.base[r * p.pts.stride_row + k * p.pts.stride_col];
+      xo[k] = __builtin_nontemporal_load(p.pts.base + r * p.pts.stride_row + k * p.pts.stride_col);
   };
   double x[D], xnext[D];
   load_x(tile, x);
@@ -611,8 +611,10 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
         if (g == 0) l0 = lo;
         safe = safe && (lo > p.conf.fmin[g]);
         if (writer && !SGP_ABL(16)) {
-          p.conf.mean[int64_t(g) * p.pts.N + row] = mu;
-          p.conf.var[int64_t(g) * p.pts.N + row] = var;
+          // streaming rows in / results out: non-temporal, so that they do not push
+          // the L^-1 chunks every workgroup re-reads out of the 4 MB L2 of the XCD
+          __builtin_nontemporal_store(mu, p.conf.mean + int64_t(g) * p.pts.N + row);
+          __builtin_nontemporal_store(var, p.conf.var + int64_t(g) * p.pts.N + row);
         }
         // Q row = [l0, u0, l1, u1, ...] (gp_opt.py:375): the intervals of the G
         // passes are collected in the padding of the wave's broadcast buffer
@@ -666,7 +668,8 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
             __builtin_amdgcn_wave_barrier();
             double2_t* dst = reinterpret_cast<double2_t*>(p.conf.Q) + row0 * p.G;
             for (int i = lane; i < nq; i += 64)
-              dst[i] = *reinterpret_cast<const double2_t*>(kbw + L::qoff(i));
+              __builtin_nontemporal_store(
+                  *reinterpret_cast<const double2_t*>(kbw + L::qoff(i)), dst + i);
             __builtin_amdgcn_wave_barrier();
           }
           if (p.conf.S) {

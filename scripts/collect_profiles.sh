@@ -36,5 +36,11 @@ if echo " $CFGS " | grep -q " 3 "; then
     python $R/bench.py --config 3 $SHORT > $OUT/pmc_l2_cfg3.log 2>&1
 fi
 cd $R
+# hardware probes behind the design decisions (standalone HIP programs)
+{
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/probe1 scripts/dev/probe_r02.hip && /tmp/probe1 | grep -v "^[ABD][0-9]*:"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/probe2 scripts/dev/probe_coexec.hip && /tmp/probe2
+} > $OUT/probes.txt 2>&1
+bash scripts/ablate.sh 3 2 > $OUT/ablation.txt 2>&1
 python scripts/profiles_digest.py $OUT > $OUT/SUMMARY.txt 2>&1
 cat $OUT/SUMMARY.txt
