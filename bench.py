@@ -234,7 +234,9 @@ def spawn_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: enough for a timed region >= 0.5 s: "
+                         "40 at configs 3 and 5, 500 at config 2, 6 at config 4)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5])
     ap.add_argument("--side", type=int, default=None,
@@ -247,6 +249,8 @@ def main():
     ap.add_argument("--launch-check", action="store_true",
                     help="only rendezvous the ranks (no device): launcher self-test")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {2: 500, 3: 40, 4: 6, 5: 40}[args.config]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus, sys.argv[1:])

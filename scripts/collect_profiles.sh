@@ -12,7 +12,7 @@ OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd $R
 for c in $CFGS; do
-  extra=""; [ $c = 4 ] && extra="--steps 6 --warmup 2 --profile-steps 3"
+  extra=""; [ $c = 4 ] && extra="--warmup 2 --profile-steps 3"
   python bench.py --config $c $extra > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err
 done
 cd /tmp && export TMPDIR=/tmp
