@@ -543,6 +543,11 @@ static int settle_max_l(sgp_grid* g) {
 // of an identical earlier one that may still be in flight).
 static int stage_gpdev(sgp_grid* g, const GpDev* host, int G) {
   sgp_ctx* ctx = g->ctx;
+  // (the set passes of a step follow its confidence pass with the same GPs)
+  if (G == g->gpdev_count && memcmp(g->gpdev_host, host, sizeof(GpDev) * G) == 0)
+    return 0;
+  memcpy(g->gpdev_host, host, sizeof(GpDev) * G);
+  g->gpdev_count = G;
   char* slot = static_cast<char*>(ctx->pinned) + ctx->pinned_cap -
                sizeof(GpDev) * SGP_MAX_GPS;
   memcpy(slot, host, sizeof(GpDev) * G);

@@ -152,6 +152,8 @@ struct sgp_grid {
   double* partial = nullptr; // block partials
   int64_t partial_cap = 0;
   GpDev* gpdev = nullptr;    // [SGP_MAX_GPS] device copy of descriptors
+  GpDev gpdev_host[SGP_MAX_GPS];   // ... and what it holds (stage_gpdev)
+  int gpdev_count = 0;
   double* scal = nullptr;    // [8] resident scalars: [0] = max l0 over S
   int l0_pending = 0;        // > 0: scal[0] is still spread over that many
                              // entries of `partial` (deferred confidence pass)

@@ -724,6 +724,92 @@ __global__ __launch_bounds__(256) void k_expt(const GpDev* gps, ExpGpSel sel,
   }
 }
 
+// One candidate (the fused single-GPU step and the probe of the first candidate):
+// T[g][0][i] with k_c evaluated where it is needed -- lane l of the wave that owns
+// row i evaluates k(x_c, X_j) for its j = l, l + 64, ... <= i -- instead of a
+// separate launch that writes k_c out first.
+template <int D>
+__global__ __launch_bounds__(256) void k_expkt(const GpDev* gps, ExpGpSel sel,
+                                               const double* xc, double* Tt,
+                                               int64_t ldk) {
+  const int g = blockIdx.y;
+  if (!sel.active[g]) return;
+  const GpDev& gp = gps[g];
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= gp.n) return;
+  double x[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) x[k] = xc[k];
+  const double* row = gp.Linv + int64_t(i) * gp.ld;
+  double acc = 0.0;
+  for (int j = lane; j <= i; j += 64) {
+    double xj[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) xj[k] = gp.Xpad[int64_t(j) * D + k];
+    acc = fma(row[j], kern_eval<D>(gp.kern, x, xj), acc);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) Tt[int64_t(g) * kMaxRhs * ldk + i] = acc;
+}
+
+// ... and W[0][j] for it: 64 columns per workgroup, the 16 waves split the rows
+// i >= j0 (four loads in flight per lane), one fold through LDS.
+__global__ __launch_bounds__(1024) void k_expw1(const GpDev* gps, ExpGpSel sel,
+                                                const double* Tt, int64_t ldk,
+                                                ExpanderOps ops) {
+  __shared__ double sh[16][64];
+  const int g = blockIdx.y;
+  if (!sel.active[g]) return;
+  const GpDev& gp = gps[g];
+  const int n = gp.n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j0 = blockIdx.x * 64, j = j0 + lane;
+  if (j0 >= gp.n_pad) return;
+  const double* T = Tt + int64_t(g) * kMaxRhs * ldk;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (j < n) {
+    const double* col = gp.Linv + j;
+    int i = j0 + wave;
+    for (; i + 48 < n; i += 64) {
+      const double l0 = (i >= j) ? col[int64_t(i) * gp.ld] : 0.0;
+      const double l1 = (i + 16 >= j) ? col[int64_t(i + 16) * gp.ld] : 0.0;
+      const double l2 = (i + 32 >= j) ? col[int64_t(i + 32) * gp.ld] : 0.0;
+      const double l3 = (i + 48 >= j) ? col[int64_t(i + 48) * gp.ld] : 0.0;
+      a0 = fma(l0, T[i], a0);
+      a1 = fma(l1, T[i + 16], a1);
+      a2 = fma(l2, T[i + 32], a2);
+      a3 = fma(l3, T[i + 48], a3);
+    }
+    for (; i < n; i += 16)
+      if (i >= j) a0 = fma(col[int64_t(i) * gp.ld], T[i], a0);
+  }
+  sh[wave][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (wave == 0 && j < gp.n_pad) {
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += sh[w][lane];
+    double* Wp = ops.Wpack + int64_t(g) * ops.wstride + (j >> 2) * 64 + (j & 3) * 16;
+    Wp[0] = (j < n) ? tot : 0.0;
+#pragma unroll
+    for (int c = 1; c < kMaxRhs; ++c) Wp[c] = 0.0;
+  }
+  if (blockIdx.x == 0 && wave == 1) {
+    double s = 0.0;
+    for (int i = lane; i < n; i += 64) s = fma(T[i], T[i], s);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+      const double s2 = gp.prior - s;
+      ops.inv_s2[g * 16] = 1.0 / s2;
+      ops.delta[g * 16] = ops.resid[g * 16] / s2;
+      ops.tn2[g * 16] = s;
+    }
+  }
+}
+
 // W[c][j] = sum_{i >= j} Li[i][j] T[c][i] straight into the packed operand
 // (Wpack[(j / 4) * 64 + (j % 4) * 16 + c], zero for j >= n and c >= m); the first
 // workgroup of a GP also leaves s2 / delta / |t|^2 of every candidate.
@@ -803,6 +889,25 @@ int expander_operands_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_h
   SGP_CHECK(ctx, buf, "device allocation failed: %s", ctx->err.c_str());
   double* Kc = buf;
   double* Tt = buf + size_t(G) * kMaxRhs * ldk;
+  if (ops.m == 1) {
+#define EXPKT_CASE(DD)                                                        \
+  case DD:                                                                    \
+    hipLaunchKernelGGL(k_expkt<DD>, dim3((n_max + 3) / 4, G), dim3(256), 0,   \
+                       ctx->stream, gps_dev, sel, ops.xc, Tt, ldk);           \
+    break;
+    switch (d) {
+      EXPKT_CASE(1) EXPKT_CASE(2) EXPKT_CASE(3) EXPKT_CASE(4)
+      EXPKT_CASE(5) EXPKT_CASE(6) EXPKT_CASE(7) EXPKT_CASE(8)
+      default:
+        sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
+        return -2;
+    }
+#undef EXPKT_CASE
+    hipLaunchKernelGGL(k_expw1, dim3((np_max + 63) / 64, G), dim3(1024), 0,
+                       ctx->stream, gps_dev, sel, Tt, ldk, ops);
+    SGP_HIP(ctx, hipGetLastError());
+    return 0;
+  }
 #define EXPK_CASE(DD)                                                         \
   case DD:                                                                    \
     hipLaunchKernelGGL(k_expk<DD>, dim3((n_max + 255) / 256, G), dim3(256), 0,\

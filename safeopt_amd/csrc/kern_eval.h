@@ -23,6 +23,7 @@
 #include "common.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kExpTabSize = 32;
 

@@ -441,12 +441,26 @@ __global__ __launch_bounds__(T) void k_maximizers_f(
     max_l = max_l_dev[0];
   }
   double v = -INFINITY;
-  for (int64_t i = int64_t(blockIdx.x) * T + threadIdx.x; i < N;
-       i += int64_t(gridDim.x) * T) {
-    const double l0 = Q[i * G * 2], u0 = Q[i * G * 2 + 1];
-    const bool m = S[i] && (u0 >= max_l);
-    M[i] = m ? 1 : 0;
-    if (m) v = fmax(v, u0 - l0);
+  // four rows per thread and trip, all loads issued before the first use (the
+  // pass is a chain of exposed memory latencies otherwise)
+  const int64_t stride = int64_t(gridDim.x) * T;
+  for (int64_t i0 = int64_t(blockIdx.x) * T + threadIdx.x; i0 < N; i0 += 4 * stride) {
+    double2_t q[4];
+    uint8_t s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = i0 + r * stride, ii = i < N ? i : i0;
+      q[r] = *reinterpret_cast<const double2_t*>(Q + ii * G * 2);
+      s[r] = S[ii];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = i0 + r * stride;
+      if (i >= N) break;
+      const bool m = s[r] && (q[r].y >= max_l);
+      M[i] = m ? 1 : 0;
+      if (m) v = fmax(v, q[r].y - q[r].x);
+    }
   }
   const double mx = block_max(v, sh);
   if (threadIdx.x == 0) {
@@ -472,33 +486,54 @@ __global__ __launch_bounds__(T) void k_candidates_f(
   for (int e = threadIdx.x; e < nwpart; e += T) mw = fmax(mw, wpart[e]);
   mw = block_max(mw, sh);
   const double max_var = mw / scaling.v[0];
-  unsigned nc = 0, nu = 0;
+  unsigned nc = 0, nu = 0, nt = 0;
   Pair best{-INFINITY, -1};
-  for (int64_t i = int64_t(blockIdx.x) * T + threadIdx.x; i < N;
-       i += int64_t(gridDim.x) * T) {
-    const bool s = S[i] != 0;
-    double wmax = -INFINITY;
-    bool c = false;
-    if (s) {
-      double smax = -INFINITY;
-      bool above = false;
-      for (int g = 0; g < G; ++g) {
-        const double width = Q[(i * G + g) * 2 + 1] - Q[(i * G + g) * 2];
-        wmax = fmax(wmax, width);
-        smax = fmax(smax, width / scaling.v[g]);
-        above = above || (width > thr_beta.v[g]);
-      }
-      c = !M[i] && (smax > max_var) && above;
-    } else {
-      ++nu;
+  // four rows per thread and trip, the loads of the four rows in flight together;
+  // nt = how many of this thread's candidates share the width of its best one
+  const int64_t stride = int64_t(gridDim.x) * T;
+  for (int64_t i0 = int64_t(blockIdx.x) * T + threadIdx.x; i0 < N; i0 += 4 * stride) {
+    int64_t ii[4];
+    uint8_t sv[4], mv[4];
+    double wmax[4], smax[4];
+    bool above[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ii[r] = (i0 + r * stride < N) ? i0 + r * stride : i0;
+      sv[r] = S[ii[r]];
+      mv[r] = M[ii[r]];
+      wmax[r] = smax[r] = -INFINITY;
+      above[r] = false;
     }
-    cand[i] = c ? 1 : 0;
-    w[i] = wmax;
-    Gm[i] = 0;
-    if (c) {
-      ++nc;
-      const Pair p{wmax, goff + i};
-      if (best.i < 0 || before_desc(p, best)) best = p;
+    for (int g = 0; g < G; ++g) {
+      double2_t q[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        q[r] = *reinterpret_cast<const double2_t*>(Q + (ii[r] * G + g) * 2);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double width = q[r].y - q[r].x;
+        wmax[r] = fmax(wmax[r], width);
+        smax[r] = fmax(smax[r], width / scaling.v[g]);
+        above[r] = above[r] || (width > thr_beta.v[g]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = i0 + r * stride;
+      if (i >= N) break;
+      const bool sf = sv[r] != 0;
+      const bool c = sf && !mv[r] && (smax[r] > max_var) && above[r];
+      if (!sf) ++nu;
+      cand[i] = c ? 1 : 0;
+      w[i] = sf ? wmax[r] : -INFINITY;
+      Gm[i] = 0;
+      if (c) {
+        ++nc;
+        const Pair p{wmax[r], goff + i};
+        if (best.i >= 0 && p.v == best.v) ++nt;
+        if (best.i < 0 || p.v > best.v) nt = 1;
+        if (best.i < 0 || before_desc(p, best)) best = p;
+      }
     }
   }
 #pragma unroll
@@ -518,13 +553,9 @@ __global__ __launch_bounds__(T) void k_candidates_f(
     block_counts[2 * blockIdx.x + threadIdx.x] = t;
   }
   // how many of this block's candidates share the width of its first one (exact
-  // ties decide the reference's visiting order, gp_opt.py:542-552): every thread
-  // re-reads the rows it wrote itself
-  unsigned nt = 0;
-  if (win.i >= 0)
-    for (int64_t i = int64_t(blockIdx.x) * T + threadIdx.x; i < N;
-         i += int64_t(gridDim.x) * T)
-      nt += (cand[i] && w[i] == win.v) ? 1u : 0u;
+  // ties decide the reference's visiting order, gp_opt.py:542-552): the threads
+  // whose own best has that width counted theirs on the way
+  if (!(win.i >= 0 && best.i >= 0 && best.v == win.v)) nt = 0;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) nt += __shfl_xor(nt, o, 64);
   __syncthreads();

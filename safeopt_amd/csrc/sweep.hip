@@ -131,7 +131,6 @@ struct SweepParams {
 };
 
 typedef const __attribute__((address_space(1))) double* gptr_t;
-typedef double double2_t __attribute__((ext_vector_type(2)));
 // the stage table is read-only for the whole launch: constant address space, so
 // that an entry is ONE scalar load (a plain global pointer becomes a vector load
 // with a full memory wait, since the kernel also stores to global memory)
@@ -885,12 +884,14 @@ __global__ __launch_bounds__(256) void k_expander_filter(const GpDev* gps, int G
   const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
   const bool valid = row < pts.N;
   const int64_t rrow = valid ? row : pts.N - 1;
-  const bool unsafe = valid && (ea.S[rrow] == 0);
-  if (__ballot(unsafe) == 0ull) return;
+  // (the row is fetched together with its S flag, not after it)
+  const uint8_t sflag = ea.S[rrow];
   double x[D];
 #pragma unroll
   for (int k = 0; k < D; ++k)
     x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
+  const bool unsafe = valid && (sflag == 0);
+  if (__ballot(unsafe) == 0ull) return;
   bool possible = false;
   if (unsafe) {
     for (int g = 0; g < G; ++g) {
@@ -920,16 +921,17 @@ __global__ __launch_bounds__(256) void k_expander_filter(const GpDev* gps, int G
   if (possible) list[at + __popcll(b & ((1ull << lane) - 1ull))] = int(row);
 }
 
-constexpr int kExpLds = 6144;     // doubles of staged training data (48 KB)
+constexpr int kExpLds = 6144;     // doubles of staged training data, at most (48 KB)
 
 template <int D>
 __global__ __launch_bounds__(256) void k_expander_list(const GpDev* gps, int G,
                                                        SweepPoints pts,
                                                        ExpanderArgs ea,
                                                        const int* count,
-                                                       const int* list) {
+                                                       const int* list,
+                                                       int stage_cap) {
   __shared__ double tab[kExpTabSize];
-  __shared__ double stage[kExpLds];      // [n_pad][D] scaled rows | [n_pad] w
+  extern __shared__ double stage[];      // [n_pad][D] scaled rows | [n_pad] w
   exp_tab_init(tab);
   __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63;
@@ -945,7 +947,7 @@ __global__ __launch_bounds__(256) void k_expander_list(const GpDev* gps, int G,
     // w_j of the single candidate sits in lane 16 (j & 3) of k-step j >> 2 of
     // the packed operand
     const double* Wp = ea.Wpack + int64_t(g) * ea.wstride;
-    const bool staged = np * (D + 1) <= kExpLds;        // block-uniform
+    const bool staged = np * (D + 1) <= stage_cap;      // block-uniform
     const double* Xj = gp.Xs;
     if (staged) {
       __syncthreads();                                   // previous GP's readers
@@ -1309,18 +1311,27 @@ int launch_fitness_small(sgp_ctx* ctx, int G, int64_t P, const double* mean,
 int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
                           const GpDev* gps_host, int G, int d, SweepPoints pts,
                           ExpanderArgs ea) {
-  (void)gps_host;
   if (pts.N <= 0) return 0;
   const int nblocks = int((pts.N + 63) / 64);
   const bool listed = ea.m == 1 && ea.count && ea.list;
-  const int nfilter = int((pts.N + 255) / 256), nlist = ctx->num_cu * 2;
+  // the listed rows are a few per cent of the shard at most, and the loop over
+  // the training points is a chain of LDS latencies: as many waves per CU as the
+  // staged training data (LDS) allows
+  int np_max = 0;
+  for (int g = 0; g < G; ++g)
+    if (ea.active[g]) np_max = std::max(np_max, gps_host[g].n_pad);
+  int stage_cap = np_max * (d + 1);
+  if (stage_cap > kExpLds) stage_cap = 0;              // read from L2 instead
+  const int per_cu = std::max(1, std::min(8, int(144 * 1024 / (stage_cap * 8 + 1024))));
+  const int nfilter = int((pts.N + 255) / 256), nlist = ctx->num_cu * per_cu;
 #define EXP_CASE(DD)                                                          \
   case DD:                                                                    \
     if (listed) {                                                             \
       hipLaunchKernelGGL(k_expander_filter<DD>, dim3(nfilter), dim3(256), 0,  \
                          ctx->stream, gps_dev, G, pts, ea, ea.count, ea.list);\
-      hipLaunchKernelGGL(k_expander_list<DD>, dim3(nlist), dim3(256), 0,      \
-                         ctx->stream, gps_dev, G, pts, ea, ea.count, ea.list);\
+      hipLaunchKernelGGL(k_expander_list<DD>, dim3(nlist), dim3(256),         \
+                         size_t(stage_cap) * 8, ctx->stream, gps_dev, G, pts, \
+                         ea, ea.count, ea.list, stage_cap);                   \
     } else {                                                                  \
       hipLaunchKernelGGL(k_expander<DD>, dim3(nblocks), dim3(256), 0,         \
                          ctx->stream, gps_dev, G, pts, ea);                   \
