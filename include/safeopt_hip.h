@@ -285,6 +285,10 @@ int sgp_timer_stop(sgp_ctx* ctx, float* ms);
 int sgp_profile_enable(sgp_ctx* ctx, int on);
 int sgp_profile_read(sgp_ctx* ctx, double* total_ms, int64_t* launches,
                      double* flops);
+/* device allocations (hipMalloc) this context has made so far: buffers grow on
+ * demand, and a growth is an allocation plus a stream sync -- a steady-state
+ * loop (same n, same grid) must leave this number unchanged                  */
+int64_t sgp_ctx_alloc_count(sgp_ctx* ctx);
 
 #ifdef __cplusplus
 }

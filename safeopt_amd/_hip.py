@@ -115,6 +115,7 @@ PROTOTYPES = {
     "sgp_timer_stop": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "sgp_profile_enable": (C.c_int, [vp, C.c_int]),
     "sgp_profile_read": (C.c_int, [vp, c_double_p, c_i64_p, c_double_p]),
+    "sgp_ctx_alloc_count": (C.c_int64, [vp]),
 
 }
 
@@ -240,6 +241,10 @@ class Context(object):
         self.check(lib().sgp_profile_read(self.h, C.byref(ms), C.byref(n),
                                           C.byref(fl)))
         return ms.value, n.value, fl.value
+
+    def alloc_count(self):
+        """Device allocations made so far (a warm loop must not add any)."""
+        return int(lib().sgp_ctx_alloc_count(self.h))
 
     # -- RCCL
     @staticmethod

@@ -120,15 +120,19 @@ void sgp_set_error(sgp_ctx* ctx, const char* fmt, ...) {
 
 int sgp_reserve(sgp_ctx* ctx, DevBuf* b, size_t bytes) {
   if (bytes <= b->cap && b->p) return 0;
+  size_t cap = bytes < 256 ? 256 : bytes;
   if (b->p) {
+    // a buffer that grows once usually grows again (one observation per BO
+    // iteration): leave room, every growth is a hipMalloc and a stream sync
+    if (cap < b->cap + b->cap / 2) cap = b->cap + b->cap / 2;
     SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SGP_HIP(ctx, hipFree(b->p));
     b->p = nullptr;
     b->cap = 0;
   }
-  size_t cap = bytes < 256 ? 256 : bytes;
   SGP_HIP(ctx, hipMalloc(&b->p, cap));
   b->cap = cap;
+  ++ctx->n_allocs;
   return 0;
 }
 
@@ -458,6 +462,7 @@ int sgp_grid_create(sgp_ctx* ctx, const double* base, int64_t N, int d,
       sgp_grid_destroy(g);
       return -1;
     }
+    ++ctx->n_allocs;
   }
   SGP_HIP(ctx, hipMemsetAsync(g->S, 0, N, ctx->stream));
   SGP_HIP(ctx, hipMemsetAsync(g->M, 0, N, ctx->stream));
@@ -1320,6 +1325,8 @@ int sgp_swarm_grow(sgp_ctx* ctx, sgp_gp* gp0, const double* S, int64_t m,
 }
 
 // ---- timing ---------------------------------------------------------------------
+int64_t sgp_ctx_alloc_count(sgp_ctx* ctx) { return ctx ? ctx->n_allocs : -1; }
+
 int sgp_timer_start(sgp_ctx* ctx) {
   SGP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   return 0;

@@ -104,6 +104,7 @@ struct sgp_ctx {
   size_t pinned_cap = 0;
   // device scratch (grown on demand)
   DevBuf scratch[8];
+  int64_t n_allocs = 0;       // hipMalloc calls so far (sgp_ctx_alloc_count)
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool profiling = false;

@@ -395,12 +395,16 @@ int publish_gp(sgp_gp* gp) {
                      : (last_rows <= 8 && nblk % 16 != 0 && no_narrow != 2) ? 2 : 0;
   const int nvb = nblk + (narrow == 2);
   const int64_t total = int64_t(nvb) * nsteps * 64;
-  SGP_TRY(sgp_reserve(ctx, &gp->Apack, size_t(total) * sizeof(double)));
+  // (capacity for every n up to the pitch of L^-1: one-row appends then never
+  // reallocate -- a reallocation is a hipMalloc and a stream sync)
+  const size_t cap_rows = size_t(std::max(gp->ld, np));
+  SGP_TRY(sgp_reserve(ctx, &gp->Apack,
+                      (cap_rows / 16 + 1) * (cap_rows / 4) * 64 * sizeof(double)));
   hipLaunchKernelGGL(k_pack, dim3(unsigned((total + 255) / 256)), dim3(256), 0,
                      ctx->stream, Li, int64_t(gp->ld), n, nblk, nsteps, narrow,
                      static_cast<double*>(gp->Apack.p));
-  SGP_TRY(sgp_reserve(ctx, &gp->Xpad, size_t(np) * d * sizeof(double)));
-  SGP_TRY(sgp_reserve(ctx, &gp->Xs, size_t(np) * d * sizeof(double)));
+  SGP_TRY(sgp_reserve(ctx, &gp->Xpad, cap_rows * d * sizeof(double)));
+  SGP_TRY(sgp_reserve(ctx, &gp->Xs, cap_rows * d * sizeof(double)));
   hipLaunchKernelGGL(k_pad_rows, dim3((np * d + 255) / 256), dim3(256), 0,
                      ctx->stream, static_cast<double*>(gp->X.p), n, np, d,
                      gp->kern, static_cast<double*>(gp->Xpad.p),

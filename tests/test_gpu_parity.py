@@ -900,3 +900,34 @@ def test_bo_loop_with_rank1_updates_matches_reference(mods, name, last):
     # remove_last_data_point -> pop -> full sweep again
     opt.remove_last_data_point()
     assert_array_equal(opt.optimize(), z["x_next_all"][last - 1])
+
+
+def test_warm_path_makes_no_device_allocations(mods):
+    """Buffers grow on demand (hipMalloc + stream sync).  A steady-state loop --
+    same data, same grid -- must not allocate at all, and a BO loop that appends
+    one observation per iteration only when a capacity is exhausted (the factor
+    is sized for 64+ appends, scratch grows geometrically)."""
+    safeopt_amd, gpy, _, _ = mods
+    from safeopt_amd import _hip
+    ctx = _hip.Context.default()
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-1, 1, size=(40, 2)); Y = smooth(X, 4) + 1.0
+    gp = gpy.models.GPRegression(X, Y, gpy.kern.RBF(2, 2., 0.5, ARD=True), noise_var=1e-4)
+    grid = safeopt_amd.linearly_spaced_combinations([(-1.5, 1.5)] * 2, 150)
+    opt = safeopt_amd.SafeOpt(gp, grid, 0., threshold=0.1)
+    for _ in range(2):
+        opt.optimize()
+    opt.get_maximum()
+    base = ctx.alloc_count()
+    for _ in range(4):
+        opt.optimize()
+        opt.get_maximum()
+    assert ctx.alloc_count() == base
+    grown = 0
+    for t in range(30):                       # n = 40 -> 70: crosses 48 and 64
+        x = opt.optimize()
+        before = ctx.alloc_count()
+        opt.add_new_data_point(x, float(smooth(x[None, :], 4)[0, 0]) + 1.0)
+        opt.optimize()
+        grown += ctx.alloc_count() - before
+    assert grown <= 6, grown
