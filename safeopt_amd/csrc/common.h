@@ -61,7 +61,7 @@ inline double kern_unit(int kind) {
 
 // One GP as the sweep kernels see it.  All pointers are device pointers.
 struct GpDev {
-  const double* Apack;  // L^-1 in MFMA A-operand order: [nvb][n_pad/4][64],
+  const double* Apack;  // L^-1 in MFMA A-operand order: [nblk][n_pad/4][64],
                         // zero above the diagonal and in the padding rows
   const double* Xpad;   // training inputs, [n_pad][d], zero padded
   const double* Xs;     // = Xpad * kern.scale0 for single-part kernels,
@@ -70,11 +70,9 @@ struct GpDev {
   int n;                // training points
   int n_pad;            // n rounded up to 16
   int nblk;             // n_pad / 16
-  int narrow;           // 1 / 2: the last row block has <= 4 / <= 8 real rows and
-                        // Apack holds them as one / two "narrow" row blocks
-                        // (k_pack): the sweep then needs one / two MFMAs per
-                        // k-step for that block instead of four
-  int nvb;              // row blocks in Apack: nblk, + 1 if narrow == 2
+  int narrow;           // 1: the last row block has <= 4 real rows and Apack holds
+                        // them in the "narrow" form (k_pack): the sweep then needs
+                        // one MFMA per k-step for that block instead of four
   // record of the last one-row append (sgp_gp_append), consumed by the
   // rank-1 update of the resident posterior: w = Ky_old^-1 k(X_old, x*)
   // (zero padded to n_pad), upd[0] = (y* - mu(x*)) / s2, upd[1] = 1 / s2,

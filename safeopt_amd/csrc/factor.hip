@@ -231,21 +231,17 @@ int factor_rec(sgp_ctx* ctx, double* A, double* Li, double* T, int64_t ld,
 // B may then hold a different point quad per block -- the plain covariance
 // register, no broadcast -- and ONE instruction per k-step covers all 16 points
 // of the wave (the padding rows would otherwise cost 3 of every 4 MFMAs of the
-// row block that meets EVERY j-block).  With 5..8 real rows (narrow == 2) the
-// block is stored as TWO such row blocks, rows 0..3 and rows 4..7: nvb = nblk + 1
-// packed row blocks, two MFMAs per k-step.
+// row block that meets EVERY j-block).
 __global__ void k_pack(const double* Li, int64_t ld, int n, int nblk,
                        int nsteps, int narrow, double* Apack) {
   const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int64_t total = int64_t(nblk + (narrow == 2)) * nsteps * 64;
+  const int64_t total = int64_t(nblk) * nsteps * 64;
   if (e >= total) return;
   const int lane = int(e & 63);
   const int64_t bs = e >> 6;
   const int s = int(bs % nsteps);
   const int b = int(bs / nsteps);
-  const int i = (narrow && b >= nblk - 1)
-                    ? 16 * (nblk - 1) + 4 * (b - (nblk - 1)) + (lane & 3)
-                    : 16 * b + (lane & 15);
+  const int i = 16 * b + ((narrow && b == nblk - 1) ? (lane & 3) : (lane & 15));
   const int j = 4 * s + (lane >> 4);
   double v = 0.0;
   if (i < n && j <= i) v = Li[int64_t(i) * ld + j];
@@ -386,20 +382,15 @@ int publish_gp(sgp_gp* gp) {
   const int n = int(gp->n), np = gp->n_pad, d = gp->kern.d;
   double* Li = static_cast<double*>(gp->Linv.p);
   const int nblk = np / 16, nsteps = np / 4;
-  // (SGP_NO_NARROW=1 / 2: the A/B switch of profiles/ -- never / only the one-block form)
-  static const int no_narrow = getenv("SGP_NO_NARROW") ? atoi(getenv("SGP_NO_NARROW")) : 0;
-  const int last_rows = n - 16 * (nblk - 1);
-  // the two-block form must not open another chunk of 16 accumulator slots
-  const int narrow = no_narrow == 1 ? 0
-                     : last_rows <= 4 ? 1
-                     : (last_rows <= 8 && nblk % 16 != 0 && no_narrow != 2) ? 2 : 0;
-  const int nvb = nblk + (narrow == 2);
-  const int64_t total = int64_t(nvb) * nsteps * 64;
+  const int64_t total = int64_t(nblk) * nsteps * 64;
+  // (SGP_NO_NARROW=1: the A/B switch of profiles/)
+  static const bool no_narrow = getenv("SGP_NO_NARROW") != nullptr;
+  const int narrow = (!no_narrow && n - 16 * (nblk - 1) <= 4) ? 1 : 0;
   // (capacity for every n up to the pitch of L^-1: one-row appends then never
   // reallocate -- a reallocation is a hipMalloc and a stream sync)
   const size_t cap_rows = size_t(std::max(gp->ld, np));
   SGP_TRY(sgp_reserve(ctx, &gp->Apack,
-                      (cap_rows / 16 + 1) * (cap_rows / 4) * 64 * sizeof(double)));
+                      (cap_rows / 16) * (cap_rows / 4) * 64 * sizeof(double)));
   hipLaunchKernelGGL(k_pack, dim3(unsigned((total + 255) / 256)), dim3(256), 0,
                      ctx->stream, Li, int64_t(gp->ld), n, nblk, nsteps, narrow,
                      static_cast<double*>(gp->Apack.p));
@@ -420,7 +411,6 @@ int publish_gp(sgp_gp* gp) {
   gp->dev.n_pad = np;
   gp->dev.nblk = nblk;
   gp->dev.narrow = narrow;
-  gp->dev.nvb = nvb;
   gp->dev.Linv = Li;
   gp->dev.ld = gp->ld;
   gp->dev.prior = gp->kern.kdiag + gp->noise_var + 1e-8 + gp->jitter;
@@ -626,12 +616,11 @@ __global__ __launch_bounds__(256) void k_small_mfma(const double* Apack,
   const double* A = Apack + int64_t(blk) * nsteps * 64 + lane;
   const double* B = Kb + int64_t(pass) * nsteps * 64 + lane;
   const bool last = blk == nblk - 1;            // covers every k-step: the mean
-  // narrow packing of the last row block (k_pack): rows 4..15 of such a packed
-  // block repeat its rows 0..3
-  const bool dup = blk >= nblk - 1 && narrow && (lane & 15) >= 4;
+  // narrow packing of the last row block (k_pack): its rows 4..15 repeat rows 0..3
+  const bool dup = last && narrow && (lane & 15) >= 4;
   double4_t acc = {0.0, 0.0, 0.0, 0.0};
   double m = 0.0;
-  const int send = (min(blk, nblk - 1) + 1) * 4;   // up to the diagonal block
+  const int send = (blk + 1) * 4;               // up to the diagonal block
 #pragma unroll 4
   for (int s = wave; s < send; s += 4) {
     const double b = B[s * 64];
@@ -652,7 +641,7 @@ __global__ __launch_bounds__(256) void k_small_mfma(const double* Apack,
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
     if (lane < 16) {
-      part[(int64_t(pass) * gridDim.x + blk) * 16 + lane] = ss;
+      part[(int64_t(pass) * nblk + blk) * 16 + lane] = ss;
       if (last)
         mean[pass * 16 + lane] =
             (shm[0][lane] + shm[1][lane]) + (shm[2][lane] + shm[3][lane]);
@@ -945,8 +934,7 @@ int posterior_small(sgp_gp* gp, const double* pts_rowmajor, int P, double* mean,
   sgp_ctx* ctx = gp->ctx;
   const int n = int(gp->n), np = gp->n_pad, nblk = np / 16, nsteps = np / 4;
   const int passes = (P + 15) / 16;
-  const int nvb = gp->dev.nvb;                 // row blocks as packed (k_pack)
-  const size_t nkb = size_t(passes) * nsteps * 64, npart = size_t(passes) * nvb * 16;
+  const size_t nkb = size_t(passes) * nsteps * 64, npart = size_t(passes) * nblk * 16;
   double* buf = static_cast<double*>(
       sgp_scratch(ctx, 6, (nkb + npart + kSmallPoints) * sizeof(double)));
   if (!buf) return -1;
@@ -967,12 +955,12 @@ int posterior_small(sgp_gp* gp, const double* pts_rowmajor, int P, double* mean,
       return -2;
   }
 #undef SMALL_CASE
-  hipLaunchKernelGGL(k_small_mfma, dim3(nvb, passes), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(k_small_mfma, dim3(nblk, passes), dim3(256), 0, ctx->stream,
                      static_cast<double*>(gp->Apack.p), Kb,
                      static_cast<double*>(gp->alpha.p), nsteps, nblk,
                      gp->dev.narrow, part, mtmp);
   hipLaunchKernelGGL(k_small_post, dim3((P + 63) / 64), dim3(64), 0, ctx->stream,
-                     part, nvb, P, gp->kern.kdiag, mtmp, mean, var);
+                     part, nblk, P, gp->kern.kdiag, mtmp, mean, var);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

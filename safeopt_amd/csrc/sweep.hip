@@ -99,8 +99,7 @@ enum : uint32_t {
   SW_GP_END = 1u << 7,      // last stage of a GP: row epilogue
   SW_TILE_END = 1u << 8,    // last stage of the tile
   SW_MEAN = 1u << 9,        // stage of the LAST chunk: accumulate alpha . k
-  SW_NARROW_SHIFT = 10,     // 2 bits: the first 0 / 1 / 2 slots hold narrow row
-                            // blocks (GpDev::narrow)
+  SW_NARROW = 1u << 10,     // slot 0 holds a narrow row block (GpDev::narrow)
   SW_G_SHIFT = 12           // GP index (3 bits)
 };
 
@@ -288,16 +287,13 @@ __device__ __forceinline__ void mfma_acc(double& c, double a, double b) {
 }
 
 //
-// The first one or two slots of the last chunk may hold NARROW row blocks
-// (k_pack): the four MFMA blocks of such a slot carry the same 4 rows, so the
-// plain covariance register kv[q] -- a different point quad per block -- is the
-// B operand and one instruction per k-step does the whole slot; its accumulator
-// is acc[S][0], in the layout rows l >> 4, point l & 15 (kMaxNarrow slots at most).
-constexpr int kMaxNarrow = 2;
-
+// Slot 0 of the last chunk may hold a NARROW row block (k_pack): its four MFMA
+// blocks carry the same <= 4 real rows, so the plain covariance register kv[q]
+// -- a different point quad per block -- is the B operand and one instruction
+// per k-step does the whole slot (accumulator accx: rows l >> 4, point l & 15).
 template <int SL, int S>
-__device__ __forceinline__ void mfma_slots(int nact, int nnarrow,
-                                           double (&acc)[SL][4],
+__device__ __forceinline__ void mfma_slots(int nact, bool narrow0,
+                                           double (&acc)[SL][4], double& accx,
                                            const double* aT,
                                            const double (&kb)[4][4],
                                            const double (&kv)[4],
@@ -309,14 +305,14 @@ __device__ __forceinline__ void mfma_slots(int nact, int nnarrow,
         for (int q = 0; q < 4; ++q) nxt[q] = aT[((S + 1) * kSteps + q) * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (S < kMaxNarrow && S < nnarrow) {
+      if (S == 0 && narrow0) {
         // four DEPENDENT MFMAs on one accumulator: the addend must not be read
         // before the previous result is written (4 wait states for this opcode;
         // nothing pads inside asm)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
-                       : "+v"(acc[S][0]) : "v"(cur[q]), "v"(kv[q]));
+                       : "+v"(accx) : "v"(cur[q]), "v"(kv[q]));
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -326,21 +322,21 @@ __device__ __forceinline__ void mfma_slots(int nact, int nnarrow,
       }
       if (S + 1 < SL)
         asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
-      mfma_slots<SL, S + 1>(nact, nnarrow, acc, aT, kb, kv, nxt, cur);
+      mfma_slots<SL, S + 1>(nact, false, acc, accx, aT, kb, kv, nxt, cur);
     }
   }
 }
 
 template <int SL>
-__device__ __forceinline__ void mfma_jblock(int nact, int nnarrow,
-                                            double (&acc)[SL][4],
+__device__ __forceinline__ void mfma_jblock(int nact, bool narrow0,
+                                            double (&acc)[SL][4], double& accx,
                                             const double* aT,
                                             const double (&kb)[4][4],
                                             const double (&kv)[4]) {
   double opsA[4], opsB[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) opsA[q] = aT[q * 64];
-  mfma_slots<SL, 0>(nact, nnarrow, acc, aT, kb, kv, opsA, opsB);
+  mfma_slots<SL, 0>(nact, narrow0, acc, accx, aT, kb, kv, opsA, opsB);
 }
 
 // SafeOptSwarm._compute_penalty (gp_opt.py:874-899) for one value.
@@ -488,7 +484,7 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
   // per-GP state
   double xs[D];
   double sq[4] = {0.0, 0.0, 0.0, 0.0}, mean = 0.0;
-  double sqx = 0.0;                 // squares of the narrow slots (mfma_slots)
+  double accx = 0.0, sqx = 0.0;     // narrow slot 0 (mfma_slots)
   double acc[kIB][4];
 #pragma unroll
   for (int b = 0; b < kIB; ++b)
@@ -567,7 +563,7 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
       __syncthreads();          // the partner group leaves its MFMA phase here
     }
     if (!SGP_ABL(8))
-      mfma_jblock<SL>(int(wcur & SW_NACT_MASK), int(wcur >> SW_NARROW_SHIFT) & 3, acc,
+      mfma_jblock<SL>(int(wcur & SW_NACT_MASK), (wcur & SW_NARROW) != 0, acc, accx,
                       cbuf + lane, kb, kv);
     if (PP) {
       __syncthreads();          // ... and enters it here
@@ -575,20 +571,16 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
     }
 
     if (wcur & SW_CHUNK_END) {
-      const int nn = int(wcur >> SW_NARROW_SHIFT) & 3;
 #pragma unroll
       for (int b = 0; b < kIB; ++b) {
-        if (b < kMaxNarrow && b < nn) {     // (wave-uniform)
-          sqx = fma(acc[b][0], acc[b][0], sqx);
-          acc[b][0] = 0.0;
-          continue;
-        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           sq[m] = fma(acc[b][m], acc[b][m], sq[m]);
           acc[b][m] = 0.0;
         }
       }
+      sqx = fma(accx, accx, sqx);
+      accx = 0.0;
     }
 
     if ((wcur & SW_GP_END) && !SGP_ABL(32)) {
@@ -1110,7 +1102,6 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB,
   for (int g = 0; g < Geff; ++g) {
     sig.push_back(gh[g].nblk);
     sig.push_back(gh[g].narrow);
-    sig.push_back(gh[g].nvb);
   }
   if (sig == ctx->stage_sig && ctx->stage_tab.p) {
     *dev = static_cast<const StageEnt*>(ctx->stage_tab.p);
@@ -1119,24 +1110,21 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB,
   }
   std::vector<StageEnt> tab;
   for (int g = 0; g < Geff; ++g) {
-    // row blocks as packed (GpDev::nvb: the narrow form of the last one may take
-    // two); j-blocks = blocks of 16 training points
-    const int nvb = gh[g].nvb, njb = gh[g].nblk, nsteps = gh[g].n_pad / 4;
-    const int nchunks = (nvb + kIB - 1) / kIB;
+    const int nblk = gh[g].nblk, nsteps = gh[g].n_pad / 4;
+    const int nchunks = (nblk + kIB - 1) / kIB;
     for (int c = 0; c < nchunks; ++c) {
-      const int b0 = c * kIB, nib = std::min(kIB, nvb - b0), bend = b0 + nib;
-      const int jend = std::min(bend, njb);
-      for (int jb = 0; jb < jend; ++jb) {
+      const int b0 = c * kIB, nib = std::min(kIB, nblk - b0), bend = b0 + nib;
+      for (int jb = 0; jb < bend; ++jb) {
         StageEnt e;
         e.a_off = uint32_t((bend - 1) * nsteps + 4 * jb);
         e.row_stride = uint32_t(nsteps);
         e.jb = uint32_t(jb);
         e.word = uint32_t(std::min(nib, bend - jb)) | (uint32_t(g) << SW_G_SHIFT);
-        if (jb == jend - 1) e.word |= SW_CHUNK_END;
+        if (jb == bend - 1) e.word |= SW_CHUNK_END;
         if (c == nchunks - 1) e.word |= SW_MEAN;
-        // the first slot(s) of the last chunk = the last row block
-        if (c == nchunks - 1) e.word |= uint32_t(gh[g].narrow) << SW_NARROW_SHIFT;
-        if (c == nchunks - 1 && jb == jend - 1) {
+        // slot 0 of the last chunk = the last row block
+        if (c == nchunks - 1 && gh[g].narrow) e.word |= SW_NARROW;
+        if (c == nchunks - 1 && jb == bend - 1) {
           e.word |= SW_GP_END;
           if (g == Geff - 1) e.word |= SW_TILE_END;
         }

@@ -93,9 +93,8 @@ def test_factor_matches_lapack(mods, n):
                                  # chunks, and every input dimension up to 8
                                  (256, 2), (257, 2), (1040, 3), (100, 5),
                                  (100, 7), (33, 8),
-                                 # last row block with 5..8 rows (two narrow row
-                                 # blocks), also right behind a chunk boundary
-                                 # and where that form must not be taken (16 k blocks)
+                                 # last row block with 5..8 rows, also right behind
+                                 # a chunk boundary and with 16 k row blocks
                                  (5, 1), (24, 2), (248, 2), (264, 2), (277, 3)])
 def test_predict_noiseless(mods, kind, n, d):
     _, gpy, gpn, _ = mods
