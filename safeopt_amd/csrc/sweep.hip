@@ -107,6 +107,9 @@ enum : uint32_t {
 // with any bit set): built only with -DSGP_INSTRUMENT, selected at run time by
 // SGP_ABLATE=<mask>: 1 no stage barrier, 2 no LDS-DMA, 4 no covariance
 // evaluation, 8 no MFMA, 16 no mean/var/Q stores, 32 no per-GP epilogue at all.
+// -DSGP_SEP_PROBE (a build of its own): covariances = product of D table entries
+// prefetched a stage ahead -- what a separable-RBF path on a tensor grid would
+// execute (table contents are arbitrary: timing only).
 #ifdef SGP_INSTRUMENT
 #define SGP_ABL(mask) (p.ablate & (mask))
 #else
@@ -119,6 +122,9 @@ struct SweepParams {
   int mode;
 #ifdef SGP_INSTRUMENT
   int ablate;      // timing experiments (scripts/ablate.py), see SGP_ABL
+#endif
+#ifdef SGP_SEP_PROBE
+  const double* sep_tab;   // [D][4096][1024] doubles
 #endif
   SweepPoints pts;
   ConfOut conf;
@@ -496,6 +502,13 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
   double lmax = -INFINITY;   // max l0 over the safe rows this wave has seen
   bool gp_start = true;
 
+#ifdef SGP_SEP_PROBE
+  double sep_cur[4][D], sep_next[4][D];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int k = 0; k < D; ++k) sep_cur[q][k] = sep_next[q][k] = 0.5;
+#endif
   int par = 0;
 #pragma unroll 1
   while (true) {
@@ -531,6 +544,24 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
       }
       if (next_tile) load_x(t1, xnext);
     }
+#ifdef SGP_SEP_PROBE
+    if (more) {
+      // table entries of the NEXT stage: [axis][training point][axis index]
+      const int64_t rn = int64_t(t1) * kTilePts + wave * 16 + (lane & 15);
+      int ax[D];
+      int64_t rem = rn;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        ax[k] = int(rem % 1000);
+        rem /= 1000;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+          sep_next[q][k] = p.sep_tab[(int64_t(k) * 4096 + (e1.jb * 16 + 4 * q + (lane >> 4))) * 1024 + ax[k]];
+    }
+#endif
     const int tile_after = t1;
     // the entry after that: loaded now, first used at the top of the next stage
     advance(si2, t2);
@@ -546,7 +577,18 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
     const double* xT = cbuf + kATile;
     const double* alT = cbuf + kATile + kXTile;
     double kv[4];
+#ifdef SGP_SEP_PROBE
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      kv[q] = sep_cur[q][0];
+#pragma unroll
+      for (int k = 1; k < D; ++k) kv[q] *= sep_cur[q][k];
+    }
+    if (true) {
+    } else if (!SGP_ABL(4)) {
+#else
     if (!SGP_ABL(4)) {
+#endif
       kf.template many4_t<SINGLE>(xs, xT + (lane >> 4) * D, 4 * D, tab, kv);
     } else {
       kv[0] = xs[0]; kv[1] = xs[0] + 1.0; kv[2] = xs[0] + 2.0; kv[3] = xs[0] + 3.0;
@@ -711,6 +753,12 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
     if (!more) break;
     if (!PP && !SGP_ABL(1)) __syncthreads();
     par ^= 1;
+#ifdef SGP_SEP_PROBE
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < D; ++k) sep_cur[q][k] = sep_next[q][k];
+#endif
     first = false;
     wcur = wnext;
     e0 = e1;
@@ -1179,6 +1227,19 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
 #ifdef SGP_INSTRUMENT
   static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
   pp.ablate = ablate;
+#endif
+#ifdef SGP_SEP_PROBE
+  {
+    static double* tab = nullptr;
+    if (!tab) {
+      const size_t nt = size_t(D) * 4096 * 1024;
+      SGP_HIP(ctx, hipMalloc(&tab, nt * sizeof(double)));
+      std::vector<double> h(nt);
+      for (size_t i = 0; i < nt; ++i) h[i] = 0.25 + 0.5 * double((i * 2654435761u) & 1023) / 1024.0;
+      SGP_HIP(ctx, hipMemcpy(tab, h.data(), nt * sizeof(double), hipMemcpyHostToDevice));
+    }
+    pp.sep_tab = tab;
+  }
 #endif
   const size_t lds_bytes = Lay<SL, D>::bytes(NW);
   hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE, PP>), dim3(nblocks),
