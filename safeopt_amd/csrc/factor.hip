@@ -604,13 +604,17 @@ __global__ void k_small_kb(KernDesc kd, const double* pts, int P, const double* 
   Kb[int64_t(pass) * nsteps * 64 + e] = v;
 }
 
-__global__ __launch_bounds__(256) void k_small_mfma(const double* Apack,
-                                                    const double* Kb,
-                                                    const double* alpha,
-                                                    int nsteps, int nblk, int narrow,
-                                                    double* part, double* mean) {
-  __shared__ double4_t sh[4][64];
-  __shared__ double shm[4][16];
+// One workgroup per 16-row block of L^-1 and pass of 16 points; its 16 waves
+// split the k-steps (the last row block has n / 4 of them: with four waves it was
+// a chain of n / 16 exposed load latencies) and fold their partial products
+// through LDS.
+constexpr int kSmallWaves = 16;
+
+__global__ __launch_bounds__(64 * kSmallWaves) void k_small_mfma(
+    const double* Apack, const double* Kb, const double* alpha, int nsteps,
+    int nblk, int narrow, double* part, double* mean) {
+  __shared__ double4_t sh[kSmallWaves][64];
+  __shared__ double shm[kSmallWaves][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = blockIdx.x, pass = blockIdx.y;
   const double* A = Apack + int64_t(blk) * nsteps * 64 + lane;
@@ -621,11 +625,22 @@ __global__ __launch_bounds__(256) void k_small_mfma(const double* Apack,
   double4_t acc = {0.0, 0.0, 0.0, 0.0};
   double m = 0.0;
   const int send = (blk + 1) * 4;               // up to the diagonal block
-#pragma unroll 4
-  for (int s = wave; s < send; s += 4) {
-    const double b = B[s * 64];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dup ? 0.0 : A[s * 64], b, acc, 0, 0, 0);
-    if (last) m = fma(alpha[4 * s + (lane >> 4)], b, m);
+  for (int s = wave; s < send; s += 8 * kSmallWaves) {
+    // eight k-steps of this wave, all loads issued before the first use
+    double av[8], bv[8], al[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int si = s + i * kSmallWaves;
+      const bool ok = si < send;
+      av[i] = (ok && !dup) ? A[si * 64] : 0.0;
+      bv[i] = ok ? B[si * 64] : 0.0;
+      al[i] = (ok && last) ? alpha[4 * si + (lane >> 4)] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[i], acc, 0, 0, 0);
+      m = fma(al[i], bv[i], m);
+    }
   }
   sh[wave][lane] = acc;
   if (last) {
@@ -636,28 +651,44 @@ __global__ __launch_bounds__(256) void k_small_mfma(const double* Apack,
   __syncthreads();
   if (wave == 0) {
     // D layout: column (point) = lane & 15, rows (lane >> 4) + 4 r
-    const double4_t t = sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane];
+    double4_t t = sh[0][lane];
+#pragma unroll
+    for (int w = 1; w < kSmallWaves; ++w) t += sh[w][lane];
     double ss = (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
     if (lane < 16) {
       part[(int64_t(pass) * nblk + blk) * 16 + lane] = ss;
-      if (last)
-        mean[pass * 16 + lane] =
-            (shm[0][lane] + shm[1][lane]) + (shm[2][lane] + shm[3][lane]);
+      if (last) {
+        double mm = shm[0][lane];
+#pragma unroll
+        for (int w = 1; w < kSmallWaves; ++w) mm += shm[w][lane];
+        mean[pass * 16 + lane] = mm;
+      }
     }
   }
 }
 
-__global__ void k_small_post(const double* part, int nblk, int P, double kdiag,
-                             const double* mean_in, double* mean, double* var) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  const int pass = p >> 4, c = p & 15;
+// var = k(x,x) - sum over the row blocks (fixed order), GPy clip.  One workgroup
+// per pass of 16 points: thread (point c, group q) sums the row blocks q, q + 16,
+// ..., the 16 groups are folded through LDS.
+__global__ __launch_bounds__(256) void k_small_post(const double* part, int nblk, int P,
+                                                    double kdiag, const double* mean_in,
+                                                    double* mean, double* var) {
+  __shared__ double sh[16][16];
+  const int pass = blockIdx.x, c = threadIdx.x & 15, q = threadIdx.x >> 4;
   double ss = 0.0;
-  for (int b = 0; b < nblk; ++b) ss += part[(int64_t(pass) * nblk + b) * 16 + c];
-  mean[p] = mean_in[p];
-  var[p] = fmax(kdiag - ss, 1e-15);      // GPy clip
+  for (int b = q; b < nblk; b += 16) ss += part[(int64_t(pass) * nblk + b) * 16 + c];
+  sh[q][c] = ss;
+  __syncthreads();
+  const int p = pass * 16 + c;
+  if (q == 0 && p < P) {
+    double tot = sh[0][c];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) tot += sh[g][c];
+    mean[p] = mean_in[p];
+    var[p] = fmax(kdiag - tot, 1e-15);      // GPy clip
+  }
 }
 
 // ---- operands of the rank-1 expander test, all GPs per launch ----------------------
@@ -955,11 +986,12 @@ int posterior_small(sgp_gp* gp, const double* pts_rowmajor, int P, double* mean,
       return -2;
   }
 #undef SMALL_CASE
-  hipLaunchKernelGGL(k_small_mfma, dim3(nblk, passes), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(k_small_mfma, dim3(nblk, passes), dim3(64 * kSmallWaves), 0,
+                     ctx->stream,
                      static_cast<double*>(gp->Apack.p), Kb,
                      static_cast<double*>(gp->alpha.p), nsteps, nblk,
                      gp->dev.narrow, part, mtmp);
-  hipLaunchKernelGGL(k_small_post, dim3((P + 63) / 64), dim3(64), 0, ctx->stream,
+  hipLaunchKernelGGL(k_small_post, dim3(passes), dim3(256), 0, ctx->stream,
                      part, nblk, P, gp->kern.kdiag, mtmp, mean, var);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
