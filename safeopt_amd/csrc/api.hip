@@ -11,6 +11,7 @@
 #include <new>
 
 #include "common.h"
+#include "small_path.h"
 
 namespace {
 std::string g_err;  // errors raised without a context
@@ -351,7 +352,11 @@ int sgp_gp_predict(sgp_gp* gp, const double* Xnew, int64_t N,
         tmp[size_t(r) * d + k] = Xnew[r * stride_row + k * stride_col];
     SGP_TRY(sgp_h2d(ctx, stage, tmp.data(), tmp.size() * sizeof(double)));
     double* mvs = pts;                        // [mean N | var N]
-    SGP_TRY(posterior_small(gp, stage, int(N), mvs, mvs + N));
+    SGP_TRY(sgp_h2d(ctx, gdev, &gp->dev, sizeof(GpDev)));
+    SmallBufs sb;
+    SGP_CHECK(ctx, small_reserve(ctx, &gp->dev, 1, int(N), &sb) == 0,
+              "device allocation failed: %s", ctx->err.c_str());
+    SGP_TRY(posterior_small_all(ctx, gdev, &gp->dev, 1, stage, int(N), sb, mvs, mvs + N));
     SGP_TRY(sgp_d2h(ctx, mean, mvs, size_t(N) * sizeof(double)));
     return sgp_d2h(ctx, var, mvs + N, size_t(N) * sizeof(double));
   }
@@ -1141,18 +1146,19 @@ int sgp_grid_sets_fused(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
 
 // Fitness of P <= kSmallPoints particles (row-major, device) through the
 // small-point posterior path: mean / var per GP, then the shaping kernel.
-static int fitness_small(sgp_ctx* ctx, sgp_gp* const* gps, int G,
-                         const double* pts_rowmajor, int64_t P,
+static int fitness_small(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
+                         int G, const double* pts_rowmajor, int64_t P,
                          const FitnessArgs& fa) {
   const int Geff = (fa.swarm_type == SGP_SWARM_GREEDY) ? 1 : G;
   double* mv = static_cast<double*>(
       sgp_scratch(ctx, 2, size_t(2) * SGP_MAX_GPS * kSmallPoints * sizeof(double)));
-  SGP_CHECK(ctx, mv, "device allocation failed: %s", ctx->err.c_str());
+  SmallBufs sb;
+  SGP_CHECK(ctx, mv && small_reserve(ctx, gps_host, Geff, int(P), &sb) == 0,
+            "device allocation failed: %s", ctx->err.c_str());
   double* mean = mv;
   double* var = mv + size_t(SGP_MAX_GPS) * kSmallPoints;
-  for (int g = 0; g < Geff; ++g)
-    SGP_TRY(posterior_small(gps[g], pts_rowmajor, int(P), mean + size_t(g) * P,
-                            var + size_t(g) * P));
+  SGP_TRY(posterior_small_all(ctx, gps_dev, gps_host, Geff, pts_rowmajor, int(P), sb,
+                              mean, var));
   return launch_fitness_small(ctx, G, P, mean, var, fa);
 }
 
@@ -1198,7 +1204,7 @@ int sgp_swarm_fitness(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
   fa.values = dval;
   fa.safe = dsafe;
   if (small_path_pays_all(gps, G, P)) {
-    SGP_TRY(fitness_small(ctx, gps, G, stage, P, fa));
+    SGP_TRY(fitness_small(ctx, gdev, host, G, stage, P, fa));
   } else {
     SweepPoints sp{pts, P, 1, P};
     SGP_TRY(launch_sweep_fitness(ctx, gdev, host, G, d, sp, fa));
@@ -1216,7 +1222,7 @@ int sgp_swarm_run(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
                   double* velocities, double* best_positions, double* best_values,
                   double* global_best, const double* velocity_scale,
                   const double* bounds, int init, int iters, double inertia0,
-                  double step, const double* rand, uint64_t seed) {
+                  double step_size, const double* rand, uint64_t seed) {
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   SGP_CHECK(ctx, swarm_type >= SGP_SWARM_GREEDY && swarm_type <= SGP_SWARM_SAFE_SET,
             "Invalid swarm type %d", swarm_type);
@@ -1266,27 +1272,77 @@ int sgp_swarm_run(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
   fa.values = dval;
   fa.safe = dsafe;
   const SweepPoints sp{dpos, P, d, 1};          // row-major (P, d) in place
-  const bool few = small_path_pays_all(gps, G, P);
-  auto fitness = [&]() -> int {
-    return few ? fitness_small(ctx, gps, G, dpos, P, fa)
-                 : launch_sweep_fitness(ctx, gdev, host, G, d, sp, fa);
-  };
+  const bool few = P <= kSmallSwarm && small_path_pays_all(gps, G, P);
   const double* r = drand;
-  if (init) {
-    SGP_TRY(launch_pso_init_vel(ctx, P, d, dvel, dvs, r, seed));
-    if (r) r += size_t(P) * d;
-    SGP_TRY(fitness());
-    SGP_TRY(launch_pso_best(ctx, P, d, dval, dsafe, dpos, dbest, dbv, dgb, 1));
-  }
   double inertia = inertia0;
-  for (int it = 0; it < iters; ++it) {
-    SGP_TRY(launch_pso_move(ctx, P, d, dpos, dvel, dbest, dgb, dvs,
-                            bounds ? dbd : nullptr, inertia, r, seed,
-                            uint32_t(it + 1)));
-    if (r) r += 2 * size_t(P) * d;
-    inertia += step;
-    SGP_TRY(fitness());
-    SGP_TRY(launch_pso_best(ctx, P, d, dval, dsafe, dpos, dbest, dbv, dgb, 0));
+  if (few) {
+    // small swarm: three launches per iteration -- k(X, particles), the block
+    // products on the matrix cores, and ONE workgroup for everything else
+    // (fitness, bests, and the move that opens the next iteration)
+    const int Geff = (swarm_type == SGP_SWARM_GREEDY) ? 1 : G;
+    SmallBufs sb;
+    SGP_CHECK(ctx, small_reserve(ctx, host, Geff, int(P), &sb) == 0,
+              "device allocation failed: %s", ctx->err.c_str());
+    PsoSmallArgs ps{};
+    ps.pos = dpos;
+    ps.vel = dvel;
+    ps.best = dbest;
+    ps.best_values = dbv;
+    ps.gbest = dgb;
+    ps.vscale = dvs;
+    ps.bounds = bounds ? dbd : nullptr;
+    ps.seed = seed;
+    ps.P = int(P);
+    ps.d = d;
+    auto step = [&](int is_init, int it_next) -> int {   // it_next < 0: no move
+      SGP_TRY(posterior_small_all(ctx, gdev, host, Geff, dpos, int(P), sb, nullptr,
+                                  nullptr));
+      ps.init = is_init;
+      ps.move = it_next >= 0;
+      ps.rand = r;
+      ps.draw = uint32_t(it_next + 1);
+      ps.inertia = inertia;
+      SGP_TRY(launch_pso_small_step(ctx, gdev, G, sb, fa, ps));
+      if (ps.move) {
+        if (r) r += 2 * size_t(P) * d;
+        inertia += step_size;
+      }
+      return 0;
+    };
+    if (init) {
+      SGP_TRY(launch_pso_init_vel(ctx, P, d, dvel, dvs, r, seed));
+      if (r) r += size_t(P) * d;
+      SGP_TRY(step(1, iters > 0 ? 0 : -1));
+    } else if (iters > 0) {
+      SGP_TRY(launch_pso_move(ctx, P, d, dpos, dvel, dbest, dgb, dvs,
+                              bounds ? dbd : nullptr, inertia, r, seed, 1u));
+      if (r) r += 2 * size_t(P) * d;
+      inertia += step_size;
+    }
+    for (int it = 0; it < iters; ++it)
+      SGP_TRY(step(0, it + 1 < iters ? it + 1 : -1));
+  } else {
+    // (up to kSmallPoints particles still take the few-points posterior)
+    const bool few_points = small_path_pays_all(gps, G, P);
+    auto fitness = [&]() -> int {
+      return few_points ? fitness_small(ctx, gdev, host, G, dpos, P, fa)
+                        : launch_sweep_fitness(ctx, gdev, host, G, d, sp, fa);
+    };
+    if (init) {
+      SGP_TRY(launch_pso_init_vel(ctx, P, d, dvel, dvs, r, seed));
+      if (r) r += size_t(P) * d;
+      SGP_TRY(fitness());
+      SGP_TRY(launch_pso_best(ctx, P, d, dval, dsafe, dpos, dbest, dbv, dgb, 1));
+    }
+    for (int it = 0; it < iters; ++it) {
+      SGP_TRY(launch_pso_move(ctx, P, d, dpos, dvel, dbest, dgb, dvs,
+                              bounds ? dbd : nullptr, inertia, r, seed,
+                              uint32_t(it + 1)));
+      if (r) r += 2 * size_t(P) * d;
+      inertia += step_size;
+      SGP_TRY(fitness());
+      SGP_TRY(launch_pso_best(ctx, P, d, dval, dsafe, dpos, dbest, dbv, dgb, 0));
+    }
   }
   SGP_TRY(sgp_d2h(ctx, positions, dpos, nd));
   SGP_TRY(sgp_d2h(ctx, velocities, dvel, nd));

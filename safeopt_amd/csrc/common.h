@@ -220,14 +220,9 @@ int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
 int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,
                          const GpDev* gps_host, int G, int d, SweepPoints pts,
                          FitnessArgs fa);
-int launch_fitness_small(sgp_ctx* ctx, int G, int64_t P, const double* mean,
-                         const double* var, FitnessArgs fa);
-// factor.hip: posterior of up to kSmallPoints points through triangular
-// multi-RHS products (every CU works on the same few points)
-constexpr int kSmallPoints = 64;
-int posterior_small(sgp_gp* gp, const double* pts_rowmajor, int P, double* mean,
-                    double* var);
-bool small_path_pays(const sgp_gp* gp, int64_t P);
+// few-points posterior / small-swarm step: small_path.h
+constexpr int kSmallPoints = 4096;   // few-points posterior path (factor.hip)
+constexpr int kSmallSwarm = 64;     // ... with the whole PSO step in one workgroup (swarm.hip)
 struct ExpanderArgs {
   const double* Wpack;   // [G][n_pad_max/4][64] MFMA A-operand (cand x j)
   const double* xc;      // [m][d]

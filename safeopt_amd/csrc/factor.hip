@@ -11,6 +11,7 @@
 //     else split h:  factor(A11); L21 = A21 Linv11^T; A22 -= L21 L21^T;
 //                    factor(A22); Linv21 = -Linv22 (L21 Linv11)
 #include <algorithm>
+#include "small_path.h"
 
 #include "kern_eval.h"
 
@@ -579,29 +580,30 @@ int pop_gp(sgp_gp* gp) {
 // round -- one workgroup per 16-row block of L^-1, 16 points per pass:
 //   k_small_kb   : Kb = k(X, pts) in MFMA B-operand order, zero padded
 //   k_small_mfma : |L^-1 Kb|^2 per (row block, point) on the matrix cores (the
-//                  packed A operands of the sweep), its four waves splitting
-//                  the k-steps; the last row block also forms alpha . Kb
+//                  packed A operands of the sweep), 16 waves splitting the
+//                  k-steps; the last row block also forms alpha . Kb
 //   k_small_post : var = k(x,x) - sum over row blocks, GPy clip
-// Three launches whose time does not depend on n^2 per compute unit.
+// Three launches for ALL GPs (blockIdx.z = GP) whose time does not depend on
+// n^2 per compute unit.
 template <int D>
-__global__ void k_small_kb(KernDesc kd, const double* pts, int P, const double* X,
-                           int n, int nsteps, double* Kb) {
+__global__ void k_small_kb(const GpDev* gps, const double* pts, int P, SmallBufs sb) {
+  const GpDev& gp = gps[blockIdx.z];
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int pass = blockIdx.y;
-  if (e >= nsteps * 64) return;
+  if (e >= (gp.n_pad / 4) * 64) return;
   const int lane = e & 63, s = e >> 6;
   const int pt = pass * 16 + (lane & 15), j = 4 * s + (lane >> 4);
   double v = 0.0;
-  if (pt < P && j < n) {
+  if (pt < P && j < gp.n) {
     double a[D], b[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
       a[k] = pts[int64_t(pt) * D + k];
-      b[k] = X[int64_t(j) * D + k];
+      b[k] = gp.Xpad[int64_t(j) * D + k];
     }
-    v = kern_eval<D>(kd, a, b);
+    v = kern_eval<D>(gp.kern, a, b);
   }
-  Kb[int64_t(pass) * nsteps * 64 + e] = v;
+  sb.Kb[blockIdx.z * sb.kb_stride + int64_t(pass) * sb.nsteps_max * 64 + e] = v;
 }
 
 // One workgroup per 16-row block of L^-1 and pass of 16 points; its 16 waves
@@ -610,34 +612,38 @@ __global__ void k_small_kb(KernDesc kd, const double* pts, int P, const double* 
 // through LDS.
 constexpr int kSmallWaves = 16;
 
-__global__ __launch_bounds__(64 * kSmallWaves) void k_small_mfma(
-    const double* Apack, const double* Kb, const double* alpha, int nsteps,
-    int nblk, int narrow, double* part, double* mean) {
+__global__ __launch_bounds__(64 * kSmallWaves) void k_small_mfma(const GpDev* gps,
+                                                                 SmallBufs sb) {
   __shared__ double4_t sh[kSmallWaves][64];
   __shared__ double shm[kSmallWaves][16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const GpDev& gp = gps[blockIdx.z];
+  const int nblk = gp.nblk, nsteps = gp.n_pad / 4;
   const int blk = blockIdx.x, pass = blockIdx.y;
-  const double* A = Apack + int64_t(blk) * nsteps * 64 + lane;
-  const double* B = Kb + int64_t(pass) * nsteps * 64 + lane;
+  if (blk >= nblk) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double* A = gp.Apack + int64_t(blk) * nsteps * 64 + lane;
+  const double* B = sb.Kb + blockIdx.z * sb.kb_stride +
+                    int64_t(pass) * sb.nsteps_max * 64 + lane;
   const bool last = blk == nblk - 1;            // covers every k-step: the mean
   // narrow packing of the last row block (k_pack): its rows 4..15 repeat rows 0..3
-  const bool dup = last && narrow && (lane & 15) >= 4;
+  const bool dup = last && gp.narrow && (lane & 15) >= 4;
   double4_t acc = {0.0, 0.0, 0.0, 0.0};
   double m = 0.0;
   const int send = (blk + 1) * 4;               // up to the diagonal block
-  for (int s = wave; s < send; s += 8 * kSmallWaves) {
-    // eight k-steps of this wave, all loads issued before the first use
-    double av[8], bv[8], al[8];
+  constexpr int kInFlight = 8;                  // k-steps of a wave per batch (16: slower)
+  for (int s = wave; s < send; s += kInFlight * kSmallWaves) {
+    // all loads of the batch are issued before the first use
+    double av[kInFlight], bv[kInFlight], al[kInFlight];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < kInFlight; ++i) {
       const int si = s + i * kSmallWaves;
       const bool ok = si < send;
       av[i] = (ok && !dup) ? A[si * 64] : 0.0;
       bv[i] = ok ? B[si * 64] : 0.0;
-      al[i] = (ok && last) ? alpha[4 * si + (lane >> 4)] : 0.0;
+      al[i] = (ok && last) ? gp.alpha[4 * si + (lane >> 4)] : 0.0;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < kInFlight; ++i) {
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[i], acc, 0, 0, 0);
       m = fma(al[i], bv[i], m);
     }
@@ -658,36 +664,30 @@ __global__ __launch_bounds__(64 * kSmallWaves) void k_small_mfma(
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
     if (lane < 16) {
-      part[(int64_t(pass) * nblk + blk) * 16 + lane] = ss;
+      sb.part[blockIdx.z * sb.part_stride + (int64_t(pass) * sb.nblk_max + blk) * 16 + lane] = ss;
       if (last) {
         double mm = shm[0][lane];
 #pragma unroll
         for (int w = 1; w < kSmallWaves; ++w) mm += shm[w][lane];
-        mean[pass * 16 + lane] = mm;
+        sb.mtmp[(blockIdx.z * sb.passes + pass) * 16 + lane] = mm;
       }
     }
   }
 }
 
-// var = k(x,x) - sum over the row blocks (fixed order), GPy clip.  One workgroup
-// per pass of 16 points: thread (point c, group q) sums the row blocks q, q + 16,
-// ..., the 16 groups are folded through LDS.
-__global__ __launch_bounds__(256) void k_small_post(const double* part, int nblk, int P,
-                                                    double kdiag, const double* mean_in,
-                                                    double* mean, double* var) {
+// var = k(x,x) - sum over the row blocks (small_block_sum), GPy clip.  One
+// workgroup per pass of 16 points and GP; mean / var are [G][P].
+__global__ __launch_bounds__(256) void k_small_post(const GpDev* gps, SmallBufs sb,
+                                                    int P, double* mean, double* var) {
   __shared__ double sh[16][16];
-  const int pass = blockIdx.x, c = threadIdx.x & 15, q = threadIdx.x >> 4;
-  double ss = 0.0;
-  for (int b = q; b < nblk; b += 16) ss += part[(int64_t(pass) * nblk + b) * 16 + c];
-  sh[q][c] = ss;
-  __syncthreads();
-  const int p = pass * 16 + c;
-  if (q == 0 && p < P) {
-    double tot = sh[0][c];
-#pragma unroll
-    for (int g = 1; g < 16; ++g) tot += sh[g][c];
-    mean[p] = mean_in[p];
-    var[p] = fmax(kdiag - tot, 1e-15);      // GPy clip
+  const int g = blockIdx.y, pass = blockIdx.x;
+  const GpDev& gp = gps[g];
+  const double tot = small_block_sum(sb.part + g * sb.part_stride, sb.nblk_max,
+                                     gp.nblk, pass, sh);
+  const int p = pass * 16 + (threadIdx.x & 15);
+  if ((threadIdx.x >> 4) == 0 && p < P) {
+    mean[int64_t(g) * P + p] = sb.mtmp[g * sb.passes * 16 + p];
+    var[int64_t(g) * P + p] = fmax(gp.kern.kdiag - tot, 1e-15);      // GPy clip
   }
 }
 
@@ -954,45 +954,57 @@ int expander_operands_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_h
 }
 
 bool small_path_pays(const sgp_gp* gp, int64_t P) {
-  // sweep: ~3 us per 16 x 256 stage on one CU (n = 200: 13 stages, n = 2000:
-  // 573); few-points path: three launches per GP.  Measured crossover
-  // (scripts/dev/swarm_small.py): between n = 50 and n = 200.
+  // The sweep needs >= 256 tiles of 64 rows to fill the chip; a tile walks
+  // through all n^2 / 512 block products on one compute unit (n = 2000: 2.8 ms
+  // whatever the number of tiles up to 512).  The few-points path spreads
+  // (P / 16) x (n / 16) workgroups of a few microseconds each over the chip:
+  // n = 2000, P = 2000: 0.3 ms.  Below n ~ 128 a tile is as short as the three
+  // launches (measured crossover, scripts/dev/swarm_small.py: n between 50 and 200).
   return P >= 1 && P <= kSmallPoints && gp->n >= 128;
 }
 
-int posterior_small(sgp_gp* gp, const double* pts_rowmajor, int P, double* mean,
-                    double* var) {
-  sgp_ctx* ctx = gp->ctx;
-  const int n = int(gp->n), np = gp->n_pad, nblk = np / 16, nsteps = np / 4;
-  const int passes = (P + 15) / 16;
-  const size_t nkb = size_t(passes) * nsteps * 64, npart = size_t(passes) * nblk * 16;
-  double* buf = static_cast<double*>(
-      sgp_scratch(ctx, 6, (nkb + npart + kSmallPoints) * sizeof(double)));
+int small_reserve(sgp_ctx* ctx, const GpDev* gps_host, int G, int P, SmallBufs* sb) {
+  int np_max = 0;
+  for (int g = 0; g < G; ++g) np_max = std::max(np_max, gps_host[g].n_pad);
+  sb->passes = (P + 15) / 16;
+  sb->nsteps_max = np_max / 4;
+  sb->nblk_max = np_max / 16;
+  sb->kb_stride = int64_t(sb->passes) * sb->nsteps_max * 64;
+  sb->part_stride = int64_t(sb->passes) * sb->nblk_max * 16;
+  double* buf = static_cast<double*>(sgp_scratch(
+      ctx, 6, size_t(G) * (sb->kb_stride + sb->part_stride + sb->passes * 16) * sizeof(double)));
   if (!buf) return -1;
-  double* Kb = buf;
-  double* part = buf + nkb;
-  double* mtmp = part + npart;
+  sb->Kb = buf;
+  sb->part = buf + size_t(G) * sb->kb_stride;
+  sb->mtmp = sb->part + size_t(G) * sb->part_stride;
+  return 0;
+}
+
+// |L^-1 k(X, pts)|^2 per row block and alpha . k(X, pts) of all G GPs (two
+// launches); `post` adds the block sums -> mean / var [G][P].
+int posterior_small_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
+                        int G, const double* pts_rowmajor, int P, const SmallBufs& sb,
+                        double* mean, double* var) {
+  const int d = gps_host[0].kern.d;
 #define SMALL_CASE(DD)                                                         \
   case DD:                                                                     \
-    hipLaunchKernelGGL(k_small_kb<DD>, dim3((nsteps * 64 + 255) / 256, passes),\
-                       dim3(256), 0, ctx->stream, gp->kern, pts_rowmajor, P,   \
-                       static_cast<double*>(gp->X.p), n, nsteps, Kb);          \
+    hipLaunchKernelGGL(k_small_kb<DD>,                                         \
+                       dim3((sb.nsteps_max * 64 + 255) / 256, sb.passes, G),   \
+                       dim3(256), 0, ctx->stream, gps_dev, pts_rowmajor, P, sb);\
     break;
-  switch (gp->kern.d) {
+  switch (d) {
     SMALL_CASE(1) SMALL_CASE(2) SMALL_CASE(3) SMALL_CASE(4)
     SMALL_CASE(5) SMALL_CASE(6) SMALL_CASE(7) SMALL_CASE(8)
     default:
-      sgp_set_error(ctx, "input dimension %d not in 1..%d", gp->kern.d, SGP_MAX_D);
+      sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
       return -2;
   }
 #undef SMALL_CASE
-  hipLaunchKernelGGL(k_small_mfma, dim3(nblk, passes), dim3(64 * kSmallWaves), 0,
-                     ctx->stream,
-                     static_cast<double*>(gp->Apack.p), Kb,
-                     static_cast<double*>(gp->alpha.p), nsteps, nblk,
-                     gp->dev.narrow, part, mtmp);
-  hipLaunchKernelGGL(k_small_post, dim3(passes), dim3(256), 0, ctx->stream,
-                     part, nblk, P, gp->kern.kdiag, mtmp, mean, var);
+  hipLaunchKernelGGL(k_small_mfma, dim3(sb.nblk_max, sb.passes, G),
+                     dim3(64 * kSmallWaves), 0, ctx->stream, gps_dev, sb);
+  if (mean && var)
+    hipLaunchKernelGGL(k_small_post, dim3(sb.passes, G), dim3(256), 0, ctx->stream,
+                       gps_dev, sb, P, mean, var);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -12,6 +12,8 @@
 //                list in parallel.
 // The covariance matrix is never stored.
 #include "kern_eval.h"
+#include "fitness.h"
+#include "small_path.h"
 
 namespace {
 
@@ -244,6 +246,108 @@ __global__ __launch_bounds__(1024) void k_pso_gbest(int64_t P, int d,
   }
 }
 
+// Fitness of a few particles from resident mean / var ([G][P]): the path of
+// SafeOptSwarm._compute_particle_fitness for P <= kSmallPoints.
+__global__ void k_fitness_small(int G, int64_t P, const double* mean,
+                                const double* var, FitnessArgs f) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  double out;
+  bool ok;
+  shape_particle(f, G,
+                 [&](int g, double* mu, double* v) {
+                   *mu = mean[int64_t(g) * P + i];
+                   *v = var[int64_t(g) * P + i];
+                 },
+                 &out, &ok);
+  f.values[i] = out;
+  f.safe[i] = ok ? 1 : 0;
+}
+
+// One PSO iteration of a small swarm (P <= kSmallSwarm) behind the two posterior launches
+// (k_small_kb, k_small_mfma), in ONE workgroup: block sums -> mean / var of every
+// GP, fitness, personal bests, global best (first index on ties) and the move
+// that opens the next iteration.  Same arithmetic, statement for statement, as
+// k_small_post + k_fitness_small + k_pso_best + k_pso_gbest + k_pso_move.
+__global__ __launch_bounds__(256) void k_pso_small_step(const GpDev* gps, int G,
+                                                        SmallBufs sb, FitnessArgs f,
+                                                        PsoSmallArgs ps) {
+  __shared__ double sh[16][16];
+  __shared__ double smean[SGP_MAX_GPS][kSmallSwarm], svar[SGP_MAX_GPS][kSmallSwarm];
+  __shared__ double sbv[kSmallSwarm];
+  const int t = threadIdx.x, P = ps.P, d = ps.d;
+  const int Geff = (f.swarm_type == SGP_SWARM_GREEDY) ? 1 : G;
+  for (int g = 0; g < Geff; ++g) {
+    for (int pass = 0; pass < sb.passes; ++pass) {
+      const double tot = small_block_sum(sb.part + g * sb.part_stride, sb.nblk_max,
+                                         gps[g].nblk, pass, sh);
+      const int p = pass * 16 + (t & 15);
+      if ((t >> 4) == 0 && p < P) {
+        smean[g][p] = sb.mtmp[g * sb.passes * 16 + p];
+        svar[g][p] = fmax(gps[g].kern.kdiag - tot, 1e-15);      // GPy clip
+      }
+    }
+  }
+  __syncthreads();
+  if (t < P) {
+    double out;
+    bool ok;
+    shape_particle(f, G,
+                   [&](int g, double* mu, double* v) {
+                     *mu = smean[g][t];
+                     *v = svar[g][t];
+                   },
+                   &out, &ok);
+    f.values[t] = out;
+    f.safe[t] = ok ? 1 : 0;
+    // personal bests (k_pso_best)
+    const bool better = ps.init || (out > ps.best_values[t] && ok);
+    double bv = ps.best_values[t];
+    if (better) {
+      bv = out;
+      ps.best_values[t] = out;
+      for (int k = 0; k < d; ++k) ps.best[t * d + k] = ps.pos[t * d + k];
+    }
+    sbv[t] = bv;
+  }
+  __syncthreads();
+  // global best: argmax of the personal bests, first index on ties (k_pso_gbest)
+  if (t < 64) {
+    double v = t < P ? sbv[t] : -INFINITY;
+    long long idx = t < P ? t : -1;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const double ov = __shfl_xor(v, o, 64);
+      const long long oi = __shfl_xor(idx, o, 64);
+      if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) {
+        v = ov;
+        idx = oi;
+      }
+    }
+    if (t < d) ps.gbest[t] = ps.best[idx * d + t];
+  }
+  if (!ps.move) return;
+  __syncthreads();
+  // the move that opens the next iteration (k_pso_move)
+  for (int e = t; e < P * d; e += 256) {
+    const int k = e % d;
+    const double x = ps.pos[e];
+    const double to_global = ps.gbest[k] - x;
+    const double to_own = ps.best[e] - x;
+    const double r1 = ps.rand ? ps.rand[e] : philox_uniform(ps.seed, ps.draw, uint64_t(e));
+    const double r2 = ps.rand ? ps.rand[P * d + e]
+                              : philox_uniform(ps.seed, ps.draw, uint64_t(P * d + e));
+    double v = ps.vel[e] * ps.inertia;
+    v = v + (r1 * to_own + r2 * to_global) / ps.vscale[k];
+    const double vmax = 10.0 * ps.vscale[k];
+    v = fmin(fmax(v, -vmax), vmax);
+    ps.vel[e] = v;
+    double xn = x + v;
+    if (ps.bounds) xn = fmin(fmax(xn, ps.bounds[2 * k]), ps.bounds[2 * k + 1]);
+    ps.pos[e] = xn;
+  }
+}
+
 }  // namespace
 
 int launch_pso_init_vel(sgp_ctx* ctx, int64_t P, int d, double* vel,
@@ -272,6 +376,22 @@ int launch_pso_best(sgp_ctx* ctx, int64_t P, int d, const double* values,
                      ctx->stream, P, d, values, safe, pos, best, best_values, init);
   hipLaunchKernelGGL(k_pso_gbest, dim3(1), dim3(1024), 0, ctx->stream, P, d,
                      best_values, best, gbest);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_fitness_small(sgp_ctx* ctx, int G, int64_t P, const double* mean,
+                         const double* var, FitnessArgs fa) {
+  hipLaunchKernelGGL(k_fitness_small, dim3(unsigned((P + 255) / 256)), dim3(256),
+                     0, ctx->stream, G, P, mean, var, fa);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_pso_small_step(sgp_ctx* ctx, const GpDev* gps_dev, int G, const SmallBufs& sb,
+                          FitnessArgs fa, PsoSmallArgs ps) {
+  hipLaunchKernelGGL(k_pso_small_step, dim3(1), dim3(256), 0, ctx->stream, gps_dev, G,
+                     sb, fa, ps);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -42,6 +42,7 @@
 #include <vector>
 
 #include "kern_eval.h"
+#include "fitness.h"
 
 namespace {
 
@@ -344,72 +345,6 @@ __device__ __forceinline__ void mfma_jblock(int nact, bool narrow0,
   for (int q = 0; q < 4; ++q) opsA[q] = aT[q * 64];
   mfma_slots<SL, 0>(nact, narrow0, acc, accx, aT, kb, kv, opsA, opsB);
 }
-
-// SafeOptSwarm._compute_penalty (gp_opt.py:874-899) for one value.
-__device__ __forceinline__ double swarm_penalty(double slack) {
-  double pen = fmin(slack, 0.0);
-  if (slack < 0.0 && slack > -0.001) pen *= 2.0;
-  if (slack <= -0.001 && slack > -0.1) pen *= 5.0;
-  if (slack <= -0.1 && slack > -1.0) pen *= 10.0;
-  if (slack < -1.0) pen = -300.0 * pen * pen;
-  return pen;
-}
-
-// The fitness shaping of SafeOptSwarm._compute_particle_fitness
-// (gp_opt.py:925-1013) on resident mean / var ([G][P]) -- the epilogue of
-// k_sweep<.., MODE_FITNESS> as a kernel of its own, for the small-swarm path
-// (posterior_small in factor.hip) where the posterior does not come out of the
-// sweep.  One thread per particle; same formulas, same order as the epilogue.
-__global__ void k_fitness_small(int G, int64_t P, const double* mean,
-                                const double* var, FitnessArgs f) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  const int st = f.swarm_type;
-  const int Geff = (st == SGP_SWARM_GREEDY) ? 1 : G;
-  bool safe = true;
-  double values = 0.0, interest = 1.0, total_pen = 0.0, lower = 0.0;
-  for (int g = 0; g < Geff; ++g) {
-    const double mu = mean[int64_t(g) * P + i];
-    const double sd = sqrt(var[int64_t(g) * P + i]);
-    lower = mu - f.beta * sd;
-    if (g == 0) {
-      values = sd / f.scaling[0];
-      if (st == SGP_SWARM_EXPANDERS) interest = double(G);
-      if (st == SGP_SWARM_MAXIMIZERS) {
-        const double upper = mu + f.beta * sd;
-        const double z = 10.0 * (upper - f.best_lower_bound) / f.scaling[0];
-        interest = 1.0 / (1.0 + exp(-z));  // scipy.special.expit
-      }
-    } else {
-      values = fmax(values, sd / f.scaling[g]);
-    }
-    if (f.fmin[g] != -INFINITY) {
-      double slack = lower - f.fmin[g];
-      safe = safe && (slack >= 0.0);
-      if (st != SGP_SWARM_SAFE_SET) {
-        slack = slack / f.scaling[g];
-        total_pen += swarm_penalty(slack);
-        if (st == SGP_SWARM_EXPANDERS) {
-          const double z = slack / 0.2;   // scipy.stats.norm.pdf(slack, scale=0.2)
-          interest *= exp(-0.5 * z * z) / 2.5066282746310002 / 0.2;
-        }
-      }
-    }
-  }
-  double out;
-  bool ok = safe;
-  if (st == SGP_SWARM_GREEDY) {
-    out = lower;
-    ok = true;
-  } else if (st == SGP_SWARM_SAFE_SET) {
-    out = lower;
-  } else {
-    out = (values + total_pen) * interest;
-  }
-  f.values[i] = out;
-  f.safe[i] = ok ? 1 : 0;
-}
-
 
 // PP ("ping-pong", NW = 8, one workgroup per CU): waves 0-3 and 4-7 -- the two
 // waves of every SIMD -- run half a stage apart, separated by workgroup
@@ -1348,14 +1283,6 @@ int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,
   return launch_sweep(ctx, p, gps_host, d);
 }
 
-
-int launch_fitness_small(sgp_ctx* ctx, int G, int64_t P, const double* mean,
-                         const double* var, FitnessArgs fa) {
-  hipLaunchKernelGGL(k_fitness_small, dim3(unsigned((P + 255) / 256)), dim3(256),
-                     0, ctx->stream, G, P, mean, var, fa);
-  SGP_HIP(ctx, hipGetLastError());
-  return 0;
-}
 
 int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
                           const GpDev* gps_host, int G, int d, SweepPoints pts,

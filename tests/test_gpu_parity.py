@@ -715,9 +715,10 @@ def test_swarm_fitness_config5_reduced(mods):
         assert_allclose(v, vo, rtol=1e-7, atol=1e-8)
 
 
-@pytest.mark.parametrize("n,P", [(130, 5), (400, 1), (500, 20), (2000, 64), (2000, 17)])
+@pytest.mark.parametrize("n,P", [(130, 5), (400, 1), (500, 20), (2000, 64), (2000, 17),
+                                 (2000, 300), (300, 1000), (1000, 4096), (700, 4097)])
 def test_few_points_path(mods, n, P):
-    """P <= 64 points at n >= 128: posterior and swarm fitness come out of the
+    """P <= 4096 points at n >= 128 (4097: the sweep again): posterior and swarm fitness come out of the
     triangular multi-RHS path (posterior_small) instead of one sweep tile --
     SafeOptSwarm's default swarm (20 particles) and the single-point predictions
     of gp_opt.py:1117, 1132.  Same oracle, same tolerances."""
@@ -741,9 +742,11 @@ def test_few_points_path(mods, n, P):
         assert_allclose(v, vo, rtol=1e-7, atol=1e-8)
 
 
-def test_device_pso_few_points_path_bit_identical(mods):
+@pytest.mark.parametrize("swarm_size", [30, 100])
+def test_device_pso_few_points_path_bit_identical(mods, swarm_size):
     """Device PSO == host loop also when the fitness takes the few-points path
-    (n = 600 observations, 30 particles)."""
+    (n = 600 observations; 30 particles: the whole step in one workgroup, 100:
+    few-points posterior + the separate PSO kernels)."""
     safeopt_amd, gpy, _, _ = mods
     from bench import make_config, build_gps
     cfg = make_config(5)
@@ -752,11 +755,11 @@ def test_device_pso_few_points_path_bit_identical(mods):
     for pso in ("host", "device"):
         gps = build_gps(cfg, gpy)
         o = safeopt_amd.SafeOptSwarm(gps, cfg["fmin"], bounds=[(-5., 5.)] * 4,
-                                     threshold=cfg["threshold"], swarm_size=30, pso=pso)
+                                     threshold=cfg["threshold"], swarm_size=swarm_size, pso=pso)
         o.best_lower_bound = 0.4
         np.random.seed(3)
         sw = o.swarms["expanders"]
-        sw.init_swarm(np.random.default_rng(1).uniform(-1, 1, size=(30, 4)))
+        sw.init_swarm(np.random.default_rng(1).uniform(-1, 1, size=(swarm_size, 4)))
         sw.run_swarm(15)
         out.append((sw.positions.copy(), sw.velocities.copy(), sw.best_positions.copy(),
                     np.array(sw.best_values), np.array(sw.global_best)))
