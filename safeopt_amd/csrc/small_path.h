@@ -18,12 +18,14 @@ struct SmallBufs {
 // Sum over the row blocks of one GP for the 16 points of `pass`, in a fixed
 // order: thread (c = t & 15, q = t >> 4) of a 256-thread workgroup adds the row
 // blocks q, q + 16, ...; the 16 groups are folded through LDS by the q == 0
-// threads.  Returns the total for point c in the threads with q == 0; every
+// threads (a larger workgroup may run several such sums side by side: tl, sh).  Returns the total for point c in the threads with q == 0; every
 // thread of the workgroup must call it (two barriers).
 __device__ __forceinline__ double small_block_sum(const double* part_g, int nblk_max,
                                                   int nblk, int pass,
-                                                  double (*sh)[16]) {
-  const int c = threadIdx.x & 15, q = threadIdx.x >> 4;
+                                                  double (*sh)[16],
+                                                  int tl = -1) {
+  if (tl < 0) tl = threadIdx.x;             // (tl: index within a group of 256)
+  const int c = tl & 15, q = tl >> 4;
   double ss = 0.0;
   for (int b = q; b < nblk; b += 16)
     ss += part_g[(int64_t(pass) * nblk_max + b) * 16 + c];

@@ -269,23 +269,26 @@ __global__ void k_fitness_small(int G, int64_t P, const double* mean,
 // GP, fitness, personal bests, global best (first index on ties) and the move
 // that opens the next iteration.  Same arithmetic, statement for statement, as
 // k_small_post + k_fitness_small + k_pso_best + k_pso_gbest + k_pso_move.
-__global__ __launch_bounds__(256) void k_pso_small_step(const GpDev* gps, int G,
-                                                        SmallBufs sb, FitnessArgs f,
-                                                        PsoSmallArgs ps) {
-  __shared__ double sh[16][16];
+__global__ __launch_bounds__(1024) void k_pso_small_step(const GpDev* gps, int G,
+                                                         SmallBufs sb, FitnessArgs f,
+                                                         PsoSmallArgs ps) {
+  __shared__ double sh[4][16][16];
   __shared__ double smean[SGP_MAX_GPS][kSmallSwarm], svar[SGP_MAX_GPS][kSmallSwarm];
   __shared__ double sbv[kSmallSwarm];
   const int t = threadIdx.x, P = ps.P, d = ps.d;
   const int Geff = (f.swarm_type == SGP_SWARM_GREEDY) ? 1 : G;
-  for (int g = 0; g < Geff; ++g) {
-    for (int pass = 0; pass < sb.passes; ++pass) {
-      const double tot = small_block_sum(sb.part + g * sb.part_stride, sb.nblk_max,
-                                         gps[g].nblk, pass, sh);
-      const int p = pass * 16 + (t & 15);
-      if ((t >> 4) == 0 && p < P) {
-        smean[g][p] = sb.mtmp[g * sb.passes * 16 + p];
-        svar[g][p] = fmax(gps[g].kern.kdiag - tot, 1e-15);      // GPy clip
-      }
+  // block sums of (GP, pass) pairs, four pairs side by side
+  const int grp = t >> 8, tl = t & 255, npairs = Geff * sb.passes;
+  for (int base = 0; base < npairs; base += 4) {
+    const int pair = base + grp;
+    const bool valid = pair < npairs;
+    const int g = valid ? pair / sb.passes : 0, pass = valid ? pair % sb.passes : 0;
+    const double tot = small_block_sum(sb.part + g * sb.part_stride, sb.nblk_max,
+                                       valid ? gps[g].nblk : 0, pass, sh[grp], tl);
+    const int p = pass * 16 + (tl & 15);
+    if (valid && (tl >> 4) == 0 && p < P) {
+      smean[g][p] = sb.mtmp[g * sb.passes * 16 + p];
+      svar[g][p] = fmax(gps[g].kern.kdiag - tot, 1e-15);      // GPy clip
     }
   }
   __syncthreads();
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(256) void k_pso_small_step(const GpDev* gps, int G,
   if (!ps.move) return;
   __syncthreads();
   // the move that opens the next iteration (k_pso_move)
-  for (int e = t; e < P * d; e += 256) {
+  for (int e = t; e < P * d; e += 1024) {
     const int k = e % d;
     const double x = ps.pos[e];
     const double to_global = ps.gbest[k] - x;
@@ -390,7 +393,7 @@ int launch_fitness_small(sgp_ctx* ctx, int G, int64_t P, const double* mean,
 
 int launch_pso_small_step(sgp_ctx* ctx, const GpDev* gps_dev, int G, const SmallBufs& sb,
                           FitnessArgs fa, PsoSmallArgs ps) {
-  hipLaunchKernelGGL(k_pso_small_step, dim3(1), dim3(256), 0, ctx->stream, gps_dev, G,
+  hipLaunchKernelGGL(k_pso_small_step, dim3(1), dim3(1024), 0, ctx->stream, gps_dev, G,
                      sb, fa, ps);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
