@@ -51,12 +51,10 @@ constexpr int kSteps = kJC / 4;        // MFMA k-steps per stage
 
 // LDS layout for SL accumulator slots per wave (SL x 16 rows of L^-1 per chunk):
 //   [2][A chunk | training rows | alpha]  exp table  [NW] broadcast buffers
-// SL = 16: 256 VGPRs, two waves per SIMD (two 4-wave workgroups per CU).
-// SL = 32 (experiment, -DSGP_SWEEP_SLOTS32): the accumulators take 256 registers
-//   by themselves -- one wave per SIMD with the 512-entry unified register file
-//   (AGPRs), one workgroup per CU; twice the matrix work per stage for the same
-//   evaluation / staging / bookkeeping.  Measured 1.6-1.8x slower: a lone wave
-//   exposes every latency and the compiler shuffles accumulators through AGPRs.
+// SL = 16: 256 VGPRs, two waves per SIMD (two 4-wave workgroups per CU).  (32
+// slots with one wave per SIMD and AGPRs, 8-wave workgroups and an explicit
+// ping-pong of the two waves of a SIMD were measured and dropped:
+// profiles/r02/experiments.txt, commits 1869720 and ad93c1b.)
 // A wave's broadcast buffer holds 4 k-rows of 64 doubles, kKbRow doubles apart
 // (an odd multiple of 16: the k-rows then sit on disjoint banks).  The padding
 // between them doubles as the staging area of the wave's Q rows (kQCap doubles):
@@ -108,9 +106,6 @@ enum : uint32_t {
 // with any bit set): built only with -DSGP_INSTRUMENT, selected at run time by
 // SGP_ABLATE=<mask>: 1 no stage barrier, 2 no LDS-DMA, 4 no covariance
 // evaluation, 8 no MFMA, 16 no mean/var/Q stores, 32 no per-GP epilogue at all.
-// -DSGP_SEP_PROBE (a build of its own): covariances = product of D table entries
-// prefetched a stage ahead -- what a separable-RBF path on a tensor grid would
-// execute (table contents are arbitrary: timing only).
 #ifdef SGP_INSTRUMENT
 #define SGP_ABL(mask) (p.ablate & (mask))
 #else
@@ -123,9 +118,6 @@ struct SweepParams {
   int mode;
 #ifdef SGP_INSTRUMENT
   int ablate;      // timing experiments (scripts/ablate.py), see SGP_ABL
-#endif
-#ifdef SGP_SEP_PROBE
-  const double* sep_tab;   // [D][4096][1024] doubles
 #endif
   SweepPoints pts;
   ConfOut conf;
@@ -217,14 +209,14 @@ __device__ __forceinline__ void stage_dma(const GpView& gp, const StageEnt& e,
 // 16 D and 16 doubles in GpDev::Xs / alpha -- wave 0 moves the rows (8 D lanes x
 // 16 B), the last wave the alpha run (8 lanes x 16 B); the other lanes are
 // masked off and write nothing.
-template <int D, int NW, int SL, int WX = 0, int WA = NW - 1>
+template <int D, int NW, int SL>
 __device__ __forceinline__ void stage_x_dma(const GpView& gp, const StageEnt& e,
                                             double* buf, int wave, int lane) {
-  if (wave == WX) {
+  if (wave == 0) {
     if (lane < 8 * D)
       lds_dma16(gp.Xs + int64_t(e.jb) * (kJC * D) + unsigned(lane) * 2u,
                 buf + Lay<SL, D>::kATile, 0);
-  } else if (wave == WA) {
+  } else if (wave == NW - 1) {
     if (lane < 8)
       lds_dma16(gp.alpha + int64_t(e.jb) * kJC + unsigned(lane) * 2u,
                 buf + Lay<SL, D>::kATile + Lay<SL, D>::kXTile, 0);
@@ -346,16 +338,8 @@ __device__ __forceinline__ void mfma_jblock(int nact, bool narrow0,
   mfma_slots<SL, 0>(nact, narrow0, acc, accx, aT, kb, kv, opsA, opsB);
 }
 
-// PP ("ping-pong", NW = 8, one workgroup per CU): waves 0-3 and 4-7 -- the two
-// waves of every SIMD -- run half a stage apart, separated by workgroup
-// barriers: while one group streams its MFMAs the other evaluates covariances,
-// issues the LDS-DMA of the next stage and runs the row epilogues at raised
-// priority.  An fp64 MFMA occupies its SIMD for 16 cycles and the partner wave
-// gets an issue slot between two of them: the partner's scalar / LDS / DMA
-// instructions ride in those gaps, only its VALU work costs matrix time.
-template <int D, int NW, int SL, int MODE, bool SINGLE, bool PP>
-__global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams p) {
-  static_assert(!PP || NW == 8, "ping-pong pairs the two waves of a SIMD");
+template <int D, int NW, int SL, int MODE, bool SINGLE>
+__global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   constexpr int kTilePts = 16 * NW;
   typedef Lay<SL, D> L;
   constexpr int kATile = L::kATile, kBuf = L::kBuf, kXTile = L::kXTile;
@@ -370,8 +354,6 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* kbw = lds + kKbOff + wave * kKbBuf;
-  const bool late = PP && wave >= NW / 2;     // the group that runs half a stage behind
-  constexpr int WX = PP ? NW / 2 : 0;         // waves that stage training rows / alpha
   const int st = p.fit.swarm_type;
   const int ntiles = int((p.pts.N + kTilePts - 1) / kTilePts);
   const stage_ptr_t stages = (stage_ptr_t)(p.stages);
@@ -410,8 +392,7 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
   double kdiag = p.gps[0].kern.kdiag;
   StageEnt e1 = load_stage(stages, 0);
   stage_dma<NW, SL>(gv, e1, lds, wave, lane);
-  stage_x_dma<D, NW, SL, WX>(gv, e1, lds, wave, lane);
-  StageEnt e0 = e1;        // the stage being multiplied (PP: its copy is issued late)
+  stage_x_dma<D, NW, SL>(gv, e1, lds, wave, lane);
   uint32_t wcur = e1.word;
   int si1 = 0, t1 = tile;
   advance(si1, t1);
@@ -419,8 +400,6 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
   if (have1) e1 = load_stage(stages, si1);
   int si2 = si1, t2 = t1;
   __syncthreads();
-  if (late) __builtin_amdgcn_s_barrier();
-  bool first = true;
 
   // per-GP state
   double xs[D];
@@ -437,13 +416,6 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
   double lmax = -INFINITY;   // max l0 over the safe rows this wave has seen
   bool gp_start = true;
 
-#ifdef SGP_SEP_PROBE
-  double sep_cur[4][D], sep_next[4][D];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int k = 0; k < D; ++k) sep_cur[q][k] = sep_next[q][k] = 0.5;
-#endif
   int par = 0;
 #pragma unroll 1
   while (true) {
@@ -454,20 +426,7 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
     const bool more = have1;
     const uint32_t wnext = e1.word;
     const bool next_tile = more && si1 == 0;
-    if (PP) __builtin_amdgcn_s_setprio(3);
-    if (PP && !late) {
-      // early group: its share of THIS stage's A chunk (the buffer was still
-      // being multiplied by the late group one interval ago)
-      if (!first) {
-        const int g_c = int(wcur >> SW_G_SHIFT) & 7;
-        if (g_c != gv_g) {
-          gv.load(p.gps[g_c]);
-          gv_g = g_c;
-        }
-        if (!SGP_ABL(2)) stage_dma<NW, SL>(gv, e0, cbuf, wave, lane);
-      }
-      if (next_tile) load_x(t1, xnext);
-    } else if (more) {
+    if (more) {
       const int g_n = int(wnext >> SW_G_SHIFT) & 7;
       if (g_n != gv_g) {
         gv.load(p.gps[g_n]);
@@ -475,28 +434,10 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
       }
       if (!SGP_ABL(2)) {
         stage_dma<NW, SL>(gv, e1, nbuf, wave, lane);
-        stage_x_dma<D, NW, SL, WX>(gv, e1, nbuf, wave, lane);
+        stage_x_dma<D, NW, SL>(gv, e1, nbuf, wave, lane);
       }
       if (next_tile) load_x(t1, xnext);
     }
-#ifdef SGP_SEP_PROBE
-    if (more) {
-      // table entries of the NEXT stage: [axis][training point][axis index]
-      const int64_t rn = int64_t(t1) * kTilePts + wave * 16 + (lane & 15);
-      int ax[D];
-      int64_t rem = rn;
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        ax[k] = int(rem % 1000);
-        rem /= 1000;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-          sep_next[q][k] = p.sep_tab[(int64_t(k) * 4096 + (e1.jb * 16 + 4 * q + (lane >> 4))) * 1024 + ax[k]];
-    }
-#endif
     const int tile_after = t1;
     // the entry after that: loaded now, first used at the top of the next stage
     advance(si2, t2);
@@ -512,18 +453,7 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
     const double* xT = cbuf + kATile;
     const double* alT = cbuf + kATile + kXTile;
     double kv[4];
-#ifdef SGP_SEP_PROBE
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      kv[q] = sep_cur[q][0];
-#pragma unroll
-      for (int k = 1; k < D; ++k) kv[q] *= sep_cur[q][k];
-    }
-    if (true) {
-    } else if (!SGP_ABL(4)) {
-#else
     if (!SGP_ABL(4)) {
-#endif
       kf.template many4_t<SINGLE>(xs, xT + (lane >> 4) * D, 4 * D, tab, kv);
     } else {
       kv[0] = xs[0]; kv[1] = xs[0] + 1.0; kv[2] = xs[0] + 2.0; kv[3] = xs[0] + 3.0;
@@ -535,17 +465,9 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
     }
     double kb[4][4];
     if (!SGP_ABL(8)) broadcast_quads<L::kKbRow>(kv, kbw, lane, kb);
-    if (PP) {
-      __builtin_amdgcn_s_setprio(0);
-      __syncthreads();          // the partner group leaves its MFMA phase here
-    }
     if (!SGP_ABL(8))
       mfma_jblock<SL>(int(wcur & SW_NACT_MASK), (wcur & SW_NARROW) != 0, acc, accx,
                       cbuf + lane, kb, kv);
-    if (PP) {
-      __syncthreads();          // ... and enters it here
-      __builtin_amdgcn_s_setprio(3);
-    }
 
     if (wcur & SW_CHUNK_END) {
 #pragma unroll
@@ -686,25 +608,13 @@ __global__ __launch_bounds__(64 * NW, SL == 32 ? 1 : 2) void k_sweep(SweepParams
     }
 
     if (!more) break;
-    if (!PP && !SGP_ABL(1)) __syncthreads();
+    if (!SGP_ABL(1)) __syncthreads();
     par ^= 1;
-#ifdef SGP_SEP_PROBE
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int k = 0; k < D; ++k) sep_cur[q][k] = sep_next[q][k];
-#endif
-    first = false;
     wcur = wnext;
-    e0 = e1;
     e1 = e2;
     si1 = si2;
     t1 = t2;
     have1 = have2;
-  }
-  if (PP) {
-    __builtin_amdgcn_s_setprio(0);
-    if (!late) __builtin_amdgcn_s_barrier();
   }
   if (conf && p.conf.S) {
     lmax = wave_max(lmax);
@@ -1062,17 +972,8 @@ __global__ __launch_bounds__(256) void k_rank1(const GpDev* gps, int G,
 
 
 // ---- launch -----------------------------------------------------------------------
-// Waves per workgroup: 4 (two workgroups per CU).  A build with -DSGP_SWEEP_WAVES8
-// also carries the 8-wave variant (one workgroup per CU, half the L2 -> LDS
-// traffic), selected at run time by SGP_SWEEP_WAVES=8: the A/B switch of profiles/.
-int sweep_waves() {
-#ifdef SGP_SWEEP_WAVES8
-  static const int nw = (getenv("SGP_SWEEP_WAVES") && atoi(getenv("SGP_SWEEP_WAVES")) == 8) ? 8 : 4;
-  return nw;
-#else
-  return 4;
-#endif
-}
+// Waves per workgroup: 4 (two workgroups per CU).
+int sweep_waves() { return 4; }
 
 // The stage sequence of one tile: for every GP, for every chunk of 16 row blocks
 // of L^-1, the j-blocks 0 .. bend-1 (only the slots at or below the diagonal are
@@ -1125,19 +1026,20 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB,
 }
 
 // persistent: as many workgroups as are resident at once (256 VGPRs per thread
-// -> 8 waves per CU; the 32-slot experiment: 4) walk over the tiles
+// -> 8 waves per CU) walk over the tiles
 int sweep_grid_blocks(int num_cu, int64_t N, int nw, int slots) {
+  (void)slots;
   const int64_t ntiles = (N + 16 * nw - 1) / (16 * nw);
-  const int64_t resident = int64_t(num_cu) * (slots == 32 ? 1 : 8 / nw);
+  const int64_t resident = int64_t(num_cu) * (8 / nw);
   return int(ntiles < resident ? ntiles : resident);
 }
 
-template <int D, int NW, int SL, int MODE, bool SINGLE, bool PP = false>
+template <int D, int NW, int SL, int MODE, bool SINGLE>
 int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep<D, NW, SL, MODE, SINGLE, PP>),
+                     reinterpret_cast<const void*>(&k_sweep<D, NW, SL, MODE, SINGLE>),
                      hipFuncAttributeMaxDynamicSharedMemorySize,
                      int(Lay<SL, D>::bytes(NW))));
     attr_set = true;
@@ -1163,21 +1065,8 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
   pp.ablate = ablate;
 #endif
-#ifdef SGP_SEP_PROBE
-  {
-    static double* tab = nullptr;
-    if (!tab) {
-      const size_t nt = size_t(D) * 4096 * 1024;
-      SGP_HIP(ctx, hipMalloc(&tab, nt * sizeof(double)));
-      std::vector<double> h(nt);
-      for (size_t i = 0; i < nt; ++i) h[i] = 0.25 + 0.5 * double((i * 2654435761u) & 1023) / 1024.0;
-      SGP_HIP(ctx, hipMemcpy(tab, h.data(), nt * sizeof(double), hipMemcpyHostToDevice));
-    }
-    pp.sep_tab = tab;
-  }
-#endif
   const size_t lds_bytes = Lay<SL, D>::bytes(NW);
-  hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE, PP>), dim3(nblocks),
+  hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE>), dim3(nblocks),
                      dim3(64 * NW), lds_bytes, ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
   if (e1) SGP_HIP(ctx, hipEventRecord(e1, ctx->stream));
@@ -1195,22 +1084,6 @@ int launch_sweep_w(sgp_ctx* ctx, const SweepParams& p, double flops) {
 
 template <int D>
 int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
-#ifdef SGP_SWEEP_WAVES8
-  if (sweep_waves() == 8) {
-    static const bool pp = getenv("SGP_SWEEP_PP") != nullptr;
-    if (pp) {
-      if (p.mode == MODE_CONF)
-        return p.single ? launch_sweep_v<D, 8, 16, MODE_CONF, true, true>(ctx, p, flops)
-                        : launch_sweep_v<D, 8, 16, MODE_CONF, false, true>(ctx, p, flops);
-      return p.single ? launch_sweep_v<D, 8, 16, MODE_FITNESS, true, true>(ctx, p, flops)
-                      : launch_sweep_v<D, 8, 16, MODE_FITNESS, false, true>(ctx, p, flops);
-    }
-    return launch_sweep_w<D, 8, 16>(ctx, p, flops);
-  }
-#endif
-#ifdef SGP_SWEEP_SLOTS32
-  if (p.slots == 32) return launch_sweep_w<D, 4, 32>(ctx, p, flops);
-#endif
   return launch_sweep_w<D, 4, 16>(ctx, p, flops);
 }
 
@@ -1224,14 +1097,7 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
     flops += (double(gh[g].n) * gh[g].n + 2.0 * gh[g].n) * double(p.pts.N);
   if (p.pts.N <= 0) return 0;
   SweepParams q = p;
-  // 16 accumulator slots per wave.  (A build with -DSGP_SWEEP_SLOTS32 also
-  // carries the 32-slot / one-wave-per-SIMD variant, SGP_SWEEP_SLOTS=32 selects
-  // it: measured 1.6-1.8x SLOWER, profiles/README.md.)
-  q.slots = 16;
-#ifdef SGP_SWEEP_SLOTS32
-  static const int force = getenv("SGP_SWEEP_SLOTS") ? atoi(getenv("SGP_SWEEP_SLOTS")) : 0;
-  if (force == 32 && sweep_waves() == 4) q.slots = 32;
-#endif
+  q.slots = 16;            // accumulator slots per wave
   SGP_TRY(stage_table(ctx, gh, Geff, q.slots, &q.stages, &q.nstages));
   q.single = 1;
   for (int g = 0; g < Geff; ++g) q.single = q.single && gh[g].kern.n_parts == 1;

@@ -42,5 +42,9 @@ cd $R
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/probe2 scripts/dev/probe_coexec.hip && /tmp/probe2
 } > $OUT/probes.txt 2>&1
 bash scripts/ablate.sh 3 2 > $OUT/ablation.txt 2>&1
+# what a user of the drop-in sees per BO iteration (incremental path) and per
+# SafeOptSwarm.optimize() with the default swarm
+{ python scripts/bench_bo_loop.py --config 2; python scripts/bench_bo_loop.py --config 3; } > $OUT/bo_loop.json 2>$OUT/bo_loop.err
+python scripts/dev/swarm_small.py > $OUT/swarm_small_now.txt 2>&1
 python scripts/profiles_digest.py $OUT > $OUT/SUMMARY.txt 2>&1
 cat $OUT/SUMMARY.txt

@@ -143,7 +143,7 @@ def main(argv):
                     w = csv.writer(fh)
                     w.writerow(["pass", "kernel", "counter", "avg_value_per_dispatch"])
                     w.writerows(rows[c])
-        for name in ("ablation.txt", "probes.txt"):
+        for name in ("ablation.txt", "probes.txt", "bo_loop.json"):
             if os.path.exists(os.path.join(d, name)):
                 shutil.copy(os.path.join(d, name), os.path.join(dst, name))
         tj = os.path.join(ROOT, "profiles", "traffic.json")
