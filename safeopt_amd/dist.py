@@ -146,10 +146,18 @@ def _rdzv_dir():
 
 
 def _launcher_start():
-    """Start time of the launching process (0 if /proc does not tell)."""
+    """Start time (epoch seconds) of the launching process; 0 if /proc does not
+    tell.  From the ``starttime`` field of /proc/<pid>/stat and the boot time --
+    the timestamps of the /proc/<pid> directory itself are those of the first
+    lookup, not of the process."""
     try:
-        return os.stat("/proc/%d" % os.getppid()).st_mtime
-    except OSError:
+        with open("/proc/%d/stat" % os.getppid()) as f:
+            fields = f.read().rsplit(")", 1)[1].split()
+        ticks = float(fields[19])              # field 22 of the full line
+        with open("/proc/stat") as f:
+            btime = next(float(l.split()[1]) for l in f if l.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, IndexError, ValueError, StopIteration):
         return 0.0
 
 
@@ -180,7 +188,7 @@ def _file_rendezvous(rank, world, port, timeout):
         os.replace(tmp, path)                  # atomic publish
         return uid, path
     deadline = time.time() + timeout
-    born = _launcher_start() - 1.0
+    born = _launcher_start() - 2.0         # (file times may be coarser than ours)
     while True:
         try:
             if os.stat(path).st_mtime >= born:

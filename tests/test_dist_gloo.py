@@ -4,6 +4,7 @@ NumPy oracle standing in for the per-rank HIP kernels.  Result must equal the
 reference's golden vectors, i.e. the unsharded run."""
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -220,3 +221,29 @@ def test_file_rendezvous_rejects_foreign_and_stale_files(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError, match="closed early"):
         dist._fetch_uid("127.0.0.1", port, timeout=5.0)
     t.join(); srv.close()
+
+
+def test_file_rendezvous_three_processes(tmp_path):
+    """The single-node exchange of the ncclUniqueId for real: three worker
+    processes of one launcher (this test), the readers polling BEFORE rank 0
+    publishes.  (No device: the unique id is a stand-in token.)"""
+    code = r"""
+import os, sys, time
+sys.path.insert(0, %r)
+from safeopt_amd import dist, _hip
+rank = int(sys.argv[1])
+_hip.Context.comm_unique_id = staticmethod(lambda: bytes(range(128)))
+if rank == 0:
+    time.sleep(1.0)
+uid, path = dist._file_rendezvous(rank, 3, 29871, timeout=30.0)
+print(uid.hex())
+""" % REPO
+    env = dict(os.environ, SAFEOPT_RDZV_DIR=str(tmp_path), SAFEOPT_RDZV_NONCE="t3")
+    os.chmod(str(tmp_path), 0o700)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in (1, 2, 0)]
+    outs = [p.communicate(timeout=60) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err
+        assert out.strip() == bytes(range(128)).hex()
