@@ -865,21 +865,15 @@ class SafeOptSwarm(GaussianProcessOptimization):
                  swarm_size=20, pso='device'):
         if pso not in ('device', 'device-rng', 'host'):
             raise ValueError("pso must be 'device', 'device-rng' or 'host'")
-        super(SafeOptSwarm, self).__init__(gp, fmin=fmin, beta=beta,
-                                           num_contexts=0,
-                                           threshold=threshold,
-                                           scaling=scaling)
-        self.S = np.asarray(self.gps[0].X)
-        self.swarm_size = swarm_size
-        self.max_iters = 100
-
-        if not isinstance(bounds, list):
-            self.bounds = [bounds] * self.S.shape[1]
-        else:
-            self.bounds = bounds
-
+        GaussianProcessOptimization.__init__(self, gp, fmin=fmin, beta=beta, num_contexts=0,
+                                             threshold=threshold, scaling=scaling)
+        # the safe set starts as the observed inputs; one (min, max) pair may
+        # stand for every dimension
+        safe_points = np.asarray(self.gps[0].X)
+        self.S, self.greedy_point = safe_points, safe_points[0, :]
+        self.swarm_size, self.max_iters = swarm_size, 100
+        self.bounds = bounds if isinstance(bounds, list) else [bounds] * safe_points.shape[1]
         self.best_lower_bound = -np.inf
-        self.greedy_point = self.S[0, :]
         self.optimal_velocities = self.optimize_particle_velocity()
 
         # pso='device' (default): whole swarm runs on the GPU with NumPy's
