@@ -18,8 +18,9 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libsafeopt_hip.so")
 SOURCES = ["api.hip", "sweep.hip", "factor.hip", "sets.hip", "swarm.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kern_eval.h"),
-           os.path.join(REPO, "include", "safeopt_hip.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "kern_eval.h", "fitness.h",
+                                            "small_path.h")] + \
+          [os.path.join(REPO, "include", "safeopt_hip.h")]
 BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
         "-I", os.path.join(REPO, "include"), "-I", CSRC, "-Wall",
         "-Wno-unused-function"]
