@@ -173,7 +173,8 @@ int sgp_grid_lipschitz_check(sgp_grid* grid, int G, const double* fmin,
  * context's stream, device-resident operands), so the front half of
  * compute_sets costs one device round trip per rank instead of three.
  * out5[0] = GLOBAL max(u0[M]-l0[M]); *max_l_out = GLOBAL max(l0[S]) (-inf: no
- * safe point on any rank); the other outputs describe this rank's shard.      */
+ * safe point on any rank); the other outputs (out5 has SIX entries, as for
+ * sgp_grid_sets_front) describe this rank's shard.                            */
 int sgp_grid_sets_front_comm(sgp_grid* grid, const double* scaling,
                              const double* thr_beta, double* out5, double* x_top,
                              double* mean_top, double* q_top, double* max_l_out);
@@ -183,8 +184,10 @@ int sgp_grid_sets_front_comm(sgp_grid* grid, const double* scaling,
  *   have_max_var = 1 the caller already ran sgp_grid_maximizers and passes the
  *   all-reduced max_var), candidate mask, counts, this shard's first
  *   candidate in visiting order and its rows.
- *   out5 = {max(u0[M]-l0[M]) (0 if given), #candidates, #unsafe, w_top,
- *           idx_top or -1}
+ *   out5 (SIX entries) = {max(u0[M]-l0[M]) (0 if given), #candidates, #unsafe,
+ *           w_top, idx_top or -1, #candidates of this shard whose width equals
+ *           w_top bit for bit (exact ties decide the reference's visiting
+ *           order, gp_opt.py:542-552)}
  * back = expander test of ONE candidate on this shard's unsafe rows
  *   (gp_opt.py:579-606), G mark if mark != 0 and every active GP certified it
  *   (gp_opt.py:615; single rank only), then the M|G arg-max (:642-644).       */

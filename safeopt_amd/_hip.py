@@ -511,7 +511,7 @@ class DeviceGrid(object):
     def sets_front(self, max_l, max_var, scaling, thr_beta):
         scaling = f64(scaling)
         thr_beta = f64(thr_beta)
-        out5 = np.empty(5)
+        out5 = np.empty(6)           # [5] = candidates tied with the first one
         x = np.empty(self.d)
         mean = np.empty(self.G)
         q = np.empty(2 * self.G)
@@ -523,7 +523,7 @@ class DeviceGrid(object):
 
     def sets_front_comm(self, scaling, thr_beta):
         scaling, thr_beta = f64(scaling), f64(thr_beta)
-        out5 = np.empty(5)
+        out5 = np.empty(6)
         x = np.empty(self.d)
         mean = np.empty(self.G)
         q = np.empty(2 * self.G)

@@ -974,6 +974,11 @@ int sgp_grid_sets_front(sgp_grid* g, double max_l, int have_max_var,
   out5[2] = double(cnt[1]);
   out5[3] = host[3];
   out5[4] = (nfound > 0) ? double(idx) : -1.0;
+  {
+    int ntied = 0;       // candidates that share the first one's width
+    memcpy(&ntied, reinterpret_cast<const char*>(&host[5]) + 4, 4);
+    out5[5] = double(ntied);
+  }
   memcpy(x_top, &host[6], size_t(d) * 8);
   memcpy(mean_top, &host[6 + d], size_t(G) * 8);
   memcpy(q_top, &host[6 + d + G], size_t(2 * G) * 8);
@@ -1031,6 +1036,11 @@ int sgp_grid_sets_front_comm(sgp_grid* g, const double* scaling,
   out5[2] = double(cnt[1]);
   out5[3] = host[3];
   out5[4] = (nfound > 0) ? double(idx) : -1.0;
+  {
+    int ntied = 0;       // candidates that share the first one's width
+    memcpy(&ntied, reinterpret_cast<const char*>(&host[5]) + 4, 4);
+    out5[5] = double(ntied);
+  }
   memcpy(x_top, &host[6], size_t(d) * 8);
   memcpy(mean_top, &host[6 + d], size_t(G) * 8);
   memcpy(q_top, &host[6 + d + G], size_t(2 * G) * 8);

@@ -566,6 +566,7 @@ class SafeOpt(GaussianProcessOptimization):
                                                      self.scaling, thr_beta)
                 n_cand, n_unsafe, w_c, idx_c = (out5[1], out5[2],
                                                 float(out5[3]), int(out5[4]))
+                n_tied = int(out5[5]) if len(out5) > 5 else None
             else:
                 if self._max_l is None:
                     # deferred confidence pass: max l0 and the maximiser width
@@ -582,16 +583,22 @@ class SafeOpt(GaussianProcessOptimization):
                     out5, x_l, mu_l, q_l = be.sets_front(
                         self._max_l, width / self.scaling[0], self.scaling,
                         thr_beta)
+                tied_l = out5[5] if len(out5) > 5 else np.nan
                 pk = self._comm.allgather(
-                    np.concatenate([out5[1:5], x_l, mu_l, q_l]))
+                    np.concatenate([out5[1:5], [tied_l], x_l, mu_l, q_l]))
                 n_cand, n_unsafe = pk[:, 0].sum(), pk[:, 1].sum()
                 w_b, i_b = merge_topk(pk[:, 2], pk[:, 3].astype(np.int64), 1)
                 idx_c = int(i_b[0]) if i_b.size else -1
                 w_c = float(w_b[0]) if i_b.size else -np.inf
                 r = int(np.flatnonzero(pk[:, 3].astype(np.int64) == idx_c)[0]) \
                     if idx_c >= 0 else 0
-                x_c, mu_c, q_c = (pk[r, 4:4 + d], pk[r, 4 + d:4 + d + G],
-                                  pk[r, 4 + d + G:])
+                x_c, mu_c, q_c = (pk[r, 5:5 + d], pk[r, 5 + d:5 + d + G],
+                                  pk[r, 5 + d + G:])
+                # candidates of ALL shards tied with the first one: a shard whose
+                # own first candidate is narrower holds none of that width
+                holds = (pk[:, 3] >= 0) & (pk[:, 2] == w_c)
+                tied = pk[holds, 4].sum()
+                n_tied = None if np.isnan(tied) else int(tied)
             self._stale.update(M=True, G=True)
             if n_cand == 0 or n_unsafe == 0 or not np.any(active) or idx_c < 0:
                 if fused is not None:       # G untouched: the arg-max over M holds

@@ -126,11 +126,12 @@ class OracleGridBackend(object):
         w, idx = self.topk(0, np.inf, np.iinfo(np.int64).max, 1)
         d, G = self.x.shape[1], len(self.gps)
         x, mean, q = np.zeros(d), np.zeros(G), np.zeros(2 * G)
-        out5 = np.array([width, nc, nu, -np.inf, -1.0])
+        out5 = np.array([width, nc, nu, -np.inf, -1.0, 0.0])
         if idx.size:
             xs, ms, _v, qs = self.gather_rows(idx)
             x, mean, q = xs[0], ms[0], qs[0]
             out5[3], out5[4] = w[0], float(idx[0])
+            out5[5] = float(np.sum(self.cand & (self.w == w[0])))   # tied with it
         return out5, x, mean, q
 
     def sets_back(self, beta, fmin, xc, mu_c, u_c, near_frac, gidx_c, scaling, mark):
