@@ -390,7 +390,11 @@ class SafeOpt(GaussianProcessOptimization):
                     arr[off:off + c] = allp[r][:c]
                     off += c
             self._stale[name] = False
-        return getattr(self, '_' + name)
+        # a read-only view: the device does not see element-wise writes into a
+        # host mirror (``opt.Q[...] = ...`` raises; assign ``opt.Q = array``)
+        view = getattr(self, '_' + name).view()
+        view.flags.writeable = False
+        return view
 
     @property
     def Q(self):

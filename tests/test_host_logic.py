@@ -223,3 +223,27 @@ def test_sample_gp_function_matches_reference():
                 np.testing.assert_allclose(f(xq[:7]), z[key + "_noisy2"], rtol=0, atol=1e-9)
     with pytest.raises(ValueError):
         safeopt_amd.sample_gp_function(k, bounds, 0.1, 5, interpolation="cubic")
+
+
+def test_mirrors_are_read_only_and_the_setter_uploads():
+    """Element-wise writes into a host mirror would not reach the device: they
+    raise; assigning the whole array goes through the setter."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import safeopt_amd
+    from oracle import gp_numpy as gpn
+    from _golden import load, make_kernel
+    from _oracle_backend import OracleGridBackend
+    z, meta = load("ties_1d_seed0")
+    gp = gpn.GPRegression(z["X0"], z["Y0"], make_kernel(gpn, meta["kernels"][0]),
+                          noise_var=meta["noise_vars"][0])
+    opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"],
+                              _backend_factory=OracleGridBackend)
+    opt.update_confidence_intervals()
+    q = opt.Q
+    for mirror in (q, opt.S, opt.M, opt.G):
+        with pytest.raises(ValueError):
+            mirror[0] = 1
+    new = np.array(q) + 0.25
+    opt.Q = new
+    assert np.array_equal(opt.Q, new)
