@@ -1,6 +1,8 @@
-"""Cost of the multi-rank control flow (4 device round trips + 4 RCCL
-collectives) measured on ONE GPU: a one-rank RCCL communicator that claims
-world = 2 towards the host driver, so SafeOpt takes the N-rank branches."""
+"""Cost of the multi-rank control flow (2 device round trips + 2 RCCL collectives
+per certified step, the scalar all-reduces in stream) measured on ONE GPU: a
+one-rank RCCL communicator that claims world = 2 towards the host driver, so
+SafeOpt takes the N-rank branches on its half of the grid; the same half run as a
+single-rank problem is the reference point."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -27,16 +29,28 @@ class Pretend(object):
         self.c.barrier()
 
 
-cfg = bench.make_config(2)
-for world, in_stream in ((1, False), (2, False), (2, True)):
-    gps = bench.build_gps(cfg, gpy)
-    opt = safeopt_amd.SafeOpt(gps[0], cfg["grid"], 0., threshold=cfg["threshold"],
-                              comm=Pretend(comm, world, in_stream))
+def timed(opt):
     for _ in range(3):
         x = opt.optimize()
     ctx.sync(); t0 = time.perf_counter()
-    for _ in range(20):
+    for _ in range(40):
         x = opt.optimize()
-    ctx.sync(); dt = (time.perf_counter() - t0) / 20
-    print("control flow of world=%d (in-stream scalars: %s): %.3f ms/step, x=%s"
-          % (world, in_stream, dt * 1e3, x))
+    ctx.sync()
+    return (time.perf_counter() - t0) / 40 * 1e3, x
+
+
+for k in (2, 3):
+    cfg = bench.make_config(k)
+    G = cfg["G"]
+    half = cfg["grid"][:cfg["grid"].shape[0] // 2]
+    fmin = cfg["fmin"] if G > 1 else 0.
+    gps = bench.build_gps(cfg, gpy)
+    t1, _ = timed(safeopt_amd.SafeOpt(gps if G > 1 else gps[0], half, fmin, threshold=cfg["threshold"]))
+    print("config %d, %d rows as a single-rank problem: %.3f ms/step" % (k, half.shape[0], t1))
+    for in_stream in (False, True):
+        gps = bench.build_gps(cfg, gpy)
+        opt = safeopt_amd.SafeOpt(gps if G > 1 else gps[0], cfg["grid"], fmin, threshold=cfg["threshold"],
+                                  comm=Pretend(comm, 2, in_stream))
+        t2, _ = timed(opt)
+        print("config %d, the same rows as rank 0 of 2 (in-stream scalars: %s): %.3f ms/step  (+%.3f ms)"
+              % (k, in_stream, t2, t2 - t1))
