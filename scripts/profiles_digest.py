@@ -98,8 +98,9 @@ def digest(d):
                 rows[c].append(("pmc_mfma", k, n, val))
             if k in f and k in w:
                 fs, ws = mean(f[k]["FETCH_SIZE"]), mean(w[k]["WRITE_SIZE"])
-                out.append("   PMC %s: FETCH_SIZE %.0f KB (x2 gfx950 correction -> %.1f MB) + WRITE_SIZE %.0f KB "
-                           "= %.1f MB HBM traffic per launch" % (k, fs, 2 * fs / 1024, ws, (2 * fs + ws) / 1024))
+                out.append("   PMC %s: FETCH_SIZE %.0f KiB (x2 gfx950 correction -> %.1f MB) + WRITE_SIZE %.0f KiB "
+                           "(%.1f MB) = %.1f MB (1e6 B) HBM traffic per launch"
+                           % (k, fs, 2 * fs * 1024 / 1e6, ws, ws * 1024 / 1e6, (2 * fs + ws) * 1024 / 1e6))
                 rows[c] += [("pmc_fetch", k, "FETCH_SIZE", fs), ("pmc_write", k, "WRITE_SIZE", ws)]
                 traffic["config%d" % c] = dict(
                     kernel=k, FETCH_SIZE_KB=fs, WRITE_SIZE_KB=ws,
