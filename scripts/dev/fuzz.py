@@ -10,11 +10,13 @@ from oracle import gp_numpy as gpn, safeopt_numpy as son
 
 KINDS = ["RBF", "Matern32", "Matern52"]
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+dmax = int(sys.argv[2]) if len(sys.argv) > 2 else 4      # input dimensions 1..dmax
+Gmax = int(sys.argv[3]) if len(sys.argv) > 3 else 3      # 1..Gmax GPs
 bad = 0
 worst = 0.0
 for t in range(trials):
     rng = np.random.default_rng(1000 + t)
-    n, d, G = int(rng.integers(1, 300)), int(rng.integers(1, 5)), int(rng.integers(1, 4))
+    n, d, G = int(rng.integers(1, 300)), int(rng.integers(1, dmax + 1)), int(rng.integers(1, Gmax + 1))
     N = int(rng.integers(1, 3000))
     X = rng.uniform(-2, 2, size=(n, d))
     grid = rng.uniform(-3, 3, size=(N, d))
