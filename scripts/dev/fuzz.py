@@ -47,6 +47,29 @@ for t in range(trials):
         Q = son.confidence_intervals(gos, grid, 2.)
     dq = float(np.max(np.abs(opt.Q - Q)))
     worst = max(worst, dq)
+    if dq > 1e-8:
+        # which side is off?  float128 restatement of the posterior at the worst row
+        r = int(np.argmax(np.max(np.abs(opt.Q - Q), axis=1)))
+        g = int(np.argmax(np.abs(opt.Q - Q)[r]) // 2)
+        ld = np.longdouble
+        K = gos[g].kern.K(X).astype(ld) + (gos[g].noise_var + 1e-8) * np.eye(n, dtype=ld)
+        ks = gos[g].kern.K(X, grid[r:r + 1]).astype(ld)[:, 0]
+        # Gaussian elimination in long double (no LAPACK for float128)
+        A = np.concatenate([K, ks[:, None], np.asarray(gos[g].Y, dtype=ld)], axis=1)
+        for c in range(n):
+            pv = c + int(np.argmax(np.abs(A[c:, c])))
+            A[[c, pv]] = A[[pv, c]]
+            A[c] /= A[c, c]
+            for rr in range(n):
+                if rr != c:
+                    A[rr] -= A[rr, c] * A[c]
+        var = float(gos[g].kern.Kdiag(grid[r:r + 1])[0] - ks @ A[:, n])
+        mu = float(ks @ A[:, n + 1])
+        sd = np.sqrt(max(var, 1e-15))
+        ref = np.array([mu - 2. * sd, mu + 2. * sd])
+        print("trial %d n=%d d=%d G=%d: dQ=%.2g at row %d GP %d; vs float128: device %.2g, oracle %.2g (var=%.3g)"
+              % (t, n, d, G, dq, r, g, np.max(np.abs(opt.Q[r, 2 * g:2 * g + 2] - ref)),
+                 np.max(np.abs(Q[r, 2 * g:2 * g + 2] - ref)), var))
     # north-star tolerance: 1e-5 relative (to the prior standard deviation)
     ok = dq < 1e-5 and empty == oempty
     sets_ok = True
