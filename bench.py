@@ -206,6 +206,24 @@ def cpu_baseline(cfg, sample_rows, dev_Q=None, row_offset=0):
     return out, parity
 
 
+def full_grid_check(cfg, opt, chosen_index):
+    """One oracle run over the WHOLE grid (checker only, after the timed region):
+    are the safe set, maximisers, expanders and the chosen row identical?"""
+    from oracle import gp_numpy as gpn
+    from oracle import safeopt_numpy as son
+    gps = build_gps(cfg, gpn)
+    scaling = np.sqrt([2.0] * cfg["G"])
+    t0 = time.perf_counter()
+    idx, Q, S, M, G = son.optimize_grid(gps, cfg["grid"], cfg["fmin"], scaling,
+                                        cfg["threshold"], cfg["beta"])
+    return dict(full_grid_oracle_s=time.perf_counter() - t0,
+                chosen_index_identical=bool(chosen_index == int(idx)),
+                S_identical=bool(np.array_equal(opt.S, S)),
+                M_identical=bool(np.array_equal(opt.M, M)),
+                G_identical=bool(np.array_equal(opt.G, G)),
+                q_linf=float(np.max(np.abs(opt.Q - Q))))
+
+
 def spawn_ranks(n, argv):
     """``python bench.py --gpus N`` from a bare shell: start the N ranks (one
     process per GPU, torchrun-style environment) and pass rank 0's line on."""
@@ -244,6 +262,11 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=None,
                     help="rows of the CPU-baseline sample (default: ~2.5 s per run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-chosen", dest="check_chosen", action="store_true", default=None,
+                    help="after the timed region, run the oracle ONCE on the whole grid and "
+                         "report whether S / M / G and the chosen index are identical "
+                         "(default: on at configs 2 and 3 -- 7 s / 28 s of host work)")
+    ap.add_argument("--no-check-chosen", dest="check_chosen", action="store_false")
     ap.add_argument("--profile-steps", type=int, default=10,
                     help="steps of the separate (untimed) per-launch hipEvent pass")
     ap.add_argument("--launch-check", action="store_true",
@@ -251,6 +274,8 @@ def main():
     args = ap.parse_args()
     if args.steps is None:
         args.steps = {2: 500, 3: 40, 4: 6, 5: 40}[args.config]
+    if args.check_chosen is None:
+        args.check_chosen = args.config in (2, 3) and args.side is None
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus, sys.argv[1:])
@@ -389,6 +414,8 @@ def main():
         res["cpu_baseline"] = base
         res["parity"] = parity
         res["speedup_vs_cpu"] = res["value"] / base["value"]
+        if args.check_chosen:
+            res["parity"].update(full_grid_check(cfg, opt, res.get("chosen_index")))
     print(json.dumps(res))
 
 
