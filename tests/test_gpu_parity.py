@@ -293,6 +293,14 @@ def test_tied_widths_golden(mods, seed):
     # the whole step in one call gives the same sets (Q is recomputed: no ties then,
     # but the path through sets_fused with its tie count must still agree)
     assert_array_equal(opt.S, z["S"]); assert_array_equal(opt.M, z["M"])
+    # the tie count the front half reports (it travels with the first candidate on N
+    # ranks): candidates whose width equals the first one's bit for bit
+    be = opt._backend
+    opt.Q = z["Q"]
+    thr_beta = np.atleast_1d(np.asarray(meta["threshold"], dtype=float) * meta["beta"])
+    out5, _x, _m, _q = be.sets_front(opt._max_l, None, opt.scaling, thr_beta)
+    cand, width = be.candidate_widths()
+    assert int(out5[5]) == int(np.sum(cand & (width == out5[3]))) == int(z["n_tied_top"])
 
 
 def test_topk_order_and_ties(mods):
