@@ -401,6 +401,9 @@ def main():
         if tr and args.side is None and world == 1:
             res["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
             res["roofline"]["traffic_source"] = tr["note"]
+            if "mfma_pipe_busy" in tr:       # SQ_VALU_MFMA_BUSY_CYCLES, same PMC passes
+                res["roofline"]["mfma_pipe_busy"] = tr["mfma_pipe_busy"]
+                res["roofline"]["clock_ghz_under_profiler"] = tr["clock_ghz_under_profiler"]
     except (OSError, ValueError):
         pass
     if args.config != 5:
