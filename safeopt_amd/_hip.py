@@ -116,6 +116,7 @@ PROTOTYPES = {
     "sgp_profile_enable": (C.c_int, [vp, C.c_int]),
     "sgp_profile_read": (C.c_int, [vp, c_double_p, c_i64_p, c_double_p]),
     "sgp_ctx_alloc_count": (C.c_int64, [vp]),
+    "sgp_ctx_set_sweep": (C.c_int, [vp, C.c_int]),
 
 }
 
@@ -245,6 +246,12 @@ class Context(object):
     def alloc_count(self):
         """Device allocations made so far (a warm loop must not add any)."""
         return int(lib().sgp_ctx_alloc_count(self.h))
+
+    def set_sweep(self, which):
+        """Posterior-sweep kernel: 'auto' | 'classic' (4 waves) | 'pair' (paired
+        waves); returns the previous setting."""
+        names = ("auto", "classic", "pair")
+        return names[int(lib().sgp_ctx_set_sweep(self.h, names.index(which)))]
 
     # -- RCCL
     @staticmethod

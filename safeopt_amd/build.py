@@ -17,9 +17,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libsafeopt_hip.so")
-SOURCES = ["api.hip", "sweep.hip", "factor.hip", "sets.hip", "swarm.hip"]
+SOURCES = ["api.hip", "sweep.hip", "sweep_pair.hip", "factor.hip", "sets.hip", "swarm.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "kern_eval.h", "fitness.h",
-                                            "small_path.h")] + \
+                                            "small_path.h", "sweep_shared.h")] + \
           [os.path.join(REPO, "include", "safeopt_hip.h")]
 BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
         "-I", os.path.join(REPO, "include"), "-I", CSRC, "-Wall",
@@ -62,7 +62,7 @@ def build(force=False, verbose=False):
         if verbose and r.stderr.strip():
             print(r.stderr)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
     if jobs or force or _stale(OUT, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"])

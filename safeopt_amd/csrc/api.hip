@@ -220,6 +220,7 @@ void sgp_destroy(sgp_ctx* ctx) {
   for (auto& b : ctx->scratch)
     if (b.p) (void)hipFree(b.p);
   if (ctx->stage_tab.p) (void)hipFree(ctx->stage_tab.p);
+  if (ctx->pstage_tab.p) (void)hipFree(ctx->pstage_tab.p);
   for (auto e : ctx->prof_events) (void)hipEventDestroy(e);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -258,7 +259,7 @@ void sgp_gp_destroy(sgp_gp* gp) {
   sgp_ctx* ctx = gp->ctx;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DevBuf* bufs[] = {&gp->X, &gp->Y, &gp->Xpad, &gp->Xs, &gp->alpha, &gp->Apack,
+  DevBuf* bufs[] = {&gp->X, &gp->Y, &gp->Xpad, &gp->Xs, &gp->XA, &gp->alpha, &gp->Apack,
                     &gp->Linv, &gp->Kmat, &gp->work, &gp->tvec, &gp->updw,
                     &gp->upd};
   for (DevBuf* b : bufs)
@@ -1392,6 +1393,13 @@ int sgp_swarm_grow(sgp_ctx* ctx, sgp_gp* gp0, const double* S, int64_t m,
 
 // ---- timing ---------------------------------------------------------------------
 int64_t sgp_ctx_alloc_count(sgp_ctx* ctx) { return ctx ? ctx->n_allocs : -1; }
+
+int sgp_ctx_set_sweep(sgp_ctx* ctx, int which) {
+  if (!ctx) return -1;
+  const int old = ctx->sweep_choice;
+  if (which >= 0 && which <= 2) ctx->sweep_choice = which;
+  return old;
+}
 
 int sgp_timer_start(sgp_ctx* ctx) {
   SGP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));

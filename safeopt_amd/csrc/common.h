@@ -67,6 +67,9 @@ struct GpDev {
   const double* Xs;     // = Xpad * kern.scale0 for single-part kernels,
                         //   else = Xpad (KernFast::operator() convention)
   const double* alpha;  // Ky^-1 y, [n_pad], zero padded
+  const double* XA;     // per j-block of 16 training points: [16 d of Xs | 16 of
+                        // alpha], contiguous -- ONE LDS-DMA source per stage of
+                        // the paired sweep (sweep_pair.hip)
   int n;                // training points
   int n_pad;            // n rounded up to 16
   int nblk;             // n_pad / 16
@@ -113,6 +116,12 @@ struct sgp_ctx {
   DevBuf stage_tab;
   std::vector<int> stage_sig;
   int stage_count = 0;
+  // ... and of the paired sweep (sweep_pair.hip: pair_stage_table)
+  DevBuf pstage_tab;
+  std::vector<uint64_t> pstage_sig;
+  int pstage_count = 0;
+  int sweep_partials = 0;     // partials of max l0[S] the last confidence sweep left
+  int sweep_choice = 0;       // sgp_ctx_set_sweep: 0 auto, 1 4-wave, 2 paired
   // RCCL
   void* comm = nullptr;  // ncclComm_t
   int rank = 0, world = 1;
@@ -129,7 +138,7 @@ struct sgp_gp {
   int n_f = 0;    // multiple of 32 (factorisation leaves)
   int ld = 0;     // leading dimension / row capacity of Linv, Kmat, work
   bool upd_valid = false;  // dev.upd* describes the step to the current data
-  DevBuf X, Y, Xpad, Xs, alpha, Apack, Linv, Kmat, work, tvec, updw, upd;
+  DevBuf X, Y, Xpad, Xs, XA, alpha, Apack, Linv, Kmat, work, tvec, updw, upd;
   GpDev dev;      // filled by set_data
 };
 

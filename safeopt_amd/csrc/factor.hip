@@ -337,14 +337,22 @@ int launch_tri_mtv(sgp_ctx* ctx, const double* Li, int64_t ld, int n,
   return 0;
 }
 
-// Xpad = zero-padded X; Xs = Xpad * scale0 per column (products of parts: copy)
-__global__ void k_pad_rows(const double* X, int n, int n_pad, int d,
-                           KernDesc kd, double* Xpad, double* Xs) {
+// Xpad = zero-padded X; Xs = Xpad * scale0 per column (products of parts: copy);
+// XA = the same rows and alpha interleaved per block of 16 training points:
+// [16 d of Xs | 16 of alpha] (GpDev::XA)
+__global__ void k_pad_rows(const double* X, const double* alpha, int n, int n_pad,
+                           int d, KernDesc kd, double* Xpad, double* Xs,
+                           double* XA) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_pad * d) return;
   const double v = (e < n * d) ? X[e] : 0.0;
+  const double vs = (kd.n_parts == 1) ? v * kd.scale0[e % d] : v;
   Xpad[e] = v;
-  Xs[e] = (kd.n_parts == 1) ? v * kd.scale0[e % d] : v;
+  Xs[e] = vs;
+  const int row = e / d, col = e - row * d, jb = row >> 4, r = row & 15;
+  double* blk = XA + size_t(jb) * (16 * d + 16);
+  blk[r * d + col] = vs;
+  if (col == 0) blk[16 * d + r] = alpha[row];     // zero beyond n (publish_gp)
 }
 
 
@@ -397,15 +405,18 @@ int publish_gp(sgp_gp* gp) {
                      static_cast<double*>(gp->Apack.p));
   SGP_TRY(sgp_reserve(ctx, &gp->Xpad, cap_rows * d * sizeof(double)));
   SGP_TRY(sgp_reserve(ctx, &gp->Xs, cap_rows * d * sizeof(double)));
+  SGP_TRY(sgp_reserve(ctx, &gp->XA, (cap_rows / 16 + 1) * (16 * d + 16) * sizeof(double)));
   hipLaunchKernelGGL(k_pad_rows, dim3((np * d + 255) / 256), dim3(256), 0,
-                     ctx->stream, static_cast<double*>(gp->X.p), n, np, d,
+                     ctx->stream, static_cast<double*>(gp->X.p),
+                     static_cast<double*>(gp->alpha.p), n, np, d,
                      gp->kern, static_cast<double*>(gp->Xpad.p),
-                     static_cast<double*>(gp->Xs.p));
+                     static_cast<double*>(gp->Xs.p), static_cast<double*>(gp->XA.p));
   SGP_HIP(ctx, hipGetLastError());
   gp->dev.Apack = static_cast<double*>(gp->Apack.p);
   gp->dev.Xpad = static_cast<double*>(gp->Xpad.p);
   gp->dev.Xs = static_cast<double*>(gp->Xs.p);
   gp->dev.alpha = static_cast<double*>(gp->alpha.p);
+  gp->dev.XA = static_cast<double*>(gp->XA.p);
   gp->dev.upd_w = static_cast<double*>(gp->updw.p);
   gp->dev.upd = static_cast<double*>(gp->upd.p);
   gp->dev.n = n;

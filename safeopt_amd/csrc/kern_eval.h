@@ -61,43 +61,48 @@ __device__ __forceinline__ double exp2_32(double u, const double* tab) {
 // minimises live registers at the 256-VGPR limit), which leaves the kernel
 // latency bound; step-major order keeps 4 independent instructions in flight.
 #define SGP_FENCE() __builtin_amdgcn_sched_barrier(0)
-__device__ __forceinline__ void exp2_32x4(const double (&u)[4], const double* tab,
-                                          double (&out)[4]) {
-  double kf[4], w[4], t[4], p[4];
-  int k[4];
+template <int NV>
+__device__ __forceinline__ void exp2_32xn(const double (&u)[NV], const double* tab,
+                                          double (&out)[NV]) {
+  double kf[NV], w[NV], t[NV], p[NV];
+  int k[NV];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) kf[q] = rint(u[q]);
+  for (int q = 0; q < NV; ++q) kf[q] = rint(u[q]);
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NV; ++q) {
     k[q] = int(kf[q]);
     w[q] = u[q] - kf[q];
   }
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NV; ++q) {
     t[q] = tab[k[q] & 31];
     p[q] = fma(w[q], SGP_E6, SGP_E5);
   }
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) p[q] = fma(w[q], p[q], SGP_E4);
+  for (int q = 0; q < NV; ++q) p[q] = fma(w[q], p[q], SGP_E4);
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) p[q] = fma(w[q], p[q], SGP_E3);
+  for (int q = 0; q < NV; ++q) p[q] = fma(w[q], p[q], SGP_E3);
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) p[q] = fma(w[q], p[q], SGP_E2);
+  for (int q = 0; q < NV; ++q) p[q] = fma(w[q], p[q], SGP_E2);
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) p[q] = fma(w[q], p[q], SGP_E1);
+  for (int q = 0; q < NV; ++q) p[q] = fma(w[q], p[q], SGP_E1);
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) p[q] = fma(w[q], p[q], 1.0);
+  for (int q = 0; q < NV; ++q) p[q] = fma(w[q], p[q], 1.0);
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) out[q] = ldexp(t[q] * p[q], k[q] >> 5);
+  for (int q = 0; q < NV; ++q) out[q] = ldexp(t[q] * p[q], k[q] >> 5);
   SGP_FENCE();
+}
+__device__ __forceinline__ void exp2_32x4(const double (&u)[4], const double* tab,
+                                          double (&out)[4]) {
+  exp2_32xn<4>(u, tab, out);
 }
 
 // Four square roots, step-major: v_rsq_f64 seed (relative error 5e-8 on
@@ -130,23 +135,27 @@ __device__ __forceinline__ void sqrt4(const double (&xin)[4], double (&out)[4]) 
 }
 
 // The same for strictly positive arguments (no clamp).
-__device__ __forceinline__ void sqrt4_pos(const double (&x)[4], double (&out)[4]) {
-  double y[4], g[4], r[4];
+template <int NV>
+__device__ __forceinline__ void sqrtn_pos(const double (&x)[NV], double (&out)[NV]) {
+  double y[NV], g[NV], r[NV];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) y[q] = __builtin_amdgcn_rsq(x[q]);
+  for (int q = 0; q < NV; ++q) y[q] = __builtin_amdgcn_rsq(x[q]);
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NV; ++q) {
     g[q] = x[q] * y[q];
     y[q] = 0.5 * y[q];
   }
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) r[q] = fma(-g[q], g[q], x[q]);
+  for (int q = 0; q < NV; ++q) r[q] = fma(-g[q], g[q], x[q]);
   SGP_FENCE();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) out[q] = fma(r[q], y[q], g[q]);
+  for (int q = 0; q < NV; ++q) out[q] = fma(r[q], y[q], g[q]);
   SGP_FENCE();
+}
+__device__ __forceinline__ void sqrt4_pos(const double (&x)[4], double (&out)[4]) {
+  sqrtn_pos<4>(x, out);
 }
 
 __device__ __forceinline__ double k_of_r2(int kind, double r2) {
@@ -209,6 +218,23 @@ struct KernFast {
     m2 = uni((kind0 == SGP_MATERN52) ? var0 * 0.00015639746546816451 : 0.0);
 #pragma unroll
     for (int i = 0; i < D; ++i) sc[i] = uni(k.scale0[i]);
+  }
+
+  // The same from a descriptor in CONSTANT address space (read-only for the whole
+  // launch): every field is a scalar load -- no vector load + readfirstlane, and
+  // no vmcnt wait that would sit out the LDS-DMA traffic in flight.
+  typedef const __attribute__((address_space(4))) KernDesc* const_desc_t;
+  __device__ __forceinline__ KernFast() : kd(nullptr) {}
+  __device__ __forceinline__ void load_const(const KernDesc* generic) {
+    kd = generic;
+    const const_desc_t k = (const_desc_t)generic;
+    single = k->n_parts == 1;
+    kind0 = k->kind[0];
+    var0 = k->variance[0];
+    m1 = uni(-var0 * SGP_E1);
+    m2 = uni((kind0 == SGP_MATERN52) ? var0 * 0.00015639746546816451 : 0.0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) sc[i] = k->scale0[i];
   }
 
   // candidate row -> the form operator() expects (scaled when `single`)
@@ -291,20 +317,20 @@ struct KernFast {
     for (int i = 0; i < D; ++i) xs[i] = SINGLE ? x[i] * sc[i] : x[i];
   }
 
-  template <bool SINGLE>
-  __device__ __forceinline__ void many4_t(const double* xs, const double* ys,
+  template <int NV, bool SINGLE>
+  __device__ __forceinline__ void manyn_t(const double* xs, const double* ys,
                                           int stride, const double* tab,
-                                          double (&out)[4]) const {
+                                          double (&out)[NV]) const {
     if (SINGLE) {
-      double r2[4], u[4], e[4], y[4][D];
-      // all the training rows first (one LDS round trip, not four)
+      double r2[NV], u[NV], e[NV], y[NV][D];
+      // all the training rows first (one LDS round trip, not NV)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < NV; ++q)
 #pragma unroll
         for (int i = 0; i < D; ++i) y[q][i] = ys[q * stride + i];
       SGP_FENCE();
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NV; ++q) {
         // 1e-300 instead of 0: the square root below needs no clamp, and it is
         // far below the last bit of any distance that matters
         r2[q] = 1e-300;
@@ -316,24 +342,31 @@ struct KernFast {
       }
       if (kind0 == SGP_RBF) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) u[q] = -r2[q];
-        exp2_32x4(u, tab, e);
+        for (int q = 0; q < NV; ++q) u[q] = -r2[q];
+        exp2_32xn<NV>(u, tab, e);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) out[q] = var0 * e[q];
+        for (int q = 0; q < NV; ++q) out[q] = var0 * e[q];
       } else {
-        double rr[4];
-        sqrt4_pos(r2, rr);
+        double rr[NV];
+        sqrtn_pos<NV>(r2, rr);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) u[q] = -rr[q];
-        exp2_32x4(u, tab, e);
+        for (int q = 0; q < NV; ++q) u[q] = -rr[q];
+        exp2_32xn<NV>(u, tab, e);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NV; ++q)
           out[q] = fma(u[q], fma(u[q], m2, m1), var0) * e[q];
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) out[q] = kern_eval<D>(*kd, xs, ys + q * stride);
+      for (int q = 0; q < NV; ++q) out[q] = kern_eval<D>(*kd, xs, ys + q * stride);
     }
+  }
+
+  template <bool SINGLE>
+  __device__ __forceinline__ void many4_t(const double* xs, const double* ys,
+                                          int stride, const double* tab,
+                                          double (&out)[4]) const {
+    manyn_t<4, SINGLE>(xs, ys, stride, tab, out);
   }
 
   // both arguments raw (unscaled) rows

@@ -41,8 +41,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "kern_eval.h"
-#include "fitness.h"
+#include "sweep_shared.h"
 
 namespace {
 
@@ -79,8 +78,6 @@ struct Lay {
     return (i / (kQPad / 2)) * kKbRow + 64 + 2 * (i % (kQPad / 2));
   }
 };
-
-enum { MODE_CONF = 0, MODE_FITNESS = 1 };
 
 // One stage of the flattened (GP, chunk, j-block) sequence of a tile, built on
 // the host (build_stage_table).  Slot s of the staged A chunk holds row block
@@ -281,9 +278,7 @@ __device__ __forceinline__ void load_slot(double (&ops)[4], const double* aT,
 // The MFMA goes through inline asm with the accumulator tied to destination AND
 // addend: the builtin lets the register allocator rename the destination, which
 // costs v_mov_b64 copies at every join of the guarded sequence.
-__device__ __forceinline__ void mfma_acc(double& c, double a, double b) {
-  asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
+// (mfma_acc: sweep_shared.h)
 
 //
 // Slot 0 of the last chunk may hold a NARROW row block (k_pack): its four MFMA
@@ -1045,21 +1040,8 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
     attr_set = true;
   }
   const int nblocks = sweep_grid_blocks(ctx->num_cu, p.pts.N, NW, SL);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ctx->profiling) {
-    if (ctx->prof_used + 2 > ctx->prof_events.size()) {
-      for (int i = 0; i < 2; ++i) {
-        hipEvent_t e;
-        SGP_HIP(ctx, hipEventCreate(&e));
-        ctx->prof_events.push_back(e);
-      }
-    }
-    e0 = ctx->prof_events[ctx->prof_used];
-    e1 = ctx->prof_events[ctx->prof_used + 1];
-    ctx->prof_used += 2;
-    ctx->prof_flops += flops;
-    SGP_HIP(ctx, hipEventRecord(e0, ctx->stream));
-  }
+  SweepTimer timer;
+  SGP_TRY(timer.begin(ctx, flops));
   SweepParams pp = p;
 #ifdef SGP_INSTRUMENT
   static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
@@ -1069,8 +1051,7 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE>), dim3(nblocks),
                      dim3(64 * NW), lds_bytes, ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
-  if (e1) SGP_HIP(ctx, hipEventRecord(e1, ctx->stream));
-  return 0;
+  return timer.end(ctx);
 }
 
 template <int D, int NW, int SL>
@@ -1096,6 +1077,14 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
   for (int g = 0; g < Geff; ++g)
     flops += (double(gh[g].n) * gh[g].n + 2.0 * gh[g].n) * double(p.pts.N);
   if (p.pts.N <= 0) return 0;
+  if (pair_sweep_wanted(ctx, gh, Geff)) {
+    // more than 256 rows of L^-1: the paired-wave kernel (sweep_pair.hip)
+    SweepArgs a{p.gps, p.G, p.mode, p.pts, p.conf, p.fit};
+    ctx->sweep_partials = pair_sweep_partials(ctx, p.pts.N);
+    return launch_sweep_pair(ctx, a, gh, d, Geff, flops);
+  }
+  ctx->sweep_partials = sweep_grid_blocks(ctx->num_cu, p.pts.N, sweep_waves(), 16) *
+                        sweep_waves();
   SweepParams q = p;
   q.slots = 16;            // accumulator slots per wave
   SGP_TRY(stage_table(ctx, gh, Geff, q.slots, &q.stages, &q.nstages));
@@ -1117,11 +1106,11 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
 
 }  // namespace
 
-// Number of partials of max l0[S] a confidence sweep leaves in ConfOut::partial:
-// one per wave of every launched workgroup.
+// Number of partials of max l0[S] the LAST confidence sweep left in
+// ConfOut::partial (one per wave / wave pair of every launched workgroup).
 int sweep_num_partials(const sgp_ctx* ctx, int64_t N) {
-  const int nw = sweep_waves();
-  return sweep_grid_blocks(ctx->num_cu, N, nw, 16) * nw;
+  (void)N;
+  return ctx->sweep_partials;
 }
 
 int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,

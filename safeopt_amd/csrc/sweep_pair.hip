@@ -1,0 +1,721 @@
+// posterior_sweep, paired-wave form: the kernel for factors with more than 256
+// rows (BASELINE.json configs 3, 4, 5).
+//
+// Same mathematics as sweep.hip (gp.predict_noiseless + the Q update of
+// SafeOpt.update_confidence_intervals, safeopt/gp_opt.py:453-481, and
+// SafeOptSwarm._compute_particle_fitness, :901-1013): for every candidate row
+//     v = L^-1 k(X, x),  var = k(x,x) - |v|^2,  mean = alpha . k(X, x)
+// with k(X, x) evaluated on the fly and L^-1 k on the fp64 matrix cores.
+//
+// What is different: a covariance value is evaluated ONCE per (row, training
+// point) up to n = 512 (sweep.hip re-evaluates the j-blocks for every chunk of
+// 256 rows of L^-1: 48 instead of 32 evaluations per tile at n = 500, 159
+// instead of 63 at n = 1000), and each wave evaluates only HALF of its tile's
+// values:
+//   * workgroup = 8 waves = 4 PAIRS; the two waves of a pair (w, w + 4: the two
+//     waves of one SIMD) own the SAME 16 candidate rows and split the row blocks
+//     of L^-1 between them (global slot t of a chunk of 32 row blocks belongs to
+//     wave t & 1): 2 x 16 accumulator slots cover 512 rows in ONE pass;
+//   * wave h of a pair evaluates the training points 8 h .. 8 h + 7 of a
+//     j-block (two values per lane instead of four) and writes them to the
+//     pair's LDS buffer in MFMA B-operand order; both waves read all 16 from
+//     there.  The exchange is software pipelined: the values of stage s + 1 are
+//     evaluated during stage s, so the one barrier per stage that the staged
+//     L^-1 chunk needs anyway also orders the exchange;
+//   * wave 0 of a pair multiplies first and evaluates afterwards, wave 1 the
+//     other way round: the SIMD they share always has one MFMA stream to issue
+//     while the other wave is in its VALU phase.
+// The stage sequence comes from a host-built table with ABSOLUTE source
+// addresses (one scalar load per stage, no pointer arithmetic on the device);
+// the training rows and alpha of a j-block are one contiguous block
+// (GpDev::XA) and arrive with a single LDS-DMA instruction two stages ahead.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "sweep_shared.h"
+
+namespace {
+
+constexpr int kJC = 16;                // training points per stage (one j-block)
+constexpr int kSteps = kJC / 4;        // MFMA k-steps per stage
+constexpr int kPairSlots = 32;         // row blocks of L^-1 per accumulator chunk
+constexpr int kWaveSlots = 16;         // ... per wave (128 accumulator VGPRs)
+constexpr int kPairs = 4;              // pairs per workgroup (64 rows per tile)
+constexpr int kTileRows = 16 * kPairs;
+constexpr int kKbRow = 80;             // doubles between the k-rows of a B buffer
+
+// One stage (GP, chunk, j-block) of a tile.  Global slot t of the staged chunk
+// holds row block bend-1-t, k-steps 4 jb .. 4 jb + 3; its source is
+// a_src - t * rs_bytes.
+struct PStage {
+  uint64_t a_src;      // device address of slot 0's 2 KB
+  uint64_t xa_next;    // device address of the [16 d | 16] block of the NEXT stage
+                       // of the (cyclic) sequence
+  uint32_t rs_bytes;   // bytes between consecutive row blocks in Apack
+  uint32_t word;       // PW_*
+  uint32_t pad0, pad1;
+};
+enum : uint32_t {
+  PW_NACT_MASK = 63u,       // active global slots 0 .. nact-1 (1..32)
+  PW_CHUNK_END = 1u << 6,   // last j-block of an accumulator chunk: fold
+  PW_GP_END = 1u << 7,      // last stage of a GP: row epilogue
+  PW_TILE_END = 1u << 8,    // last stage of the tile
+  PW_MEAN = 1u << 9,        // stage of the LAST chunk: accumulate alpha . k
+  PW_NARROW = 1u << 10,     // global slot 0 holds a narrow row block (k_pack)
+  PW_GP_FIRST = 1u << 11,   // first stage of a GP
+  PW_G_SHIFT = 12           // GP index (3 bits)
+};
+
+// LDS (doubles):  [2][A chunk 64 KB]  [2][16 D rows | 16 alpha]  exp table
+//                 [4 pairs][2][B operands]  [4 pairs][2][32] pair exchange
+//                 [4 pairs] staged Q rows
+template <int D>
+struct LayP {
+  static constexpr int kATile = kPairSlots * kSteps * 64;   // 8192 doubles
+  static constexpr int kXBuf = kJC * D + kJC;
+  static constexpr int kXOff = 2 * kATile;
+  static constexpr int kTabOff = kXOff + 2 * kXBuf;
+  static constexpr int kKbOff = kTabOff + kExpTabSize;
+  static constexpr int kKbBuf = 4 * kKbRow;                 // one B buffer
+  static constexpr int kExOff = kKbOff + kPairs * 2 * kKbBuf;
+  static constexpr int kQOff = kExOff + kPairs * 2 * 32;
+  static constexpr int kQMaxG = 6;                          // staged Q rows: G <= 6
+  static constexpr int kQCap = 16 * 2 * kQMaxG;             // doubles per pair
+  static constexpr int kTotal = kQOff + kPairs * kQCap;
+  static constexpr size_t bytes() { return size_t(kTotal) * sizeof(double); }
+};
+static_assert(LayP<8>::bytes() <= 160 * 1024, "LDS budget of one workgroup per CU");
+
+struct PairParams {
+  const GpDev* gps;
+  int G;
+  SweepPoints pts;
+  ConfOut conf;
+  FitnessArgs fit;
+  const PStage* stages;   // [nstages] one tile's stage sequence (all GPs)
+  int nstages;
+#ifdef SGP_INSTRUMENT
+  int ablate;
+#endif
+};
+
+#ifdef SGP_INSTRUMENT
+#define PGP_ABL(mask) (p.ablate & (mask))
+#else
+#define PGP_ABL(mask) false
+#endif
+
+typedef const __attribute__((address_space(4))) PStage* pstage_ptr_t;
+typedef const __attribute__((address_space(4))) GpDev* gpdev_cptr_t;
+
+__device__ __forceinline__ PStage load_pstage(pstage_ptr_t t, int i) {
+  PStage e;      // member-wise: scalar loads (dwordx4 + dwordx2)
+  e.a_src = t[i].a_src;
+  e.xa_next = t[i].xa_next;
+  e.rs_bytes = t[i].rs_bytes;
+  e.word = t[i].word;
+  e.pad0 = e.pad1 = 0;
+  return e;
+}
+
+// global -> LDS without a VGPR round trip: "scalar base + 32-bit lane offset"
+// (the builtin only produces the 64-bit-VGPR-address form, one VALU add per
+// copy).  M0 carries the wave-uniform LDS byte address.
+__device__ __forceinline__ void dma_2k(uint64_t src, uint32_t lds_addr, uint32_t voff) {
+  asm volatile(
+      "s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:1024"
+      :: "s"(lds_addr), "v"(voff), "s"(src) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_1k(uint64_t src, uint32_t lds_addr, uint32_t voff) {
+  asm volatile(
+      "s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2"
+      :: "s"(lds_addr), "v"(voff), "s"(src) : "memory", "m0");
+}
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ uint32_t lds_addr_of(const double* p) {
+  return uint32_t(uintptr_t((const __attribute__((address_space(3))) void*)p));
+}
+
+// A chunk of stage `e` -> LDS image [global slot][k-step][lane] (2 KB per slot):
+// wave w copies the global slots w, w + 8, w + 16, w + 24 below nact.
+__device__ __forceinline__ void a_dma(const PStage& e, uint32_t dst0, int wave,
+                                      uint32_t voff) {
+  const int left = int(e.word & PW_NACT_MASK) - wave;
+  const uint64_t step = uint64_t(e.rs_bytes) * 8;
+  uint64_t src = e.a_src - uint64_t(uint32_t(wave)) * e.rs_bytes;
+  uint32_t dst = dst0 + uint32_t(wave) * 2048u;
+  if (left > 0) {
+    dma_2k(src, dst, voff);
+    if (left > 8) {
+      dma_2k(src - step, dst + 8 * 2048, voff);
+      if (left > 16) {
+        dma_2k(src - 2 * step, dst + 16 * 2048, voff);
+        if (left > 24) dma_2k(src - 3 * step, dst + 24 * 2048, voff);
+      }
+    }
+  }
+}
+
+// [16 D training rows | 16 alpha] of one j-block: 128 D + 128 bytes, one wave.
+template <int D>
+__device__ __forceinline__ void xa_dma(uint64_t src, uint32_t dst, int lane,
+                                       uint32_t voff) {
+  constexpr int kLanes = 8 * D + 8;              // 16 bytes each
+  if (lane < (kLanes < 64 ? kLanes : 64)) dma_1k(src, dst, voff);
+  if (kLanes > 64) {
+    if (lane < kLanes - 64) dma_1k(src + 1024, dst + 1024, voff);
+  }
+}
+
+// ---- matrix part (operand maps: see sweep.hip) ------------------------------------
+// Local slot S of wave h is global slot 2 S + h; aT points at the wave's first slot
+// (+ lane), consecutive local slots are 2 * kSteps * 64 doubles apart.
+template <int S, bool NARROW_OK>
+__device__ __forceinline__ void pair_slots(int nw, bool narrow0,
+                                           double (&acc)[kWaveSlots][4], double& accx,
+                                           const double* aT,
+                                           const double (&kb)[4][4],
+                                           const double (&kvn)[4],
+                                           double (&cur)[4], double (&nxt)[4]) {
+  if constexpr (S < kWaveSlots) {
+    if (S < nw) {
+      if (S + 1 < kWaveSlots) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nxt[q] = aT[((S + 1) * 2 * kSteps + q) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (NARROW_OK && S == 0 && narrow0) {
+        // four DEPENDENT MFMAs on one accumulator (4 wait states by hand)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
+                       : "+v"(accx) : "v"(cur[q]), "v"(kvn[q]));
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) mfma_acc(acc[S][m], cur[q], kb[m][q]);
+        }
+      }
+      if (S + 1 < kWaveSlots)
+        asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
+      pair_slots<S + 1, false>(nw, false, acc, accx, aT, kb, kvn, nxt, cur);
+    }
+  }
+}
+
+// per-tile state of the row epilogue (only the finishing wave of a pair has it)
+struct RowState {
+  bool safe = true;
+  double l0 = 0.0, values = 0.0, interest = 1.0, total_pen = 0.0, lower = 0.0;
+  double lmax = -INFINITY;   // max l0 over the safe rows this wave has seen
+};
+
+// One GP's posterior at the wave's 16 rows -> confidence interval / fitness
+// shaping; at the end of a tile the rows leave.  `mu`, `var` are complete
+// (both halves of the pair); lane l works on row l & 15.
+template <int D, int MODE>
+__device__ __forceinline__ void row_epilogue(const PairParams& p, RowState& rs,
+                                             uint32_t w, int tile, int pr, int lane,
+                                             double mu, double var, double* qst) {
+  typedef LayP<D> L;
+  constexpr bool conf = MODE == MODE_CONF;
+  const double sd = sqrt(var);
+  const int g = int(w >> PW_G_SHIFT) & 7;
+  const int64_t row = int64_t(tile) * kTileRows + pr * 16 + (lane & 15);
+  const bool writer = (row < p.pts.N) && (lane < 16);
+  const int st = p.fit.swarm_type;
+  if (conf) {
+    // update_confidence_intervals + compute_safe_set (gp_opt.py:453-481)
+    const double lo = mu - p.conf.beta * sd;
+    const double up = mu + p.conf.beta * sd;
+    if (g == 0) rs.l0 = lo;
+    rs.safe = rs.safe && (lo > p.conf.fmin[g]);
+    if (writer && !PGP_ABL(16)) {
+      __builtin_nontemporal_store(mu, p.conf.mean + int64_t(g) * p.pts.N + row);
+      __builtin_nontemporal_store(var, p.conf.var + int64_t(g) * p.pts.N + row);
+    }
+    // Q row = [l0, u0, l1, u1, ...] (gp_opt.py:375): collected in LDS, written
+    // as ONE contiguous block per wave at the end of the tile
+    if (p.conf.Q && lane < 16 && !PGP_ABL(16)) {
+      if (p.G <= L::kQMaxG)
+        *reinterpret_cast<double2_t*>(qst + (lane * p.G + g) * 2) = double2_t{lo, up};
+      else if (writer)
+        *reinterpret_cast<double2_t*>(p.conf.Q + (row * p.G + g) * 2) =
+            double2_t{lo, up};
+    }
+  } else {
+    // SafeOptSwarm._compute_particle_fitness, gp_opt.py:925-1013
+    const FitnessArgs& f = p.fit;
+    rs.lower = mu - f.beta * sd;
+    if (g == 0) {
+      rs.values = sd / f.scaling[0];
+      if (st == SGP_SWARM_EXPANDERS) rs.interest = double(p.G);
+      if (st == SGP_SWARM_MAXIMIZERS) {
+        const double upper = mu + f.beta * sd;
+        const double z = 10.0 * (upper - f.best_lower_bound) / f.scaling[0];
+        rs.interest = 1.0 / (1.0 + exp(-z));  // scipy.special.expit
+      }
+    } else {
+      rs.values = fmax(rs.values, sd / f.scaling[g]);
+    }
+    if (f.fmin[g] != -INFINITY) {
+      double slack = rs.lower - f.fmin[g];
+      rs.safe = rs.safe && (slack >= 0.0);
+      if (st != SGP_SWARM_SAFE_SET) {
+        slack = slack / f.scaling[g];
+        rs.total_pen += swarm_penalty(slack);
+        if (st == SGP_SWARM_EXPANDERS) {
+          // scipy.stats.norm.pdf(slack, scale=0.2)
+          const double z = slack / 0.2;
+          rs.interest *= exp(-0.5 * z * z) / 2.5066282746310002 / 0.2;
+        }
+      }
+    }
+  }
+
+  if (w & PW_TILE_END) {
+    if (conf) {
+      if (p.conf.Q && p.G <= L::kQMaxG && !PGP_ABL(16)) {
+        const int64_t row0 = int64_t(tile) * kTileRows + pr * 16;
+        const int64_t left = p.pts.N - row0;
+        const int nq = (left >= 16 ? 16 : (left > 0 ? int(left) : 0)) * p.G;
+        __builtin_amdgcn_wave_barrier();
+        double2_t* dst = reinterpret_cast<double2_t*>(p.conf.Q) + row0 * p.G;
+        for (int i = lane; i < nq; i += 64)
+          __builtin_nontemporal_store(
+              *reinterpret_cast<const double2_t*>(qst + 2 * i), dst + i);
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (p.conf.S) {
+        if (writer) p.conf.S[row] = rs.safe ? 1 : 0;
+        rs.lmax = fmax(rs.lmax, (writer && rs.safe) ? rs.l0 : -INFINITY);
+      }
+    } else if (writer) {
+      double out;
+      bool ok = rs.safe;
+      if (st == SGP_SWARM_GREEDY) {
+        out = rs.lower;
+        ok = true;
+      } else if (st == SGP_SWARM_SAFE_SET) {
+        out = rs.lower;
+      } else {
+        out = (rs.values + rs.total_pen) * rs.interest;
+      }
+      p.fit.values[row] = out;
+      p.fit.safe[row] = ok ? 1 : 0;
+    }
+    rs.safe = true;
+    rs.l0 = rs.values = rs.total_pen = rs.lower = 0.0;
+    rs.interest = 1.0;
+  }
+}
+
+// The persistent stage loop of one wave; H = its half of the pair (compile time:
+// the two halves run the phases of a stage in opposite order).
+template <int D, int MODE, bool SINGLE, int H>
+__device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
+                                          const int lane, const int wave) {
+  typedef LayP<D> L;
+  constexpr bool conf = MODE == MODE_CONF;
+  const int pr = wave & 3;
+  const int k4 = lane >> 4, c16 = lane & 15;
+  const double* tab = lds + L::kTabOff;
+  const pstage_ptr_t stages = (pstage_ptr_t)(p.stages);
+  const gpdev_cptr_t gpc = (gpdev_cptr_t)(p.gps);
+  const int nstages = p.nstages;
+  const int ntiles = int((p.pts.N + kTileRows - 1) / kTileRows);
+  const int tstep = int(gridDim.x);
+  int tile = int(blockIdx.x);          // tile of the stage being multiplied
+  int left = ((ntiles - tile + tstep - 1) / tstep) * nstages;   // stages to go
+
+  double* kbp = lds + L::kKbOff + pr * (2 * L::kKbBuf);   // the pair's B buffers
+  double* exch = lds + L::kExOff + pr * 64;                // ... exchange [2][32]
+  double* qst = lds + L::kQOff + pr * L::kQCap;            // ... staged Q rows
+  const uint32_t lds_a = lds_addr_of(lds);
+  const uint32_t lds_xa = lds_addr_of(lds + L::kXOff);
+  const uint32_t voff = uint32_t(lane) * 16u;
+
+  // candidate rows of the tile being EVALUATED (one stage ahead of the
+  // multiplication) and, prefetched, of the tile after it
+  auto load_x = [&](int t, double (&xo)[D]) {
+    int64_t r = int64_t(t) * kTileRows + pr * 16 + c16;
+    r = r < p.pts.N ? r : p.pts.N - 1;
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      xo[k] = __builtin_nontemporal_load(p.pts.base + r * p.pts.stride_row +
+                                         k * p.pts.stride_col);
+  };
+  double x_e[D], x_n[D], xs_e[D];
+  int tile_e = tile;
+  load_x(tile_e, x_e);
+  load_x(tile_e + tstep, x_n);
+  KernFast<D> kf;
+  kf.load_const(&p.gps[0].kern);
+  kf.template prep_t<SINGLE>(x_e, xs_e);
+
+  // covariances of one stage: this wave's half (training points 8 H .. 8 H + 7 of
+  // the j-block) -> the pair's B buffer, [k][q pair][point][2]
+  double mean = 0.0, mean_done = 0.0;
+  auto evaluate = [&](uint32_t w1, bool tile_first, const double* xa, double* kbw) {
+    if (w1 & PW_GP_FIRST) {
+      if (tile_first) {
+        tile_e += tstep;
+#pragma unroll
+        for (int k = 0; k < D; ++k) x_e[k] = x_n[k];
+        load_x(tile_e + tstep, x_n);
+      }
+      kf.load_const(&p.gps[int(w1 >> PW_G_SHIFT) & 7].kern);
+      kf.template prep_t<SINGLE>(x_e, xs_e);
+    }
+    double kv[2];
+    if (!PGP_ABL(4)) {
+      kf.template manyn_t<2, SINGLE>(xs_e, xa + (8 * H + k4) * D, 4 * D, tab, kv);
+    } else {
+      kv[0] = xs_e[0];
+      kv[1] = xs_e[0] + 1.0;
+    }
+    if (w1 & PW_MEAN) {
+      const double* al = xa + kJC * D + 8 * H + k4;
+      mean = fma(al[0], kv[0], mean);
+      mean = fma(al[4], kv[1], mean);
+    }
+    *reinterpret_cast<double2_t*>(kbw + k4 * kKbRow + H * 32 + c16 * 2) =
+        double2_t{kv[0], kv[1]};
+  };
+
+  // ---- prologue: A chunk and training block of stage 0, covariances of stage 0
+  PStage e1 = load_pstage(stages, 0);
+  a_dma(e1, lds_a, wave, voff);
+  if (wave == 7) {
+    const PStage el = load_pstage(stages, nstages - 1);
+    xa_dma<D>(el.xa_next, lds_xa, lane, voff);                      // block of stage 0
+    xa_dma<D>(e1.xa_next, lds_xa + L::kXBuf * 8, lane, voff);      // ... of stage 1
+  }
+  uint32_t wcur = e1.word;
+  int si = 0;                               // position of the current stage in the table
+  wait_dma();
+  __syncthreads();
+  {
+    // (stage 0 is the first stage of GP 0: kf / xs_e are set up already)
+    const uint32_t w0 = wcur & ~uint32_t(PW_GP_FIRST);
+    evaluate(w0, false, lds + L::kXOff, kbp);
+  }
+  int si1 = (nstages > 1) ? 1 : 0;
+  if (left > 1) e1 = load_pstage(stages, si1);
+  __syncthreads();
+
+  // accumulators
+  double sq[4] = {0.0, 0.0, 0.0, 0.0};
+  double accx = 0.0, sqx = 0.0;     // narrow slot 0 (H == 0 only)
+  double acc[kWaveSlots][4];
+#pragma unroll
+  for (int b = 0; b < kWaveSlots; ++b)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[b][m] = 0.0;
+  RowState rs;                       // (H == 1: the finishing wave)
+  double keep_ssq = 0.0, keep_mu = 0.0;
+  uint32_t pend_w = 0;               // GP-end word waiting for its epilogue
+  int pend_tile = 0;
+
+  auto multiply = [&](uint32_t w, const double* abuf, const double* kbr) {
+    const int nw = (int(w & PW_NACT_MASK) - H + 1) >> 1;   // this wave's active slots
+    if (nw > 0 && !PGP_ABL(8)) {
+      // B operands: operand (q, m) of lane (k, a, j) is the value of training
+      // point 4 q + k at row 4 m + j
+      const double2_t* r = reinterpret_cast<const double2_t*>(
+          kbr + k4 * kKbRow + (lane & 3) * 2);
+      double kb[4][4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const double2_t a = r[m * 4], b = r[16 + m * 4];
+        kb[m][0] = a.x; kb[m][1] = a.y; kb[m][2] = b.x; kb[m][3] = b.y;
+      }
+      double kvn[4] = {0.0, 0.0, 0.0, 0.0};
+      const bool narrow0 = H == 0 && (w & PW_NARROW) != 0;
+      if (H == 0 && narrow0) {
+        // the plain covariance register of lane (k, point): all four k-steps
+        const double2_t* rn = reinterpret_cast<const double2_t*>(
+            kbr + k4 * kKbRow + c16 * 2);
+        const double2_t a = rn[0], b = rn[16];
+        kvn[0] = a.x; kvn[1] = a.y; kvn[2] = b.x; kvn[3] = b.y;
+      }
+      const double* aT = abuf + H * (kSteps * 64) + lane;
+      double opsA[4], opsB[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) opsA[q] = aT[q * 64];
+      pair_slots<0, H == 0>(nw, narrow0, acc, accx, aT, kb, kvn, opsA, opsB);
+    }
+    if (w & PW_CHUNK_END) {
+#pragma unroll
+      for (int b = 0; b < kWaveSlots; ++b) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          sq[m] = fma(acc[b][m], acc[b][m], sq[m]);
+          acc[b][m] = 0.0;
+        }
+      }
+      if (H == 0) {
+        sqx = fma(accx, accx, sqx);
+        accx = 0.0;
+      }
+    }
+  };
+
+  // this wave's share of |L^-1 k|^2 and alpha . k at the 16 rows (lane l: row l & 15)
+  auto gp_partials = [&](double& ssq, double& mu) {
+    const bool a0 = (lane & 4) != 0, a1 = (lane & 8) != 0;
+    double v0 = (a0 ? sq[1] : sq[0]) + __shfl_xor(a0 ? sq[0] : sq[1], 4, 64);
+    double v1 = (a0 ? sq[3] : sq[2]) + __shfl_xor(a0 ? sq[2] : sq[3], 4, 64);
+    double s = (a1 ? v1 : v0) + __shfl_xor(a1 ? v0 : v1, 8, 64);
+    if (H == 0) s += sqx;
+    ssq = sum_lane_groups(s);
+    mu = sum_lane_groups(mean_done);
+    sq[0] = sq[1] = sq[2] = sq[3] = 0.0;
+    sqx = 0.0;
+  };
+
+  auto finish = [&](int par_prev) {
+    const double* ex = exch + par_prev * 32;
+    const double ssq = keep_ssq + ex[c16];
+    const double mu = keep_mu + ex[16 + c16];
+    const int g = int(pend_w >> PW_G_SHIFT) & 7;
+    const double kdiag = gpc[g].kern.kdiag;
+    const double var = fmax(kdiag - ssq, 1e-15);  // GPy clip
+    row_epilogue<D, MODE>(p, rs, pend_w, pend_tile, pr, lane, mu, var, qst);
+    pend_w = 0;
+  };
+
+  int par = 0;
+#pragma unroll 1
+  while (true) {
+    const bool more = left > 1;
+    const uint32_t wnext = e1.word;
+    const bool next_tile_first = si1 == 0;
+
+    if (H == 1 && pend_w != 0 && !PGP_ABL(32)) finish(par ^ 1);
+
+    // ---- prefetch: A chunk of the next stage, training block of the one after it
+    if (more && !PGP_ABL(2)) {
+      a_dma(e1, lds_a + uint32_t(par ^ 1) * (L::kATile * 8), wave, voff);
+      if (wave == 7) xa_dma<D>(e1.xa_next, lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
+    }
+    int si2 = si1 + 1;
+    if (si2 == nstages) si2 = 0;
+    PStage e2 = e1;
+    if (left > 2) e2 = load_pstage(stages, si2);
+
+    const double* abuf = lds + par * L::kATile;
+    const double* kbr = kbp + par * L::kKbBuf;
+    double* kbw = kbp + (par ^ 1) * L::kKbBuf;
+    const double* xa = lds + L::kXOff + (par ^ 1) * L::kXBuf;
+
+    if (H == 0) multiply(wcur, abuf, kbr);
+    if (wcur & PW_GP_END) {
+      mean_done = mean;
+      mean = 0.0;
+    }
+    if (more) evaluate(wnext, next_tile_first, xa, kbw);
+    if (H == 1) multiply(wcur, abuf, kbr);
+
+    if (wcur & PW_GP_END) {
+      double ssq, mu;
+      gp_partials(ssq, mu);
+      if (H == 0) {
+        if (lane < 16) {
+          exch[par * 32 + lane] = ssq;
+          exch[par * 32 + 16 + lane] = mu;
+        }
+      } else {
+        keep_ssq = ssq;
+        keep_mu = mu;
+        pend_w = wcur;
+        pend_tile = tile;
+      }
+      if (wcur & PW_TILE_END) tile += tstep;
+    }
+
+    if (!more) break;
+    wait_dma();
+    if (!PGP_ABL(1)) __syncthreads();
+    par ^= 1;
+    wcur = wnext;
+    e1 = e2;
+    si = si1;
+    si1 = si2;
+    --left;
+  }
+  (void)si;
+  __syncthreads();
+  if (H == 1) {
+    if (pend_w != 0 && !PGP_ABL(32)) finish(par);
+    if (conf && p.conf.S) {
+      const double m = wave_max(rs.lmax);
+      if (lane == 0) p.conf.partial[int(blockIdx.x) * kPairs + pr] = m;
+    }
+  }
+}
+
+template <int D, int MODE, bool SINGLE>
+__global__ __launch_bounds__(512, 1) void k_sweep_pair(PairParams p) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  exp_tab_init(lds + LayP<D>::kTabOff);   // visible after the first barrier
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (int(blockIdx.x) * kTileRows >= p.pts.N) return;
+  if (wave < 4)
+    pair_loop<D, MODE, SINGLE, 0>(p, lds, lane, wave);
+  else
+    pair_loop<D, MODE, SINGLE, 1>(p, lds, lane, wave);
+}
+
+// ---- host side ------------------------------------------------------------------
+// The stage sequence of one tile: for every GP, for every chunk of 32 row blocks
+// of L^-1, the j-blocks 0 .. bend-1.  Entries hold absolute addresses, so the
+// table is rebuilt when a block count OR a buffer address changes (buffers are
+// sized for the pitch of L^-1: one-row appends keep their addresses).
+int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d,
+                     const PStage** dev, int* nstages) {
+  std::vector<uint64_t> sig(1, uint64_t(Geff));
+  sig.push_back(uint64_t(d));
+  for (int g = 0; g < Geff; ++g) {
+    sig.push_back(uint64_t(gh[g].nblk));
+    sig.push_back(uint64_t(gh[g].narrow));
+    sig.push_back(reinterpret_cast<uint64_t>(gh[g].Apack));
+    sig.push_back(reinterpret_cast<uint64_t>(gh[g].XA));
+  }
+  if (sig == ctx->pstage_sig && ctx->pstage_tab.p) {
+    *dev = static_cast<const PStage*>(ctx->pstage_tab.p);
+    *nstages = ctx->pstage_count;
+    return 0;
+  }
+  std::vector<PStage> tab;
+  std::vector<uint64_t> xa;
+  const uint64_t xa_block = uint64_t(16 * d + 16) * sizeof(double);
+  for (int g = 0; g < Geff; ++g) {
+    const int nblk = gh[g].nblk, nsteps = gh[g].n_pad / 4;
+    const int nchunks = (nblk + kPairSlots - 1) / kPairSlots;
+    const uint64_t apack = reinterpret_cast<uint64_t>(gh[g].Apack);
+    for (int c = 0; c < nchunks; ++c) {
+      const int b0 = c * kPairSlots, nib = std::min(kPairSlots, nblk - b0),
+                bend = b0 + nib;
+      for (int jb = 0; jb < bend; ++jb) {
+        PStage e{};
+        e.a_src = apack + (uint64_t(bend - 1) * nsteps + 4 * uint64_t(jb)) * 512;
+        e.rs_bytes = uint32_t(nsteps) * 512u;
+        e.word = uint32_t(std::min(nib, bend - jb)) | (uint32_t(g) << PW_G_SHIFT);
+        if (jb == bend - 1) e.word |= PW_CHUNK_END;
+        if (c == nchunks - 1) e.word |= PW_MEAN;
+        if (c == nchunks - 1 && gh[g].narrow) e.word |= PW_NARROW;
+        if (c == 0 && jb == 0) e.word |= PW_GP_FIRST;
+        if (c == nchunks - 1 && jb == bend - 1) {
+          e.word |= PW_GP_END;
+          if (g == Geff - 1) e.word |= PW_TILE_END;
+        }
+        tab.push_back(e);
+        xa.push_back(reinterpret_cast<uint64_t>(gh[g].XA) + uint64_t(jb) * xa_block);
+      }
+    }
+  }
+  for (size_t i = 0; i < tab.size(); ++i) tab[i].xa_next = xa[(i + 1) % tab.size()];
+  SGP_TRY(sgp_reserve(ctx, &ctx->pstage_tab, tab.size() * sizeof(PStage)));
+  SGP_TRY(sgp_h2d(ctx, ctx->pstage_tab.p, tab.data(), tab.size() * sizeof(PStage)));
+  ctx->pstage_sig = sig;
+  ctx->pstage_count = int(tab.size());
+  *dev = static_cast<const PStage*>(ctx->pstage_tab.p);
+  *nstages = ctx->pstage_count;
+  return 0;
+}
+
+// persistent: one workgroup per CU (512 threads, ~156 KB of LDS)
+int pair_grid_blocks(int num_cu, int64_t N) {
+  const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
+  return int(ntiles < num_cu ? ntiles : num_cu);
+}
+
+template <int D, int MODE, bool SINGLE>
+int launch_pair_v(sgp_ctx* ctx, const PairParams& p, double flops) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    SGP_HIP(ctx, hipFuncSetAttribute(
+                     reinterpret_cast<const void*>(&k_sweep_pair<D, MODE, SINGLE>),
+                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                     int(LayP<D>::bytes())));
+    attr_set = true;
+  }
+  const int nblocks = pair_grid_blocks(ctx->num_cu, p.pts.N);
+  SweepTimer timer;
+  SGP_TRY(timer.begin(ctx, flops));
+  PairParams pp = p;
+#ifdef SGP_INSTRUMENT
+  static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
+  pp.ablate = ablate;
+#endif
+  hipLaunchKernelGGL((k_sweep_pair<D, MODE, SINGLE>), dim3(nblocks), dim3(512),
+                     LayP<D>::bytes(), ctx->stream, pp);
+  SGP_HIP(ctx, hipGetLastError());
+  return timer.end(ctx);
+}
+
+template <int D>
+int launch_pair_d(sgp_ctx* ctx, const PairParams& p, int mode, bool single,
+                  double flops) {
+  if (mode == MODE_CONF)
+    return single ? launch_pair_v<D, MODE_CONF, true>(ctx, p, flops)
+                  : launch_pair_v<D, MODE_CONF, false>(ctx, p, flops);
+  return single ? launch_pair_v<D, MODE_FITNESS, true>(ctx, p, flops)
+                : launch_pair_v<D, MODE_FITNESS, false>(ctx, p, flops);
+}
+
+}  // namespace
+
+// The paired kernel pays off once a factor needs more than one pass of the
+// 4-wave kernel (more than 256 rows); sgp_ctx_set_sweep or SGP_SWEEP=pair|classic
+// force a choice (A/B runs of profiles/, tests).
+bool pair_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff) {
+  static const char* force = getenv("SGP_SWEEP");
+  if (ctx->sweep_choice == 2) return true;
+  if (ctx->sweep_choice == 1) return false;
+  if (force && force[0] == 'p') return true;
+  if (force && force[0] == 'c') return false;
+  int np = 0;
+  for (int g = 0; g < Geff; ++g) np = std::max(np, gh[g].n_pad);
+  return np > 256;
+}
+
+int pair_sweep_partials(const sgp_ctx* ctx, int64_t N) {
+  return pair_grid_blocks(ctx->num_cu, N) * kPairs;
+}
+
+int launch_sweep_pair(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d,
+                      int Geff, double flops) {
+  PairParams p{};
+  p.gps = a.gps;
+  p.G = a.G;
+  p.pts = a.pts;
+  p.conf = a.conf;
+  p.fit = a.fit;
+  SGP_TRY(pair_stage_table(ctx, gh, Geff, d, &p.stages, &p.nstages));
+  bool single = true;
+  for (int g = 0; g < Geff; ++g) single = single && gh[g].kern.n_parts == 1;
+  switch (d) {
+    case 1: return launch_pair_d<1>(ctx, p, a.mode, single, flops);
+    case 2: return launch_pair_d<2>(ctx, p, a.mode, single, flops);
+    case 3: return launch_pair_d<3>(ctx, p, a.mode, single, flops);
+    case 4: return launch_pair_d<4>(ctx, p, a.mode, single, flops);
+    case 5: return launch_pair_d<5>(ctx, p, a.mode, single, flops);
+    case 6: return launch_pair_d<6>(ctx, p, a.mode, single, flops);
+    case 7: return launch_pair_d<7>(ctx, p, a.mode, single, flops);
+    case 8: return launch_pair_d<8>(ctx, p, a.mode, single, flops);
+  }
+  sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
+  return -2;
+}

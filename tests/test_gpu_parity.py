@@ -114,6 +114,95 @@ def test_predict_noiseless(mods, kind, n, d):
     assert v.min() >= 1e-15
 
 
+# The whole-grid sweep (SafeOpt.update_confidence_intervals, gp_opt.py:453-481)
+# through both sweep kernels: the 4-wave kernel (csrc/sweep.hip) and the
+# paired-wave kernel (csrc/sweep_pair.hip), each FORCED on every shape -- one
+# j-block, ragged tiles, accumulator-chunk boundaries of both (256 / 512 rows),
+# narrow last row blocks (n = 16 k + 1..4), up to 8 GPs (more than the 6 whose Q
+# rows are staged in LDS), GPs of different sizes in one launch, d up to 8.
+SWEEP_CASES = [
+    # kind, d, [n per GP], N
+    ("RBF", 1, [1], 70), ("Matern52", 2, [17], 64), ("RBF", 2, [16, 3], 129),
+    ("Matern32", 2, [200], 1000), ("RBF", 2, [255, 257], 777),
+    ("Matern52", 2, [500, 500, 500], 2000), ("RBF", 3, [512], 640),
+    ("RBF", 3, [513, 40], 999), ("Matern52", 2, [529], 1111),
+    ("RBF", 3, [1000], 1500), ("Matern32", 4, [1040, 100], 700),
+    ("RBF", 4, [2000, 2000], 300), ("RBF", 2, [33] * 8, 500),
+    ("Matern52", 5, [300] * 7, 321), ("RBF", 8, [130, 290], 450),
+    ("Matern32", 6, [600], 200), ("RBF", 7, [64, 1, 270], 260),
+]
+
+
+@pytest.mark.parametrize("which", ["classic", "pair"])
+@pytest.mark.parametrize("kind,d,ns,N", SWEEP_CASES)
+def test_grid_sweep_both_kernels(mods, which, kind, d, ns, N):
+    _, gpy, gpn, son = mods
+    from safeopt_amd import _hip
+    rng = np.random.default_rng(sum(ns) + 17 * d + N)
+    gps, gos = [], []
+    for i, n in enumerate(ns):
+        X = rng.uniform(-2, 2, size=(n, d)); Y = smooth(X, 5 + i) + 0.3
+        gps.append(gpy.models.GPRegression(X, Y, kernels(gpy.kern, kind, d), noise_var=0.05 ** 2))
+        gos.append(gpn.GPRegression(X, Y, kernels(gpn, kind, d), noise_var=0.05 ** 2))
+    pts = rng.uniform(-3, 3, size=(N, d))
+    G = len(ns)
+    fmin = np.where(np.arange(G) % 3 == 2, -np.inf, 0.1)
+    ctx = gps[0]._fitted().ctx
+    old = ctx.set_sweep(which)
+    try:
+        grid = _hip.DeviceGrid(ctx, pts, G)
+        max_l, any_safe = grid.confidence([g._fitted() for g in gps], 2.0, fmin)
+        Q = grid.download(_hip.Q); S = grid.download(_hip.S)
+        mean = grid.download(_hip.MEAN); var = grid.download(_hip.VAR)
+    finally:
+        ctx.set_sweep(old)
+    Qo = np.empty((N, 2 * G))
+    for i, go in enumerate(gos):
+        mo, vo = go.predict_noiseless(pts)
+        check_posterior(mean[i][:, None], var[i][:, None], mo, vo, 1.7)
+        sd = np.sqrt(vo[:, 0])
+        Qo[:, 2 * i] = mo[:, 0] - 2.0 * sd; Qo[:, 2 * i + 1] = mo[:, 0] + 2.0 * sd
+    assert_allclose(Q, Qo, rtol=0, atol=2e-8)
+    # Q is exactly what mean / var give (same arithmetic as the reference line)
+    for i in range(G):
+        sd = np.sqrt(var[i])
+        assert_array_equal(Q[:, 2 * i], mean[i] - 2.0 * sd)
+        assert_array_equal(Q[:, 2 * i + 1], mean[i] + 2.0 * sd)
+    So = np.all(Q[:, ::2] > fmin, axis=1)
+    assert_array_equal(S, So)
+    assert any_safe == bool(So.any())
+    if So.any():
+        assert max_l == Q[So, 0].max()
+
+
+@pytest.mark.parametrize("which", ["classic", "pair"])
+def test_swarm_fitness_both_kernels(mods, which):
+    """_compute_particle_fitness (gp_opt.py:901-1013) on more particles than the
+    few-points path takes, through both sweep kernels."""
+    safeopt_amd, gpy, gpn, son = mods
+    from safeopt_amd import _hip
+    rng = np.random.default_rng(11)
+    d, P = 3, 5000
+    gps, gos = [], []
+    for i, n in enumerate([300, 530]):
+        X = rng.uniform(-2, 2, size=(n, d)); Y = smooth(X, 9 + i) + 0.2
+        gps.append(gpy.models.GPRegression(X, Y, kernels(gpy.kern, "RBF", d), noise_var=0.05 ** 2))
+        gos.append(gpn.GPRegression(X, Y, kernels(gpn, "RBF", d), noise_var=0.05 ** 2))
+    parts = rng.uniform(-2.5, 2.5, size=(P, d))
+    fmin = np.array([0.0, 0.1]); scaling = np.array([1.3, 1.1])
+    ctx = gps[0]._fitted().ctx
+    old = ctx.set_sweep(which)
+    try:
+        for st in ["greedy", "maximizers", "expanders", "safe_set"]:
+            v, s = _hip.swarm_fitness(ctx, [g._fitted() for g in gps], st, parts, 2.0,
+                                      fmin, scaling, 0.4)
+            vo, so = son.swarm_fitness(gos, parts, st, 2., fmin, scaling, 0.4)
+            assert_array_equal(s, so)
+            assert_allclose(v, vo, rtol=1e-7, atol=1e-8)
+    finally:
+        ctx.set_sweep(old)
+
+
 def test_predict_product_kernel_and_refit(mods):
     _, gpy, gpn, _ = mods
     rng = np.random.default_rng(5)
