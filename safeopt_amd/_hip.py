@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsafeopt_hip.so")
+# (SAFEOPT_HIP_LIB: another build of the same library, for same-box A/B runs)
+LIB_PATH = os.environ.get("SAFEOPT_HIP_LIB") or os.path.join(_HERE, "libsafeopt_hip.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)

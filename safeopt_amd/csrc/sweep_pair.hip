@@ -47,6 +47,28 @@ constexpr int kPairs = 4;              // pairs per workgroup (64 rows per tile)
 constexpr int kTileRows = 16 * kPairs;
 constexpr int kKbRow = 80;             // doubles between the k-rows of a B buffer
 
+// experiment switches (scripts/dev/build_variant.sh; defaults = the kept kernel)
+#ifndef PGP_ORDER
+#define PGP_ORDER 0     // 0: half 0 multiplies first, half 1 evaluates first
+#endif                  // 1: both multiply first   2: both evaluate first
+#ifndef PGP_ADJ
+#define PGP_ADJ 0       // 1: pairs are adjacent waves (2p, 2p+1) instead of (p, p+4)
+#endif
+#ifndef PGP_DMA_LATE
+#define PGP_DMA_LATE 0  // 1: waves that multiply first issue their LDS-DMA after it
+#endif
+#ifndef PGP_DMA_MODE
+#define PGP_DMA_MODE 2  // 0: every wave issues its share of the next A chunk at the top
+#endif                  //    of the stage (slots w, w+8, ..)
+                        // 1: every wave, interleaved with its own slot sequence
+                        // 2: the waves of half 0 only (slots w, w+4, ..), interleaved
+#ifndef PGP_EVAL_PRIO
+#define PGP_EVAL_PRIO 3 // s_setprio level of the evaluation (VALU) phase
+#endif
+#ifndef PGP_H1_PRIO
+#define PGP_H1_PRIO 0   // s_setprio level of half 1 outside its evaluation phase
+#endif
+
 // One stage (GP, chunk, j-block) of a tile.  Global slot t of the staged chunk
 // holds row block bend-1-t, k-steps 4 jb .. 4 jb + 3; its source is
 // a_src - t * rs_bytes.
@@ -100,7 +122,24 @@ struct PairParams {
 #ifdef SGP_INSTRUMENT
   int ablate;
 #endif
+#ifdef PGP_STAMPS
+  unsigned long long* stamps;   // [blocks][8 waves][8] cycles per phase (debug build)
+#endif
 };
+
+// Per-phase cycle stamps of the stage loop (-DPGP_STAMPS, scripts/dev): s_memtime at
+// the phase boundaries, summed per wave.  Perturbs the run (every stamp drains the
+// LDS / scalar-load counter); for attribution only.
+#ifdef PGP_STAMPS
+#define PGP_STAMP(i)                                                   \
+  do {                                                                 \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();        \
+    stamp_acc[i] += (unsigned int)(t_ - stamp_prev);                   \
+    stamp_prev = t_;                                                   \
+  } while (0)
+#else
+#define PGP_STAMP(i) do {} while (0)
+#endif
 
 #ifdef SGP_INSTRUMENT
 #define PGP_ABL(mask) (p.ablate & (mask))
@@ -174,16 +213,38 @@ __device__ __forceinline__ void xa_dma(uint64_t src, uint32_t dst, int lane,
   }
 }
 
+// The share of one wave in the copy of the next A chunk, issued piecewise between
+// the slots of the running stage (PGP_DMA_MODE 1, 2): group i is the global slot
+// w + kStride i, wanted when left > kStride i.
+struct DmaPlan {
+  uint64_t src0;     // source of the wave's first slot
+  uint64_t step;     // bytes between its consecutive slots (kStride row blocks)
+  uint32_t dst0;     // LDS byte address of the wave's first slot
+  uint32_t voff;
+  int left;          // active slots - first slot of the wave
+  bool on;
+};
+template <int kGroups>
+__device__ __forceinline__ void dma_group(const DmaPlan& d, int i) {
+  constexpr int kStride = 32 / (kGroups > 0 ? kGroups : 1);   // global slots between groups
+  if (d.on && d.left > kStride * i)
+    dma_2k(d.src0 - uint64_t(i) * d.step, d.dst0 + uint32_t(i) * (kStride * 2048u),
+           d.voff);
+}
+
 // ---- matrix part (operand maps: see sweep.hip) ------------------------------------
 // Local slot S of wave h is global slot 2 S + h; aT points at the wave's first slot
 // (+ lane), consecutive local slots are 2 * kSteps * 64 doubles apart.
-template <int S, bool NARROW_OK>
+// kGroups > 0: one group of the wave's LDS-DMA share goes out after every
+// (16 / kGroups)-th slot.
+template <int S, bool NARROW_OK, int kGroups>
 __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
                                            double (&acc)[kWaveSlots][4], double& accx,
                                            const double* aT,
                                            const double (&kb)[4][4],
                                            const double (&kvn)[4],
-                                           double (&cur)[4], double (&nxt)[4]) {
+                                           double (&cur)[4], double (&nxt)[4],
+                                           const DmaPlan& dma) {
   if constexpr (S < kWaveSlots) {
     if (S < nw) {
       if (S + 1 < kWaveSlots) {
@@ -206,7 +267,11 @@ __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
       }
       if (S + 1 < kWaveSlots)
         asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
-      pair_slots<S + 1, false>(nw, false, acc, accx, aT, kb, kvn, nxt, cur);
+      if constexpr (kGroups > 0) {
+        constexpr int kEvery = kWaveSlots / kGroups;
+        if (S % kEvery == 0) dma_group<kGroups>(dma, S / kEvery);
+      }
+      pair_slots<S + 1, false, kGroups>(nw, false, acc, accx, aT, kb, kvn, nxt, cur, dma);
     }
   }
 }
@@ -325,7 +390,8 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
                                           const int lane, const int wave) {
   typedef LayP<D> L;
   constexpr bool conf = MODE == MODE_CONF;
-  const int pr = wave & 3;
+  constexpr bool kMultFirst = PGP_ORDER == 0 ? H == 0 : PGP_ORDER == 1;
+  const int pr = PGP_ADJ ? wave >> 1 : wave & 3;
   const int k4 = lane >> 4, c16 = lane & 15;
   const double* tab = lds + L::kTabOff;
   const pstage_ptr_t stages = (pstage_ptr_t)(p.stages);
@@ -425,7 +491,9 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   uint32_t pend_w = 0;               // GP-end word waiting for its epilogue
   int pend_tile = 0;
 
-  auto multiply = [&](uint32_t w, const double* abuf, const double* kbr) {
+  constexpr int kDmaGroups = PGP_DMA_MODE == 1 ? 4 : (PGP_DMA_MODE == 2 && H == 0 ? 8 : 0);
+  auto multiply = [&](uint32_t w, const double* abuf, const double* kbr,
+                      const DmaPlan& dma) {
     const int nw = (int(w & PW_NACT_MASK) - H + 1) >> 1;   // this wave's active slots
     if (nw > 0 && !PGP_ABL(8)) {
       // B operands: operand (q, m) of lane (k, a, j) is the value of training
@@ -451,7 +519,15 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       double opsA[4], opsB[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) opsA[q] = aT[q * 64];
-      pair_slots<0, H == 0>(nw, narrow0, acc, accx, aT, kb, kvn, opsA, opsB);
+      pair_slots<0, H == 0, kDmaGroups>(nw, narrow0, acc, accx, aT, kb, kvn, opsA,
+                                        opsB, dma);
+    }
+    if constexpr (kDmaGroups > 0) {
+      // groups whose slot was not active (the hook sits behind slot kEvery * i)
+      constexpr int kEvery = kWaveSlots / (kDmaGroups > 0 ? kDmaGroups : 1);
+#pragma unroll
+      for (int i = 0; i < kDmaGroups; ++i)
+        if (!(nw > kEvery * i && !PGP_ABL(8))) dma_group<kDmaGroups>(dma, i);
     }
     if (w & PW_CHUNK_END) {
 #pragma unroll
@@ -493,7 +569,12 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     pend_w = 0;
   };
 
+#ifdef PGP_STAMPS
+  unsigned int stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
   int par = 0;
+  if (H == 1 && PGP_H1_PRIO) __builtin_amdgcn_s_setprio(PGP_H1_PRIO);
 #pragma unroll 1
   while (true) {
     const bool more = left > 1;
@@ -501,12 +582,30 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     const bool next_tile_first = si1 == 0;
 
     if (H == 1 && pend_w != 0 && !PGP_ABL(32)) finish(par ^ 1);
+    PGP_STAMP(0);   // deferred row epilogue
 
     // ---- prefetch: A chunk of the next stage, training block of the one after it
-    if (more && !PGP_ABL(2)) {
-      a_dma(e1, lds_a + uint32_t(par ^ 1) * (L::kATile * 8), wave, voff);
-      if (wave == 7) xa_dma<D>(e1.xa_next, lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
+    auto prefetch = [&]() {
+      if (more && !PGP_ABL(2)) {
+        if (PGP_DMA_MODE == 0)
+          a_dma(e1, lds_a + uint32_t(par ^ 1) * (L::kATile * 8), wave, voff);
+        if (wave == 7)
+          xa_dma<D>(e1.xa_next, lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
+      }
+    };
+    if (!(PGP_DMA_LATE && kMultFirst)) prefetch();
+    DmaPlan plan{};
+    if constexpr (kDmaGroups > 0) {
+      // first global slot of this wave in the copy: w (all waves) or w of 0..3
+      const int w0 = PGP_DMA_MODE == 1 ? wave : (PGP_ADJ ? wave >> 1 : wave & 3);
+      plan.src0 = e1.a_src - uint64_t(uint32_t(w0)) * e1.rs_bytes;
+      plan.step = uint64_t(e1.rs_bytes) * (32 / (kDmaGroups > 0 ? kDmaGroups : 1));
+      plan.dst0 = lds_a + uint32_t(par ^ 1) * (L::kATile * 8) + uint32_t(w0) * 2048u;
+      plan.voff = voff;
+      plan.left = int(wnext & PW_NACT_MASK) - w0;
+      plan.on = more && !PGP_ABL(2);
     }
+    PGP_STAMP(1);   // LDS-DMA issue
     int si2 = si1 + 1;
     if (si2 == nstages) si2 = 0;
     PStage e2 = e1;
@@ -517,13 +616,23 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     double* kbw = kbp + (par ^ 1) * L::kKbBuf;
     const double* xa = lds + L::kXOff + (par ^ 1) * L::kXBuf;
 
-    if (H == 0) multiply(wcur, abuf, kbr);
+    if (kMultFirst) {
+      multiply(wcur, abuf, kbr, plan);
+      PGP_STAMP(2);   // matrix phase (B operand reads, slots, chunk fold)
+    }
+    if (PGP_DMA_LATE && kMultFirst) prefetch();
     if (wcur & PW_GP_END) {
       mean_done = mean;
       mean = 0.0;
     }
+    if (PGP_EVAL_PRIO) __builtin_amdgcn_s_setprio(PGP_EVAL_PRIO);
     if (more) evaluate(wnext, next_tile_first, xa, kbw);
-    if (H == 1) multiply(wcur, abuf, kbr);
+    if (PGP_EVAL_PRIO) __builtin_amdgcn_s_setprio(H == 1 ? PGP_H1_PRIO : 0);
+    PGP_STAMP(3);     // covariance evaluation
+    if (!kMultFirst) {
+      multiply(wcur, abuf, kbr, plan);
+      PGP_STAMP(2);
+    }
 
     if (wcur & PW_GP_END) {
       double ssq, mu;
@@ -542,9 +651,12 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       if (wcur & PW_TILE_END) tile += tstep;
     }
 
+    PGP_STAMP(4);     // GP-end partials
     if (!more) break;
     wait_dma();
+    PGP_STAMP(5);     // wait for this wave's LDS-DMA
     if (!PGP_ABL(1)) __syncthreads();
+    PGP_STAMP(6);     // barrier
     par ^= 1;
     wcur = wnext;
     e1 = e2;
@@ -553,6 +665,12 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     --left;
   }
   (void)si;
+#ifdef PGP_STAMPS
+  if (lane == 0) {
+    unsigned long long* o = p.stamps + (size_t(blockIdx.x) * 8 + wave) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = stamp_acc[i];
+  }
+#endif
   __syncthreads();
   if (H == 1) {
     if (pend_w != 0 && !PGP_ABL(32)) finish(par);
@@ -571,7 +689,7 @@ __global__ __launch_bounds__(512, 1) void k_sweep_pair(PairParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (int(blockIdx.x) * kTileRows >= p.pts.N) return;
-  if (wave < 4)
+  if (PGP_ADJ ? (wave & 1) == 0 : wave < 4)
     pair_loop<D, MODE, SINGLE, 0>(p, lds, lane, wave);
   else
     pair_loop<D, MODE, SINGLE, 1>(p, lds, lane, wave);
@@ -659,9 +777,35 @@ int launch_pair_v(sgp_ctx* ctx, const PairParams& p, double flops) {
   static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
   pp.ablate = ablate;
 #endif
+#ifdef PGP_STAMPS
+  static unsigned long long* stamps_dev = nullptr;
+  if (!stamps_dev) SGP_HIP(ctx, hipMalloc(&stamps_dev, size_t(4096) * 64 * 8));
+  pp.stamps = stamps_dev;
+#endif
   hipLaunchKernelGGL((k_sweep_pair<D, MODE, SINGLE>), dim3(nblocks), dim3(512),
                      LayP<D>::bytes(), ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
+#ifdef PGP_STAMPS
+  {
+    std::vector<unsigned long long> h(size_t(nblocks) * 64);
+    SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SGP_HIP(ctx, hipMemcpy(h.data(), stamps_dev, h.size() * 8, hipMemcpyDeviceToHost));
+    static const char* names[8] = {"epilogue", "dma-issue", "matrix", "evaluate",
+                                   "gp-end", "dma-wait", "barrier", "-"};
+    for (int half = 0; half < 2; ++half) {
+      double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
+      for (int b = 0; b < nblocks; ++b)
+        for (int w = 4 * half; w < 4 * half + 4; ++w)
+          for (int i = 0; i < 8; ++i) sum[i] += double(h[(size_t(b) * 8 + w) * 8 + i]);
+      for (int i = 0; i < 8; ++i) tot += sum[i];
+      fprintf(stderr, "stamps half %d (ticks per wave, %% of loop):", half);
+      for (int i = 0; i < 7; ++i)
+        fprintf(stderr, "  %s %.0f (%.1f%%)", names[i], sum[i] / (4.0 * nblocks),
+                100.0 * sum[i] / tot);
+      fprintf(stderr, "  | loop %.0f\n", tot / (4.0 * nblocks));
+    }
+  }
+#endif
   return timer.end(ctx);
 }
 

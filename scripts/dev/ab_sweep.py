@@ -28,7 +28,7 @@ def run(k, reps):
     if k == 5:
         parts = cfg["particles"]
         scaling = np.ones(G)
-        for which in ("classic", "pair"):
+        for which in ((ONLY,) if ONLY else ("classic", "pair")):
             ctx.set_sweep(which)
             res = [_hip.swarm_fitness(ctx, devs, "maximizers", parts, 2.0, fmin, scaling, 0.4)]
             ctx.profile_enable(True)
@@ -43,7 +43,7 @@ def run(k, reps):
         if k == 4:
             pts = pts[4000000:5000000]       # one rank's share of the 200^3 grid
         grid = _hip.DeviceGrid(ctx, pts, G)
-        for which in ("classic", "pair"):
+        for which in ((ONLY,) if ONLY else ("classic", "pair")):
             ctx.set_sweep(which)
             grid.confidence(devs, 2.0, fmin)
             Q = grid.download(_hip.Q)
@@ -55,12 +55,20 @@ def run(k, reps):
             ctx.profile_enable(False)
             out[which] = (ms / n, fl / ms / 1e9, Q)
     ctx.set_sweep("auto")
+    if ONLY:
+        b = out[ONLY]
+        print("cfg %d %s: %.3f ms (%.1f TF, %.3f of 78.6)%s" % (
+            k, ONLY, b[0], b[1], b[1] / 78.6, TAG), flush=True)
+        return
     a, b = out["classic"], out["pair"]
     diff = float(np.max(np.abs(a[2] - b[2])))
     print("cfg %d: classic %.3f ms (%.1f TF, %.3f of 78.6) | pair %.3f ms (%.1f TF, %.3f of 78.6) | "
           "pair/classic %.3f | max |diff| %.2e" %
           (k, a[0], a[1], a[1] / 78.6, b[0], b[1], b[1] / 78.6, b[0] / a[0], diff), flush=True)
 
+
+ONLY = os.environ.get("AB_ONLY")          # "pair" | "classic": time one kernel only
+TAG = "  [%s]" % os.environ["AB_TAG"] if os.environ.get("AB_TAG") else ""
 
 if __name__ == "__main__":
     ks = [int(a) for a in sys.argv[1:]] or [3, 2, 4, 5]

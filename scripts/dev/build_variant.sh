@@ -1,0 +1,15 @@
+#!/bin/bash
+# Build a variant of the library with extra flags for the sweep translation units:
+#   scripts/dev/build_variant.sh NAME "-DPGP_ORDER=1 ..."   -> scripts/dev/ab/NAME.so
+# (the other objects come from the in-tree build; run python -m safeopt_amd.build first)
+set -e
+cd "$(dirname "$0")/../.."
+NAME=$1; FLAGS=$2
+C=safeopt_amd/csrc; O=/tmp/variant_$NAME; mkdir -p $O scripts/dev/ab
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -I $C -Wall -Wno-unused-function"
+/opt/rocm/bin/hipcc $BASE $FLAGS -c $C/sweep_pair.hip -o $O/sweep_pair.o &
+/opt/rocm/bin/hipcc $BASE $FLAGS -c $C/sweep.hip -o $O/sweep.o &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scripts/dev/ab/$NAME.so \
+  $C/api.o $O/sweep.o $O/sweep_pair.o $C/factor.o $C/sets.o $C/swarm.o -ldl
+echo built scripts/dev/ab/$NAME.so
