@@ -303,8 +303,13 @@ __device__ __forceinline__ void mfma_slots(int nact, bool narrow0,
         // four DEPENDENT MFMAs on one accumulator: the addend must not be read
         // before the previous result is written (4 wait states for this opcode;
         // nothing pads inside asm)
+        // (s_nop 1: the register copy of accx the compiler puts in front of this
+        // block is a VALU write, two wait states before an MFMA may read it -- the
+        // hazard recogniser does not see into the asm)
+        asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
+                     : "+v"(accx) : "v"(cur[0]), "v"(kv[0]));
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 1; q < 4; ++q)
           asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
                        : "+v"(accx) : "v"(cur[q]), "v"(kv[q]));
       } else {

@@ -49,7 +49,7 @@ constexpr int kKbRow = 80;             // doubles between the k-rows of a B buff
 
 // experiment switches (scripts/dev/build_variant.sh; defaults = the kept kernel)
 #ifndef PGP_ORDER
-#define PGP_ORDER 0     // 0: half 0 multiplies first, half 1 evaluates first
+#define PGP_ORDER 2     // 0: half 0 multiplies first, half 1 evaluates first
 #endif                  // 1: both multiply first   2: both evaluate first
 #ifndef PGP_ADJ
 #define PGP_ADJ 0       // 1: pairs are adjacent waves (2p, 2p+1) instead of (p, p+4)
@@ -64,6 +64,14 @@ constexpr int kKbRow = 80;             // doubles between the k-rows of a B buff
                         // 2: the waves of half 0 only (slots w, w+4, ..), interleaved
 #ifndef PGP_EVAL_PRIO
 #define PGP_EVAL_PRIO 3 // s_setprio level of the evaluation (VALU) phase
+#endif
+#ifndef PGP_OPS_EARLY
+#define PGP_OPS_EARLY -1 // waves that evaluate first fetch the operands of their matrix
+#endif                   // phase BEFORE the evaluation (their latency passes under the
+                         // VALU burst): 0 no, 1 all of them, 2 the B operands only;
+                         // -1: 2 in the instances that have the registers for it
+#ifndef PGP_PRIO_ALL
+#define PGP_PRIO_ALL 0  // 1: everything outside the slot sequence runs at priority 3
 #endif
 #ifndef PGP_H1_PRIO
 #define PGP_H1_PRIO 0   // s_setprio level of half 1 outside its evaluation phase
@@ -88,6 +96,7 @@ enum : uint32_t {
   PW_MEAN = 1u << 9,        // stage of the LAST chunk: accumulate alpha . k
   PW_NARROW = 1u << 10,     // global slot 0 holds a narrow row block (k_pack)
   PW_GP_FIRST = 1u << 11,   // first stage of a GP
+  PW_LAST_GP = 1u << 15,    // stage of the last GP of the tile
   PW_G_SHIFT = 12           // GP index (3 bits)
 };
 
@@ -237,7 +246,14 @@ __device__ __forceinline__ void dma_group(const DmaPlan& d, int i) {
 // (+ lane), consecutive local slots are 2 * kSteps * 64 doubles apart.
 // kGroups > 0: one group of the wave's LDS-DMA share goes out after every
 // (16 / kGroups)-th slot.
-template <int S, bool NARROW_OK, int kGroups>
+//
+// ASM_MFMA: the matrix instructions as inline asm with tied accumulators (see
+// sweep_shared.h).  The compiler cannot pad hazards around instructions it does not
+// see, and in instances that SPILL it stores accumulators right behind their last
+// MFMA (needs 9 wait states, gets 0 -- scripts/dev/check_mfma_hazards.py finds
+// such code): the instances for d >= 6, the ones that run out of registers, use the
+// builtin instead (a few register copies at the joins of the slot sequence).
+template <int S, bool NARROW_OK, int kGroups, bool ASM_MFMA>
 __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
                                            double (&acc)[kWaveSlots][4], double& accx,
                                            const double* aT,
@@ -252,15 +268,39 @@ __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
         for (int q = 0; q < 4; ++q) nxt[q] = aT[((S + 1) * 2 * kSteps + q) * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (NARROW_OK && S == 0 && narrow0) {
-        // four DEPENDENT MFMAs on one accumulator (4 wait states by hand)
+      // The matrix instructions are inline asm: the compiler's hazard recogniser
+      // does not see them.  A register copy it places at the join in front of a
+      // slot (VALU write) needs two wait states before an MFMA may read that
+      // register: every slot opens with s_nop 1.
+      if (!ASM_MFMA) {
+        if (NARROW_OK && S == 0 && narrow0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+          for (int q = 0; q < 4; ++q)
+            accx = __builtin_amdgcn_mfma_f64_4x4x4f64(cur[q], kvn[q], accx, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+              acc[S][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(cur[q], kb[m][q], acc[S][m],
+                                                             0, 0, 0);
+          }
+        }
+      } else if (NARROW_OK && S == 0 && narrow0) {
+        // four DEPENDENT MFMAs on one accumulator (4 wait states by hand)
+        asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
+                     : "+v"(accx) : "v"(cur[0]), "v"(kvn[0]));
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
           asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
                        : "+v"(accx) : "v"(cur[q]), "v"(kvn[q]));
       } else {
+        asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0"
+                     : "+v"(acc[S][0]) : "v"(cur[0]), "v"(kb[0][0]));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int m = 1; m < 4; ++m) mfma_acc(acc[S][m], cur[0], kb[m][0]);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
 #pragma unroll
           for (int m = 0; m < 4; ++m) mfma_acc(acc[S][m], cur[q], kb[m][q]);
         }
@@ -271,7 +311,8 @@ __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
         constexpr int kEvery = kWaveSlots / kGroups;
         if (S % kEvery == 0) dma_group<kGroups>(dma, S / kEvery);
       }
-      pair_slots<S + 1, false, kGroups>(nw, false, acc, accx, aT, kb, kvn, nxt, cur, dma);
+      pair_slots<S + 1, false, kGroups, ASM_MFMA>(nw, false, acc, accx, aT, kb, kvn, nxt,
+                                                  cur, dma);
     }
   }
 }
@@ -391,6 +432,11 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   typedef LayP<D> L;
   constexpr bool conf = MODE == MODE_CONF;
   constexpr bool kMultFirst = PGP_ORDER == 0 ? H == 0 : PGP_ORDER == 1;
+  // (32 more live registers across the evaluation: instances that would spill for
+  // it -- d >= 6, swarm mode and product kernels from d = 4 -- do without)
+  constexpr int kOpsEarly =
+      PGP_OPS_EARLY >= 0 ? PGP_OPS_EARLY
+                         : ((D <= 3 || (conf && SINGLE && D <= 5)) ? 2 : 0);
   const int pr = PGP_ADJ ? wave >> 1 : wave & 3;
   const int k4 = lane >> 4, c16 = lane & 15;
   const double* tab = lds + L::kTabOff;
@@ -419,27 +465,32 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       xo[k] = __builtin_nontemporal_load(p.pts.base + r * p.pts.stride_row +
                                          k * p.pts.stride_col);
   };
-  double x_e[D], x_n[D], xs_e[D];
+  // x_raw: raw rows of the tile being evaluated -- until the scaled rows of its
+  // LAST GP are formed, from then on already the rows of the next tile (the load
+  // has a whole GP's stages to arrive)
+  double x_raw[D], xs_e[D];
   int tile_e = tile;
-  load_x(tile_e, x_e);
-  load_x(tile_e + tstep, x_n);
+  load_x(tile_e, x_raw);
   KernFast<D> kf;
   kf.load_const(&p.gps[0].kern);
-  kf.template prep_t<SINGLE>(x_e, xs_e);
+  kf.template prep_t<SINGLE>(x_raw, xs_e);
+  if (stages[0].word & PW_LAST_GP) {
+    tile_e += tstep;
+    load_x(tile_e, x_raw);
+  }
 
   // covariances of one stage: this wave's half (training points 8 H .. 8 H + 7 of
   // the j-block) -> the pair's B buffer, [k][q pair][point][2]
-  double mean = 0.0, mean_done = 0.0;
+  double mean = 0.0;
   auto evaluate = [&](uint32_t w1, bool tile_first, const double* xa, double* kbw) {
-    if (w1 & PW_GP_FIRST) {
-      if (tile_first) {
-        tile_e += tstep;
-#pragma unroll
-        for (int k = 0; k < D; ++k) x_e[k] = x_n[k];
-        load_x(tile_e + tstep, x_n);
-      }
+    if (__builtin_expect((w1 & PW_GP_FIRST) != 0, 0)) {
+      (void)tile_first;
       kf.load_const(&p.gps[int(w1 >> PW_G_SHIFT) & 7].kern);
-      kf.template prep_t<SINGLE>(x_e, xs_e);
+      kf.template prep_t<SINGLE>(x_raw, xs_e);
+      if (w1 & PW_LAST_GP) {
+        tile_e += tstep;
+        load_x(tile_e, x_raw);
+      }
     }
     double kv[2];
     if (!PGP_ABL(4)) {
@@ -479,8 +530,8 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   __syncthreads();
 
   // accumulators
-  double sq[4] = {0.0, 0.0, 0.0, 0.0};
-  double accx = 0.0, sqx = 0.0;     // narrow slot 0 (H == 0 only)
+  double ssq_run = 0.0;             // folded squares of the finished chunks (per lane)
+  double accx = 0.0;                // narrow slot 0 (H == 0 only)
   double acc[kWaveSlots][4];
 #pragma unroll
   for (int b = 0; b < kWaveSlots; ++b)
@@ -492,35 +543,48 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   int pend_tile = 0;
 
   constexpr int kDmaGroups = PGP_DMA_MODE == 1 ? 4 : (PGP_DMA_MODE == 2 && H == 0 ? 8 : 0);
-  auto multiply = [&](uint32_t w, const double* abuf, const double* kbr,
-                      const DmaPlan& dma) {
-    const int nw = (int(w & PW_NACT_MASK) - H + 1) >> 1;   // this wave's active slots
-    if (nw > 0 && !PGP_ABL(8)) {
-      // B operands: operand (q, m) of lane (k, a, j) is the value of training
-      // point 4 q + k at row 4 m + j
+  // B operands of a stage (operand (q, m) of lane (k, a, j) = value of training
+  // point 4 q + k at row 4 m + j), the plain covariance register for a narrow slot
+  // 0, and the A operands of the wave's first slot
+  struct Ops {
+    double kb[4][4];
+    double kvn[4];
+    double a0[4];
+  };
+  auto fetch_ops = [&](const double* abuf, const double* kbr, Ops& o, int part) {
+    // part 1: B operands, part 2: the rest, 3: both
+    if (part & 1) {
       const double2_t* r = reinterpret_cast<const double2_t*>(
           kbr + k4 * kKbRow + (lane & 3) * 2);
-      double kb[4][4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const double2_t a = r[m * 4], b = r[16 + m * 4];
-        kb[m][0] = a.x; kb[m][1] = a.y; kb[m][2] = b.x; kb[m][3] = b.y;
+        o.kb[m][0] = a.x; o.kb[m][1] = a.y; o.kb[m][2] = b.x; o.kb[m][3] = b.y;
       }
-      double kvn[4] = {0.0, 0.0, 0.0, 0.0};
-      const bool narrow0 = H == 0 && (w & PW_NARROW) != 0;
-      if (H == 0 && narrow0) {
-        // the plain covariance register of lane (k, point): all four k-steps
-        const double2_t* rn = reinterpret_cast<const double2_t*>(
-            kbr + k4 * kKbRow + c16 * 2);
-        const double2_t a = rn[0], b = rn[16];
-        kvn[0] = a.x; kvn[1] = a.y; kvn[2] = b.x; kvn[3] = b.y;
-      }
-      const double* aT = abuf + H * (kSteps * 64) + lane;
-      double opsA[4], opsB[4];
+    }
+    if (!(part & 2)) return;
+    if (H == 0) {
+      // (read whether slot 0 is narrow or not: two LDS reads are cheaper than a
+      // branch and four register moves next to the matrix instructions)
+      const double2_t* rn = reinterpret_cast<const double2_t*>(
+          kbr + k4 * kKbRow + c16 * 2);
+      const double2_t a = rn[0], b = rn[16];
+      o.kvn[0] = a.x; o.kvn[1] = a.y; o.kvn[2] = b.x; o.kvn[3] = b.y;
+    }
+    const double* aT = abuf + H * (kSteps * 64) + lane;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) opsA[q] = aT[q * 64];
-      pair_slots<0, H == 0, kDmaGroups>(nw, narrow0, acc, accx, aT, kb, kvn, opsA,
-                                        opsB, dma);
+    for (int q = 0; q < 4; ++q) o.a0[q] = aT[q * 64];
+  };
+  auto multiply = [&](uint32_t w, const double* abuf, Ops& o, const DmaPlan& dma) {
+    const int nw = (int(w & PW_NACT_MASK) - H + 1) >> 1;   // this wave's active slots
+    if (nw > 0 && !PGP_ABL(8)) {
+      const bool narrow0 = H == 0 && (w & PW_NARROW) != 0;
+      const double* aT = abuf + H * (kSteps * 64) + lane;
+      double opsB[4];
+      if (PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(0);
+      pair_slots<0, H == 0, kDmaGroups, (D <= 5)>(nw, narrow0, acc, accx, aT, o.kb,
+                                                  o.kvn, o.a0, opsB, dma);
+      if (PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(3);
     }
     if constexpr (kDmaGroups > 0) {
       // groups whose slot was not active (the hook sits behind slot kEvery * i)
@@ -529,7 +593,10 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       for (int i = 0; i < kDmaGroups; ++i)
         if (!(nw > kEvery * i && !PGP_ABL(8))) dma_group<kDmaGroups>(dma, i);
     }
-    if (w & PW_CHUNK_END) {
+    if (__builtin_expect((w & PW_CHUNK_END) != 0, 0)) {
+      // squares of the chunk's accumulators, folded at once to this wave's share of
+      // |L^-1 k|^2 per row (lane l: row l & 15): one register survives the chunk
+      double sq[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int b = 0; b < kWaveSlots; ++b) {
 #pragma unroll
@@ -538,24 +605,25 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
           acc[b][m] = 0.0;
         }
       }
+      // sq[m]: partial sums for column 4m + (lane & 3) over this lane's rows.
+      // Transposing fold over the lanes that share (lane & 3): after the xor-4 and
+      // xor-8 exchanges each lane holds the quad of its OWN column (lane & 15).
+      const bool a0 = (lane & 4) != 0, a1 = (lane & 8) != 0;
+      const double v0 = (a0 ? sq[1] : sq[0]) + __shfl_xor(a0 ? sq[0] : sq[1], 4, 64);
+      const double v1 = (a0 ? sq[3] : sq[2]) + __shfl_xor(a0 ? sq[2] : sq[3], 4, 64);
+      double t = (a1 ? v1 : v0) + __shfl_xor(a1 ? v0 : v1, 8, 64);
       if (H == 0) {
-        sqx = fma(accx, accx, sqx);
+        t = fma(accx, accx, t);     // (narrow slot 0: rows l >> 4, row-of-tile l & 15)
         accx = 0.0;
       }
+      ssq_run += t;
     }
   };
 
-  // this wave's share of |L^-1 k|^2 and alpha . k at the 16 rows (lane l: row l & 15)
-  auto gp_partials = [&](double& ssq, double& mu) {
-    const bool a0 = (lane & 4) != 0, a1 = (lane & 8) != 0;
-    double v0 = (a0 ? sq[1] : sq[0]) + __shfl_xor(a0 ? sq[0] : sq[1], 4, 64);
-    double v1 = (a0 ? sq[3] : sq[2]) + __shfl_xor(a0 ? sq[2] : sq[3], 4, 64);
-    double s = (a1 ? v1 : v0) + __shfl_xor(a1 ? v0 : v1, 8, 64);
-    if (H == 0) s += sqx;
-    ssq = sum_lane_groups(s);
-    mu = sum_lane_groups(mean_done);
-    sq[0] = sq[1] = sq[2] = sq[3] = 0.0;
-    sqx = 0.0;
+  // this wave's share of |L^-1 k|^2 at the 16 rows (lane l: row l & 15)
+  auto gp_partials = [&](double& ssq) {
+    ssq = sum_lane_groups(ssq_run);
+    ssq_run = 0.0;
   };
 
   auto finish = [&](int par_prev) {
@@ -575,6 +643,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
 #endif
   int par = 0;
   if (H == 1 && PGP_H1_PRIO) __builtin_amdgcn_s_setprio(PGP_H1_PRIO);
+  if (PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
   while (true) {
     const bool more = left > 1;
@@ -616,35 +685,43 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     double* kbw = kbp + (par ^ 1) * L::kKbBuf;
     const double* xa = lds + L::kXOff + (par ^ 1) * L::kXBuf;
 
+    Ops ops;
     if (kMultFirst) {
-      multiply(wcur, abuf, kbr, plan);
+      fetch_ops(abuf, kbr, ops, 3);
+      multiply(wcur, abuf, ops, plan);
       PGP_STAMP(2);   // matrix phase (B operand reads, slots, chunk fold)
+    } else if (kOpsEarly) {
+      fetch_ops(abuf, kbr, ops, kOpsEarly == 2 ? 1 : 3);
     }
     if (PGP_DMA_LATE && kMultFirst) prefetch();
-    if (wcur & PW_GP_END) {
-      mean_done = mean;
+    if (__builtin_expect((wcur & PW_GP_END) != 0, 0)) {
+      // alpha . k of the GP that ends here (the evaluation below may already belong
+      // to the next one): half 0 hands its share over, half 1 keeps it
+      const double mu = sum_lane_groups(mean);
       mean = 0.0;
+      if (H == 0) {
+        if (lane < 16) exch[par * 32 + 16 + lane] = mu;
+      } else {
+        keep_mu = mu;
+      }
     }
-    if (PGP_EVAL_PRIO) __builtin_amdgcn_s_setprio(PGP_EVAL_PRIO);
+    if (PGP_EVAL_PRIO && !PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(PGP_EVAL_PRIO);
     if (more) evaluate(wnext, next_tile_first, xa, kbw);
-    if (PGP_EVAL_PRIO) __builtin_amdgcn_s_setprio(H == 1 ? PGP_H1_PRIO : 0);
+    if (PGP_EVAL_PRIO && !PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(H == 1 ? PGP_H1_PRIO : 0);
     PGP_STAMP(3);     // covariance evaluation
     if (!kMultFirst) {
-      multiply(wcur, abuf, kbr, plan);
+      if (kOpsEarly != 1) fetch_ops(abuf, kbr, ops, kOpsEarly == 2 ? 2 : 3);
+      multiply(wcur, abuf, ops, plan);
       PGP_STAMP(2);
     }
 
-    if (wcur & PW_GP_END) {
-      double ssq, mu;
-      gp_partials(ssq, mu);
+    if (__builtin_expect((wcur & PW_GP_END) != 0, 0)) {
+      double ssq;
+      gp_partials(ssq);
       if (H == 0) {
-        if (lane < 16) {
-          exch[par * 32 + lane] = ssq;
-          exch[par * 32 + 16 + lane] = mu;
-        }
+        if (lane < 16) exch[par * 32 + lane] = ssq;
       } else {
         keep_ssq = ssq;
-        keep_mu = mu;
         pend_w = wcur;
         pend_tile = tile;
       }
@@ -734,6 +811,7 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d,
         if (c == nchunks - 1) e.word |= PW_MEAN;
         if (c == nchunks - 1 && gh[g].narrow) e.word |= PW_NARROW;
         if (c == 0 && jb == 0) e.word |= PW_GP_FIRST;
+        if (g == Geff - 1) e.word |= PW_LAST_GP;
         if (c == nchunks - 1 && jb == bend - 1) {
           e.word |= PW_GP_END;
           if (g == Geff - 1) e.word |= PW_TILE_END;

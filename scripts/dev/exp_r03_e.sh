@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 3, experiment E: priority 3 for everything outside the slot sequence
+cd "$(dirname "$0")/../.."
+export AB_ONLY=pair
+for rep in 1 2; do
+for v in cur pa pa_o1 pa_o2; do
+  lib=scripts/dev/ab/$v.so; [ $v = cur ] && lib=safeopt_amd/libsafeopt_hip.so
+  SAFEOPT_HIP_LIB=$lib AB_TAG=$v timeout 300 python scripts/dev/ab_sweep.py 3 4 5 2>&1 | tail -3
+done; done
+for v in cur_s pa_s; do SAFEOPT_HIP_LIB=scripts/dev/ab/$v.so AB_TAG=$v timeout 200 python scripts/dev/ab_sweep.py 3 2>&1 | tail -3; done

@@ -64,3 +64,19 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(root, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_inline_asm_mfma_hazards():
+    """The sweep kernels issue v_mfma_f64_4x4x4_4b_f64 from inline asm (tied
+    accumulators), which the compiler's hazard recogniser cannot pad around.  The
+    scanner walks the ISA of every kernel instance for the data hazards that can
+    then occur (VALU copy -> MFMA read, MFMA write -> spill store, ...): none may
+    be present in the shipped build (needs hipcc, no GPU)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        "scripts", "dev", "check_mfma_hazards.py")
+    spec = importlib.util.spec_from_file_location("check_mfma_hazards", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main([]) == 0
