@@ -482,9 +482,28 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   // covariances of one stage: this wave's half (training points 8 H .. 8 H + 7 of
   // the j-block) -> the pair's B buffer, [k][q pair][point][2]
   double mean = 0.0;
-  auto evaluate = [&](uint32_t w1, bool tile_first, const double* xa, double* kbw) {
+  // the wave's two training rows (8 H + k4 and 4 further) and alpha entries of a
+  // staged j-block: read FIRST in a stage, so that the evaluation does not queue
+  // behind the operand reads of the matrix phase
+  struct Rows {
+    double y[2 * D];
+    double al[2];
+  };
+  auto load_rows = [&](const double* xa, Rows& r) {
+    const double* ys = xa + (8 * H + k4) * D;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < D; ++i) r.y[q * D + i] = ys[q * 4 * D + i];
+    const double* al = xa + kJC * D + 8 * H + k4;
+    r.al[0] = al[0];
+    r.al[1] = al[4];
+  };
+  // (only where the 2 D + 2 registers are there for it; elsewhere the evaluation
+  // reads its rows itself)
+  constexpr bool kRowsFirst = kOpsEarly != 0 && SINGLE && (conf ? D <= 4 : D <= 2);
+  auto evaluate = [&](uint32_t w1, const Rows& r, const double* xa, double* kbw) {
     if (__builtin_expect((w1 & PW_GP_FIRST) != 0, 0)) {
-      (void)tile_first;
       kf.load_const(&p.gps[int(w1 >> PW_G_SHIFT) & 7].kern);
       kf.template prep_t<SINGLE>(x_raw, xs_e);
       if (w1 & PW_LAST_GP) {
@@ -494,15 +513,23 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     }
     double kv[2];
     if (!PGP_ABL(4)) {
-      kf.template manyn_t<2, SINGLE>(xs_e, xa + (8 * H + k4) * D, 4 * D, tab, kv);
+      if (kRowsFirst)
+        kf.template manyn_t<2, SINGLE>(xs_e, r.y, D, tab, kv);
+      else
+        kf.template manyn_t<2, SINGLE>(xs_e, xa + (8 * H + k4) * D, 4 * D, tab, kv);
     } else {
       kv[0] = xs_e[0];
       kv[1] = xs_e[0] + 1.0;
     }
     if (w1 & PW_MEAN) {
-      const double* al = xa + kJC * D + 8 * H + k4;
-      mean = fma(al[0], kv[0], mean);
-      mean = fma(al[4], kv[1], mean);
+      if (kRowsFirst) {
+        mean = fma(r.al[0], kv[0], mean);
+        mean = fma(r.al[1], kv[1], mean);
+      } else {
+        const double* al = xa + kJC * D + 8 * H + k4;
+        mean = fma(al[0], kv[0], mean);
+        mean = fma(al[4], kv[1], mean);
+      }
     }
     *reinterpret_cast<double2_t*>(kbw + k4 * kKbRow + H * 32 + c16 * 2) =
         double2_t{kv[0], kv[1]};
@@ -523,7 +550,9 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   {
     // (stage 0 is the first stage of GP 0: kf / xs_e are set up already)
     const uint32_t w0 = wcur & ~uint32_t(PW_GP_FIRST);
-    evaluate(w0, false, lds + L::kXOff, kbp);
+    Rows r0;
+    if (kRowsFirst) load_rows(lds + L::kXOff, r0);
+    evaluate(w0, r0, lds + L::kXOff, kbp);
   }
   int si1 = (nstages > 1) ? 1 : 0;
   if (left > 1) e1 = load_pstage(stages, si1);
@@ -648,7 +677,6 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   while (true) {
     const bool more = left > 1;
     const uint32_t wnext = e1.word;
-    const bool next_tile_first = si1 == 0;
 
     if (H == 1 && pend_w != 0 && !PGP_ABL(32)) finish(par ^ 1);
     PGP_STAMP(0);   // deferred row epilogue
@@ -686,6 +714,8 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     const double* xa = lds + L::kXOff + (par ^ 1) * L::kXBuf;
 
     Ops ops;
+    Rows rows;
+    if (kRowsFirst && !kMultFirst && more) load_rows(xa, rows);
     if (kMultFirst) {
       fetch_ops(abuf, kbr, ops, 3);
       multiply(wcur, abuf, ops, plan);
@@ -706,7 +736,8 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       }
     }
     if (PGP_EVAL_PRIO && !PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(PGP_EVAL_PRIO);
-    if (more) evaluate(wnext, next_tile_first, xa, kbw);
+    if (kRowsFirst && kMultFirst && more) load_rows(xa, rows);
+    if (more) evaluate(wnext, rows, xa, kbw);
     if (PGP_EVAL_PRIO && !PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(H == 1 ? PGP_H1_PRIO : 0);
     PGP_STAMP(3);     // covariance evaluation
     if (!kMultFirst) {
