@@ -296,9 +296,11 @@ int64_t sgp_ctx_alloc_count(sgp_ctx* ctx);
 /* Which kernel runs gp.predict_noiseless over a grid / a swarm
  * (safeopt/gp_opt.py:469, 929, 973).  0 = automatic (the paired-wave kernel once
  * a GP has more than 256 training rows, csrc/sweep_pair.hip), 1 = always the
- * 4-wave kernel (csrc/sweep.hip), 2 = always the paired-wave kernel.  Same
- * results within rounding; the switch exists for A/B measurements and tests.
- * Returns the previous setting.                                                */
+ * 4-wave kernel (csrc/sweep.hip), 2 = always the paired-wave kernel; + 4: the
+ * paired-wave kernel does not cut remainder tiles into runs of chunks (same bits
+ * either way, tests/test_gpu_parity.py).  Same results within rounding between
+ * the two kernels; the switch exists for A/B measurements and tests.  Returns
+ * the previous setting.                                                        */
 int sgp_ctx_set_sweep(sgp_ctx* ctx, int which);
 
 #ifdef __cplusplus

@@ -250,8 +250,10 @@ class Context(object):
 
     def set_sweep(self, which):
         """Posterior-sweep kernel: 'auto' | 'classic' (4 waves) | 'pair' (paired
-        waves); returns the previous setting."""
-        names = ("auto", "classic", "pair")
+        waves), '-nosplit' appended: remainder tiles are not cut into runs of
+        chunks; returns the previous setting."""
+        names = ("auto", "classic", "pair", None, "auto-nosplit", "classic-nosplit",
+                 "pair-nosplit")
         return names[int(lib().sgp_ctx_set_sweep(self.h, names.index(which)))]
 
     # -- RCCL

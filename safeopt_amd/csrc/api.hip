@@ -221,6 +221,8 @@ void sgp_destroy(sgp_ctx* ctx) {
     if (b.p) (void)hipFree(b.p);
   if (ctx->stage_tab.p) (void)hipFree(ctx->stage_tab.p);
   if (ctx->pstage_tab.p) (void)hipFree(ctx->pstage_tab.p);
+  if (ctx->pair_split.p) (void)hipFree(ctx->pair_split.p);
+  if (ctx->pair_post.p) (void)hipFree(ctx->pair_post.p);
   for (auto e : ctx->prof_events) (void)hipEventDestroy(e);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -449,7 +451,7 @@ int sgp_grid_create(sgp_ctx* ctx, const double* base, int64_t N, int d,
   g->G = G;
   g->goff = global_offset;
   const size_t nd = size_t(N) * sizeof(double);
-  g->partial_cap = N / 16 + 32;
+  g->partial_cap = N / 16 + 32 + 2048;   // (+ the split launches of sweep_pair.hip)
   struct {
     void** p;
     size_t bytes;
@@ -1397,7 +1399,7 @@ int64_t sgp_ctx_alloc_count(sgp_ctx* ctx) { return ctx ? ctx->n_allocs : -1; }
 int sgp_ctx_set_sweep(sgp_ctx* ctx, int which) {
   if (!ctx) return -1;
   const int old = ctx->sweep_choice;
-  if (which >= 0 && which <= 2) ctx->sweep_choice = which;
+  if (which >= 0 && (which & 3) <= 2 && which < 8) ctx->sweep_choice = which;
   return old;
 }
 

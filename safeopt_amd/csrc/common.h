@@ -120,6 +120,11 @@ struct sgp_ctx {
   DevBuf pstage_tab;
   std::vector<uint64_t> pstage_sig;
   int pstage_count = 0;
+  std::vector<int> pstage_chunk_start;   // first stage of every accumulator chunk, then
+                                         // the stage count
+  int pstage_chunk_off[SGP_MAX_GPS + 1] = {0};   // first chunk number of every GP
+  DevBuf pair_split;                     // per-lane partial sums of split remainder tiles
+  DevBuf pair_post;                      // [G][P] mean | var of a swarm (sweep_pair.hip)
   int sweep_partials = 0;     // partials of max l0[S] the last confidence sweep left
   int sweep_choice = 0;       // sgp_ctx_set_sweep: 0 auto, 1 4-wave, 2 paired
   // RCCL

@@ -1085,8 +1085,7 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
   if (pair_sweep_wanted(ctx, gh, Geff)) {
     // more than 256 rows of L^-1: the paired-wave kernel (sweep_pair.hip)
     SweepArgs a{p.gps, p.G, p.mode, p.pts, p.conf, p.fit};
-    ctx->sweep_partials = pair_sweep_partials(ctx, p.pts.N);
-    return launch_sweep_pair(ctx, a, gh, d, Geff, flops);
+    return launch_sweep_pair(ctx, a, gh, d, Geff, flops);   // (sets ctx->sweep_partials)
   }
   ctx->sweep_partials = sweep_grid_blocks(ctx->num_cu, p.pts.N, sweep_waves(), 16) *
                         sweep_waves();

@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "sweep_shared.h"
+#include "small_path.h"
 
 namespace {
 
@@ -97,6 +98,7 @@ enum : uint32_t {
   PW_NARROW = 1u << 10,     // global slot 0 holds a narrow row block (k_pack)
   PW_GP_FIRST = 1u << 11,   // first stage of a GP
   PW_LAST_GP = 1u << 15,    // stage of the last GP of the tile
+  PW_CHUNK_SHIFT = 16,      // running number of the accumulator chunk (6 bits)
   PW_G_SHIFT = 12           // GP index (3 bits)
 };
 
@@ -128,6 +130,23 @@ struct PairParams {
   FitnessArgs fit;
   const PStage* stages;   // [nstages] one tile's stage sequence (all GPs)
   int nstages;
+  // Work split of the launch (pair_plan).  Workgroup w runs the tiles w, w + W, ..
+  // below split_tile0 completely.  With split_parts > 0 the last split_count tiles
+  // (a remainder that would keep a few workgroups busy for one more round while
+  // the rest of the chip idles) are cut into split_parts runs of whole accumulator
+  // chunks: workgroup w < split_count * split_parts takes the stages
+  // [split_s0[i], split_s0[i + 1]), i = w % split_parts, of tile
+  // split_tile0 + w / split_parts and leaves its PER-LANE chunk sums in split_t /
+  // split_m; k_pair_split_finish adds them in the order of the unsplit loop
+  // (bit-identical results) and runs the row epilogue.
+  int geff;               // GPs in the stage table (1 for the greedy swarm)
+  int split_tile0, split_parts, split_count;
+  int split_s0[9];
+  int nchunks;            // chunks in the stage table (all GPs)
+  int chunk_off[SGP_MAX_GPS + 1];   // first chunk number of every GP
+  double* split_t;        // [split_count][nchunks][512]
+  double* split_m;        // [split_count][geff][512]
+  int split_partial0;     // first slot of the finish kernel in ConfOut::partial
 #ifdef SGP_INSTRUMENT
   int ablate;
 #endif
@@ -331,6 +350,10 @@ template <int D, int MODE>
 __device__ __forceinline__ void row_epilogue(const PairParams& p, RowState& rs,
                                              uint32_t w, int tile, int pr, int lane,
                                              double mu, double var, double* qst) {
+  // (no contraction: mu -+ beta sd must round the same way in every kernel this is
+  // inlined into -- the sweep and k_pair_split_finish -- and as in the reference,
+  // which multiplies, then adds)
+#pragma clang fp contract(off)
   typedef LayP<D> L;
   constexpr bool conf = MODE == MODE_CONF;
   const double sd = sqrt(var);
@@ -433,10 +456,9 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   constexpr bool conf = MODE == MODE_CONF;
   constexpr bool kMultFirst = PGP_ORDER == 0 ? H == 0 : PGP_ORDER == 1;
   // (32 more live registers across the evaluation: instances that would spill for
-  // it -- d >= 6, swarm mode and product kernels from d = 4 -- do without)
+  // it -- d >= 6, product kernels -- do without)
   constexpr int kOpsEarly =
-      PGP_OPS_EARLY >= 0 ? PGP_OPS_EARLY
-                         : ((D <= 3 || (conf && SINGLE && D <= 5)) ? 2 : 0);
+      PGP_OPS_EARLY >= 0 ? PGP_OPS_EARLY : ((SINGLE && D <= 5) ? 2 : 0);
   const int pr = PGP_ADJ ? wave >> 1 : wave & 3;
   const int k4 = lane >> 4, c16 = lane & 15;
   const double* tab = lds + L::kTabOff;
@@ -445,8 +467,12 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   const int nstages = p.nstages;
   const int ntiles = int((p.pts.N + kTileRows - 1) / kTileRows);
   const int tstep = int(gridDim.x);
+  // the work items of this workgroup: its whole tiles, then (split launches) one
+  // run of chunks of a remainder tile.  (What describes them is re-read from the
+  // kernel arguments where it is needed -- item set-up, chunk / GP ends -- rather
+  // than kept in scalar registers across the stage loop.)
   int tile = int(blockIdx.x);          // tile of the stage being multiplied
-  int left = ((ntiles - tile + tstep - 1) / tstep) * nstages;   // stages to go
+  int left = 0;                        // stages of the current item still to go
 
   double* kbp = lds + L::kKbOff + pr * (2 * L::kKbBuf);   // the pair's B buffers
   double* exch = lds + L::kExOff + pr * 64;                // ... exchange [2][32]
@@ -470,14 +496,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   // has a whole GP's stages to arrive)
   double x_raw[D], xs_e[D];
   int tile_e = tile;
-  load_x(tile_e, x_raw);
   KernFast<D> kf;
-  kf.load_const(&p.gps[0].kern);
-  kf.template prep_t<SINGLE>(x_raw, xs_e);
-  if (stages[0].word & PW_LAST_GP) {
-    tile_e += tstep;
-    load_x(tile_e, x_raw);
-  }
 
   // covariances of one stage: this wave's half (training points 8 H .. 8 H + 7 of
   // the j-block) -> the pair's B buffer, [k][q pair][point][2]
@@ -501,7 +520,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   };
   // (only where the 2 D + 2 registers are there for it; elsewhere the evaluation
   // reads its rows itself)
-  constexpr bool kRowsFirst = kOpsEarly != 0 && SINGLE && (conf ? D <= 4 : D <= 2);
+  constexpr bool kRowsFirst = kOpsEarly != 0 && SINGLE && D <= 2;
   auto evaluate = [&](uint32_t w1, const Rows& r, const double* xa, double* kbw) {
     if (__builtin_expect((w1 & PW_GP_FIRST) != 0, 0)) {
       kf.load_const(&p.gps[int(w1 >> PW_G_SHIFT) & 7].kern);
@@ -535,28 +554,9 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
         double2_t{kv[0], kv[1]};
   };
 
-  // ---- prologue: A chunk and training block of stage 0, covariances of stage 0
-  PStage e1 = load_pstage(stages, 0);
-  a_dma(e1, lds_a, wave, voff);
-  if (wave == 7) {
-    const PStage el = load_pstage(stages, nstages - 1);
-    xa_dma<D>(el.xa_next, lds_xa, lane, voff);                      // block of stage 0
-    xa_dma<D>(e1.xa_next, lds_xa + L::kXBuf * 8, lane, voff);      // ... of stage 1
-  }
-  uint32_t wcur = e1.word;
-  int si = 0;                               // position of the current stage in the table
-  wait_dma();
-  __syncthreads();
-  {
-    // (stage 0 is the first stage of GP 0: kf / xs_e are set up already)
-    const uint32_t w0 = wcur & ~uint32_t(PW_GP_FIRST);
-    Rows r0;
-    if (kRowsFirst) load_rows(lds + L::kXOff, r0);
-    evaluate(w0, r0, lds + L::kXOff, kbp);
-  }
-  int si1 = (nstages > 1) ? 1 : 0;
-  if (left > 1) e1 = load_pstage(stages, si1);
-  __syncthreads();
+  PStage e1{};
+  uint32_t wcur = 0;
+  int si1 = 0;
 
   // accumulators
   double ssq_run = 0.0;             // folded squares of the finished chunks (per lane)
@@ -645,7 +645,11 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
         t = fma(accx, accx, t);     // (narrow slot 0: rows l >> 4, row-of-tile l & 15)
         accx = 0.0;
       }
-      ssq_run += t;
+      if (p.split_parts > 0 && tile >= p.split_tile0)
+        p.split_t[(size_t(tile - p.split_tile0) * p.nchunks +
+                   (int(w >> PW_CHUNK_SHIFT) & 63)) * 512 + wave * 64 + lane] = t;
+      else
+        ssq_run += t;
     }
   };
 
@@ -673,6 +677,46 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   int par = 0;
   if (H == 1 && PGP_H1_PRIO) __builtin_amdgcn_s_setprio(PGP_H1_PRIO);
   if (PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(3);
+#pragma unroll 1
+  for (int item = 0; item < 2; ++item) {
+  int s_lo = 0;                        // first stage of the item
+  if (item == 0) {
+    const int whole_end = p.split_parts > 0 ? p.split_tile0 : ntiles;
+    if (int(blockIdx.x) >= whole_end) continue;
+    tile = int(blockIdx.x);
+    left = ((whole_end - tile + tstep - 1) / tstep) * nstages;
+  } else {
+    if (!(p.split_parts > 0 && int(blockIdx.x) < p.split_count * p.split_parts)) break;
+    const int part = int(blockIdx.x) % p.split_parts;
+    s_lo = p.split_s0[part];
+    tile = p.split_tile0 + int(blockIdx.x) / p.split_parts;
+    left = p.split_s0[part + 1] - s_lo;
+  }
+  // ---- start of the item.  The pipeline is primed by an EMPTY stage in front of
+  // the first one (no active slots, no flags): its iteration copies the first A
+  // chunk and evaluates the first stage's covariances with the very code every
+  // other stage runs (one copy of the evaluation in the kernel: a stage must give
+  // the same bits wherever an item begins).  Only the training block of the first
+  // stage has to be in LDS before it.
+  par = 0;
+  e1 = load_pstage(stages, s_lo);
+  if (wave == 7) {
+    const PStage el = load_pstage(stages, (s_lo == 0 ? nstages : s_lo) - 1);
+    xa_dma<D>(el.xa_next, lds_xa + L::kXBuf * 8, lane, voff);   // block of the first stage
+  }
+  wcur = 0;
+  ++left;
+  si1 = s_lo;
+  tile_e = tile;
+  load_x(tile_e, x_raw);
+  if (!(e1.word & PW_GP_FIRST)) {
+    // the item begins inside a GP (a run of chunks of a remainder tile)
+    kf.load_const(&p.gps[int(e1.word >> PW_G_SHIFT) & 7].kern);
+    kf.template prep_t<SINGLE>(x_raw, xs_e);
+  }
+  wait_dma();
+  __syncthreads();
+
 #pragma unroll 1
   while (true) {
     const bool more = left > 1;
@@ -704,7 +748,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     }
     PGP_STAMP(1);   // LDS-DMA issue
     int si2 = si1 + 1;
-    if (si2 == nstages) si2 = 0;
+    if (si2 == nstages) si2 = 0;    // (a run of chunks ends before it would wrap)
     PStage e2 = e1;
     if (left > 2) e2 = load_pstage(stages, si2);
 
@@ -727,13 +771,19 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     if (__builtin_expect((wcur & PW_GP_END) != 0, 0)) {
       // alpha . k of the GP that ends here (the evaluation below may already belong
       // to the next one): half 0 hands its share over, half 1 keeps it
-      const double mu = sum_lane_groups(mean);
-      mean = 0.0;
-      if (H == 0) {
-        if (lane < 16) exch[par * 32 + 16 + lane] = mu;
+      if (p.split_parts > 0 && tile >= p.split_tile0) {
+        // (a run of a remainder tile: per lane, summed by k_pair_split_finish)
+        p.split_m[(size_t(tile - p.split_tile0) * p.geff + (int(wcur >> PW_G_SHIFT) & 7)) * 512 +
+                  wave * 64 + lane] = mean;
       } else {
-        keep_mu = mu;
+        const double mu = sum_lane_groups(mean);
+        if (H == 0) {
+          if (lane < 16) exch[par * 32 + 16 + lane] = mu;
+        } else {
+          keep_mu = mu;
+        }
       }
+      mean = 0.0;
     }
     if (PGP_EVAL_PRIO && !PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(PGP_EVAL_PRIO);
     if (kRowsFirst && kMultFirst && more) load_rows(xa, rows);
@@ -747,14 +797,16 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     }
 
     if (__builtin_expect((wcur & PW_GP_END) != 0, 0)) {
-      double ssq;
-      gp_partials(ssq);
-      if (H == 0) {
-        if (lane < 16) exch[par * 32 + lane] = ssq;
-      } else {
-        keep_ssq = ssq;
-        pend_w = wcur;
-        pend_tile = tile;
+      if (!(p.split_parts > 0 && tile >= p.split_tile0)) {
+        double ssq;
+        gp_partials(ssq);
+        if (H == 0) {
+          if (lane < 16) exch[par * 32 + lane] = ssq;
+        } else {
+          keep_ssq = ssq;
+          pend_w = wcur;
+          pend_tile = tile;
+        }
       }
       if (wcur & PW_TILE_END) tile += tstep;
     }
@@ -768,20 +820,20 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     par ^= 1;
     wcur = wnext;
     e1 = e2;
-    si = si1;
     si1 = si2;
     --left;
   }
-  (void)si;
+  // (every wave is done with the buffers before the next item refills them)
+  __syncthreads();
+  if (H == 1 && pend_w != 0 && !PGP_ABL(32)) finish(par);
+  }   // items
 #ifdef PGP_STAMPS
   if (lane == 0) {
     unsigned long long* o = p.stamps + (size_t(blockIdx.x) * 8 + wave) * 8;
     for (int i = 0; i < 8; ++i) o[i] = stamp_acc[i];
   }
 #endif
-  __syncthreads();
   if (H == 1) {
-    if (pend_w != 0 && !PGP_ABL(32)) finish(par);
     if (conf && p.conf.S) {
       const double m = wave_max(rs.lmax);
       if (lane == 0) p.conf.partial[int(blockIdx.x) * kPairs + pr] = m;
@@ -796,11 +848,55 @@ __global__ __launch_bounds__(512, 1) void k_sweep_pair(PairParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (int(blockIdx.x) * kTileRows >= p.pts.N) return;
   if (PGP_ADJ ? (wave & 1) == 0 : wave < 4)
     pair_loop<D, MODE, SINGLE, 0>(p, lds, lane, wave);
   else
     pair_loop<D, MODE, SINGLE, 1>(p, lds, lane, wave);
+}
+
+// Remainder tiles that were cut into runs of chunks (PairParams::split_*): the
+// per-lane chunk sums are added in the order of the unsplit loop -- chunk by chunk
+// into one register, then over the lane groups, then half 1 + half 0 -- so that a
+// row's posterior does not depend on whether its tile was split (same bits), and
+// the row epilogue runs exactly as in k_sweep_pair.  One 512-thread workgroup per
+// tile, wave / lane = the wave / lane of the sweep.
+template <int MODE>
+__global__ __launch_bounds__(512) void k_pair_split_finish(PairParams p) {
+  constexpr bool conf = MODE == MODE_CONF;
+  __shared__ double sh_ex[kPairs][32];
+  __shared__ __attribute__((aligned(16))) double sh_q[kPairs][LayP<1>::kQCap];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pr = PGP_ADJ ? wave >> 1 : wave & 3;
+  const int half = PGP_ADJ ? wave & 1 : wave >> 2;
+  const int c16 = lane & 15;
+  const int pt = int(blockIdx.x);
+  const int tile = p.split_tile0 + pt;
+  RowState rs;
+  for (int g = 0; g < p.geff; ++g) {
+    double ssq_run = 0.0;
+    for (int c = p.chunk_off[g]; c < p.chunk_off[g + 1]; ++c)
+      ssq_run += p.split_t[(size_t(pt) * p.nchunks + c) * 512 + tid];
+    const double ssq = sum_lane_groups(ssq_run);
+    const double mu = sum_lane_groups(p.split_m[(size_t(pt) * p.geff + g) * 512 + tid]);
+    if (half == 0 && lane < 16) {
+      sh_ex[pr][lane] = ssq;
+      sh_ex[pr][16 + lane] = mu;
+    }
+    __syncthreads();
+    if (half == 1) {
+      const double ssq_t = ssq + sh_ex[pr][c16];
+      const double mu_t = mu + sh_ex[pr][16 + c16];
+      const double var = fmax(p.gps[g].kern.kdiag - ssq_t, 1e-15);  // GPy clip
+      uint32_t w = (uint32_t(g) << PW_G_SHIFT) | PW_GP_END;
+      if (g == p.geff - 1) w |= PW_TILE_END;
+      row_epilogue<1, MODE>(p, rs, w, tile, pr, lane, mu_t, var, sh_q[pr]);
+    }
+    __syncthreads();
+  }
+  if (half == 1 && conf && p.conf.S) {
+    const double m = wave_max(rs.lmax);
+    if (lane == 0) p.conf.partial[p.split_partial0 + pt * kPairs + pr] = m;
+  }
 }
 
 // ---- host side ------------------------------------------------------------------
@@ -825,19 +921,24 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d,
   }
   std::vector<PStage> tab;
   std::vector<uint64_t> xa;
+  std::vector<int> chunk_start;
   const uint64_t xa_block = uint64_t(16 * d + 16) * sizeof(double);
   for (int g = 0; g < Geff; ++g) {
     const int nblk = gh[g].nblk, nsteps = gh[g].n_pad / 4;
     const int nchunks = (nblk + kPairSlots - 1) / kPairSlots;
     const uint64_t apack = reinterpret_cast<uint64_t>(gh[g].Apack);
+    ctx->pstage_chunk_off[g] = int(chunk_start.size());
     for (int c = 0; c < nchunks; ++c) {
+      const uint32_t chunk_id = uint32_t(chunk_start.size());
+      chunk_start.push_back(int(tab.size()));
       const int b0 = c * kPairSlots, nib = std::min(kPairSlots, nblk - b0),
                 bend = b0 + nib;
       for (int jb = 0; jb < bend; ++jb) {
         PStage e{};
         e.a_src = apack + (uint64_t(bend - 1) * nsteps + 4 * uint64_t(jb)) * 512;
         e.rs_bytes = uint32_t(nsteps) * 512u;
-        e.word = uint32_t(std::min(nib, bend - jb)) | (uint32_t(g) << PW_G_SHIFT);
+        e.word = uint32_t(std::min(nib, bend - jb)) | (uint32_t(g) << PW_G_SHIFT) |
+                 ((chunk_id & 63u) << PW_CHUNK_SHIFT);
         if (jb == bend - 1) e.word |= PW_CHUNK_END;
         if (c == nchunks - 1) e.word |= PW_MEAN;
         if (c == nchunks - 1 && gh[g].narrow) e.word |= PW_NARROW;
@@ -853,6 +954,9 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d,
     }
   }
   for (size_t i = 0; i < tab.size(); ++i) tab[i].xa_next = xa[(i + 1) % tab.size()];
+  ctx->pstage_chunk_off[Geff] = int(chunk_start.size());
+  chunk_start.push_back(int(tab.size()));
+  ctx->pstage_chunk_start = chunk_start;
   SGP_TRY(sgp_reserve(ctx, &ctx->pstage_tab, tab.size() * sizeof(PStage)));
   SGP_TRY(sgp_h2d(ctx, ctx->pstage_tab.p, tab.data(), tab.size() * sizeof(PStage)));
   ctx->pstage_sig = sig;
@@ -868,6 +972,78 @@ int pair_grid_blocks(int num_cu, int64_t N) {
   return int(ntiles < num_cu ? ntiles : num_cu);
 }
 
+// How a launch spreads its tiles over the chip.  T tiles on C workgroups take
+// ceil(T / C) rounds; a remainder of r < C tiles keeps r workgroups busy for a whole
+// round while the others idle (config 5: 1563 tiles on 256 CUs = 6.1 rounds -> 7).
+// When that costs more than ~1 %, the remainder tiles are cut into `parts` runs of
+// whole accumulator chunks, balanced by stage count, one run per workgroup
+// (PairParams::split_*); the same cut fills the chip when there are fewer tiles
+// than CUs.  SGP_PAIR_SPLIT=0 switches it off (A/B runs).
+struct PairPlan {
+  int nblocks = 0;
+  int tile0 = 0, parts = 0, count = 0;
+  int s0[9] = {0};
+};
+PairPlan pair_plan(const sgp_ctx* ctx, int64_t N) {
+  static const bool off = getenv("SGP_PAIR_SPLIT") && atoi(getenv("SGP_PAIR_SPLIT")) == 0;
+  PairPlan pl;
+  const int C = ctx->num_cu;
+  const int64_t T = (N + kTileRows - 1) / kTileRows;
+  pl.nblocks = int(T < C ? T : C);
+  pl.tile0 = int(T);
+  const std::vector<int>& cs = ctx->pstage_chunk_start;
+  const int nchunks = int(cs.size()) - 1, nstages = ctx->pstage_count;
+  const int64_t full = T / C;
+  const int rem = int(T % C);
+  if (off || (ctx->sweep_choice & 4) || rem == 0 || nchunks < 2 || nchunks > 64 || T >= (int64_t(1) << 30)) return pl;
+  int parts = std::min(std::min(C / rem, nchunks), 8);
+  if (parts < 2) return pl;
+  // contiguous runs of chunks with the smallest possible longest run (the chunks
+  // are few: try every bound)
+  int best_max = nstages + 1, best_parts = 0, best_s0[9] = {0};
+  for (int k = parts; k >= 2; --k) {
+    // smallest bound B such that a greedy cut needs <= k runs
+    int lo = 0, hi = nstages;
+    for (int c = 0; c < nchunks; ++c) lo = std::max(lo, cs[c + 1] - cs[c]);
+    auto runs_for = [&](int B, int* s0) {
+      int runs = 0, start = 0;
+      for (int c = 0; c < nchunks; ++c) {
+        if (cs[c + 1] - cs[start] > B) {
+          if (s0 && runs < 9) s0[runs] = cs[start];
+          ++runs;
+          start = c;
+        }
+      }
+      if (s0 && runs < 9) s0[runs] = cs[start];
+      return runs + 1;
+    };
+    while (lo < hi) {
+      const int mid = (lo + hi) / 2;
+      if (runs_for(mid, nullptr) <= k) hi = mid; else lo = mid + 1;
+    }
+    if (lo < best_max) {
+      int s0[9] = {0};
+      const int r = runs_for(lo, s0);
+      s0[r] = nstages;
+      best_max = lo;
+      best_parts = r;
+      for (int i = 0; i <= r; ++i) best_s0[i] = s0[i];
+    }
+  }
+  if (best_parts < 2) return pl;
+  // rounds with and without the cut (one stage ~ equal work; the cut pipeline
+  // restarts once: count two stages for it)
+  const double with = double(full) + double(best_max + 2) / nstages;
+  const double without = double(full) + 1.0;
+  if (with > 0.99 * without) return pl;
+  pl.parts = best_parts;
+  pl.count = rem;
+  pl.tile0 = int(T) - rem;
+  for (int i = 0; i <= best_parts; ++i) pl.s0[i] = best_s0[i];
+  pl.nblocks = full > 0 ? C : rem * best_parts;
+  return pl;
+}
+
 template <int D, int MODE, bool SINGLE>
 int launch_pair_v(sgp_ctx* ctx, const PairParams& p, double flops) {
   static bool attr_set = false;
@@ -878,10 +1054,26 @@ int launch_pair_v(sgp_ctx* ctx, const PairParams& p, double flops) {
                      int(LayP<D>::bytes())));
     attr_set = true;
   }
-  const int nblocks = pair_grid_blocks(ctx->num_cu, p.pts.N);
+  const PairPlan pl = pair_plan(ctx, p.pts.N);
+  const int nblocks = pl.nblocks;
+  PairParams pp = p;
+  pp.split_tile0 = pl.tile0;
+  pp.split_parts = pl.parts;
+  pp.split_count = pl.count;
+  for (int i = 0; i < 9; ++i) pp.split_s0[i] = pl.s0[i];
+  pp.nchunks = int(ctx->pstage_chunk_start.size()) - 1;
+  for (int g = 0; g <= SGP_MAX_GPS; ++g)
+    pp.chunk_off[g] = g <= p.geff ? ctx->pstage_chunk_off[g] : ctx->pstage_chunk_off[p.geff];
+  pp.split_partial0 = nblocks * kPairs;
+  ctx->sweep_partials = nblocks * kPairs + (pl.parts > 0 ? pl.count * kPairs : 0);
+  if (pl.parts > 0) {
+    const size_t nt = size_t(pl.count) * pp.nchunks * 512, nm = size_t(pl.count) * p.geff * 512;
+    SGP_TRY(sgp_reserve(ctx, &ctx->pair_split, (nt + nm) * sizeof(double)));
+    pp.split_t = static_cast<double*>(ctx->pair_split.p);
+    pp.split_m = pp.split_t + nt;
+  }
   SweepTimer timer;
   SGP_TRY(timer.begin(ctx, flops));
-  PairParams pp = p;
 #ifdef SGP_INSTRUMENT
   static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
   pp.ablate = ablate;
@@ -893,6 +1085,9 @@ int launch_pair_v(sgp_ctx* ctx, const PairParams& p, double flops) {
 #endif
   hipLaunchKernelGGL((k_sweep_pair<D, MODE, SINGLE>), dim3(nblocks), dim3(512),
                      LayP<D>::bytes(), ctx->stream, pp);
+  if (pl.parts > 0)
+    hipLaunchKernelGGL((k_pair_split_finish<MODE>), dim3(pl.count), dim3(512), 0,
+                       ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
 #ifdef PGP_STAMPS
   {
@@ -919,13 +1114,9 @@ int launch_pair_v(sgp_ctx* ctx, const PairParams& p, double flops) {
 }
 
 template <int D>
-int launch_pair_d(sgp_ctx* ctx, const PairParams& p, int mode, bool single,
-                  double flops) {
-  if (mode == MODE_CONF)
-    return single ? launch_pair_v<D, MODE_CONF, true>(ctx, p, flops)
-                  : launch_pair_v<D, MODE_CONF, false>(ctx, p, flops);
-  return single ? launch_pair_v<D, MODE_FITNESS, true>(ctx, p, flops)
-                : launch_pair_v<D, MODE_FITNESS, false>(ctx, p, flops);
+int launch_pair_d(sgp_ctx* ctx, const PairParams& p, bool single, double flops) {
+  return single ? launch_pair_v<D, MODE_CONF, true>(ctx, p, flops)
+                : launch_pair_v<D, MODE_CONF, false>(ctx, p, flops);
 }
 
 }  // namespace
@@ -935,8 +1126,8 @@ int launch_pair_d(sgp_ctx* ctx, const PairParams& p, int mode, bool single,
 // force a choice (A/B runs of profiles/, tests).
 bool pair_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff) {
   static const char* force = getenv("SGP_SWEEP");
-  if (ctx->sweep_choice == 2) return true;
-  if (ctx->sweep_choice == 1) return false;
+  if ((ctx->sweep_choice & 3) == 2) return true;
+  if ((ctx->sweep_choice & 3) == 1) return false;
   if (force && force[0] == 'p') return true;
   if (force && force[0] == 'c') return false;
   int np = 0;
@@ -945,7 +1136,8 @@ bool pair_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff) {
 }
 
 int pair_sweep_partials(const sgp_ctx* ctx, int64_t N) {
-  return pair_grid_blocks(ctx->num_cu, N) * kPairs;
+  (void)N;
+  return ctx->sweep_partials;     // set by the launch (pair_plan)
 }
 
 int launch_sweep_pair(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d,
@@ -956,19 +1148,38 @@ int launch_sweep_pair(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d,
   p.pts = a.pts;
   p.conf = a.conf;
   p.fit = a.fit;
+  p.geff = Geff;
+  const bool fitness = a.mode == MODE_FITNESS;
+  if (fitness) {
+    // SafeOptSwarm._compute_particle_fitness (gp_opt.py:901-1013) = the posterior
+    // of the swarm's GPs (this kernel, mean / var only) + the shaping of
+    // fitness.h on those (k_fitness_small: one thread per particle, same
+    // arithmetic as the epilogue of the 4-wave kernel)
+    const size_t np = size_t(Geff) * size_t(a.pts.N);
+    SGP_TRY(sgp_reserve(ctx, &ctx->pair_post, 2 * np * sizeof(double)));
+    p.conf = ConfOut{};
+    p.conf.mean = static_cast<double*>(ctx->pair_post.p);
+    p.conf.var = p.conf.mean + np;
+    p.G = Geff;
+    for (int i = 0; i < SGP_MAX_GPS; ++i) p.conf.fmin[i] = -INFINITY;
+  }
   SGP_TRY(pair_stage_table(ctx, gh, Geff, d, &p.stages, &p.nstages));
   bool single = true;
   for (int g = 0; g < Geff; ++g) single = single && gh[g].kern.n_parts == 1;
+  int rc = -2;
   switch (d) {
-    case 1: return launch_pair_d<1>(ctx, p, a.mode, single, flops);
-    case 2: return launch_pair_d<2>(ctx, p, a.mode, single, flops);
-    case 3: return launch_pair_d<3>(ctx, p, a.mode, single, flops);
-    case 4: return launch_pair_d<4>(ctx, p, a.mode, single, flops);
-    case 5: return launch_pair_d<5>(ctx, p, a.mode, single, flops);
-    case 6: return launch_pair_d<6>(ctx, p, a.mode, single, flops);
-    case 7: return launch_pair_d<7>(ctx, p, a.mode, single, flops);
-    case 8: return launch_pair_d<8>(ctx, p, a.mode, single, flops);
+    case 1: rc = launch_pair_d<1>(ctx, p, single, flops); break;
+    case 2: rc = launch_pair_d<2>(ctx, p, single, flops); break;
+    case 3: rc = launch_pair_d<3>(ctx, p, single, flops); break;
+    case 4: rc = launch_pair_d<4>(ctx, p, single, flops); break;
+    case 5: rc = launch_pair_d<5>(ctx, p, single, flops); break;
+    case 6: rc = launch_pair_d<6>(ctx, p, single, flops); break;
+    case 7: rc = launch_pair_d<7>(ctx, p, single, flops); break;
+    case 8: rc = launch_pair_d<8>(ctx, p, single, flops); break;
+    default:
+      sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
+      return -2;
   }
-  sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
-  return -2;
+  if (rc != 0 || !fitness) return rc;
+  return launch_fitness_small(ctx, a.G, a.pts.N, p.conf.mean, p.conf.var, a.fit);
 }

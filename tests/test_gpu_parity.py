@@ -175,6 +175,44 @@ def test_grid_sweep_both_kernels(mods, which, kind, d, ns, N):
         assert max_l == Q[So, 0].max()
 
 
+@pytest.mark.parametrize("kind,d,ns,N", [("Matern52", 2, [500, 500, 500], 2000 + 64 * 256),
+                                        ("RBF", 3, [1000], 3000),
+                                        ("RBF", 4, [2000, 1500], 64 * 300 + 5),
+                                        ("Matern32", 2, [300, 20, 600], 777)])
+def test_split_remainder_tiles_same_bits(mods, kind, d, ns, N):
+    """A remainder of tiles that would occupy a few workgroups for a whole round is
+    cut into runs of accumulator chunks (sweep_pair.hip: pair_plan) whose per-lane
+    sums k_pair_split_finish adds in the order of the unsplit loop: mean, var, Q and
+    S must be the SAME BITS with and without the cut (a row's posterior must not
+    depend on where its tile lands -- also what keeps 1/2/4/8-rank runs identical)."""
+    _, gpy, gpn, son = mods
+    from safeopt_amd import _hip
+    rng = np.random.default_rng(N + d)
+    gps = []
+    for i, n in enumerate(ns):
+        X = rng.uniform(-2, 2, size=(n, d)); Y = smooth(X, 5 + i) + 0.3
+        gps.append(gpy.models.GPRegression(X, Y, kernels(gpy.kern, kind, d), noise_var=0.05 ** 2))
+    pts = rng.uniform(-3, 3, size=(N, d))
+    G = len(ns)
+    fmin = np.full(G, 0.1)
+    ctx = gps[0]._fitted().ctx
+    out = {}
+    old = ctx.set_sweep("pair")
+    try:
+        for which in ("pair", "pair-nosplit"):
+            ctx.set_sweep(which)
+            grid = _hip.DeviceGrid(ctx, pts, G)
+            ml = grid.confidence([g._fitted() for g in gps], 2.0, fmin)
+            out[which] = (ml, grid.download(_hip.Q), grid.download(_hip.S),
+                          grid.download(_hip.MEAN), grid.download(_hip.VAR))
+    finally:
+        ctx.set_sweep(old)
+    a, b = out["pair"], out["pair-nosplit"]
+    assert a[0] == b[0]
+    for x, y in zip(a[1:], b[1:]):
+        assert_array_equal(x, y)
+
+
 @pytest.mark.parametrize("which", ["classic", "pair"])
 def test_swarm_fitness_both_kernels(mods, which):
     """_compute_particle_fitness (gp_opt.py:901-1013) on more particles than the
