@@ -274,6 +274,9 @@ int sgp_swarm_run(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
  * iteration (max / any / arg-max / top-k merge).                             */
 int sgp_comm_unique_id(void* id128);              /* rank 0: ncclGetUniqueId  */
 int sgp_comm_init(sgp_ctx* ctx, const void* id128, int rank, int world);
+int sgp_comm_count(sgp_ctx* ctx, int* n);           /* ncclCommCount: ranks that
+                                                     * really joined (1 without a
+                                                     * communicator)              */
 int sgp_comm_allreduce_max(sgp_ctx* ctx, double* buf, int n);   /* in place   */
 int sgp_comm_allgather(sgp_ctx* ctx, const void* send, void* recv,
                        int64_t nbytes);           /* recv = world*nbytes      */
@@ -302,6 +305,14 @@ int64_t sgp_ctx_alloc_count(sgp_ctx* ctx);
  * the two kernels; the switch exists for A/B measurements and tests.  Returns
  * the previous setting.                                                        */
 int sgp_ctx_set_sweep(sgp_ctx* ctx, int which);
+
+/* Multi-output case: consecutive GPs of a launch with bit-identical training
+ * inputs, kernel, noise and fitting history have the same L^-1, so the variance
+ * contraction of gp.predict_noiseless (safeopt/gp_opt.py:466-476 loops over the
+ * GPs independently) is computed once and only alpha . k per GP (paired-wave
+ * kernel; identical results, tests/test_gpu_parity.py).  on = 1 (default) / 0;
+ * returns the previous setting.                                                  */
+int sgp_ctx_set_share(sgp_ctx* ctx, int on);
 
 #ifdef __cplusplus
 }

@@ -117,7 +117,9 @@ PROTOTYPES = {
     "sgp_profile_enable": (C.c_int, [vp, C.c_int]),
     "sgp_profile_read": (C.c_int, [vp, c_double_p, c_i64_p, c_double_p]),
     "sgp_ctx_alloc_count": (C.c_int64, [vp]),
+    "sgp_comm_count": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "sgp_ctx_set_sweep": (C.c_int, [vp, C.c_int]),
+    "sgp_ctx_set_share": (C.c_int, [vp, C.c_int]),
 
 }
 
@@ -212,7 +214,16 @@ class Context(object):
             device = int(os.environ.get("SAFEOPT_HIP_DEVICE",
                                         os.environ.get("LOCAL_RANK", "0")))
             n = device_count()
-            if n > 0:
+            world = int(os.environ.get("LOCAL_WORLD_SIZE",
+                                       os.environ.get("WORLD_SIZE", "1")))
+            if n > 0 and device >= n:
+                if world > 1 and "SAFEOPT_HIP_DEVICE" not in os.environ:
+                    # two ranks on one GPU: RCCL would fail or hang in
+                    # ncclCommInitRank -- say what is wrong instead
+                    raise HipError(
+                        "LOCAL_RANK %d but only %d visible GPU(s): one process per "
+                        "GPU (launch with --nproc-per-node <= %d, or set "
+                        "SAFEOPT_HIP_DEVICE explicitly)" % (device, n, n))
                 device %= n
         if device not in cls._default:
             cls._default[device] = Context(device)
@@ -247,6 +258,17 @@ class Context(object):
     def alloc_count(self):
         """Device allocations made so far (a warm loop must not add any)."""
         return int(lib().sgp_ctx_alloc_count(self.h))
+
+    def comm_count(self):
+        """Ranks of the RCCL communicator (ncclCommCount); 1 without one."""
+        n = C.c_int(0)
+        self.check(lib().sgp_comm_count(self.h, C.byref(n)))
+        return n.value
+
+    def set_share(self, on):
+        """GPs with identical inputs / kernel / noise share the variance contraction
+        of the sweep (default on); returns the previous setting."""
+        return bool(lib().sgp_ctx_set_share(self.h, int(bool(on))))
 
     def set_sweep(self, which):
         """Posterior-sweep kernel: 'auto' | 'classic' (4 waves) | 'pair' (paired

@@ -26,6 +26,7 @@ struct Rccl {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t,
                             ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
 };
 Rccl g_rccl;
 
@@ -55,6 +56,7 @@ int load_rccl(sgp_ctx* ctx) {
   SYM(AllReduce, "ncclAllReduce")
   SYM(AllGather, "ncclAllGather")
   SYM(GetErrorString, "ncclGetErrorString")
+  SYM(CommCount, "ncclCommCount")
 #undef SYM
   return 0;
 }
@@ -104,8 +106,30 @@ int collect_gps(sgp_ctx* ctx, sgp_gp* const* gps, int G, int d, GpDev* host) {
     SGP_CHECK(ctx, gps[g]->kern.d == d, "GP %d input_dim %d != %d", g,
               gps[g]->kern.d, d);
     host[g] = gps[g]->dev;
+    // same inputs, kernel, noise and jitter as the GP in front: same factor (the
+    // factorisation is deterministic), only alpha differs
+    host[g].share = -1;
+    if (ctx->share_factors && g > 0) {
+      const sgp_gp *a = gps[g - 1], *b = gps[g];
+      if (a != b && a->n == b->n && !a->xhash.empty() && a->xhash.size() == size_t(a->n) &&
+          b->xhash.size() == size_t(b->n) && a->xhash.back() == b->xhash.back() &&
+          a->prov == b->prov &&
+          memcmp(&a->kern, &b->kern, sizeof(KernDesc)) == 0 &&
+          a->noise_var == b->noise_var && a->jitter == b->jitter)
+        host[g].share = host[g - 1].share >= 0 ? host[g - 1].share : g - 1;
+    }
   }
   return 0;
+}
+
+// FNV-1a over the bytes of training rows, chained row by row (sgp_gp::xhash)
+uint64_t hash_rows(uint64_t h, const double* rows, size_t count) {
+  const unsigned char* b = reinterpret_cast<const unsigned char*>(rows);
+  for (size_t i = 0; i < count * sizeof(double); ++i) {
+    h ^= b[i];
+    h *= 1099511628211ull;
+  }
+  return h;
 }
 }  // namespace
 
@@ -285,6 +309,15 @@ int sgp_gp_set_data(sgp_gp* gp, const double* X, const double* Y, int64_t n,
   SGP_TRY(sgp_reserve(ctx, &gp->Y, size_t(gp->ld) * sizeof(double)));
   SGP_TRY(sgp_h2d(ctx, gp->X.p, X, size_t(n) * d * sizeof(double)));
   SGP_TRY(sgp_h2d(ctx, gp->Y.p, Y, size_t(n) * sizeof(double)));
+  gp->xhash.resize(size_t(n));
+  {
+    uint64_t h = 14695981039346656037ull;
+    for (int64_t i = 0; i < n; ++i) {
+      h = hash_rows(h, X + i * d, size_t(d));
+      gp->xhash[size_t(i)] = h;
+    }
+    gp->prov = 0x9e3779b97f4a7c15ull ^ uint64_t(n);
+  }
   // GPy util.linalg.jitchol: plain attempt, then jitter = mean(diag)*1e-6,
   // *10 per retry, at most 5 retries.
   gp->jitter = 0.0;
@@ -321,14 +354,25 @@ int sgp_gp_append(sgp_gp* gp, const double* x, double y, int* info) {
   double* Y = static_cast<double*>(gp->Y.p);
   SGP_TRY(sgp_h2d(ctx, X + size_t(gp->n) * d, x, size_t(d) * sizeof(double)));
   SGP_TRY(sgp_h2d(ctx, Y + gp->n, &y, sizeof(double)));
-  return append_gp(gp, y, info);
+  const int64_t n0 = gp->n;
+  SGP_TRY(append_gp(gp, y, info));
+  if (gp->n == n0 + 1) {
+    gp->xhash.resize(size_t(n0));
+    gp->xhash.push_back(hash_rows(n0 > 0 ? gp->xhash.back() : 14695981039346656037ull, x,
+                                  size_t(d)));
+    gp->prov = gp->prov * 1099511628211ull + 2;
+  }
+  return 0;
 }
 
 int sgp_gp_pop(sgp_gp* gp) {
   sgp_ctx* ctx = gp->ctx;
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   SGP_CHECK(ctx, gp->n > 1, "cannot remove the only training point");
-  return pop_gp(gp);
+  SGP_TRY(pop_gp(gp));
+  gp->xhash.resize(size_t(gp->n));
+  gp->prov = gp->prov * 1099511628211ull + 3;
+  return 0;
 }
 
 int sgp_gp_predict(sgp_gp* gp, const double* Xnew, int64_t N,
@@ -1396,6 +1440,13 @@ int sgp_swarm_grow(sgp_ctx* ctx, sgp_gp* gp0, const double* S, int64_t m,
 // ---- timing ---------------------------------------------------------------------
 int64_t sgp_ctx_alloc_count(sgp_ctx* ctx) { return ctx ? ctx->n_allocs : -1; }
 
+int sgp_ctx_set_share(sgp_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  const int old = ctx->share_factors;
+  if (on == 0 || on == 1) ctx->share_factors = on;
+  return old;
+}
+
 int sgp_ctx_set_sweep(sgp_ctx* ctx, int which) {
   if (!ctx) return -1;
   const int old = ctx->sweep_choice;
@@ -1459,6 +1510,13 @@ int sgp_comm_init(sgp_ctx* ctx, const void* id128, int rank, int world) {
   ctx->comm = comm;
   ctx->rank = rank;
   ctx->world = world;
+  return 0;
+}
+
+int sgp_comm_count(sgp_ctx* ctx, int* n) {
+  *n = 1;
+  if (!ctx->comm) return 0;       // no communicator: a single rank
+  SGP_NCCL(ctx, g_rccl.CommCount(static_cast<ncclComm_t>(ctx->comm), n));
   return 0;
 }
 

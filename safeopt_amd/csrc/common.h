@@ -73,6 +73,10 @@ struct GpDev {
   int n;                // training points
   int n_pad;            // n rounded up to 16
   int nblk;             // n_pad / 16
+  int share;            // >= 0: this GP has the same training inputs, kernel and noise
+                        // as the GP in front of it in the launch (the multi-output
+                        // case): same L^-1, so the paired sweep takes |L^-1 k|^2
+                        // from that GP and only forms alpha . k (collect_gps)
   int narrow;           // 1: the last row block has <= 4 real rows and Apack holds
                         // them in the "narrow" form (k_pack): the sweep then needs
                         // one MFMA per k-step for that block instead of four
@@ -127,6 +131,8 @@ struct sgp_ctx {
   DevBuf pair_post;                      // [G][P] mean | var of a swarm (sweep_pair.hip)
   int sweep_partials = 0;     // partials of max l0[S] the last confidence sweep left
   int sweep_choice = 0;       // sgp_ctx_set_sweep: 0 auto, 1 4-wave, 2 paired
+  int share_factors = 1;      // sgp_ctx_set_share: GPs with identical (X, kernel, noise)
+                              // share the variance contraction (paired sweep)
   // RCCL
   void* comm = nullptr;  // ncclComm_t
   int rank = 0, world = 1;
@@ -142,6 +148,10 @@ struct sgp_gp {
   int n_pad = 0;  // multiple of 16 (sweep blocks)
   int n_f = 0;    // multiple of 32 (factorisation leaves)
   int ld = 0;     // leading dimension / row capacity of Linv, Kmat, work
+  std::vector<uint64_t> xhash;   // xhash[i]: hash of the first i + 1 training rows
+  uint64_t prov = 0;             // hash of the operations that led to this factor
+                                 // (fit at n, appends, removals): two GPs with equal
+                                 // inputs AND equal history have the same bits in L^-1
   bool upd_valid = false;  // dev.upd* describes the step to the current data
   DevBuf X, Y, Xpad, Xs, XA, alpha, Apack, Linv, Kmat, work, tvec, updw, upd;
   GpDev dev;      // filled by set_data

@@ -99,6 +99,9 @@ enum : uint32_t {
   PW_GP_FIRST = 1u << 11,   // first stage of a GP
   PW_LAST_GP = 1u << 15,    // stage of the last GP of the tile
   PW_CHUNK_SHIFT = 16,      // running number of the accumulator chunk (6 bits)
+  PW_SHARED = 1u << 22,     // GP with the factor of the GP in front (GpDev::share): its
+                            // stages have no active slots, they only evaluate the
+                            // covariances for alpha . k; |L^-1 k|^2 is the leader's
   PW_G_SHIFT = 12           // GP index (3 bits)
 };
 
@@ -140,6 +143,7 @@ struct PairParams {
   // split_m; k_pair_split_finish adds them in the order of the unsplit loop
   // (bit-identical results) and runs the row epilogue.
   int geff;               // GPs in the stage table (1 for the greedy swarm)
+  unsigned shared_mask;   // bit g: GP g takes |L^-1 k|^2 from the GP in front (PW_SHARED)
   int split_tile0, split_parts, split_count;
   int split_s0[9];
   int nchunks;            // chunks in the stage table (all GPs)
@@ -458,7 +462,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   // (32 more live registers across the evaluation: instances that would spill for
   // it -- d >= 6, product kernels -- do without)
   constexpr int kOpsEarly =
-      PGP_OPS_EARLY >= 0 ? PGP_OPS_EARLY : ((SINGLE && D <= 5) ? 2 : 0);
+      PGP_OPS_EARLY >= 0 ? PGP_OPS_EARLY : ((SINGLE && D <= 4) ? 2 : 0);
   const int pr = PGP_ADJ ? wave >> 1 : wave & 3;
   const int k4 = lane >> 4, c16 = lane & 15;
   const double* tab = lds + L::kTabOff;
@@ -659,9 +663,14 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     ssq_run = 0.0;
   };
 
+  double ssq_lead = 0.0;             // |L^-1 k|^2 of the last GP with a factor of its own
   auto finish = [&](int par_prev) {
     const double* ex = exch + par_prev * 32;
-    const double ssq = keep_ssq + ex[c16];
+    double ssq = keep_ssq + ex[c16];
+    if (pend_w & PW_SHARED)
+      ssq = ssq_lead;
+    else
+      ssq_lead = ssq;
     const double mu = keep_mu + ex[16 + c16];
     const int g = int(pend_w >> PW_G_SHIFT) & 7;
     const double kdiag = gpc[g].kern.kdiag;
@@ -872,6 +881,7 @@ __global__ __launch_bounds__(512) void k_pair_split_finish(PairParams p) {
   const int pt = int(blockIdx.x);
   const int tile = p.split_tile0 + pt;
   RowState rs;
+  double ssq_lead = 0.0;
   for (int g = 0; g < p.geff; ++g) {
     double ssq_run = 0.0;
     for (int c = p.chunk_off[g]; c < p.chunk_off[g + 1]; ++c)
@@ -884,7 +894,11 @@ __global__ __launch_bounds__(512) void k_pair_split_finish(PairParams p) {
     }
     __syncthreads();
     if (half == 1) {
-      const double ssq_t = ssq + sh_ex[pr][c16];
+      double ssq_t = ssq + sh_ex[pr][c16];
+      if (p.shared_mask & (1u << g))
+        ssq_t = ssq_lead;
+      else
+        ssq_lead = ssq_t;
       const double mu_t = mu + sh_ex[pr][16 + c16];
       const double var = fmax(p.gps[g].kern.kdiag - ssq_t, 1e-15);  // GPy clip
       uint32_t w = (uint32_t(g) << PW_G_SHIFT) | PW_GP_END;
@@ -910,7 +924,7 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d,
   sig.push_back(uint64_t(d));
   for (int g = 0; g < Geff; ++g) {
     sig.push_back(uint64_t(gh[g].nblk));
-    sig.push_back(uint64_t(gh[g].narrow));
+    sig.push_back(uint64_t(gh[g].narrow) | (uint64_t(gh[g].share >= 0) << 8));
     sig.push_back(reinterpret_cast<uint64_t>(gh[g].Apack));
     sig.push_back(reinterpret_cast<uint64_t>(gh[g].XA));
   }
@@ -928,6 +942,28 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d,
     const int nchunks = (nblk + kPairSlots - 1) / kPairSlots;
     const uint64_t apack = reinterpret_cast<uint64_t>(gh[g].Apack);
     ctx->pstage_chunk_off[g] = int(chunk_start.size());
+    if (gh[g].share >= 0) {
+      // same factor as the GP in front: one "chunk" without rows -- every j-block
+      // once, for alpha . k
+      const uint32_t chunk_id = uint32_t(chunk_start.size());
+      chunk_start.push_back(int(tab.size()));
+      for (int jb = 0; jb < nblk; ++jb) {
+        PStage e{};
+        e.a_src = apack;
+        e.rs_bytes = uint32_t(nsteps) * 512u;
+        e.word = (uint32_t(g) << PW_G_SHIFT) | ((chunk_id & 63u) << PW_CHUNK_SHIFT) |
+                 PW_MEAN | PW_SHARED;
+        if (jb == 0) e.word |= PW_GP_FIRST;
+        if (g == Geff - 1) e.word |= PW_LAST_GP;
+        if (jb == nblk - 1) {
+          e.word |= PW_CHUNK_END | PW_GP_END;
+          if (g == Geff - 1) e.word |= PW_TILE_END;
+        }
+        tab.push_back(e);
+        xa.push_back(reinterpret_cast<uint64_t>(gh[g].XA) + uint64_t(jb) * xa_block);
+      }
+      continue;
+    }
     for (int c = 0; c < nchunks; ++c) {
       const uint32_t chunk_id = uint32_t(chunk_start.size());
       chunk_start.push_back(int(tab.size()));
@@ -1149,6 +1185,9 @@ int launch_sweep_pair(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d,
   p.conf = a.conf;
   p.fit = a.fit;
   p.geff = Geff;
+  p.shared_mask = 0;
+  for (int g = 0; g < Geff; ++g)
+    if (gh[g].share >= 0) p.shared_mask |= 1u << g;
   const bool fitness = a.mode == MODE_FITNESS;
   if (fitness) {
     // SafeOptSwarm._compute_particle_fitness (gp_opt.py:901-1013) = the posterior

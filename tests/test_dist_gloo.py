@@ -247,3 +247,16 @@ print(uid.hex())
     for p, (out, err) in zip(procs, outs):
         assert p.returncode == 0, err
         assert out.strip() == bytes(range(128)).hex()
+
+
+def test_two_ranks_on_one_gpu_fail_loudly(monkeypatch):
+    """LOCAL_RANK beyond the visible devices used to wrap around (two ranks on one
+    GPU: RCCL then fails or hangs in ncclCommInitRank); now the context refuses."""
+    from safeopt_amd import _hip
+    monkeypatch.setattr(_hip, "device_count", lambda: 1)
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.delenv("SAFEOPT_HIP_DEVICE", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    with pytest.raises(_hip.HipError, match="one process per GPU"):
+        _hip.Context.default()

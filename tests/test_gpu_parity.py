@@ -213,6 +213,56 @@ def test_split_remainder_tiles_same_bits(mods, kind, d, ns, N):
         assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("n,N,layout", [(300, 5000, "aaa"), (530, 3000, "aab"), (400, 20000, "abb"),
+                                        (1100, 2500, "aa")])
+def test_shared_factor_same_bits(mods, n, N, layout):
+    """BASELINE.json config 3 is a multi-output GP: its GPs have the same inputs,
+    kernel and noise, hence the same L^-1.  The paired sweep then takes |L^-1 k|^2
+    from the first of them and only forms alpha . k for the others
+    (sgp_ctx_set_share, default on): Q, S, mean and var must be the same bits as
+    with every GP swept on its own (gp_opt.py:466-476 loops independently), also
+    after identical one-row appends; GPs that differ in anything are not shared."""
+    _, gpy, gpn, son = mods
+    from safeopt_amd import _hip
+    rng = np.random.default_rng(n + N)
+    d = 2
+    Xa = rng.uniform(-2, 2, size=(n, d)); Xb = rng.uniform(-2, 2, size=(n, d))
+    gps = []
+    for i, c in enumerate(layout):
+        X = Xa if c == "a" else Xb
+        gps.append(gpy.models.GPRegression(X, smooth(X, 7 + i) + 0.3, kernels(gpy.kern, "Matern52", d),
+                                           noise_var=0.05 ** 2))
+    pts = rng.uniform(-3, 3, size=(N, d))
+    G = len(layout)
+    fmin = np.full(G, 0.1)
+    ctx = gps[0]._fitted().ctx
+
+    def sweep():
+        res = {}
+        for on in (True, False):
+            old = ctx.set_share(on)
+            try:
+                grid = _hip.DeviceGrid(ctx, pts, G)
+                ml = grid.confidence([g._fitted() for g in gps], 2.0, fmin)
+                res[on] = (ml, grid.download(_hip.Q), grid.download(_hip.S),
+                           grid.download(_hip.MEAN), grid.download(_hip.VAR))
+            finally:
+                ctx.set_share(old)
+        assert res[True][0] == res[False][0]
+        for x, y in zip(res[True][1:], res[False][1:]):
+            assert_array_equal(x, y)
+        return res[True]
+
+    r = sweep()
+    if layout[0] == layout[1]:          # equal factors: equal variances
+        assert_array_equal(r[4][0], r[4][1])
+    # the same new observation point for every GP (SafeOpt.add_new_data_point)
+    xn = rng.uniform(-1, 1, size=(1, d))
+    for i, gp in enumerate(gps):
+        gp.set_XY(np.vstack([gp.X, xn]), np.vstack([gp.Y, [[0.4 + 0.1 * i]]]))
+    sweep()
+
+
 @pytest.mark.parametrize("which", ["classic", "pair"])
 def test_swarm_fitness_both_kernels(mods, which):
     """_compute_particle_fitness (gp_opt.py:901-1013) on more particles than the
