@@ -1006,6 +1006,10 @@ int sgp_grid_sets_front(sgp_grid* g, double max_l, int have_max_var,
   SGP_TRY(launch_topk(g, 0, INFINITY, INT64_MAX, 1, res + 3,
                       reinterpret_cast<int64_t*>(res + 4),
                       reinterpret_cast<int*>(res + 5)));
+  // (the fused single-rank pass counts the ties in k_front_final; here nothing
+  // else writes that word)
+  SGP_TRY(launch_count_ties(g, res + 3, reinterpret_cast<const int*>(res + 5),
+                            reinterpret_cast<int*>(res + 5) + 1));
   SGP_TRY(launch_gather_top(g, reinterpret_cast<int64_t*>(res + 4), res + 6,
                             res + 6 + d, res + 6 + d + G));
   std::vector<double> host(nres);
@@ -1066,6 +1070,10 @@ int sgp_grid_sets_front_comm(sgp_grid* g, const double* scaling,
   SGP_TRY(launch_topk(g, 0, INFINITY, INT64_MAX, 1, res + 3,
                       reinterpret_cast<int64_t*>(res + 4),
                       reinterpret_cast<int*>(res + 5)));
+  // (the fused single-rank pass counts the ties in k_front_final; here nothing
+  // else writes that word)
+  SGP_TRY(launch_count_ties(g, res + 3, reinterpret_cast<const int*>(res + 5),
+                            reinterpret_cast<int*>(res + 5) + 1));
   SGP_TRY(launch_gather_top(g, reinterpret_cast<int64_t*>(res + 4), res + 6,
                             res + 6 + d, res + 6 + d + G));
   SGP_HIP(ctx, hipMemcpyAsync(res + nres - 1, g->scal, 8,

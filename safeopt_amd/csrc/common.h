@@ -301,6 +301,8 @@ int launch_mark_if(sgp_grid* g, int64_t li, const int32_t* flags_dev,
                    const double* fmin);
 int launch_topk(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, int k,
                 double* w_out_dev, int64_t* idx_out_dev, int* n_out_dev);
+int launch_count_ties(sgp_grid* g, const double* w_top_dev, const int* n_found_dev,
+                      int* ties_dev);
 int launch_lipschitz(sgp_grid* g, int G, const double* fmin,
                      const double* lipschitz, int m, const double* xc_dev,
                      const double* uc_dev, int32_t* flags_dev);

@@ -423,6 +423,7 @@ int publish_gp(sgp_gp* gp) {
   gp->dev.n_pad = np;
   gp->dev.nblk = nblk;
   gp->dev.narrow = narrow;
+  gp->dev.share = -1;       // (only collect_gps, which sees the other GPs, may set it)
   gp->dev.Linv = Li;
   gp->dev.ld = gp->ld;
   gp->dev.prior = gp->kern.kdiag + gp->noise_var + 1e-8 + gp->jitter;

@@ -775,6 +775,36 @@ int launch_topk(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, int k,
   return 0;
 }
 
+// Number of candidates whose width equals the first candidate's, bit for bit
+// (gp_opt.py:542-552 visits the candidates by argsort()[::-1]: among exactly tied
+// widths NumPy's sort decides, and the host has to settle the order only when
+// this count exceeds one).  *w_top / *n_found are what launch_topk(k = 1) left;
+// the count goes to ties[0] (zeroed here).
+__global__ __launch_bounds__(256) void k_count_ties(const uint8_t* cand, const double* w,
+                                                    int64_t N, const double* w_top,
+                                                    const int* n_found, int* ties) {
+  if (*n_found <= 0) return;
+  const double wt = *w_top;
+  int mine = 0;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < N;
+       i += int64_t(gridDim.x) * blockDim.x)
+    mine += (cand[i] && w[i] == wt) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(ties, mine);
+}
+
+int launch_count_ties(sgp_grid* g, const double* w_top_dev, const int* n_found_dev,
+                      int* ties_dev) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipMemsetAsync(ties_dev, 0, sizeof(int), ctx->stream));
+  const unsigned nb = unsigned(std::min<int64_t>(1024, (g->N + 1023) / 1024));
+  hipLaunchKernelGGL(k_count_ties, dim3(nb ? nb : 1), dim3(256), 0, ctx->stream, g->cand,
+                     g->w, g->N, w_top_dev, n_found_dev, ties_dev);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
 int launch_lipschitz(sgp_grid* g, int G, const double* fmin,
                      const double* lipschitz, int m, const double* xc_dev,
                      const double* uc_dev, int32_t* flags_dev) {

@@ -861,6 +861,22 @@ class SafeOpt(GaussianProcessOptimization):
         return (self.inputs[idx, :-self.num_contexts or None], v)
 
 
+def _step_into_band(value_at, lo=0.94, hi=0.95, v_max=1000., tol=1e-5):
+    """Bisection for a DECREASING ``value_at``: the midpoint ``v`` of the bracket
+    ``[a, b]`` (``value_at(a) >= hi > value_at(b)``) at which the value first lies
+    strictly inside ``(lo, hi)`` or the bracket is shorter than ``tol``."""
+    a, b = 0., v_max
+    while True:
+        v = 0.5 * (a + b)
+        c = value_at(v)
+        if c >= hi:
+            a = v
+        else:
+            b = v
+        if lo < c < hi or b - a < tol:
+            return v
+
+
 class SafeOptSwarm(GaussianProcessOptimization):
     """SafeOpt for higher dimensions with adaptive swarm discretisation.
 
@@ -907,44 +923,34 @@ class SafeOptSwarm(GaussianProcessOptimization):
                 for swarm_type in ['greedy', 'maximizers', 'expanders']}
 
     def optimize_particle_velocity(self):
-        """Velocity per dimension at which the prior correlation drops to
-        (0.94, 0.95) -- bisection as in ``gp_opt.py:818-872``."""
+        """Step length per input dimension at which a particle's prior correlation
+        with its starting point has fallen into (0.94, 0.95), the smallest over the
+        GPs, divided by sqrt(d) (``gp_opt.py:818-872``).  Stationary kernels only:
+        the correlation is probed from the origin."""
         d = self.gp.input_dim
-        origin = np.zeros((1, d), dtype=float)
-        velocities = np.empty((len(self.gps), d), dtype=float)
-        for i, gp in enumerate(self.gps):
-            for j in range(d):
-                probe = np.zeros((1, d), dtype=float)
-                upper, lower = 1000., 0.
-                while True:
-                    mid = (upper + lower) / 2
-                    probe[0, j] = mid
-                    cov = gp.kern.K(origin, probe).squeeze() / \
-                        self.scaling[i] ** 2
-                    enough = cov > 0.94
-                    not_too_fast = cov < 0.95
-                    if not_too_fast:
-                        upper = mid
-                    elif enough:
-                        lower = mid
-                    if (not_too_fast and enough) or upper - lower < 1e-5:
-                        break
-                velocities[i, j] = mid
-        velocities = np.min(velocities, axis=0)
-        velocities /= np.sqrt(d)
-        return velocities
+        origin = np.zeros((1, d))
+
+        def correlation(gp, scale, axis):
+            probe = np.zeros((1, d))
+
+            def at(v):
+                probe[0, axis] = v
+                return float(np.squeeze(gp.kern.K(origin, probe))) / scale ** 2
+            return at
+
+        per_gp = [[_step_into_band(correlation(gp, self.scaling[i], j)) for j in range(d)]
+                  for i, gp in enumerate(self.gps)]
+        return np.min(np.asarray(per_gp, dtype=float), axis=0) / np.sqrt(d)
 
     def _compute_penalty(self, slack):
-        """Piecewise penalty for constraint violation (host helper; the device
-        kernel applies the same rule inside the fused fitness)."""
-        slack = np.atleast_1d(np.asarray(slack, dtype=float))
-        pen = np.clip(slack, None, 0)
-        pen[(slack < 0) & (slack > -0.001)] *= 2
-        pen[(slack <= -0.001) & (slack > -0.1)] *= 5
-        pen[(slack <= -0.1) & (slack > -1)] *= 10
-        far = slack < -1
-        pen[far] = -300 * pen[far] ** 2
-        return pen
+        """Penalty of a constraint violation (``gp_opt.py:874-899``): zero for a
+        satisfied constraint, the (negative) slack times 2 / 5 / 10 on the bands
+        (-0.001, 0), (-1, -0.1], ..., and ``-300 slack^2`` below -1 (a slack of
+        exactly -1 keeps its own value).  Host helper; the device applies the same
+        rule inside the fitness kernels (``csrc/fitness.h``)."""
+        s = np.atleast_1d(np.asarray(slack, dtype=float))
+        return np.select([s >= 0, s > -0.001, s > -0.1, s > -1, s == -1],
+                         [np.zeros_like(s), 2 * s, 5 * s, 10 * s, s], default=-300 * (s * s))
 
     def _compute_particle_fitness(self, swarm_type, particles):
         """Fitness and safety of ``particles`` for one swarm type:

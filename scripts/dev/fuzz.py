@@ -9,14 +9,15 @@ import safeopt_amd, safeopt_amd.gpy as gpy
 from oracle import gp_numpy as gpn, safeopt_numpy as son
 
 KINDS = ["RBF", "Matern32", "Matern52"]
-trials = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-dmax = int(sys.argv[2]) if len(sys.argv) > 2 else 4      # input dimensions 1..dmax
-Gmax = int(sys.argv[3]) if len(sys.argv) > 3 else 3      # 1..Gmax GPs
-bad = 0
-worst = 0.0
-for t in range(trials):
-    rng = np.random.default_rng(1000 + t)
-    n, d, G = int(rng.integers(1, 300)), int(rng.integers(1, dmax + 1)), int(rng.integers(1, Gmax + 1))
+
+
+def run(trials=150, dmax=4, Gmax=3, nmax=300, seed0=1000, verbose=True):
+  """(mismatches, max |Q_dev - Q_oracle|) over `trials` seeded random problems."""
+  bad = 0
+  worst = 0.0
+  for t in range(trials):
+    rng = np.random.default_rng(seed0 + t)
+    n, d, G = int(rng.integers(1, nmax)), int(rng.integers(1, dmax + 1)), int(rng.integers(1, Gmax + 1))
     N = int(rng.integers(1, 3000))
     X = rng.uniform(-2, 2, size=(n, d))
     grid = rng.uniform(-3, 3, size=(N, d))
@@ -67,7 +68,7 @@ for t in range(trials):
         mu = float(ks @ A[:, n + 1])
         sd = np.sqrt(max(var, 1e-15))
         ref = np.array([mu - 2. * sd, mu + 2. * sd])
-        print("trial %d n=%d d=%d G=%d: dQ=%.2g at row %d GP %d; vs float128: device %.2g, oracle %.2g (var=%.3g)"
+        if verbose: print("trial %d n=%d d=%d G=%d: dQ=%.2g at row %d GP %d; vs float128: device %.2g, oracle %.2g (var=%.3g)"
               % (t, n, d, G, dq, r, g, np.max(np.abs(opt.Q[r, 2 * g:2 * g + 2] - ref)),
                  np.max(np.abs(Q[r, 2 * g:2 * g + 2] - ref)), var))
     # north-star tolerance: 1e-5 relative (to the prior standard deviation)
@@ -83,4 +84,12 @@ for t in range(trials):
         print("trial %d n=%d d=%d G=%d N=%d: dQ=%.2g empty=%s/%s sets equal=%s min|l-fmin|=%.2g  MISMATCH"
               % (t, n, d, G, N, dq, empty, oempty, sets_ok, margin))
         bad += 1
-print("%d trials, %d mismatches, max |Q_dev - Q_oracle| = %.3g" % (trials, bad, worst))
+  if verbose:
+    print("%d trials, %d mismatches, max |Q_dev - Q_oracle| = %.3g" % (trials, bad, worst))
+  return bad, worst
+
+
+if __name__ == "__main__":
+    a = [int(v) for v in sys.argv[1:]]
+    run(*a[:4])
+

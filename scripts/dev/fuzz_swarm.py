@@ -7,12 +7,15 @@ import safeopt_amd, safeopt_amd.gpy as gpy
 from oracle import gp_numpy as gpn, safeopt_numpy as son
 
 KINDS = ["RBF", "Matern32", "Matern52"]
-trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-bad, worst = 0, 0.0
-for t in range(trials):
-    rng = np.random.default_rng(5000 + t)
-    n, d, G = int(rng.integers(1, 400)), int(rng.integers(1, 6)), int(rng.integers(1, 4))
-    P = int(rng.integers(1, 2000))
+
+
+def run(trials=100, nmax=400, pmax=2000, seed0=5000, verbose=True):
+  """(mismatches, max relative fitness error) over seeded random swarms."""
+  bad, worst = 0, 0.0
+  for t in range(trials):
+    rng = np.random.default_rng(seed0 + t)
+    n, d, G = int(rng.integers(1, nmax)), int(rng.integers(1, 6)), int(rng.integers(1, 4))
+    P = int(rng.integers(1, pmax))
     X = rng.uniform(-2, 2, size=(n, d))
     gps, gos = [], []
     for g in range(G):
@@ -39,4 +42,11 @@ for t in range(trials):
             print("trial %d %s n=%d d=%d G=%d P=%d: err %.2g safe equal %s  MISMATCH"
                   % (t, st, n, d, G, P, err, np.array_equal(s, so)))
             bad += 1
-print("%d trials x 4 swarm types, %d mismatches, max relative fitness error %.3g" % (trials, bad, worst))
+  if verbose:
+    print("%d trials x 4 swarm types, %d mismatches, max relative fitness error %.3g" % (trials, bad, worst))
+  return bad, worst
+
+
+if __name__ == "__main__":
+    run(*[int(v) for v in sys.argv[1:3]])
+

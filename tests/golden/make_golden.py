@@ -393,7 +393,10 @@ def case_ties():
         widths = (opt.Q[:, 1] - opt.Q[:, 0])
         save("ties_1d_seed%d" % tag, meta=dict(
             kernels=[kernel_spec(k)], noise_vars=[0.05 ** 2], fmin=[0.],
-            scaling=[float(opt.scaling[0])], threshold=0., beta=2., quantum=q),
+            scaling=[float(opt.scaling[0])], threshold=0., beta=2., quantum=q,
+            # which tied candidate argsort()[::-1] visits first is NumPy's business:
+            # a host with this very NumPy must reproduce G / x_next of the fixture
+            numpy_version=np.__version__),
             parameter_set=grid, X0=X, Y0=Y, Q=opt.Q.copy(), S=opt.S.copy(),
             M=opt.M.copy(), G=opt.G.copy(), x_next=np.asarray(x).copy(),
             n_checks=np.array(calls[0] // 2),
@@ -415,8 +418,19 @@ def case_sample_gp_function():
             for mean in (None, "lin"):
                 mf = None if mean is None else (lambda x: 0.3 * x[:, :1] - 0.1)
                 np.random.seed(77)
-                f = ref.sample_gp_function(k, bounds, 0.05 ** 2, ns, interpolation=interp,
-                                           mean_function=mf)
+                seen = {}
+                orig_mvn = np.random.multivariate_normal
+
+                def mvn(mean, cov, *a, _o=orig_mvn, _s=seen, **kw):
+                    _s["cov"] = np.array(cov)          # what the reference hands over:
+                    return _o(mean, cov, *a, **kw)     # kernel.K(nodes) + 1e-6 I
+                np.random.multivariate_normal = mvn
+                try:
+                    f = ref.sample_gp_function(k, bounds, 0.05 ** 2, ns, interpolation=interp,
+                                               mean_function=mf)
+                finally:
+                    np.random.multivariate_normal = orig_mvn
+                arrs[tag + "_cov"] = seen["cov"]
                 cl = dict(zip(f.__code__.co_freevars, [c.cell_contents for c in f.__closure__]))
                 key = "%s_%s_%s" % (tag, interp, "mean" if mean else "nomean")
                 arrs[key + "_nodes"] = np.asarray(cl["inputs"]).copy()
