@@ -63,8 +63,11 @@ constexpr int kKbRow = 80;             // doubles between the k-rows of a B buff
 #endif                  //    of the stage (slots w, w+8, ..)
                         // 1: every wave, interleaved with its own slot sequence
                         // 2: the waves of half 0 only (slots w, w+4, ..), interleaved
+#ifndef PGP_DMA_EARLY
+#define PGP_DMA_EARLY 0 // 1: (mode 2) one group behind each of the first 8 slots instead
+#endif                  //    of every second slot
 #ifndef PGP_EVAL_PRIO
-#define PGP_EVAL_PRIO 3 // s_setprio level of the evaluation (VALU) phase
+#define PGP_EVAL_PRIO 0 // s_setprio level of the evaluation (VALU) phase
 #endif
 #ifndef PGP_OPS_EARLY
 #define PGP_OPS_EARLY -1 // waves that evaluate first fetch the operands of their matrix
@@ -331,8 +334,8 @@ __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
       if (S + 1 < kWaveSlots)
         asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
       if constexpr (kGroups > 0) {
-        constexpr int kEvery = kWaveSlots / kGroups;
-        if (S % kEvery == 0) dma_group<kGroups>(dma, S / kEvery);
+        constexpr int kEvery = PGP_DMA_EARLY ? 1 : kWaveSlots / kGroups;
+        if (S % kEvery == 0 && S / kEvery < kGroups) dma_group<kGroups>(dma, S / kEvery);
       }
       pair_slots<S + 1, false, kGroups, ASM_MFMA>(nw, false, acc, accx, aT, kb, kvn, nxt,
                                                   cur, dma);
@@ -621,7 +624,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     }
     if constexpr (kDmaGroups > 0) {
       // groups whose slot was not active (the hook sits behind slot kEvery * i)
-      constexpr int kEvery = kWaveSlots / (kDmaGroups > 0 ? kDmaGroups : 1);
+      constexpr int kEvery = PGP_DMA_EARLY ? 1 : kWaveSlots / (kDmaGroups > 0 ? kDmaGroups : 1);
 #pragma unroll
       for (int i = 0; i < kDmaGroups; ++i)
         if (!(nw > kEvery * i && !PGP_ABL(8))) dma_group<kDmaGroups>(dma, i);

@@ -19,6 +19,7 @@ from safeopt_amd import _hip  # noqa: E402
 
 def run(k, reps):
     ctx = _hip.Context.default()
+    ctx.set_share(os.environ.get("AB_SHARE", "0") == "1")   # headline: every GP on its own
     cfg = bench.make_config(k)
     gps = bench.build_gps(cfg, gpy)
     devs = [g._fitted() for g in gps]
