@@ -331,6 +331,9 @@ def main():
                          "report whether S / M / G and the chosen index are identical "
                          "(default: on at configs 2 and 3 -- 7 s / 28 s of host work)")
     ap.add_argument("--no-check-chosen", dest="check_chosen", action="store_false")
+    ap.add_argument("--no-shared-pass", action="store_true",
+                    help="skip the second timing pass with the factor shared between identical "
+                         "GPs (profiles: every k_sweep launch of the run is then the headline path)")
     ap.add_argument("--profile-steps", type=int, default=10,
                     help="steps of the separate (untimed) per-launch hipEvent pass")
     ap.add_argument("--launch-check", action="store_true",
@@ -433,7 +436,7 @@ def main():
     # ---- the product's default: consecutive GPs with identical (X, kernel, noise)
     # share the variance contraction -- own timing, own flop count
     shared = None
-    if cfg["G"] > 1 and args.config != 5:
+    if cfg["G"] > 1 and args.config != 5 and not args.no_shared_pass:
         ctx.set_share(True)
         for _ in range(args.warmup):
             step()

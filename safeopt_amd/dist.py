@@ -125,12 +125,15 @@ def _fetch_uid(addr, port, timeout):
 
 def _launch_tag(port):
     """16 bytes naming THIS launch: every rank of one launch derives the same
-    tag (launcher pid, MASTER_PORT, the launcher's run id / nonce), a file left
-    behind by another launch does not carry it."""
+    tag (launcher pid, MASTER_PORT, the launcher's run id / nonce and its restart
+    count), a file left behind by another launch -- or by the workers the same
+    launcher started before a restart (``torchrun --max-restarts``) -- does not
+    carry it."""
     import hashlib
     nonce = os.environ.get("SAFEOPT_RDZV_NONCE",
                            os.environ.get("TORCHELASTIC_RUN_ID", ""))
-    return hashlib.md5(("%d:%d:%s" % (os.getppid(), port, nonce)).encode()).digest()
+    restart = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    return hashlib.md5(("%d:%d:%s:%s" % (os.getppid(), port, nonce, restart)).encode()).digest()
 
 
 def _rdzv_dir():

@@ -45,12 +45,14 @@ def mean(vals):
 
 def digest(d):
     out, traffic, rows = [], {}, collections.defaultdict(list)
+    algo = {}
     for c in (2, 3, 4, 5):
         bj = os.path.join(d, "bench_cfg%d.json" % c)
         if os.path.exists(bj):
             try:
                 j = json.loads(open(bj).read().strip().splitlines()[-1])
                 rf = j["roofline"]
+                algo[c] = (rf.get("algorithmic_hbm_bytes_per_launch"), j["config"])
                 out.append("== bench.py --config %d" % c)
                 out.append("   %s" % j["config"]["workload"])
                 out.append("   value %.4g %s   ms/step %.3f (timed region %.2f s)   k_sweep %.3f ms x %d   "
@@ -102,9 +104,25 @@ def digest(d):
                            "(%.1f MB) = %.1f MB (1e6 B) HBM traffic per launch"
                            % (k, fs, 2 * fs * 1024 / 1e6, ws, ws * 1024 / 1e6, (2 * fs + ws) * 1024 / 1e6))
                 rows[c] += [("pmc_fetch", k, "FETCH_SIZE", fs), ("pmc_write", k, "WRITE_SIZE", ws)]
+                ab, cf = algo.get(c, (None, None))
+                if cf and c == 5:           # swarm fitness: particle in, value + flag out
+                    ab = cf["rows_per_gpu"] * (8.0 * cf["d"] + 9.0)
+                extra = {}
+                if ab:
+                    # 8d + 16G + 3 bytes per row; with the resident mean / var
+                    # arrays the product keeps: + 16G
+                    with_mv = ab + 16.0 * cf["G"] * cf["rows_per_gpu"] if cf and c != 5 else ab
+                    extra = dict(algorithmic_hbm_bytes_per_launch=ab,
+                                 algorithmic_incl_mean_var=with_mv,
+                                 executed_over_algorithmic_bytes=(2 * fs + ws) * 1024 / ab,
+                                 executed_over_algorithmic_incl_mean_var=(2 * fs + ws) * 1024 / with_mv)
+                    out.append("   executed / algorithmic HBM bytes: %.2fx of SURVEY 8d's %.1f MB (%.2fx of the %.1f MB that "
+                               "include the resident mean / var arrays)"
+                               % (extra["executed_over_algorithmic_bytes"], ab / 1e6,
+                                  extra["executed_over_algorithmic_incl_mean_var"], with_mv / 1e6))
                 traffic["config%d" % c] = dict(
                     kernel=k, FETCH_SIZE_KB=fs, WRITE_SIZE_KB=ws,
-                    hbm_bytes_per_launch=(2 * fs + ws) * 1024,
+                    hbm_bytes_per_launch=(2 * fs + ws) * 1024, **extra,
                     mfma_pipe_busy=util, clock_ghz_under_profiler=gui / dur if dur else 0,
                     note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE "
                          "doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md "
@@ -117,7 +135,7 @@ def digest(d):
                 out.append("PMC %s %s: %s" % (sub, k, {n: "%.4g" % x for n, x in cm.items()}))
                 for n, val in cm.items():
                     rows[3].append((sub, k, n, val))
-    for name in ("ablation.txt", "probes.txt"):
+    for name in ("ab_kernels.txt", "ablation.txt", "stamps.txt", "probes.txt"):
         p = os.path.join(d, name)
         if os.path.exists(p):
             out.append("\n== %s\n%s" % (name, open(p).read()))
@@ -145,7 +163,8 @@ def main(argv):
                     w = csv.writer(fh)
                     w.writerow(["pass", "kernel", "counter", "avg_value_per_dispatch"])
                     w.writerows(rows[c])
-        for name in ("ablation.txt", "probes.txt", "bo_loop.json"):
+        for name in ("ab_kernels.txt", "ablation.txt", "stamps.txt", "probes.txt", "bo_loop.json",
+                     "swarm_small.txt"):
             if os.path.exists(os.path.join(d, name)):
                 shutil.copy(os.path.join(d, name), os.path.join(dst, name))
         tj = os.path.join(ROOT, "profiles", "traffic.json")
