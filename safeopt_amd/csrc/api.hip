@@ -87,7 +87,11 @@ int fill_kern(sgp_ctx* ctx, KernDesc* kd, int d, int n_parts, const int* kinds,
     kd->kind[p] = kinds[p];
     kd->variance[p] = variances[p];
     kd->kdiag *= variances[p];
-    for (int k = 0; k < d; ++k) kd->inv_ls[p][k] = inv_ls[p * d + k];
+    for (int k = 0; k < d; ++k) {
+      kd->inv_ls[p][k] = inv_ls[p * d + k];
+      const double w = kd->inv_ls[p][k] * kern_unit(kinds[p]);
+      kd->wsq[p][k] = w * w;
+    }
   }
   for (int k = 0; k < d; ++k)
     kd->scale0[k] = kd->inv_ls[0][k] * kern_unit(kd->kind[0]);

@@ -48,6 +48,11 @@ struct KernDesc {
   // inv_ls[0] * kern_unit(kind[0]), in units where the exponent of the
   // covariance is a plain square / norm (see kern_eval.h, KernFast).
   double scale0[SGP_MAX_D];
+  // Products of parts in the sweep (KernFast::manyn_t): squared weights
+  // wsq[p][k] = (inv_ls[p][k] * kern_unit(kind[p]))^2 on the squared RAW coordinate
+  // differences (zero for a column the part does not use, and for p >= n_parts);
+  // the exponents of the parts then ADD: one 2^(U/32) per covariance.
+  double wsq[SGP_MAX_PARTS][SGP_MAX_D];
 };
 
 // Input scaling of the fast covariance path: with z = x * inv_ls * kern_unit,

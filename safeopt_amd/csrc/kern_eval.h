@@ -357,9 +357,91 @@ struct KernFast {
           out[q] = fma(u[q], fma(u[q], m2, m1), var0) * e[q];
       }
     } else {
+      // (two values at a time: the 4-wave sweep runs at the register limit)
+      constexpr int kStep = NV > 2 ? 2 : NV;
 #pragma unroll
-      for (int q = 0; q < NV; ++q) out[q] = kern_eval<D>(*kd, xs, ys + q * stride);
+      for (int q0 = 0; q0 < NV; q0 += kStep) {
+        double o[kStep];
+        product_n<kStep>(xs, ys + q0 * stride, stride, tab, o);
+#pragma unroll
+        for (int q = 0; q < kStep; ++q) out[q0 + q] = o[q];
+      }
     }
+  }
+
+  // Product of stationary parts, NV values: with the weights of KernDesc::wsq the
+  // part p contributes u_p = -sum_k wsq[p][k] dx_k^2 (RBF) or minus its square root
+  // (Matern) in units where the part is poly_p(u_p) 2^(u_p / 32): the exponents add,
+  // ONE 2^(U/32) per covariance, a square root and a polynomial factor per Matern
+  // part.  The weights are wave-uniform scalar loads from the descriptor (constant
+  // address space: no vector registers, no vmcnt wait); those of the first two parts
+  // are fetched up front (a part the kernel does not have weighs zero), the
+  // hyper-parameters of GPy's Prod kernel (GPy kern/src/prod.py: K = prod_p K_p).
+  // xs, ys: RAW rows.
+  template <int NV>
+  __device__ __forceinline__ void product_n(const double* xs, const double* ys,
+                                            int stride, const double* tab,
+                                            double (&out)[NV]) const {
+    const const_desc_t k = (const_desc_t)kd;
+    const int P = k->n_parts;
+    double w0[D], w1[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      w0[i] = k->wsq[0][i];
+      w1[i] = k->wsq[1][i];
+    }
+    const int kind0p = k->kind[0], kind1p = k->kind[1];
+    const double vtot = k->kdiag;
+    double d2[NV][D];
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const double t = xs[i] - ys[q * stride + i];
+        d2[q][i] = t * t;
+      }
+    double U[NV], F[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      U[q] = 0.0;
+      F[q] = vtot;
+    }
+    auto part = [&](const double (&w)[D], int kind) {
+      double r2[NV];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        r2[q] = 1e-300;
+#pragma unroll
+        for (int i = 0; i < D; ++i) r2[q] = fma(w[i], d2[q][i], r2[q]);
+      }
+      if (kind == SGP_RBF) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) U[q] -= r2[q];
+      } else {
+        double rr[NV];
+        sqrtn_pos<NV>(r2, rr);
+        // 1 + a (+ a^2 / 3), a = -u ln2 / 32
+        const double c2 = kind == SGP_MATERN52 ? 0.00015639746546816451 : 0.0;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const double u = -rr[q];
+          U[q] += u;
+          F[q] *= fma(u, fma(u, c2, -SGP_E1), 1.0);
+        }
+      }
+    };
+    part(w0, kind0p);
+    if (P > 1) part(w1, kind1p);
+    for (int p = 2; p < P; ++p) {        // (wave-uniform, rare)
+      double w[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) w[i] = k->wsq[p][i];
+      part(w, k->kind[p]);
+    }
+    double e[NV];
+    exp2_32xn<NV>(U, tab, e);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) out[q] = F[q] * e[q];
   }
 
   template <bool SINGLE>

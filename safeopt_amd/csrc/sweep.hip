@@ -45,6 +45,13 @@
 
 namespace {
 
+// 1: a wave's share of the next A chunk (slots w, w + 4, ..) is copied piecewise
+// between the slots of the running stage instead of in one burst behind the barrier
+// (the paired kernel's finding, profiles/r03/experiments.txt section 4)
+#ifndef SGP_DMA_SPREAD
+#define SGP_DMA_SPREAD 1
+#endif
+
 constexpr int kJC = 16;                // training points per stage (one j-block)
 constexpr int kSteps = kJC / 4;        // MFMA k-steps per stage
 
@@ -285,13 +292,28 @@ __device__ __forceinline__ void load_slot(double (&ops)[4], const double* aT,
 // blocks carry the same <= 4 real rows, so the plain covariance register kv[q]
 // -- a different point quad per block -- is the B operand and one instruction
 // per k-step does the whole slot (accumulator accx: rows l >> 4, point l & 15).
-template <int SL, int S>
+// The wave's share of the copy of the NEXT stage's A chunk: group i is slot
+// w + NW i, wanted when left > NW i; issued behind slot NW i of the running stage.
+struct DmaShare {
+  uint64_t src0, step;
+  uint32_t dst0, voff;
+  int left;
+  bool on;
+};
+template <int NW>
+__device__ __forceinline__ void dma_share_group(const DmaShare& d, int i) {
+  if (d.on && d.left > NW * i)
+    dma_2k(d.src0 - uint64_t(i) * d.step, d.dst0 + uint32_t(i) * (NW * 2048u), d.voff);
+}
+
+template <int SL, int S, int NW, bool SPREAD>
 __device__ __forceinline__ void mfma_slots(int nact, bool narrow0,
                                            double (&acc)[SL][4], double& accx,
                                            const double* aT,
                                            const double (&kb)[4][4],
                                            const double (&kv)[4],
-                                           double (&cur)[4], double (&nxt)[4]) {
+                                           double (&cur)[4], double (&nxt)[4],
+                                           const DmaShare& dma) {
   if constexpr (S < SL) {
     if (S < nact) {
       if (S + 1 < SL) {
@@ -321,26 +343,35 @@ __device__ __forceinline__ void mfma_slots(int nact, bool narrow0,
       }
       if (S + 1 < SL)
         asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
-      mfma_slots<SL, S + 1>(nact, false, acc, accx, aT, kb, kv, nxt, cur);
+      if (SPREAD && S % NW == 0) dma_share_group<NW>(dma, S / NW);
+      mfma_slots<SL, S + 1, NW, SPREAD>(nact, false, acc, accx, aT, kb, kv, nxt, cur, dma);
     }
   }
 }
 
-template <int SL>
+template <int SL, int NW, bool SPREAD>
 __device__ __forceinline__ void mfma_jblock(int nact, bool narrow0,
                                             double (&acc)[SL][4], double& accx,
                                             const double* aT,
                                             const double (&kb)[4][4],
-                                            const double (&kv)[4]) {
+                                            const double (&kv)[4], const DmaShare& dma) {
   double opsA[4], opsB[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) opsA[q] = aT[q * 64];
-  mfma_slots<SL, 0>(nact, narrow0, acc, accx, aT, kb, kv, opsA, opsB);
+  mfma_slots<SL, 0, NW, SPREAD>(nact, narrow0, acc, accx, aT, kb, kv, opsA, opsB, dma);
+  if (SPREAD) {
+    // groups whose slot was not active (the hook sits behind slot NW i)
+#pragma unroll
+    for (int i = 0; i < SL / NW; ++i)
+      if (!(nact > NW * i)) dma_share_group<NW>(dma, i);
+  }
 }
 
 template <int D, int NW, int SL, int MODE, bool SINGLE>
 __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   constexpr int kTilePts = 16 * NW;
+  // (the instances that have the registers for it: the others would spill)
+  constexpr bool kSpread = SGP_DMA_SPREAD && MODE == MODE_CONF && SINGLE;
   typedef Lay<SL, D> L;
   constexpr int kATile = L::kATile, kBuf = L::kBuf, kXTile = L::kXTile;
   constexpr int kTabOff = L::kTabOff, kKbOff = L::kKbOff, kKbBuf = L::kKbBuf;
@@ -433,10 +464,21 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
         gv_g = g_n;
       }
       if (!SGP_ABL(2)) {
-        stage_dma<NW, SL>(gv, e1, nbuf, wave, lane);
+        if (!kSpread) stage_dma<NW, SL>(gv, e1, nbuf, wave, lane);
         stage_x_dma<D, NW, SL>(gv, e1, nbuf, wave, lane);
       }
       if (next_tile) load_x(t1, xnext);
+    }
+    DmaShare share{};
+    if (kSpread) {
+      const uint64_t rs_bytes = uint64_t(e1.row_stride) * 512u;
+      share.src0 = reinterpret_cast<uint64_t>((const double*)gv.Apack) +
+                   uint64_t(e1.a_off) * 512u - uint64_t(uint32_t(wave)) * rs_bytes;
+      share.step = rs_bytes * NW;
+      share.dst0 = lds_addr_of(nbuf) + uint32_t(wave) * 2048u;
+      share.voff = uint32_t(lane) * 16u;
+      share.left = int(wnext & SW_NACT_MASK) - wave;
+      share.on = more && !SGP_ABL(2);
     }
     const int tile_after = t1;
     // the entry after that: loaded now, first used at the top of the next stage
@@ -465,9 +507,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     }
     double kb[4][4];
     if (!SGP_ABL(8)) broadcast_quads<L::kKbRow>(kv, kbw, lane, kb);
-    if (!SGP_ABL(8))
-      mfma_jblock<SL>(int(wcur & SW_NACT_MASK), (wcur & SW_NARROW) != 0, acc, accx,
-                      cbuf + lane, kb, kv);
+    if (!SGP_ABL(8)) {
+      mfma_jblock<SL, NW, kSpread>(int(wcur & SW_NACT_MASK), (wcur & SW_NARROW) != 0, acc, accx,
+                          cbuf + lane, kb, kv, share);
+    } else if (kSpread) {
+#pragma unroll
+      for (int i = 0; i < SL / NW; ++i) dma_share_group<NW>(share, i);
+    }
 
     if (wcur & SW_CHUNK_END) {
 #pragma unroll
@@ -608,6 +654,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     }
 
     if (!more) break;
+    if (kSpread) wait_dma();       // (asm copies: the compiler does not count them)
     if (!SGP_ABL(1)) __syncthreads();
     par ^= 1;
     wcur = wnext;

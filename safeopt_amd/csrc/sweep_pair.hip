@@ -78,6 +78,19 @@ constexpr int kKbRow = 80;             // doubles between the k-rows of a B buff
 #define PGP_PRIO_ALL 0  // 1: everything outside the slot sequence runs at priority 3
 #endif
 #ifndef PGP_H1_PRIO
+#ifndef PGP_STAGE_LATE
+#define PGP_STAGE_LATE 0   // stage-table prefetch: 0 in front of the evaluation, 1 behind it,
+                           // 2 at the start of the wave's second slot.  (0: the scalar load in
+                           // flight makes the evaluation wait for the B operand reads as well --
+                           // and that is FASTER, +1..2 % for 1 and 2: the waves of a SIMD then
+                           // start their VALU bursts together; experiments.txt section 10)
+#endif
+#ifndef PGP_EVAL_BARRIER
+#define PGP_EVAL_BARRIER 0
+#endif
+#ifndef PGP_ROWS_WAIT
+#define PGP_ROWS_WAIT 0    // 1: the training rows are waited for BEFORE the B operand reads go out
+#endif
 #define PGP_H1_PRIO 0   // s_setprio level of half 1 outside its evaluation phase
 #endif
 
@@ -195,27 +208,7 @@ __device__ __forceinline__ PStage load_pstage(pstage_ptr_t t, int i) {
   return e;
 }
 
-// global -> LDS without a VGPR round trip: "scalar base + 32-bit lane offset"
-// (the builtin only produces the 64-bit-VGPR-address form, one VALU add per
-// copy).  M0 carries the wave-uniform LDS byte address.
-__device__ __forceinline__ void dma_2k(uint64_t src, uint32_t lds_addr, uint32_t voff) {
-  asm volatile(
-      "s_mov_b32 m0, %0\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "global_load_lds_dwordx4 %1, %2 offset:1024"
-      :: "s"(lds_addr), "v"(voff), "s"(src) : "memory", "m0");
-}
-__device__ __forceinline__ void dma_1k(uint64_t src, uint32_t lds_addr, uint32_t voff) {
-  asm volatile(
-      "s_mov_b32 m0, %0\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2"
-      :: "s"(lds_addr), "v"(voff), "s"(src) : "memory", "m0");
-}
-__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-__device__ __forceinline__ uint32_t lds_addr_of(const double* p) {
-  return uint32_t(uintptr_t((const __attribute__((address_space(3))) void*)p));
-}
+// (dma_2k / dma_1k / wait_dma / lds_addr_of: sweep_shared.h)
 
 // A chunk of stage `e` -> LDS image [global slot][k-step][lane] (2 KB per slot):
 // wave w copies the global slots w, w + 8, w + 16, w + 24 below nact.
@@ -279,6 +272,16 @@ __device__ __forceinline__ void dma_group(const DmaPlan& d, int i) {
 // MFMA (needs 9 wait states, gets 0 -- scripts/dev/check_mfma_hazards.py finds
 // such code): the instances for d >= 6, the ones that run out of registers, use the
 // builtin instead (a few register copies at the joins of the slot sequence).
+//
+// The stage-table entry after the next one is fetched at the start of local slot 1
+// (StageAhead): a scalar load in flight turns the next LDS wait into a wait for
+// everything, and here that wait is a whole slot away.
+struct StageAhead {
+  pstage_ptr_t stages;
+  int index;
+  bool want;       // (false as well in instances that fetch the entry elsewhere)
+  PStage e;
+};
 template <int S, bool NARROW_OK, int kGroups, bool ASM_MFMA>
 __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
                                            double (&acc)[kWaveSlots][4], double& accx,
@@ -286,13 +289,14 @@ __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
                                            const double (&kb)[4][4],
                                            const double (&kvn)[4],
                                            double (&cur)[4], double (&nxt)[4],
-                                           const DmaPlan& dma) {
+                                           const DmaPlan& dma, StageAhead& sa) {
   if constexpr (S < kWaveSlots) {
     if (S < nw) {
       if (S + 1 < kWaveSlots) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) nxt[q] = aT[((S + 1) * 2 * kSteps + q) * 64];
       }
+      if (S == 1 && sa.want) sa.e = load_pstage(sa.stages, sa.index);
       __builtin_amdgcn_sched_barrier(0);
       // The matrix instructions are inline asm: the compiler's hazard recogniser
       // does not see them.  A register copy it places at the join in front of a
@@ -338,7 +342,7 @@ __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
         if (S % kEvery == 0 && S / kEvery < kGroups) dma_group<kGroups>(dma, S / kEvery);
       }
       pair_slots<S + 1, false, kGroups, ASM_MFMA>(nw, false, acc, accx, aT, kb, kvn, nxt,
-                                                  cur, dma);
+                                                  cur, dma, sa);
     }
   }
 }
@@ -466,6 +470,9 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   // it -- d >= 6, product kernels -- do without)
   constexpr int kOpsEarly =
       PGP_OPS_EARLY >= 0 ? PGP_OPS_EARLY : ((SINGLE && D <= 4) ? 2 : 0);
+  // (only where the B operands are fetched in front of the evaluation does the place
+  // of the stage-table fetch matter -- and elsewhere the registers are not there)
+  constexpr int kStageLate = kOpsEarly != 0 ? PGP_STAGE_LATE : 0;
   const int pr = PGP_ADJ ? wave >> 1 : wave & 3;
   const int k4 = lane >> 4, c16 = lane & 15;
   const double* tab = lds + L::kTabOff;
@@ -611,15 +618,18 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
 #pragma unroll
     for (int q = 0; q < 4; ++q) o.a0[q] = aT[q * 64];
   };
-  auto multiply = [&](uint32_t w, const double* abuf, Ops& o, const DmaPlan& dma) {
+  auto multiply = [&](uint32_t w, const double* abuf, Ops& o, const DmaPlan& dma,
+                      StageAhead& sa) {
     const int nw = (int(w & PW_NACT_MASK) - H + 1) >> 1;   // this wave's active slots
+    if (sa.want && !(nw > 1 && !PGP_ABL(8)))
+      sa.e = load_pstage(sa.stages, sa.index);
     if (nw > 0 && !PGP_ABL(8)) {
       const bool narrow0 = H == 0 && (w & PW_NARROW) != 0;
       const double* aT = abuf + H * (kSteps * 64) + lane;
       double opsB[4];
       if (PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(0);
       pair_slots<0, H == 0, kDmaGroups, (D <= 5)>(nw, narrow0, acc, accx, aT, o.kb,
-                                                  o.kvn, o.a0, opsB, dma);
+                                                  o.kvn, o.a0, opsB, dma, sa);
       if (PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(3);
     }
     if constexpr (kDmaGroups > 0) {
@@ -761,8 +771,11 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     PGP_STAMP(1);   // LDS-DMA issue
     int si2 = si1 + 1;
     if (si2 == nstages) si2 = 0;    // (a run of chunks ends before it would wrap)
-    PStage e2 = e1;
-    if (left > 2) e2 = load_pstage(stages, si2);
+    // (the table entry after the next one is fetched BEHIND the evaluation: a scalar
+    // load in flight turns every LDS wait into a wait for everything, and the
+    // evaluation would stand behind the operand reads issued in front of it)
+    StageAhead sa{stages, si2, kStageLate == 2 && left > 2, e1};
+    if (kStageLate == 0 && left > 2) sa.e = load_pstage(stages, si2);
 
     const double* abuf = lds + par * L::kATile;
     const double* kbr = kbp + par * L::kKbBuf;
@@ -771,10 +784,16 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
 
     Ops ops;
     Rows rows;
-    if (kRowsFirst && !kMultFirst && more) load_rows(xa, rows);
+    if (kRowsFirst && !kMultFirst && more) {
+      load_rows(xa, rows);
+      if (PGP_ROWS_WAIT) {
+        // (in-order LDS returns: with nothing else in flight this waits for the rows)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
     if (kMultFirst) {
       fetch_ops(abuf, kbr, ops, 3);
-      multiply(wcur, abuf, ops, plan);
+      multiply(wcur, abuf, ops, plan, sa);
       PGP_STAMP(2);   // matrix phase (B operand reads, slots, chunk fold)
     } else if (kOpsEarly) {
       fetch_ops(abuf, kbr, ops, kOpsEarly == 2 ? 1 : 3);
@@ -801,10 +820,15 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     if (kRowsFirst && kMultFirst && more) load_rows(xa, rows);
     if (more) evaluate(wnext, rows, xa, kbw);
     if (PGP_EVAL_PRIO && !PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(H == 1 ? PGP_H1_PRIO : 0);
+    // (a second, bare barrier: no wave of the workgroup starts its matrix instructions
+    // while another still evaluates -- VALU under a partner's MFMA stream gets one
+    // issue slot in 45..72 cycles)
+    if (PGP_EVAL_BARRIER && !kMultFirst && more) __builtin_amdgcn_s_barrier();
     PGP_STAMP(3);     // covariance evaluation
+    if (kStageLate == 1 && left > 2) sa.e = load_pstage(stages, si2);
     if (!kMultFirst) {
       if (kOpsEarly != 1) fetch_ops(abuf, kbr, ops, kOpsEarly == 2 ? 2 : 3);
-      multiply(wcur, abuf, ops, plan);
+      multiply(wcur, abuf, ops, plan, sa);
       PGP_STAMP(2);
     }
 
@@ -831,7 +855,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     PGP_STAMP(6);     // barrier
     par ^= 1;
     wcur = wnext;
-    e1 = e2;
+    e1 = sa.e;
     si1 = si2;
     --left;
   }

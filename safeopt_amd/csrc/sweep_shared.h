@@ -50,6 +50,28 @@ __device__ __forceinline__ void mfma_acc(double& c, double a, double b) {
   asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
+// global -> LDS without a VGPR round trip: "scalar base + 32-bit lane offset"
+// (the builtin only produces the 64-bit-VGPR-address form, one VALU add per
+// copy).  M0 carries the wave-uniform LDS byte address.
+__device__ __forceinline__ void dma_2k(uint64_t src, uint32_t lds_addr, uint32_t voff) {
+  asm volatile(
+      "s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:1024"
+      :: "s"(lds_addr), "v"(voff), "s"(src) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_1k(uint64_t src, uint32_t lds_addr, uint32_t voff) {
+  asm volatile(
+      "s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2"
+      :: "s"(lds_addr), "v"(voff), "s"(src) : "memory", "m0");
+}
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ uint32_t lds_addr_of(const double* p) {
+  return uint32_t(uintptr_t((const __attribute__((address_space(3))) void*)p));
+}
+
 // sweep_pair.hip
 bool pair_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff);
 int pair_sweep_partials(const sgp_ctx* ctx, int64_t N);
