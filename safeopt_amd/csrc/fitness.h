@@ -1,7 +1,7 @@
 // The fitness shaping of SafeOptSwarm._compute_particle_fitness
 // (gp_opt.py:925-1013) and SafeOptSwarm._compute_penalty (gp_opt.py:874-899),
-// shared by the epilogue of k_sweep<.., MODE_FITNESS> (sweep.hip) and the
-// few-points kernels (swarm.hip).
+// shared by k_fitness_small (swarm.hip: the pass behind the posterior sweep of a
+// fitness call, launch_sweep in sweep.hip) and the few-points kernels (swarm.hip).
 #pragma once
 #include "common.h"
 

@@ -120,8 +120,8 @@ int swarm_grow_chunks(int64_t m) { return int((m + kGrowChunk - 1) / kGrowChunk)
 
 // ---- particle swarm on the device ---------------------------------------------------
 // SwarmOptimization.init_swarm / run_swarm (safeopt/swarm.py:61-146) with the
-// swarm state resident in HBM for the whole run; the fitness is the fused
-// posterior sweep (k_sweep, MODE_FITNESS) on the same buffers.  This file is
+// swarm state resident in HBM for the whole run; the fitness is the posterior
+// sweep + shaping pass (launch_sweep_fitness) on the same buffers.  This file is
 // built with -ffp-contract=off and the update below mirrors NumPy's evaluation
 // order, so that with the reference's own random numbers (rand != nullptr,
 // drawn by np.random.rand on the host in the reference's order) the run is

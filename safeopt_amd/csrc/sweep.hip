@@ -41,6 +41,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "small_path.h"
 #include "sweep_shared.h"
 
 namespace {
@@ -385,7 +386,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* kbw = lds + kKbOff + wave * kKbBuf;
-  const int st = p.fit.swarm_type;
   const int ntiles = int((p.pts.N + kTilePts - 1) / kTilePts);
   const stage_ptr_t stages = (stage_ptr_t)(p.stages);
   const int nstages = p.nstages;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     for (int m = 0; m < 4; ++m) acc[b][m] = 0.0;
   // per-tile state of the row epilogue (confidence sweep / swarm fitness)
   bool safe = true;
-  double l0 = 0.0, values = 0.0, interest = 1.0, total_pen = 0.0, lower = 0.0;
+  double l0 = 0.0;
   double lmax = -INFINITY;   // max l0 over the safe rows this wave has seen
   bool gp_start = true;
 
@@ -573,34 +573,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
             *reinterpret_cast<double2_t*>(p.conf.Q + (row * p.G + g) * 2) =
                 double2_t{lo, up};
         }
-      } else {
-        // SafeOptSwarm._compute_particle_fitness, gp_opt.py:925-1013
-        const FitnessArgs& f = p.fit;
-        lower = mu - f.beta * sd;
-        if (g == 0) {
-          values = sd / f.scaling[0];
-          if (st == SGP_SWARM_EXPANDERS) interest = double(p.G);
-          if (st == SGP_SWARM_MAXIMIZERS) {
-            const double upper = mu + f.beta * sd;
-            const double z = 10.0 * (upper - f.best_lower_bound) / f.scaling[0];
-            interest = 1.0 / (1.0 + exp(-z));  // scipy.special.expit
-          }
-        } else {
-          values = fmax(values, sd / f.scaling[g]);
-        }
-        if (f.fmin[g] != -INFINITY) {
-          double slack = lower - f.fmin[g];
-          safe = safe && (slack >= 0.0);
-          if (st != SGP_SWARM_SAFE_SET) {
-            slack = slack / f.scaling[g];
-            total_pen += swarm_penalty(slack);
-            if (st == SGP_SWARM_EXPANDERS) {
-              // scipy.stats.norm.pdf(slack, scale=0.2)
-              const double z = slack / 0.2;
-              interest *= exp(-0.5 * z * z) / 2.5066282746310002 / 0.2;
-            }
-          }
-        }
       }
 
       if (wcur & SW_TILE_END) {
@@ -622,23 +594,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
             // written once, when the wave has walked all its tiles)
             lmax = fmax(lmax, (writer && safe) ? l0 : -INFINITY);
           }
-        } else if (writer) {
-          double out;
-          bool ok = safe;
-          if (st == SGP_SWARM_GREEDY) {
-            out = lower;
-            ok = true;
-          } else if (st == SGP_SWARM_SAFE_SET) {
-            out = lower;
-          } else {
-            out = (values + total_pen) * interest;
-          }
-          p.fit.values[row] = out;
-          p.fit.safe[row] = ok ? 1 : 0;
         }
         safe = true;
-        l0 = values = total_pen = lower = 0.0;
-        interest = 1.0;
+        l0 = 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) x[k] = xnext[k];
         tile = tile_after;
@@ -1108,17 +1066,17 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
 
 template <int D, int NW, int SL>
 int launch_sweep_w(sgp_ctx* ctx, const SweepParams& p, double flops) {
-  if (p.mode == MODE_CONF)
-    return p.single ? launch_sweep_v<D, NW, SL, MODE_CONF, true>(ctx, p, flops)
-                    : launch_sweep_v<D, NW, SL, MODE_CONF, false>(ctx, p, flops);
-  return p.single ? launch_sweep_v<D, NW, SL, MODE_FITNESS, true>(ctx, p, flops)
-                  : launch_sweep_v<D, NW, SL, MODE_FITNESS, false>(ctx, p, flops);
+  return p.single ? launch_sweep_v<D, NW, SL, MODE_CONF, true>(ctx, p, flops)
+                  : launch_sweep_v<D, NW, SL, MODE_CONF, false>(ctx, p, flops);
 }
 
 template <int D>
 int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
   return launch_sweep_w<D, 4, 16>(ctx, p, flops);
 }
+
+int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d, int Geff,
+                     double flops);
 
 int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
   // algorithmic flops: G * (n^2 + 2n) per row
@@ -1129,8 +1087,33 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
   for (int g = 0; g < Geff; ++g)
     flops += (double(gh[g].n) * gh[g].n + 2.0 * gh[g].n) * double(p.pts.N);
   if (p.pts.N <= 0) return 0;
+  SweepParams q = p;
+  const bool fitness = p.mode == MODE_FITNESS;
+  if (fitness) {
+    // SafeOptSwarm._compute_particle_fitness (gp_opt.py:901-1013) = the posterior of
+    // the swarm's GPs (the sweep, mean / var only) + the shaping of fitness.h on
+    // those (k_fitness_small: one thread per particle).  The particles are few next
+    // to a grid: the 16 bytes per (GP, particle) in between cost nothing, and the
+    // sweep kernels need no second set of instances (which spilled registers).
+    const size_t np = size_t(Geff) * size_t(p.pts.N);
+    SGP_TRY(sgp_reserve(ctx, &ctx->pair_post, 2 * np * sizeof(double)));
+    q.mode = MODE_CONF;
+    q.conf = ConfOut{};
+    q.conf.mean = static_cast<double*>(ctx->pair_post.p);
+    q.conf.var = q.conf.mean + np;
+    q.G = Geff;
+    for (int i = 0; i < SGP_MAX_GPS; ++i) q.conf.fmin[i] = -INFINITY;
+  }
+  int rc = launch_posterior(ctx, q, gh, d, Geff, flops);
+  if (rc != 0 || !fitness) return rc;
+  return launch_fitness_small(ctx, p.G, p.pts.N, q.conf.mean, q.conf.var, p.fit);
+}
+
+// The confidence sweep proper: the paired-wave kernel from 257 rows of L^-1 on,
+// the 4-wave kernel below.
+int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d, int Geff,
+                     double flops) {
   if (pair_sweep_wanted(ctx, gh, Geff)) {
-    // more than 256 rows of L^-1: the paired-wave kernel (sweep_pair.hip)
     SweepArgs a{p.gps, p.G, p.mode, p.pts, p.conf, p.fit};
     return launch_sweep_pair(ctx, a, gh, d, Geff, flops);   // (sets ctx->sweep_partials)
   }

@@ -1215,20 +1215,7 @@ int launch_sweep_pair(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d,
   p.shared_mask = 0;
   for (int g = 0; g < Geff; ++g)
     if (gh[g].share >= 0) p.shared_mask |= 1u << g;
-  const bool fitness = a.mode == MODE_FITNESS;
-  if (fitness) {
-    // SafeOptSwarm._compute_particle_fitness (gp_opt.py:901-1013) = the posterior
-    // of the swarm's GPs (this kernel, mean / var only) + the shaping of
-    // fitness.h on those (k_fitness_small: one thread per particle, same
-    // arithmetic as the epilogue of the 4-wave kernel)
-    const size_t np = size_t(Geff) * size_t(a.pts.N);
-    SGP_TRY(sgp_reserve(ctx, &ctx->pair_post, 2 * np * sizeof(double)));
-    p.conf = ConfOut{};
-    p.conf.mean = static_cast<double*>(ctx->pair_post.p);
-    p.conf.var = p.conf.mean + np;
-    p.G = Geff;
-    for (int i = 0; i < SGP_MAX_GPS; ++i) p.conf.fmin[i] = -INFINITY;
-  }
+  // (a.mode is MODE_CONF: launch_sweep turns a fitness call into posterior + shaping)
   SGP_TRY(pair_stage_table(ctx, gh, Geff, d, &p.stages, &p.nstages));
   bool single = true;
   for (int g = 0; g < Geff; ++g) single = single && gh[g].kern.n_parts == 1;
@@ -1246,6 +1233,5 @@ int launch_sweep_pair(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d,
       sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
       return -2;
   }
-  if (rc != 0 || !fitness) return rc;
-  return launch_fitness_small(ctx, a.G, a.pts.N, p.conf.mean, p.conf.var, a.fit);
+  return rc;
 }
