@@ -217,6 +217,25 @@ int sgp_grid_sets_fused(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                         double* x_top, double* mean_top, double* q_top,
                         int32_t* flags, double* value, int64_t* gidx,
                         double* max_l_out);
+/* The same on N ranks (row shards, sgp_comm_init on the grid's context) after a
+ * confidence pass without read-back: max l0[S] and the maximiser width are
+ * all-reduced in stream; every rank's first candidate (with its row, counts and
+ * tie count) goes through ONE in-stream all-gather and is merged on the device
+ * into the first candidate of the WHOLE grid in the visiting order of
+ * gp_opt.py:542-552; every rank scans its own unsafe rows for it, the G flags are
+ * all-reduced (max) in stream (gp_opt.py:611-612: any over all rows), the owner
+ * of the candidate marks G if every active GP certified it, and the (value,
+ * index) pairs of the local M|G arg-maxima are all-gathered and merged
+ * (gp_opt.py:635, 642-644: first index among equals).  One stream sync; every
+ * rank returns the same numbers: counts are totals over the grid, indices are
+ * global.  Without a communicator (one rank) it equals sgp_grid_sets_fused with
+ * max_l = NaN.                                                                  */
+int sgp_grid_sets_fused_comm(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
+                             const double* fmin, const double* scaling,
+                             const double* thr_beta, double near_frac, double* out5,
+                             double* x_top, double* mean_top, double* q_top,
+                             int32_t* flags, double* value, int64_t* gidx,
+                             double* max_l_out);
 /* gp_opt.py:615: G[idx] = True for owned global indices                      */
 int sgp_grid_mark_expanders(sgp_grid* grid, const int64_t* gidx, int m);
 /* ... and G[gidx] = False: when exact ties in the visiting order

@@ -85,6 +85,11 @@ PROTOTYPES = {
                                       C.c_double, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_i32_p,
                                       c_double_p, c_i64_p, c_double_p]),
+    "sgp_grid_sets_fused_comm": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p,
+                                           c_double_p, c_double_p, C.c_double,
+                                           c_double_p, c_double_p, c_double_p,
+                                           c_double_p, c_i32_p, c_double_p, c_i64_p,
+                                           c_double_p]),
     "sgp_grid_sets_back": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p,
                                      c_double_p, c_double_p, c_double_p,
                                      C.c_double, C.c_int64, C.c_int,
@@ -593,6 +598,24 @@ class DeviceGrid(object):
         self.ctx.check(lib().sgp_grid_sets_fused(
             self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin),
             float('nan') if max_l is None else float(max_l), dptr(scaling),
+            dptr(thr_beta), float(near_frac), dptr(out5), dptr(x), dptr(mean),
+            dptr(q), flags.ctypes.data_as(c_i32_p), C.byref(v), C.byref(i),
+            C.byref(ml)))
+        return out5, x, mean, q, flags, v.value, i.value, ml.value
+
+    def sets_fused_comm(self, gps, beta, fmin, scaling, thr_beta, near_frac):
+        """N-rank certified step in one round trip (merges behind in-stream collectives)."""
+        fmin, scaling, thr_beta = f64(fmin), f64(scaling), f64(thr_beta)
+        out5 = np.empty(6)
+        x = np.empty(self.d)
+        mean = np.empty(self.G)
+        q = np.empty(2 * self.G)
+        flags = np.zeros(self.G, dtype=np.int32)
+        v = C.c_double(0)
+        i = C.c_int64(0)
+        ml = C.c_double(0)
+        self.ctx.check(lib().sgp_grid_sets_fused_comm(
+            self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin), dptr(scaling),
             dptr(thr_beta), float(near_frac), dptr(out5), dptr(x), dptr(mean),
             dptr(q), flags.ctypes.data_as(c_i32_p), C.byref(v), C.byref(i),
             C.byref(ml)))

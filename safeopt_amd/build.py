@@ -66,6 +66,14 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     if jobs or force or _stale(OUT, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"])
+    # test harness for the device-side merges of the N-rank step (tests/native): its own
+    # translation unit around csrc/sets.hip, linked against the library for the rest
+    hs = os.path.join(REPO, "tests", "native", "merge_check.hip")
+    if os.path.exists(hs):
+        hb = os.path.join(REPO, "tests", "native", "merge_check")
+        if force or _stale(hb, [hs, os.path.join(CSRC, "sets.hip"), OUT] + HEADERS):
+            run([hipcc] + BASE + EXTRA["sets.hip"] +
+                [hs, "-o", hb, "-L", PKG, "-l:libsafeopt_hip.so", "-Wl,-rpath," + PKG])
     return OUT
 
 

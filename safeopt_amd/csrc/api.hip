@@ -1213,6 +1213,126 @@ int sgp_grid_sets_fused(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   return 0;
 }
 
+// N-rank certified step with ONE stream sync (the N-rank counterpart of
+// sgp_grid_sets_fused; gp_opt.py:511-557, 611-612, 635, 642-644): the front half of
+// sgp_grid_sets_front_comm on this rank's shard, then IN STREAM
+//   all-gather of every rank's front block  -> k_merge_front: the first candidate
+//     of the whole grid in visiting order, total counts, ties over all shards,
+//     staged as the operand of the expander test on every rank;
+//   the probe scan of that candidate over this rank's unsafe rows;
+//   all-reduce (max) of the G flags;
+//   conditional G mark by the rank that owns the candidate + local M | G arg-max;
+//   all-gather of the (value, index) pairs -> k_merge_argmax.
+// Every rank reads back the same block.  Without a communicator (one rank) the
+// collectives are skipped and the merges run over one block.
+int sgp_grid_sets_fused_comm(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
+                             const double* fmin, const double* scaling,
+                             const double* thr_beta, double near_frac, double* out5,
+                             double* x_top, double* mean_top, double* q_top,
+                             int32_t* flags, double* value, int64_t* gidx,
+                             double* max_l_out) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  const int d = g->d;
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+  SGP_CHECK(ctx, comm || ctx->world <= 1,
+            "rank %d of %d has no communicator in the grid's context: the "
+            "in-stream collectives cannot run (sgp_comm_init on THIS context)",
+            ctx->rank, ctx->world);
+  const int world = comm ? ctx->world : 1;
+  // device block: merged result (layout of sgp_grid_sets_fused) | this rank's front
+  // block | gathered front blocks | this rank's (value, index) | gathered pairs
+  const size_t nfront = 6 + size_t(d) + 3 * size_t(G);
+  const size_t nfl = (size_t(G) + 1) / 2;
+  const size_t nres = nfront + nfl + 3;
+  const size_t total = nres + 1 + nfront * (1 + size_t(world)) + 2 * (1 + size_t(world));
+  double* res = static_cast<double*>(sgp_scratch(ctx, 1, (total + 8) * 8));
+  SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
+  double* mine = res + nres + 1;
+  double* all = mine + nfront;
+  double* pair = all + nfront * size_t(world);
+  double* pairs = pair + 2;
+  GpDev ghost[SGP_MAX_GPS];
+  SGP_TRY(collect_gps(ctx, gps, G, d, ghost));
+  ExpanderBufs eb;
+  SGP_TRY(expander_bufs(g, ghost, G, &eb));
+
+  // ---- front half on this shard (as sgp_grid_sets_front_comm)
+  SGP_TRY(settle_max_l(g));
+  if (comm)
+    SGP_NCCL(ctx, g_rccl.AllReduce(g->scal, g->scal, 1, ncclFloat64, ncclMax,
+                                   comm, ctx->stream));
+  SGP_TRY(launch_maximizers(g, 0.0, g->scal));
+  SGP_TRY(launch_reduce_max(ctx, g->partial, (g->N + 255) / 256, mine));
+  if (comm)
+    SGP_NCCL(ctx, g_rccl.AllReduce(mine, mine, 1, ncclFloat64, ncclMax, comm,
+                                   ctx->stream));
+  SGP_TRY(launch_candidates(g, 0.0, mine, scaling, thr_beta, 0,
+                            reinterpret_cast<unsigned long long*>(mine + 1)));
+  SGP_TRY(launch_topk(g, 0, INFINITY, INT64_MAX, 1, mine + 3,
+                      reinterpret_cast<int64_t*>(mine + 4),
+                      reinterpret_cast<int*>(mine + 5)));
+  SGP_TRY(launch_count_ties(g, mine + 3, reinterpret_cast<const int*>(mine + 5),
+                            reinterpret_cast<int*>(mine + 5) + 1));
+  SGP_TRY(launch_gather_top(g, reinterpret_cast<int64_t*>(mine + 4), mine + 6,
+                            mine + 6 + d, mine + 6 + d + G));
+
+  // ---- first candidate of the whole grid
+  const double* blocks = mine;
+  if (comm) {
+    SGP_NCCL(ctx, g_rccl.AllGather(mine, all, nfront, ncclFloat64, comm, ctx->stream));
+    blocks = all;
+  }
+  SGP_TRY(launch_merge_front(g, blocks, world, int(nfront), res, eb.xc,
+                             int((eb.bx + eb.bv) / 8), eb.flags, int(eb.bf / 4)));
+  // ---- probe scan over this shard, flags over all shards
+  int32_t* dfl = nullptr;
+  SGP_TRY(enqueue_expander(g, gps, G, beta, fmin, 1, nullptr, nullptr, nullptr,
+                           near_frac, &dfl, nullptr, true));
+  if (comm)
+    SGP_NCCL(ctx, g_rccl.AllReduce(dfl, dfl, size_t(G), ncclInt32, ncclMax, comm,
+                                   ctx->stream));
+  // ---- conditional G mark (owner of the candidate) + arg-max over the whole grid
+  SGP_TRY(launch_argmax_marked(
+      g, scaling, fmin, dfl, reinterpret_cast<int64_t*>(res + 4),
+      reinterpret_cast<int*>(res + 5), reinterpret_cast<int32_t*>(res + nfront),
+      pair, reinterpret_cast<int64_t*>(pair + 1)));
+  const double* prs = pair;
+  if (comm) {
+    SGP_NCCL(ctx, g_rccl.AllGather(pair, pairs, 2, ncclFloat64, comm, ctx->stream));
+    prs = pairs;
+  }
+  SGP_TRY(launch_merge_argmax(ctx, prs, world, res + nfront + nfl,
+                              reinterpret_cast<int64_t*>(res + nfront + nfl + 1)));
+  SGP_HIP(ctx, hipMemcpyAsync(res + nfront + nfl + 2, g->scal, 8,
+                              hipMemcpyDeviceToDevice, ctx->stream));
+
+  std::vector<double> host(nres);
+  SGP_TRY(sgp_d2h(ctx, host.data(), res, nres * 8));
+  unsigned long long cnt[2];
+  int64_t idx;
+  int nfound, ntied;
+  memcpy(cnt, &host[1], 16);
+  memcpy(&idx, &host[4], 8);
+  memcpy(&nfound, &host[5], 4);
+  memcpy(&ntied, reinterpret_cast<const char*>(&host[5]) + 4, 4);
+  out5[0] = host[0];
+  out5[1] = double(cnt[0]);
+  out5[2] = double(cnt[1]);
+  out5[3] = host[3];
+  out5[4] = (nfound > 0) ? double(idx) : -1.0;
+  out5[5] = double(ntied);
+  memcpy(x_top, &host[6], size_t(d) * 8);
+  memcpy(mean_top, &host[6 + d], size_t(G) * 8);
+  memcpy(q_top, &host[6 + d + G], size_t(2 * G) * 8);
+  memcpy(flags, &host[nfront], size_t(G) * 4);
+  *value = host[nfront + nfl];
+  memcpy(gidx, &host[nfront + nfl + 1], 8);
+  *max_l_out = host[nfront + nfl + 2];
+  return 0;
+}
+
 // Fitness of P <= kSmallPoints particles (row-major, device) through the
 // small-point posterior path: mean / var per GP, then the shaping kernel.
 static int fitness_small(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,

@@ -318,6 +318,10 @@ int launch_sets_front_fused(sgp_grid* g, double max_l, const double* l0_part,
                             const double* scaling, const double* thr_beta,
                             double* res, double* max_l_slot, double* xc,
                             int n_xc_resid, int32_t* flags, int n_flag_words);
+int launch_merge_front(sgp_grid* g, const double* all, int world, int nfront, double* res,
+                       double* xc, int n_xc_resid, int32_t* flags, int n_flag_words);
+int launch_merge_argmax(sgp_ctx* ctx, const double* all, int world, double* out_v,
+                        int64_t* out_i);
 int launch_argmax_marked(sgp_grid* g, const double* scaling, const double* fmin,
                          const int32_t* flags_dev, const int64_t* cand_gidx_dev,
                          const int* nfound_dev, int32_t* flags_out,

@@ -710,6 +710,84 @@ __global__ __launch_bounds__(T) void k_argmax_final_f(
   if (threadIdx.x < G) flags_out[threadIdx.x] = flags[threadIdx.x];
 }
 
+// ---- N ranks: merges behind in-stream all-gathers ------------------------------------
+// Every rank's front block ([0] max width | [1..2] counts (u64) | [3] w_top | [4]
+// idx_top (i64) | [5] n_found, n_tied (int) | x[d] | mean[G] | q[2G]) gathered into
+// `all` [world][nfront]: the first candidate of the WHOLE grid in visiting order
+// (gp_opt.py:542-552: width descending, among equal widths the larger index first),
+// total counts, the number of candidates tied with it over all shards -> `res` in the
+// same layout, and the candidate staged as the operand of the expander test exactly
+// as k_front_final stages it (xc, resid[g * 16] = u_g - mu_g; flags zeroed).  One
+// wave; every rank computes the same block.
+__global__ __launch_bounds__(64) void k_merge_front(
+    const double* all, int world, int nfront, int d, int G, double* res, double* xc,
+    int n_xc_resid, int32_t* flags, int n_flag_words) {
+  const int lane = threadIdx.x;
+  for (int e = lane; e < n_xc_resid; e += 64) xc[e] = 0.0;
+  for (int e = lane; e < n_flag_words; e += 64) flags[e] = 0;
+  __shared__ int win_rank;
+  if (lane == 0) {
+    unsigned long long ta = 0, tb = 0;
+    Pair best{-INFINITY, -1};
+    int wr = -1;
+    for (int r = 0; r < world; ++r) {
+      const double* b = all + size_t(r) * nfront;
+      ta += reinterpret_cast<const unsigned long long*>(b)[1];
+      tb += reinterpret_cast<const unsigned long long*>(b)[2];
+      const int found = reinterpret_cast<const int*>(b + 5)[0];
+      const Pair p{b[3], reinterpret_cast<const int64_t*>(b)[4]};
+      if (found > 0 && p.i >= 0 && (best.i < 0 || before_desc(p, best))) {
+        best = p;
+        wr = r;
+      }
+    }
+    int ties = 0;
+    for (int r = 0; r < world; ++r) {
+      const double* b = all + size_t(r) * nfront;
+      if (reinterpret_cast<const int*>(b + 5)[0] > 0 && b[3] == best.v)
+        ties += reinterpret_cast<const int*>(b + 5)[1];
+    }
+    res[0] = all[0];                      // (all-reduced before: the same everywhere)
+    reinterpret_cast<unsigned long long*>(res)[1] = ta;
+    reinterpret_cast<unsigned long long*>(res)[2] = tb;
+    res[3] = best.v;
+    reinterpret_cast<int64_t*>(res)[4] = best.i;
+    reinterpret_cast<int*>(res + 5)[0] = wr >= 0 ? 1 : 0;
+    reinterpret_cast<int*>(res + 5)[1] = wr >= 0 ? ties : 0;
+    win_rank = wr;
+  }
+  __syncthreads();
+  const int wr = win_rank;
+  if (wr < 0) return;
+  const double* b = all + size_t(wr) * nfront;
+  double* resid = xc + (n_xc_resid - G * 16);
+  for (int k = lane; k < d; k += 64) {
+    res[6 + k] = b[6 + k];
+    xc[k] = b[6 + k];
+  }
+  for (int g = lane; g < G; g += 64) {
+    const double mu = b[6 + d + g];
+    res[6 + d + g] = mu;
+    resid[g * 16] = b[6 + d + G + 2 * g + 1] - mu;
+  }
+  for (int q = lane; q < 2 * G; q += 64) res[6 + d + G + q] = b[6 + d + G + q];
+}
+
+// Every rank's (value, global index) of the M | G arg-max gathered into `all`
+// [world][2]: np.argmax over the whole grid (larger value first, among equals the
+// smaller index) -- gp_opt.py:635, 642-644.
+__global__ void k_merge_argmax(const double* all, int world, double* out_v,
+                               int64_t* out_i) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Pair best{-INFINITY, -1};
+  for (int r = 0; r < world; ++r) {
+    const Pair p{all[2 * r], reinterpret_cast<const int64_t*>(all)[2 * r + 1]};
+    if (before_first(p, best)) best = p;
+  }
+  *out_v = best.v;
+  *out_i = best.i;
+}
+
 inline unsigned nblk(int64_t N, int per) { return unsigned((N + per - 1) / per); }
 
 }  // namespace
@@ -958,6 +1036,23 @@ int launch_argmax_marked(sgp_grid* g, const double* scaling, const double* fmin,
                      nfound_dev, pv, pi);
   hipLaunchKernelGGL(k_argmax_final_f, dim3(1), dim3(T), 0, ctx->stream, pv, pi,
                      int64_t(nb), flags_dev, g->G, flags_out, value_dev, idx_dev);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_merge_front(sgp_grid* g, const double* all, int world, int nfront, double* res,
+                       double* xc, int n_xc_resid, int32_t* flags, int n_flag_words) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_merge_front, dim3(1), dim3(64), 0, ctx->stream, all, world, nfront,
+                     g->d, g->G, res, xc, n_xc_resid, flags, n_flag_words);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_merge_argmax(sgp_ctx* ctx, const double* all, int world, double* out_v,
+                        int64_t* out_i) {
+  hipLaunchKernelGGL(k_merge_argmax, dim3(1), dim3(64), 0, ctx->stream, all, world, out_v,
+                     out_i);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

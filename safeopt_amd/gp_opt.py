@@ -282,6 +282,10 @@ class _HipGridBackend(object):
         return self.grid.sets_fused(self._dev(), beta, fmin, max_l, scaling,
                                     thr_beta, near_frac)
 
+    def sets_fused_comm(self, beta, fmin, scaling, thr_beta, near_frac):
+        return self.grid.sets_fused_comm(self._dev(), beta, fmin, scaling,
+                                         thr_beta, near_frac)
+
     def sets_back(self, beta, fmin, xc, mu_c, u_c, near_frac, gidx_c, scaling,
                   mark):
         return self.grid.sets_back(self._dev(), beta, fmin, xc, mu_c, u_c,
@@ -544,9 +548,10 @@ class SafeOpt(GaussianProcessOptimization):
         active = self.fmin != -np.inf
         world = self._comm.world
         if not full_sets and not self.use_lipschitz and hasattr(be, 'sets_front'):
-            # Fused passes.  One GPU: 2 device round trips.  N GPUs: 3 round
-            # trips + 3 scalar collectives (max_var; every rank's first
-            # candidate with its rows; probe flags + local arg-max).
+            # Fused passes.  One GPU, or N GPUs with an in-stream communicator
+            # behind a deferred confidence pass: ONE device round trip.  Otherwise
+            # 2 (one GPU) / 3 round trips + 3 scalar collectives (max_var; every
+            # rank's first candidate with its rows; probe flags + local arg-max).
             d = self.inputs.shape[1]
             fused = None
             n_tied = None           # candidates tied with the first one (None: unknown)
@@ -571,6 +576,23 @@ class SafeOpt(GaussianProcessOptimization):
                 n_cand, n_unsafe, w_c, idx_c = (out5[1], out5[2],
                                                 float(out5[3]), int(out5[4]))
                 n_tied = int(out5[5]) if len(out5) > 5 else None
+            elif (self._max_l is None and np.any(active)
+                  and hasattr(be, 'sets_fused_comm')):
+                # N ranks, deferred confidence pass: the whole certified step in one
+                # device round trip -- the first-candidate merge, the probe flags and
+                # the arg-max merge run on the device behind in-stream collectives,
+                # every rank reads back the same (global) numbers
+                (out5, x_c, mu_c, q_c, f_flags, f_val, f_idx,
+                 max_l) = be.sets_fused_comm(beta, self.fmin, self.scaling,
+                                             thr_beta, 0.5)
+                self._max_l, self._any_safe = max_l, bool(max_l > -np.inf)
+                if not self._any_safe:
+                    self._stale.update(M=True, G=True)
+                    return
+                n_cand, n_unsafe, w_c, idx_c = (out5[1], out5[2],
+                                                float(out5[3]), int(out5[4]))
+                fused = (f_flags, f_val, f_idx)
+                n_tied = int(out5[5])
             else:
                 if self._max_l is None:
                     # deferred confidence pass: max l0 and the maximiser width
@@ -614,12 +636,13 @@ class SafeOpt(GaussianProcessOptimization):
                 flags, val, idx = be.sets_back(beta, self.fmin, x_c, mu_c,
                                                q_c[1::2], 0.5, idx_c,
                                                self.scaling, world == 1)
-            if world > 1:
+            merged = fused is not None       # (flags and arg-max already global)
+            if world > 1 and not merged:
                 pk = self._comm.allgather(np.concatenate(
                     [flags.astype(np.float64), [val, float(idx)]]))
                 flags = pk[:, :G].max(axis=0)
             if np.all(flags[active] != 0):
-                if world > 1:
+                if world > 1 and not merged:
                     if be.owns(idx_c):
                         be.mark_expanders(np.array([idx_c], dtype=np.int64))
                     # arg-max over M on every rank + the certified expander

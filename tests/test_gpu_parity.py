@@ -1028,8 +1028,29 @@ def test_multirank_control_flow_on_one_gpu(mods):
         return safeopt_amd.SafeOpt(gps, grid, cfg["fmin"], threshold=cfg["threshold"], comm=comm)
     a, b = make(cfg["grid"], comm), make(half, None)
     assert a._shard == (0, half.shape[0])
+    # the certified step of the N-rank driver is ONE device round trip: first-candidate
+    # merge, probe flags and arg-max merge on the device behind in-stream collectives
+    calls = {"fused_comm": 0, "host_gathers": 0}
+    inner = a._backend.sets_fused_comm
+
+    def counted(*args, **kw):
+        calls["fused_comm"] += 1
+        return inner(*args, **kw)
+    a._backend.sets_fused_comm = counted
+    gather = comm.allgather
+
+    def counted_gather(x):
+        calls["host_gathers"] += 1
+        return gather(x)
+    comm.allgather = counted_gather
     for it in range(4):
+        before = dict(calls)
         xa, xb = a.optimize(), b.optimize()
+        assert calls["fused_comm"] == before["fused_comm"] + 1
+        # (host collectives only when the probe does not certify the first candidate
+        # or exact ties have to be settled)
+        if a._argmax_cache is not None and calls["host_gathers"] != before["host_gathers"]:
+            assert calls["host_gathers"] - before["host_gathers"] <= 2
         assert_array_equal(xa, xb)
         n = half.shape[0]
         assert_array_equal(a._backend.download(_hip.Q), b.Q)
@@ -1038,6 +1059,104 @@ def test_multirank_control_flow_on_one_gpu(mods):
         y = np.array([[_bumps(np.atleast_2d(xa), 102 + g)[0] + 1.0 for g in range(3)]])
         a.add_new_data_point(xa, y)
         b.add_new_data_point(xb, y)
+
+
+def test_fused_comm_step_equals_fused_step(mods):
+    """sgp_grid_sets_fused_comm (front half, merges behind the -- here one-rank --
+    in-stream collectives, probe, mark, arg-max) returns what sgp_grid_sets_fused
+    returns on the same grid, with and without a communicator in the context, and
+    leaves the same M / G."""
+    safeopt_amd, gpy, _, _ = mods
+    from safeopt_amd import _hip
+    from bench import make_config, build_gps
+    ctx = _hip.Context.default()
+    cfg = make_config(3, side=70)
+    cfg["X"], cfg["Y"] = cfg["X"][:20], cfg["Y"][:20]      # (wide intervals: expanders exist)
+    gps = build_gps(cfg, gpy)
+    devs = [g._fitted() for g in gps]
+    G = cfg["G"]
+    fmin = np.array(cfg["fmin"], dtype=float)
+    scaling = np.full(G, 2.0 ** 0.5)
+    thr = np.full(G, 0.05)
+    grid = _hip.DeviceGrid(ctx, cfg["grid"], G)
+    out = {}
+    for name in ("fused", "comm"):
+        grid.confidence(devs, 2.0, fmin, defer=True)
+        if name == "fused":
+            r = grid.sets_fused(devs, 2.0, fmin, None, scaling, thr, 0.5)
+        else:
+            r = grid.sets_fused_comm(devs, 2.0, fmin, scaling, thr, 0.5)
+        out[name] = r + (grid.download(_hip.M), grid.download(_hip.G))
+    for x, y in zip(out["fused"], out["comm"]):
+        assert_array_equal(np.asarray(x), np.asarray(y))
+    assert out["comm"][0][4] >= 0          # (a candidate was found: the test is not void)
+
+
+def test_device_merges_of_the_n_rank_step(mods):
+    """k_merge_front / k_merge_argmax on gathered blocks of 1..8 ranks (the harness
+    tests/native/merge_check.hip feeds them what the in-stream all-gathers of
+    sgp_grid_sets_fused_comm would deliver) against the NumPy merges of
+    safeopt_amd/dist.py that the gloo tests pin to unsharded runs: first candidate in
+    visiting order with forced width ties across ranks, shards without a candidate,
+    total counts, tie counts, staged expander operand, first-index arg-max."""
+    import os, struct, subprocess
+    from safeopt_amd import dist
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "merge_check")
+    assert os.path.exists(exe), "python -m safeopt_amd.build builds tests/native/merge_check"
+    rng = np.random.default_rng(77)
+    for trial in range(40):
+        world = int(rng.integers(1, 9))
+        d, G = int(rng.integers(1, 9)), int(rng.integers(1, 5))
+        nfront = 6 + d + 3 * G
+        blocks = np.zeros((world, nfront))
+        raw = blocks.view(np.uint8).reshape(world, nfront * 8)
+        found = rng.random(world) < (0.0 if trial == 0 else 0.75)
+        widths = rng.choice([0.5, 1.25, 1.25, 3.0], size=world)      # ties across ranks
+        idx = rng.permutation(10 ** 6)[:world].astype(np.int64)
+        ntied = rng.integers(1, 5, size=world).astype(np.int32)
+        counts = rng.integers(0, 2 ** 40, size=(world, 2)).astype(np.uint64)
+        blocks[:, 0] = 0.875
+        blocks[:, 6:] = rng.normal(size=(world, nfront - 6))
+        for r in range(world):
+            raw[r, 8:24] = counts[r].view(np.uint8)
+            blocks[r, 3] = widths[r] if found[r] else -np.inf
+            raw[r, 32:40] = np.array([idx[r] if found[r] else -1], dtype=np.int64).view(np.uint8)
+            raw[r, 40:48] = np.array([int(found[r]), ntied[r] if found[r] else 0],
+                                     dtype=np.int32).view(np.uint8)
+        vals = rng.choice([-np.inf, 0.1, 0.7, 0.7], size=world)
+        aidx = rng.permutation(10 ** 6)[:world].astype(np.int64)
+        aidx[vals == -np.inf] = -1
+        pairs = np.zeros((world, 2))
+        pairs[:, 0] = vals
+        pairs.view(np.int64)[:, 1] = aidx
+        out = subprocess.run([exe], input=struct.pack("4i", world, nfront, d, G) +
+                             blocks.tobytes() + pairs.tobytes(),
+                             capture_output=True, timeout=120)
+        assert out.returncode == 0, out.stderr.decode()
+        got = np.frombuffer(out.stdout, dtype=np.float64)
+        res, xc, resid = got[:nfront], got[nfront:nfront + d], got[nfront + d:nfront + d + G]
+        v_got = got[nfront + d + G]
+        i_got = int(got[nfront + d + G + 1:].view(np.int64)[0])
+        # ---- expectation from the NumPy merges
+        w_b, i_b = dist.merge_topk(np.where(found, widths, -np.inf),
+                                   np.where(found, idx, -1), 1)
+        assert res[0] == 0.875
+        assert_array_equal(res[1:3].view(np.uint64), counts.sum(axis=0))
+        head = res[5:6].view(np.int32)
+        if i_b.size == 0:
+            assert head[0] == 0 and head[1] == 0 and res[4:5].view(np.int64)[0] == -1
+        else:
+            r = int(np.flatnonzero(found & (idx == i_b[0]))[0])
+            assert res[3] == w_b[0] and res[4:5].view(np.int64)[0] == i_b[0]
+            assert head[0] == 1
+            assert head[1] == int(ntied[found & (widths == w_b[0])].sum())
+            assert_array_equal(res[6:], blocks[r, 6:])
+            assert_array_equal(xc, blocks[r, 6:6 + d])
+            assert_array_equal(resid, blocks[r, 6 + d + G + 1::2][:G] - blocks[r, 6 + d:6 + d + G])
+        v_e, i_e = dist.merge_argmax(vals, aidx)
+        assert i_got == int(i_e)
+        if i_e >= 0:
+            assert v_got == v_e
 
 
 def _dev_script(name):
