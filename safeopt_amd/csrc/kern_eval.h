@@ -314,7 +314,7 @@ struct KernFast {
   template <bool SINGLE>
   __device__ __forceinline__ void prep_t(const double* x, double* xs) const {
 #pragma unroll
-    for (int i = 0; i < D; ++i) xs[i] = SINGLE ? x[i] * sc[i] : x[i];
+    for (int i = 0; i < D; ++i) xs[i] = (SINGLE || single) ? x[i] * sc[i] : x[i];
   }
 
   template <int NV, bool SINGLE>
@@ -375,19 +375,21 @@ struct KernFast {
   // ONE 2^(U/32) per covariance, a square root and a polynomial factor per Matern
   // part.  The weights are wave-uniform scalar loads from the descriptor (constant
   // address space: no vector registers, no vmcnt wait); those of the first two parts
-  // are fetched up front (a part the kernel does not have weighs zero), the
-  // hyper-parameters of GPy's Prod kernel (GPy kern/src/prod.py: K = prod_p K_p).
-  // xs, ys: RAW rows.
+  // are fetched up front (a part the kernel does not have weighs zero).  GPy's Prod
+  // kernel: K = prod_p K_p (GPy kern/src/prod.py).  xs, ys: RAW rows (products) or
+  // the pre-scaled ones of a single-part GP.
   template <int NV>
   __device__ __forceinline__ void product_n(const double* xs, const double* ys,
                                             int stride, const double* tab,
                                             double (&out)[NV]) const {
     const const_desc_t k = (const_desc_t)kd;
     const int P = k->n_parts;
+    // (a single-part GP in a launch that also has products: its training rows are
+    // stored pre-scaled, GpDev::Xs, and prep_t scaled the candidate row -- weights 1)
     double w0[D], w1[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-      w0[i] = k->wsq[0][i];
+      w0[i] = single ? 1.0 : k->wsq[0][i];
       w1[i] = k->wsq[1][i];
     }
     const int kind0p = k->kind[0], kind1p = k->kind[1];

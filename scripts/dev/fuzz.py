@@ -11,7 +11,7 @@ from oracle import gp_numpy as gpn, safeopt_numpy as son
 KINDS = ["RBF", "Matern32", "Matern52"]
 
 
-def run(trials=150, dmax=4, Gmax=3, nmax=300, seed0=1000, verbose=True):
+def run(trials=150, dmax=4, Gmax=3, nmax=300, seed0=1000, verbose=True, products=False):
   """(mismatches, max |Q_dev - Q_oracle|) over `trials` seeded random problems."""
   bad = 0
   worst = 0.0
@@ -28,10 +28,22 @@ def run(trials=150, dmax=4, Gmax=3, nmax=300, seed0=1000, verbose=True):
         var = float(rng.uniform(0.5, 3.0))
         y = (np.sin(X.sum(1) + g) + 1.0 + 0.3 * rng.normal(size=n))[:, None]
         noise = float(rng.uniform(0.01, 0.2)) ** 2
-        gps.append(gpy.models.GPRegression(X, y, getattr(gpy.kern, kind)(d, variance=var, lengthscale=ls, ARD=True),
-                                           noise_var=noise))
-        gos.append(gpn.GPRegression(X, y, getattr(gpn, kind)(d, variance=var, lengthscale=ls, ARD=True),
-                                    noise_var=noise))
+        def kern(ns):
+            return getattr(ns, kind)(d, variance=var, lengthscale=ls, ARD=True)
+        if products and d >= 2 and rng.random() < 0.3:
+            # a product of two parts on random (possibly overlapping) column sets
+            cols = [np.sort(rng.choice(d, size=int(rng.integers(1, d + 1)), replace=False))
+                    for _ in range(2)]
+            kinds2 = [KINDS[int(rng.integers(0, 3))] for _ in range(2)]
+            ls2 = [rng.uniform(0.5, 2.0, size=len(c)) for c in cols]
+
+            def kern(ns):
+                parts = [getattr(ns, kk)(len(c), variance=var ** 0.5, lengthscale=l, ARD=True,
+                                         active_dims=list(c))
+                         for kk, c, l in zip(kinds2, cols, ls2)]
+                return parts[0] * parts[1]
+        gps.append(gpy.models.GPRegression(X, y, kern(gpy.kern), noise_var=noise))
+        gos.append(gpn.GPRegression(X, y, kern(gpn), noise_var=noise))
     fmin = [float(rng.uniform(-0.5, 1.0)) if (g == 0 or rng.random() < 0.7) else -np.inf for g in range(G)]
     thr = float(rng.uniform(0, 0.5))
     opt = safeopt_amd.SafeOpt(gps if G > 1 else gps[0], grid, fmin if G > 1 else fmin[0], threshold=thr)

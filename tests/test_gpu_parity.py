@@ -175,6 +175,72 @@ def test_grid_sweep_both_kernels(mods, which, kind, d, ns, N):
         assert max_l == Q[So, 0].max()
 
 
+def product_kernel(ns, d, spec, seed):
+    """Prod kernel from ``spec`` = [(kind, columns), ...] (columns may overlap)."""
+    rng = np.random.default_rng(seed)
+    k = None
+    for kind, cols in spec:
+        part = getattr(ns, kind)(len(cols), variance=float(rng.uniform(0.6, 1.8)),
+                                 lengthscale=rng.uniform(0.7, 1.9, size=len(cols)),
+                                 ARD=True, active_dims=list(cols))
+        k = part if k is None else k * part
+    return k
+
+
+# Products of parts (GPy's Prod kernel; the reference's context example multiplies a
+# kernel over the parameters by one over the context): KernFast::product_n adds the
+# parts' exponents -- disjoint and OVERLAPPING column sets, 2 to 4 parts, every kind,
+# a single-part GP in the same launch, both sweep kernels, n across 256 / 512.
+PRODUCT_CASES = [
+    # d, [(n, spec or kind)], N
+    (2, [(60, [("RBF", [0]), ("RBF", [1])])], 500),
+    (2, [(200, [("Matern52", [0]), ("RBF", [1])]), (90, "Matern32")], 1000),
+    (3, [(300, [("Matern32", [0, 1]), ("Matern52", [1, 2])])], 640),
+    (3, [(257, [("RBF", [0, 1, 2]), ("Matern52", [0, 1, 2])]), (256, "RBF")], 777),
+    (4, [(530, [("RBF", [0]), ("Matern32", [1]), ("Matern52", [2, 3])])], 333),
+    (4, [(100, [("RBF", [0, 1]), ("RBF", [2]), ("Matern52", [3]), ("Matern32", [0, 3])]),
+         (1040, [("Matern52", [0, 1, 2]), ("RBF", [3])])], 450),
+    (6, [(150, [("Matern52", [0, 1, 2, 3]), ("RBF", [4, 5])])], 260),
+    (8, [(70, [("RBF", list(range(7))), ("Matern32", [7])]), (300, "Matern52")], 200),
+]
+
+
+@pytest.mark.parametrize("which", ["classic", "pair"])
+@pytest.mark.parametrize("d,gpspec,N", PRODUCT_CASES)
+def test_grid_sweep_product_kernels(mods, which, d, gpspec, N):
+    _, gpy, gpn, son = mods
+    from safeopt_amd import _hip
+    rng = np.random.default_rng(N + 31 * d)
+    gps, gos = [], []
+    for i, (n, spec) in enumerate(gpspec):
+        X = rng.uniform(-2, 2, size=(n, d)); Y = smooth(X, 5 + i) + 0.3
+        if isinstance(spec, str):
+            k, ko = kernels(gpy.kern, spec, d), kernels(gpn, spec, d)
+        else:
+            k, ko = product_kernel(gpy.kern, d, spec, n), product_kernel(gpn, d, spec, n)
+        gps.append(gpy.models.GPRegression(X, Y, k, noise_var=0.05 ** 2))
+        gos.append(gpn.GPRegression(X, Y, ko, noise_var=0.05 ** 2))
+    pts = rng.uniform(-3, 3, size=(N, d))
+    G = len(gps)
+    fmin = np.full(G, 0.1)
+    ctx = gps[0]._fitted().ctx
+    old = ctx.set_sweep(which)
+    try:
+        grid = _hip.DeviceGrid(ctx, pts, G)
+        grid.confidence([g._fitted() for g in gps], 2.0, fmin)
+        Q = grid.download(_hip.Q)
+        mean = grid.download(_hip.MEAN); var = grid.download(_hip.VAR)
+    finally:
+        ctx.set_sweep(old)
+    for i, go in enumerate(gos):
+        mo, vo = go.predict_noiseless(pts)
+        kdiag = float(go.kern.Kdiag(pts[:1])[0])
+        check_posterior(mean[i][:, None], var[i][:, None], mo, vo, kdiag)
+        sd = np.sqrt(vo[:, 0])
+        assert_allclose(Q[:, 2 * i], mo[:, 0] - 2.0 * sd, rtol=0, atol=2e-8)
+        assert_allclose(Q[:, 2 * i + 1], mo[:, 0] + 2.0 * sd, rtol=0, atol=2e-8)
+
+
 @pytest.mark.parametrize("kind,d,ns,N", [("Matern52", 2, [500, 500, 500], 2000 + 64 * 256),
                                         ("RBF", 3, [1000], 3000),
                                         ("RBF", 4, [2000, 1500], 64 * 300 + 5),
@@ -1176,6 +1242,11 @@ def test_randomised_optimize_slice(mods):
     with identical S / M / G / chosen point and Q within the north star's 1e-5."""
     bad, worst = _dev_script("fuzz").run(trials=200, dmax=5, Gmax=4, nmax=500, seed0=31000,
                                          verbose=False)
+    assert bad == 0
+    assert worst < 1e-5
+    # ... and 100 more with products of two parts (overlapping column sets included) mixed in
+    bad, worst = _dev_script("fuzz").run(trials=100, dmax=5, Gmax=3, nmax=500, seed0=47000,
+                                         verbose=False, products=True)
     assert bad == 0
     assert worst < 1e-5
 
