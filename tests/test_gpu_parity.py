@@ -1258,6 +1258,11 @@ def test_randomised_swarm_fitness_slice(mods):
                                                verbose=False)
     assert bad == 0
     assert worst < 1e-5
+    # ... and 60 more with products of two parts mixed in
+    bad, worst = _dev_script("fuzz_swarm").run(trials=60, nmax=600, pmax=7000, seed0=58000,
+                                               verbose=False, products=True)
+    assert bad == 0
+    assert worst < 1e-5
 
 
 def test_rank1_soak_against_refit(mods):
