@@ -58,7 +58,12 @@ fi
 {
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/probe1 scripts/dev/probe_r02.hip && /tmp/probe1 | grep -v "^[ABD][0-9]*:"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/probe2 scripts/dev/probe_coexec.hip && /tmp/probe2
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/probe3 scripts/dev/probe_interleave.hip && /tmp/probe3
 } > $OUT/probes.txt 2>&1
+# product kernels (the reference's context example) on both sweep kernels; cost of the
+# N-rank control flow on one GPU (one-rank RCCL communicator posing as world 2)
+python scripts/dev/ab_product.py 64 200 256 > $OUT/product_kernels.txt 2>&1
+python scripts/dev/multirank_path_cost.py 2>&1 | tail -6 > $OUT/multirank_path_cost.txt
 # what a user of the drop-in sees per BO iteration (incremental path) and per
 # SafeOptSwarm.optimize() with the default swarm
 { python scripts/bench_bo_loop.py --config 2; python scripts/bench_bo_loop.py --config 3; } > $OUT/bo_loop.json 2>$OUT/bo_loop.err

@@ -164,7 +164,7 @@ def main(argv):
                     w.writerow(["pass", "kernel", "counter", "avg_value_per_dispatch"])
                     w.writerows(rows[c])
         for name in ("ab_kernels.txt", "ablation.txt", "stamps.txt", "probes.txt", "bo_loop.json",
-                     "swarm_small.txt"):
+                     "swarm_small.txt", "product_kernels.txt", "multirank_path_cost.txt"):
             if os.path.exists(os.path.join(d, name)):
                 shutil.copy(os.path.join(d, name), os.path.join(dst, name))
         tj = os.path.join(ROOT, "profiles", "traffic.json")
