@@ -175,6 +175,53 @@ def test_grid_sweep_both_kernels(mods, which, kind, d, ns, N):
         assert max_l == Q[So, 0].max()
 
 
+@pytest.mark.parametrize("which", ["RBF", "Matern32", "Matern52", "RBF*Matern52", "Matern32*RBF*Matern52"])
+def test_device_gp_against_sklearn(mods, which):
+    """The product's GP handle (safeopt_amd/gpy.py -> C ABI -> device) against
+    scikit-learn's GaussianProcessRegressor -- a third implementation that shares
+    nothing with oracle/gp_numpy.py (whose kernel-parameter plumbing resembles
+    gpy.py's): ARD lengthscales, every kind, products of parts on the same columns."""
+    _, gpy, _, _ = mods
+    skgp = pytest.importorskip("sklearn.gaussian_process")
+    from sklearn.gaussian_process import kernels as skk
+    rng = np.random.default_rng(len(which))
+    n, d = 70, 3
+    X = rng.uniform(-2, 2, (n, d))
+    Y = np.sin(X.sum(1))[:, None] + 0.1 * rng.normal(size=(n, 1))
+    Xs = rng.uniform(-3, 3, (400, d))
+    noise = 0.04
+    k, ks, vtot = None, None, 1.0
+    for i, kind in enumerate(which.split("*")):
+        ls = rng.uniform(0.6, 2.0, size=d)
+        var = float(rng.uniform(0.7, 1.6))
+        vtot *= var
+        part = getattr(gpy.kern, kind)(d, variance=var, lengthscale=ls, ARD=True)
+        spart = (skk.RBF(ls, "fixed") if kind == "RBF" else
+                 skk.Matern(ls, "fixed", nu=1.5 if kind == "Matern32" else 2.5))
+        k = part if k is None else k * part
+        ks = spart if ks is None else ks * spart
+    gpr = skgp.GaussianProcessRegressor(skk.ConstantKernel(vtot, "fixed") * ks,
+                                        alpha=noise + 1e-8, optimizer=None).fit(X, Y)
+    mu, std = gpr.predict(Xs, return_std=True)
+    gp = gpy.models.GPRegression(X, Y, k, noise_var=noise)
+    m, v = gp.predict_noiseless(Xs)
+    assert_allclose(m.ravel(), mu.ravel(), rtol=1e-8, atol=1e-10)
+    assert np.max(np.abs(v.ravel() - std ** 2)) / vtot < 1e-8
+    # ... and through the grid sweep (both kernels)
+    from safeopt_amd import _hip
+    dev = gp._fitted()
+    for name in ("classic", "pair"):
+        old = dev.ctx.set_sweep(name)
+        try:
+            grid = _hip.DeviceGrid(dev.ctx, Xs, 1)
+            grid.confidence([dev], 2.0, np.zeros(1))
+            mean = grid.download(_hip.MEAN)[0]; var = grid.download(_hip.VAR)[0]
+        finally:
+            dev.ctx.set_sweep(old)
+        assert_allclose(mean, mu.ravel(), rtol=1e-8, atol=1e-10)
+        assert np.max(np.abs(var - std ** 2)) / vtot < 1e-8
+
+
 def product_kernel(ns, d, spec, seed):
     """Prod kernel from ``spec`` = [(kind, columns), ...] (columns may overlap)."""
     rng = np.random.default_rng(seed)
