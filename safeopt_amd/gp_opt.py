@@ -25,6 +25,8 @@ from __future__ import annotations
 import logging
 from functools import partial
 
+import weakref
+
 import numpy as np
 
 from . import _hip
@@ -157,6 +159,26 @@ class GaussianProcessOptimization(object):
             if not np.isnan(value):
                 self._remove_last_data_point(gp)
         self._x, self._y = self._x[:-1, :], self._y[:-1, :]
+
+
+class _WriteBackView(np.ndarray):
+    """View of the host mirror of ``Q`` that remembers element-wise writes: the
+    reference mutates ``opt.Q`` in place (``gp_opt.py:374-390, 475-476``) and user
+    code may do the same (``opt.Q[:, 0] = ...``); the optimiser uploads the mirror
+    before the next device pass that reads the intervals.  (Writes that bypass
+    ``__setitem__`` -- ``np.add(..., out=opt.Q)`` -- are not seen: assign
+    ``opt.Q = array`` for those.)"""
+
+    _owner = None
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, '_owner', None)
+
+    def __setitem__(self, key, value):
+        np.ndarray.__setitem__(self, key, value)
+        owner = self._owner() if self._owner is not None else None
+        if owner is not None:
+            owner._q_written = True
 
 
 class _HipGridBackend(object):
@@ -358,6 +380,7 @@ class SafeOpt(GaussianProcessOptimization):
         self._Q = np.empty((N, 2 * len(self.gps)), dtype=float)
         self._S, self._M, self._G = (np.zeros(N, dtype=bool) for _ in range(3))
         self._stale = dict(Q=False, S=False, M=False, G=False)
+        self._q_written = False
 
         # this rank's contiguous block of rows, resident on its GPU
         self._comm = comm if comm is not None else LocalComm()
@@ -394,16 +417,26 @@ class SafeOpt(GaussianProcessOptimization):
                     arr[off:off + c] = allp[r][:c]
                     off += c
             self._stale[name] = False
-        # a read-only view: the device does not see element-wise writes into a
-        # host mirror (``opt.Q[...] = ...`` raises; assign ``opt.Q = array``)
+        # S / M / G are results: read-only views (the device would not see writes);
+        # Q goes out as a write-back view, see the property
         view = getattr(self, '_' + name).view()
         view.flags.writeable = False
         return view
 
     @property
     def Q(self):
-        """Confidence intervals ``[l_0, u_0, l_1, u_1, ...]`` per row."""
-        return self._mirror('Q', _hip.Q)
+        """Confidence intervals ``[l_0, u_0, l_1, u_1, ...]`` per row.  Writable:
+        element-wise writes are uploaded before the next pass that reads them."""
+        self._mirror('Q', _hip.Q)
+        view = self._Q.view(_WriteBackView)
+        view._owner = weakref.ref(self)
+        return view
+
+    def _flush_Q(self):
+        """Upload ``Q`` if user code wrote into the mirror since the last pass."""
+        if self._q_written:
+            self._q_written = False
+            self.Q = self._Q.copy()
 
     @Q.setter
     def Q(self, value):
@@ -414,6 +447,7 @@ class SafeOpt(GaussianProcessOptimization):
         red = self._comm.allreduce_max(np.array([m, float(a)]))
         self._max_l, self._any_safe = red[0], bool(red[1] > 0)
         np.copyto(self._Q, value)
+        self._q_written = False
         self._stale.update(Q=False, S=True)
         self._ci_fresh = True
         self._argmax_cache = None
@@ -506,11 +540,13 @@ class SafeOpt(GaussianProcessOptimization):
             red = self._comm.allreduce_max(np.array([m, float(a)]))
             self._max_l, self._any_safe = red[0], bool(red[1] > 0)
         self._stale.update(Q=True, S=True)
+        self._q_written = False          # (the sweep overwrites the intervals)
         self._ci_fresh = True
         self._argmax_cache = None
 
     def compute_safe_set(self):
         """``S = all(l_i > fmin_i)``; fused into the sweep, nothing to redo."""
+        self._flush_Q()
         if not self._ci_fresh:
             self.update_confidence_intervals(context=self.context)
 
@@ -836,6 +872,7 @@ class SafeOpt(GaussianProcessOptimization):
 
     def get_new_query_point(self, ucb=False):
         """Next parameters to evaluate (first index wins among equals)."""
+        self._flush_Q()
         if not self._any_safe:
             raise EnvironmentError('There are no safe points to evaluate.')
         mode = _hip.ARGMAX_UCB if ucb else _hip.ARGMAX_MG_WIDTH

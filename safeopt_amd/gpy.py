@@ -69,6 +69,15 @@ class _Kern(object):
                 inv_ls[i, p.active_dims] = 1.0 / ls
         return d, kinds, variances, inv_ls
 
+    def _signature(self):
+        """The hyper-parameters as they are NOW (cheap: a few byte strings): the GP
+        handle compares it with the one it was fitted with, so that an edit in place
+        (``kern.lengthscale[0] = 2.``, ``kern.variance = 3.``) takes effect at the next
+        use, as GPy's parameter observers make it."""
+        return tuple((np.asarray(p.variance, dtype=float).tobytes(),
+                      np.asarray(p.lengthscale, dtype=float).tobytes())
+                     for p in self._parts())
+
     def K(self, X, X2=None):
         """Covariance matrix ``k(X, X2)`` (``X2=None``: ``k(X, X)``)."""
         X = np.atleast_2d(np.asarray(X, dtype=float))
@@ -169,6 +178,7 @@ class GPRegression(object):
         self._ctx = _hip.Context.default(device)
         self._dev = None
         self._dev_key = None
+        self._sig = None
         self._dev_fitted = False
         #: one-row changes of the data use bordered updates (set False to
         #: re-factorise from scratch on every ``set_XY`` like GPy)
@@ -189,6 +199,7 @@ class GPRegression(object):
             self._dev = _hip.DeviceGP(self._ctx, desc, self.noise_var)
             self._dev_key = key
             self._dev_fitted = False
+        self._sig = (self.kern._signature(), self.noise_var)
         return self._dev
 
     def set_XY(self, X, Y):
@@ -216,11 +227,12 @@ class GPRegression(object):
         self._dev_fitted = True
 
     def _fitted(self):
-        """Device GP, fitted.  Hot path: no host work when nothing changed.
-        Hyper-parameters are re-read on ``set_XY`` and on
-        ``parameters_changed()``."""
+        """Device GP, fitted.  Hot path: a comparison of the hyper-parameter bytes
+        when nothing changed; an edited kernel parameter or ``noise_var`` refits the
+        device model here, at the next use (GPy refits through its observers)."""
         if self._dev is not None and self._dev_fitted:
-            return self._dev
+            if (self.kern._signature(), self.noise_var) == self._sig:
+                return self._dev
         dev = self._device_gp()
         if not self._dev_fitted:
             dev.set_data(self.X, self.Y[:, 0])
@@ -228,9 +240,9 @@ class GPRegression(object):
         return dev
 
     def parameters_changed(self):
-        """Call after editing ``kern.variance`` / ``kern.lengthscale`` /
-        ``noise_var`` in place: refits the device model with the new values
-        (GPy triggers this through its parameter setters)."""
+        """Refit the device model with the current hyper-parameters NOW.  Not needed
+        for correctness -- an edit of ``kern.variance`` / ``kern.lengthscale`` /
+        ``noise_var`` is noticed at the next use -- kept for code that called it."""
         self._dev_fitted = False
         self._fitted()
 

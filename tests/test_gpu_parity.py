@@ -222,6 +222,74 @@ def test_device_gp_against_sklearn(mods, which):
         assert np.max(np.abs(var - std ** 2)) / vtot < 1e-8
 
 
+def test_hyperparameter_edits_take_effect_like_gpy(mods):
+    """GPy refits when a kernel parameter is assigned or edited in place; the handle
+    notices at the next use (no ``parameters_changed()`` call): predictions and a whole
+    ``SafeOpt.optimize()`` after the edit equal a freshly built model's."""
+    safeopt_amd, gpy, _, _ = mods
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-2, 2, (60, 2)); Y = smooth(X, 3) + 0.4
+    Xs = rng.uniform(-3, 3, (300, 2))
+
+    def fresh(var, ls, noise):
+        k = gpy.kern.Matern52(2, variance=var, lengthscale=ls, ARD=True)
+        return gpy.models.GPRegression(X, Y, k, noise_var=noise)
+    gp = fresh(1.5, [1.0, 1.3], 0.01)
+    m0, v0 = gp.predict_noiseless(Xs)
+    gp.kern.lengthscale[0] = 0.7                    # in place
+    m1, v1 = gp.predict_noiseless(Xs)
+    mf, vf = fresh(1.5, [0.7, 1.3], 0.01).predict_noiseless(Xs)
+    assert_array_equal(m1, mf); assert_array_equal(v1, vf)
+    assert np.max(np.abs(m1 - m0)) > 1e-3
+    gp.kern.variance = 2.5                          # assignment
+    gp.noise_var = 0.04
+    m2, v2 = gp.predict_noiseless(Xs)
+    mf, vf = fresh(2.5, [0.7, 1.3], 0.04).predict_noiseless(Xs)
+    assert_array_equal(m2, mf); assert_array_equal(v2, vf)
+    # inside a BO loop: the resident posterior of the grid follows
+    grid = safeopt_amd.linearly_spaced_combinations([(-3, 3)] * 2, 60)
+    a = safeopt_amd.SafeOpt(fresh(1.5, [1.0, 1.3], 0.01), grid, 0.0, threshold=0.1)
+    a.optimize()
+    a.gp.kern.lengthscale[:] = [0.8, 0.9]
+    xa = a.optimize()
+    b = safeopt_amd.SafeOpt(fresh(1.5, [0.8, 0.9], 0.01), grid, 0.0, threshold=0.1)
+    xb = b.optimize()
+    assert_array_equal(xa, xb)
+    assert_array_equal(a.Q, b.Q)
+    for name in ("S", "M", "G"):
+        assert_array_equal(getattr(a, name), getattr(b, name))
+
+
+def test_q_written_in_place_reaches_the_device(mods):
+    """``opt.Q[...] = ...`` (the reference mutates ``Q`` in place) is uploaded before
+    the next pass on the HIP backend and equals ``opt.Q = array``."""
+    safeopt_amd, gpy, _, _ = mods
+    rng = np.random.default_rng(11)
+    X = rng.uniform(-2, 2, (25, 2)); Y = smooth(X, 3) + 0.4
+    grid = safeopt_amd.linearly_spaced_combinations([(-3, 3)] * 2, 50)
+
+    def make():
+        k = gpy.kern.RBF(2, variance=1.5, lengthscale=[1.0, 1.3], ARD=True)
+        opt = safeopt_amd.SafeOpt(gpy.models.GPRegression(X, Y, k, noise_var=0.01), grid, 0.0,
+                                  threshold=0.1)
+        opt.update_confidence_intervals()
+        return opt
+    a, b = make(), make()
+    target = np.array(a.Q)
+    target[100:400, 0] -= 0.3
+    target[[7, 9], 1] += 2.0
+    a.Q[100:400, 0] -= 0.3
+    a.Q[[7, 9], 1] += 2.0
+    b.Q = target
+    a.compute_sets(); b.compute_sets()
+    assert_array_equal(a.Q, target)
+    for name in ("S", "M", "G"):
+        assert_array_equal(getattr(a, name), getattr(b, name))
+    assert_array_equal(a.get_new_query_point(), b.get_new_query_point())
+    with pytest.raises(ValueError):
+        a.S[0] = True
+
+
 def product_kernel(ns, d, spec, seed):
     """Prod kernel from ``spec`` = [(kind, columns), ...] (columns may overlap)."""
     rng = np.random.default_rng(seed)

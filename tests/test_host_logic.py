@@ -225,9 +225,11 @@ def test_sample_gp_function_matches_reference():
         safeopt_amd.sample_gp_function(k, bounds, 0.1, 5, interpolation="cubic")
 
 
-def test_mirrors_are_read_only_and_the_setter_uploads():
-    """Element-wise writes into a host mirror would not reach the device: they
-    raise; assigning the whole array goes through the setter."""
+def test_q_mirror_writes_reach_the_device_and_the_setter_uploads():
+    """``opt.Q`` can be mutated in place as in the reference (``gp_opt.py:374-390,
+    475-476``): an element-wise write into the mirror is uploaded before the next
+    pass that reads the intervals, and gives what assigning the whole array gives;
+    ``S`` / ``M`` / ``G`` are results and stay read-only."""
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import safeopt_amd
@@ -235,15 +237,37 @@ def test_mirrors_are_read_only_and_the_setter_uploads():
     from _golden import load, make_kernel
     from _oracle_backend import OracleGridBackend
     z, meta = load("ties_1d_seed0")
-    gp = gpn.GPRegression(z["X0"], z["Y0"], make_kernel(gpn, meta["kernels"][0]),
-                          noise_var=meta["noise_vars"][0])
-    opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"],
-                              _backend_factory=OracleGridBackend)
-    opt.update_confidence_intervals()
-    q = opt.Q
-    for mirror in (q, opt.S, opt.M, opt.G):
+
+    def make():
+        gp = gpn.GPRegression(z["X0"], z["Y0"], make_kernel(gpn, meta["kernels"][0]),
+                              noise_var=meta["noise_vars"][0])
+        opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"],
+                                  _backend_factory=OracleGridBackend)
+        opt.update_confidence_intervals()
+        return opt
+    opt = make()
+    for mirror in (opt.S, opt.M, opt.G):
         with pytest.raises(ValueError):
             mirror[0] = 1
-    new = np.array(q) + 0.25
+    new = np.array(opt.Q) + 0.25
     opt.Q = new
     assert np.array_equal(opt.Q, new)
+    # in place: a slice, a fancy index and a view of a view
+    a, b = make(), make()
+    target = np.array(a.Q)
+    target[:, 0] -= 0.5
+    target[[3, 5], 1] = 7.0
+    target[10:20][:, 1] += 0.125
+    a.Q[:, 0] -= 0.5
+    a.Q[[3, 5], 1] = 7.0
+    a.Q[10:20][:, 1] += 0.125
+    b.Q = target
+    assert np.array_equal(a.Q, target)
+    a.compute_sets(); b.compute_sets()
+    for name in ("S", "M", "G"):
+        assert np.array_equal(getattr(a, name), getattr(b, name))
+    assert np.array_equal(a.get_new_query_point(), b.get_new_query_point())
+    # a fresh sweep overwrites hand-made intervals, written either way
+    a.Q[:, 0] = -9.0
+    a.update_confidence_intervals()
+    assert np.array_equal(a.Q, make().Q)
