@@ -85,6 +85,11 @@ constexpr int kKbRow = 80;             // doubles between the k-rows of a B buff
                            // and that is FASTER, +1..2 % for 1 and 2: the waves of a SIMD then
                            // start their VALU bursts together; experiments.txt section 10)
 #endif
+#ifndef PGP_NOP_ALL
+#define PGP_NOP_ALL 1      // 1: every slot opens with s_nop 1; 0: slot 0 only (-0.1..0.6 %, but the
+                           // padding is what covers register copies the compiler may place at a join:
+                           // kept, experiments.txt section 10)
+#endif
 #ifndef PGP_EVAL_BARRIER
 #define PGP_EVAL_BARRIER 0
 #endif
@@ -325,8 +330,11 @@ __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
           asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
                        : "+v"(accx) : "v"(cur[q]), "v"(kvn[q]));
       } else {
-        asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0"
-                     : "+v"(acc[S][0]) : "v"(cur[0]), "v"(kb[0][0]));
+        if (PGP_NOP_ALL || S == 0)
+          asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0"
+                       : "+v"(acc[S][0]) : "v"(cur[0]), "v"(kb[0][0]));
+        else
+          mfma_acc(acc[S][0], cur[0], kb[0][0]);
 #pragma unroll
         for (int m = 1; m < 4; ++m) mfma_acc(acc[S][m], cur[0], kb[m][0]);
 #pragma unroll
