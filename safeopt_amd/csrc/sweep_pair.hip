@@ -85,6 +85,9 @@ constexpr int kKbRow = 80;             // doubles between the k-rows of a B buff
                            // and that is FASTER, +1..2 % for 1 and 2: the waves of a SIMD then
                            // start their VALU bursts together; experiments.txt section 10)
 #endif
+#ifndef PGP_FIN_HALF
+#define PGP_FIN_HALF 1     // which half finishes the rows of a pair
+#endif
 #ifndef PGP_NOP_ALL
 #define PGP_NOP_ALL 1      // 1: every slot opens with s_nop 1; 0: slot 0 only (-0.1..0.6 %, but the
                            // padding is what covers register copies the compiler may place at a join:
@@ -588,7 +591,10 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   for (int b = 0; b < kWaveSlots; ++b)
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[b][m] = 0.0;
-  RowState rs;                       // (H == 1: the finishing wave)
+  // the half whose wave finishes a pair's rows (sums the two partial |L^-1 k|^2 and
+  // alpha . k, runs the row epilogue one stage later); the other hands its share over
+  constexpr int kFin = PGP_FIN_HALF;
+  RowState rs;                       // (H == kFin: the finishing wave)
   double keep_ssq = 0.0, keep_mu = 0.0;
   uint32_t pend_w = 0;               // GP-end word waiting for its epilogue
   int pend_tile = 0;
@@ -752,7 +758,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     const bool more = left > 1;
     const uint32_t wnext = e1.word;
 
-    if (H == 1 && pend_w != 0 && !PGP_ABL(32)) finish(par ^ 1);
+    if (H == kFin && pend_w != 0 && !PGP_ABL(32)) finish(par ^ 1);
     PGP_STAMP(0);   // deferred row epilogue
 
     // ---- prefetch: A chunk of the next stage, training block of the one after it
@@ -816,7 +822,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
                   wave * 64 + lane] = mean;
       } else {
         const double mu = sum_lane_groups(mean);
-        if (H == 0) {
+        if (H != kFin) {
           if (lane < 16) exch[par * 32 + 16 + lane] = mu;
         } else {
           keep_mu = mu;
@@ -844,7 +850,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       if (!(p.split_parts > 0 && tile >= p.split_tile0)) {
         double ssq;
         gp_partials(ssq);
-        if (H == 0) {
+        if (H != kFin) {
           if (lane < 16) exch[par * 32 + lane] = ssq;
         } else {
           keep_ssq = ssq;
@@ -869,7 +875,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   }
   // (every wave is done with the buffers before the next item refills them)
   __syncthreads();
-  if (H == 1 && pend_w != 0 && !PGP_ABL(32)) finish(par);
+  if (H == kFin && pend_w != 0 && !PGP_ABL(32)) finish(par);
   }   // items
 #ifdef PGP_STAMPS
   if (lane == 0) {
@@ -877,7 +883,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     for (int i = 0; i < 8; ++i) o[i] = stamp_acc[i];
   }
 #endif
-  if (H == 1) {
+  if (H == kFin) {
     if (conf && p.conf.S) {
       const double m = wave_max(rs.lmax);
       if (lane == 0) p.conf.partial[int(blockIdx.x) * kPairs + pr] = m;

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../.."
 NAME=$1; FLAGS=$2
 C=safeopt_amd/csrc; O=/tmp/variant_$NAME; mkdir -p $O scripts/dev/ab
-BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -I $C -Wall -Wno-unused-function"
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -I $C -Wall -Wno-unused-function -Wno-inline-asm"
 /opt/rocm/bin/hipcc $BASE $FLAGS -c $C/sweep_pair.hip -o $O/sweep_pair.o &
 /opt/rocm/bin/hipcc $BASE $FLAGS -c $C/sweep.hip -o $O/sweep.o &
 wait
