@@ -980,6 +980,30 @@ int sgp_grid_expander_check(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   return 0;
 }
 
+// Host copy of a front block ([0] max width | [1..2] counts (u64) | [3] w_top | [4]
+// idx_top (i64) | [5] n_found, n_tied (int) | x[d] | mean[G] | q[2G]) -> the caller's
+// arrays; out5[4] = -1 when the shard / grid has no candidate, out5[5] = number of
+// candidates that share the first one's width.
+static void unpack_front(const double* host, int d, int G, double* out5, double* x_top,
+                         double* mean_top, double* q_top) {
+  unsigned long long cnt[2];
+  int64_t idx;
+  int nfound, ntied;
+  memcpy(cnt, &host[1], 16);
+  memcpy(&idx, &host[4], 8);
+  memcpy(&nfound, &host[5], 4);
+  memcpy(&ntied, reinterpret_cast<const char*>(&host[5]) + 4, 4);
+  out5[0] = host[0];
+  out5[1] = double(cnt[0]);
+  out5[2] = double(cnt[1]);
+  out5[3] = host[3];
+  out5[4] = (nfound > 0) ? double(idx) : -1.0;
+  out5[5] = double(ntied);
+  memcpy(x_top, &host[6], size_t(d) * 8);
+  memcpy(mean_top, &host[6 + d], size_t(G) * 8);
+  memcpy(q_top, &host[6 + d + G], size_t(2 * G) * 8);
+}
+
 // Single-rank fast path, front half of compute_sets (gp_opt.py:511-552) with
 // ONE stream sync: M, max_var, candidate mask, counts and the first candidate
 // in visiting order together with its rows.
@@ -1018,48 +1042,24 @@ int sgp_grid_sets_front(sgp_grid* g, double max_l, int have_max_var,
                             res + 6 + d, res + 6 + d + G));
   std::vector<double> host(nres);
   SGP_TRY(sgp_d2h(ctx, host.data(), res, nres * 8));
-  unsigned long long cnt[2];
-  int64_t idx;
-  int nfound;
-  memcpy(cnt, &host[1], 16);
-  memcpy(&idx, &host[4], 8);
-  memcpy(&nfound, &host[5], 4);
-  out5[0] = host[0];
-  out5[1] = double(cnt[0]);
-  out5[2] = double(cnt[1]);
-  out5[3] = host[3];
-  out5[4] = (nfound > 0) ? double(idx) : -1.0;
-  {
-    int ntied = 0;       // candidates that share the first one's width
-    memcpy(&ntied, reinterpret_cast<const char*>(&host[5]) + 4, 4);
-    out5[5] = double(ntied);
-  }
-  memcpy(x_top, &host[6], size_t(d) * 8);
-  memcpy(mean_top, &host[6 + d], size_t(G) * 8);
-  memcpy(q_top, &host[6 + d + G], size_t(2 * G) * 8);
+  unpack_front(host.data(), d, G, out5, x_top, mean_top, q_top);
   return 0;
 }
 
-// N-rank front half with the cross-rank scalars kept on the device: max l0[S]
-// (left in g->scal[0] by a confidence pass without read-back) and the maximiser
-// width are all-reduced IN STREAM (RCCL on the context's stream), the kernels
-// read them from device memory, and one read-back returns this rank's counts,
-// its first candidate and the global max l0.  Without a communicator (one
-// rank) the all-reduces are skipped.
-int sgp_grid_sets_front_comm(sgp_grid* g, const double* scaling,
-                             const double* thr_beta, double* out5, double* x_top,
-                             double* mean_top, double* q_top, double* max_l_out) {
+// Front half of compute_sets on this rank's shard with the cross-rank scalars kept
+// on the device: max l0[S] (left in g->scal[0] by a confidence pass without
+// read-back) and the maximiser width are all-reduced IN STREAM, the kernels read
+// them from device memory; `res` (device) receives the front block of
+// unpack_front.  Without a communicator (one rank) the all-reduces are skipped.
+static int front_half_in_stream(sgp_grid* g, const double* scaling, const double* thr_beta,
+                                double* res) {
   sgp_ctx* ctx = g->ctx;
-  SGP_HIP(ctx, hipSetDevice(ctx->device));
   const int d = g->d, G = g->G;
-  const size_t nres = 7 + size_t(d) + 3 * size_t(G);   // front block + max_l
-  double* res = static_cast<double*>(sgp_scratch(ctx, 1, (nres + 8) * 8));
-  SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
   SGP_TRY(settle_max_l(g));
   ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
   SGP_CHECK(ctx, comm || ctx->world <= 1,
             "rank %d of %d has no communicator in the grid's context: the "
-            "in-stream all-reduces cannot run (sgp_comm_init on THIS context)",
+            "in-stream collectives cannot run (sgp_comm_init on THIS context)",
             ctx->rank, ctx->world);
   if (comm)
     SGP_NCCL(ctx, g_rccl.AllReduce(g->scal, g->scal, 1, ncclFloat64, ncclMax,
@@ -1080,29 +1080,30 @@ int sgp_grid_sets_front_comm(sgp_grid* g, const double* scaling,
                             reinterpret_cast<int*>(res + 5) + 1));
   SGP_TRY(launch_gather_top(g, reinterpret_cast<int64_t*>(res + 4), res + 6,
                             res + 6 + d, res + 6 + d + G));
+  return 0;
+}
+
+// N-rank front half with the cross-rank scalars kept on the device: max l0[S]
+// (left in g->scal[0] by a confidence pass without read-back) and the maximiser
+// width are all-reduced IN STREAM (RCCL on the context's stream), the kernels
+// read them from device memory, and one read-back returns this rank's counts,
+// its first candidate and the global max l0.  Without a communicator (one
+// rank) the all-reduces are skipped.
+int sgp_grid_sets_front_comm(sgp_grid* g, const double* scaling,
+                             const double* thr_beta, double* out5, double* x_top,
+                             double* mean_top, double* q_top, double* max_l_out) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  const int d = g->d, G = g->G;
+  const size_t nres = 7 + size_t(d) + 3 * size_t(G);   // front block + max_l
+  double* res = static_cast<double*>(sgp_scratch(ctx, 1, (nres + 8) * 8));
+  SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
+  SGP_TRY(front_half_in_stream(g, scaling, thr_beta, res));
   SGP_HIP(ctx, hipMemcpyAsync(res + nres - 1, g->scal, 8,
                               hipMemcpyDeviceToDevice, ctx->stream));
   std::vector<double> host(nres);
   SGP_TRY(sgp_d2h(ctx, host.data(), res, nres * 8));
-  unsigned long long cnt[2];
-  int64_t idx;
-  int nfound;
-  memcpy(cnt, &host[1], 16);
-  memcpy(&idx, &host[4], 8);
-  memcpy(&nfound, &host[5], 4);
-  out5[0] = host[0];
-  out5[1] = double(cnt[0]);
-  out5[2] = double(cnt[1]);
-  out5[3] = host[3];
-  out5[4] = (nfound > 0) ? double(idx) : -1.0;
-  {
-    int ntied = 0;       // candidates that share the first one's width
-    memcpy(&ntied, reinterpret_cast<const char*>(&host[5]) + 4, 4);
-    out5[5] = double(ntied);
-  }
-  memcpy(x_top, &host[6], size_t(d) * 8);
-  memcpy(mean_top, &host[6 + d], size_t(G) * 8);
-  memcpy(q_top, &host[6 + d + G], size_t(2 * G) * 8);
+  unpack_front(host.data(), d, G, out5, x_top, mean_top, q_top);
   *max_l_out = host[nres - 1];
   return 0;
 }
@@ -1189,23 +1190,7 @@ int sgp_grid_sets_fused(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
       res + nfront + nfl, reinterpret_cast<int64_t*>(res + nfront + nfl + 1)));
   std::vector<double> host(nres);
   SGP_TRY(sgp_d2h(ctx, host.data(), res, nres * 8));
-  unsigned long long cnt[2];
-  int64_t idx;
-  int nfound;
-  memcpy(cnt, &host[1], 16);
-  memcpy(&idx, &host[4], 8);
-  memcpy(&nfound, &host[5], 4);
-  out5[0] = host[0];
-  out5[1] = double(cnt[0]);
-  out5[2] = double(cnt[1]);
-  out5[3] = host[3];
-  out5[4] = (nfound > 0) ? double(idx) : -1.0;
-  int ntied = 0;
-  memcpy(&ntied, reinterpret_cast<const char*>(&host[5]) + 4, 4);
-  out5[5] = double(ntied);      // candidates that share the first one's width
-  memcpy(x_top, &host[6], size_t(d) * 8);
-  memcpy(mean_top, &host[6 + d], size_t(G) * 8);
-  memcpy(q_top, &host[6 + d + G], size_t(2 * G) * 8);
+  unpack_front(host.data(), d, G, out5, x_top, mean_top, q_top);
   memcpy(flags, &host[nfront], size_t(G) * 4);
   *value = host[nfront + nfl];
   memcpy(gidx, &host[nfront + nfl + 1], 8);
@@ -1258,25 +1243,8 @@ int sgp_grid_sets_fused_comm(sgp_grid* g, sgp_gp* const* gps, int G, double beta
   ExpanderBufs eb;
   SGP_TRY(expander_bufs(g, ghost, G, &eb));
 
-  // ---- front half on this shard (as sgp_grid_sets_front_comm)
-  SGP_TRY(settle_max_l(g));
-  if (comm)
-    SGP_NCCL(ctx, g_rccl.AllReduce(g->scal, g->scal, 1, ncclFloat64, ncclMax,
-                                   comm, ctx->stream));
-  SGP_TRY(launch_maximizers(g, 0.0, g->scal));
-  SGP_TRY(launch_reduce_max(ctx, g->partial, (g->N + 255) / 256, mine));
-  if (comm)
-    SGP_NCCL(ctx, g_rccl.AllReduce(mine, mine, 1, ncclFloat64, ncclMax, comm,
-                                   ctx->stream));
-  SGP_TRY(launch_candidates(g, 0.0, mine, scaling, thr_beta, 0,
-                            reinterpret_cast<unsigned long long*>(mine + 1)));
-  SGP_TRY(launch_topk(g, 0, INFINITY, INT64_MAX, 1, mine + 3,
-                      reinterpret_cast<int64_t*>(mine + 4),
-                      reinterpret_cast<int*>(mine + 5)));
-  SGP_TRY(launch_count_ties(g, mine + 3, reinterpret_cast<const int*>(mine + 5),
-                            reinterpret_cast<int*>(mine + 5) + 1));
-  SGP_TRY(launch_gather_top(g, reinterpret_cast<int64_t*>(mine + 4), mine + 6,
-                            mine + 6 + d, mine + 6 + d + G));
+  // ---- front half on this shard
+  SGP_TRY(front_half_in_stream(g, scaling, thr_beta, mine));
 
   // ---- first candidate of the whole grid
   const double* blocks = mine;
@@ -1310,22 +1278,7 @@ int sgp_grid_sets_fused_comm(sgp_grid* g, sgp_gp* const* gps, int G, double beta
 
   std::vector<double> host(nres);
   SGP_TRY(sgp_d2h(ctx, host.data(), res, nres * 8));
-  unsigned long long cnt[2];
-  int64_t idx;
-  int nfound, ntied;
-  memcpy(cnt, &host[1], 16);
-  memcpy(&idx, &host[4], 8);
-  memcpy(&nfound, &host[5], 4);
-  memcpy(&ntied, reinterpret_cast<const char*>(&host[5]) + 4, 4);
-  out5[0] = host[0];
-  out5[1] = double(cnt[0]);
-  out5[2] = double(cnt[1]);
-  out5[3] = host[3];
-  out5[4] = (nfound > 0) ? double(idx) : -1.0;
-  out5[5] = double(ntied);
-  memcpy(x_top, &host[6], size_t(d) * 8);
-  memcpy(mean_top, &host[6 + d], size_t(G) * 8);
-  memcpy(q_top, &host[6 + d + G], size_t(2 * G) * 8);
+  unpack_front(host.data(), d, G, out5, x_top, mean_top, q_top);
   memcpy(flags, &host[nfront], size_t(G) * 4);
   *value = host[nfront + nfl];
   memcpy(gidx, &host[nfront + nfl + 1], 8);
