@@ -1283,6 +1283,9 @@ def test_device_merges_of_the_n_rank_step(mods):
     import os, struct, subprocess
     from safeopt_amd import dist
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "merge_check")
+    if not os.path.exists(exe):
+        from safeopt_amd import build as _build      # (hipcc is on the GPU box as well)
+        _build.build()
     assert os.path.exists(exe), "python -m safeopt_amd.build builds tests/native/merge_check"
     rng = np.random.default_rng(77)
     for trial in range(40):
