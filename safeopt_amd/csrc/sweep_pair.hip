@@ -111,7 +111,8 @@ struct PStage {
                        // of the (cyclic) sequence
   uint32_t rs_bytes;   // bytes between consecutive row blocks in Apack
   uint32_t word;       // PW_*
-  uint32_t pad0, pad1;
+  uint32_t g_next;     // GP of the NEXT stage (whose riders' alpha blocks go with xa_next)
+  uint32_t pad1;
 };
 enum : uint32_t {
   PW_NACT_MASK = 63u,       // active global slots 0 .. nact-1 (1..32)
@@ -132,22 +133,33 @@ enum : uint32_t {
 // LDS (doubles):  [2][A chunk 64 KB]  [2][16 D rows | 16 alpha]  exp table
 //                 [4 pairs][2][B operands]  [4 pairs][2][32] pair exchange
 //                 [4 pairs] staged Q rows
-template <int D>
+// R > 0 (riders, see kMaxRide): R more alpha blocks behind a training block, R more
+// 16-double rows in a pair's exchange buffer.
+template <int D, int R = 0>
 struct LayP {
   static constexpr int kATile = kPairSlots * kSteps * 64;   // 8192 doubles
-  static constexpr int kXBuf = kJC * D + kJC;
+  static constexpr int kXBuf = kJC * D + kJC * (1 + R);
   static constexpr int kXOff = 2 * kATile;
   static constexpr int kTabOff = kXOff + 2 * kXBuf;
   static constexpr int kKbOff = kTabOff + kExpTabSize;
   static constexpr int kKbBuf = 4 * kKbRow;                 // one B buffer
   static constexpr int kExOff = kKbOff + kPairs * 2 * kKbBuf;
-  static constexpr int kQOff = kExOff + kPairs * 2 * 32;
+  static constexpr int kExRow = 16 * (2 + R);               // [|L^-1 k|^2 | alpha.k | riders]
+  static constexpr int kQOff = kExOff + kPairs * 2 * kExRow;
   static constexpr int kQMaxG = 6;                          // staged Q rows: G <= 6
   static constexpr int kQCap = 16 * 2 * kQMaxG;             // doubles per pair
   static constexpr int kTotal = kQOff + kPairs * kQCap;
   static constexpr size_t bytes() { return size_t(kTotal) * sizeof(double); }
 };
+// GPs that share the factor of the GP in front of them (GpDev::share: same inputs,
+// kernel, noise -- the outputs of a multi-output GP) and RIDE with it: the covariances
+// the leader evaluates are theirs as well, so their alpha . k is formed in the
+// leader's stages and they have no stages of their own.  Up to kMaxRide per leader
+// (what the LDS of a d <= 4 instance has room for); further followers keep stages
+// without rows (PW_SHARED).
+constexpr int kMaxRide = 2;
 static_assert(LayP<8>::bytes() <= 160 * 1024, "LDS budget of one workgroup per CU");
+static_assert(LayP<4, kMaxRide>::bytes() <= 160 * 1024, "LDS budget with riders");
 
 struct PairParams {
   const GpDev* gps;
@@ -168,6 +180,8 @@ struct PairParams {
   // (bit-identical results) and runs the row epilogue.
   int geff;               // GPs in the stage table (1 for the greedy swarm)
   unsigned shared_mask;   // bit g: GP g takes |L^-1 k|^2 from the GP in front (PW_SHARED)
+  int nride[SGP_MAX_GPS];             // riders of GP g (the GPs g + 1 .. g + nride[g])
+  long long ride_delta[SGP_MAX_GPS];  // rider g: bytes from its leader's XA to its own
   int split_tile0, split_parts, split_count;
   int split_s0[9];
   int nchunks;            // chunks in the stage table (all GPs)
@@ -206,13 +220,15 @@ struct PairParams {
 typedef const __attribute__((address_space(4))) PStage* pstage_ptr_t;
 typedef const __attribute__((address_space(4))) GpDev* gpdev_cptr_t;
 
+template <bool RIDE = false>
 __device__ __forceinline__ PStage load_pstage(pstage_ptr_t t, int i) {
-  PStage e;      // member-wise: scalar loads (dwordx4 + dwordx2)
+  PStage e;      // member-wise: scalar loads (dwordx4 + dwordx2 [+ dword])
   e.a_src = t[i].a_src;
   e.xa_next = t[i].xa_next;
   e.rs_bytes = t[i].rs_bytes;
   e.word = t[i].word;
-  e.pad0 = e.pad1 = 0;
+  e.g_next = RIDE ? t[i].g_next : 0;
+  e.pad1 = 0;
   return e;
 }
 
@@ -246,6 +262,20 @@ __device__ __forceinline__ void xa_dma(uint64_t src, uint32_t dst, int lane,
   if (lane < (kLanes < 64 ? kLanes : 64)) dma_1k(src, dst, voff);
   if (kLanes > 64) {
     if (lane < kLanes - 64) dma_1k(src + 1024, dst + 1024, voff);
+  }
+}
+
+// ... and the alpha blocks (16 doubles each) of the riders of GP g behind it: the same
+// j-block of every rider's own [16 d | 16 alpha] array.
+template <int D>
+__device__ __forceinline__ void rider_dma(const int (&nride)[SGP_MAX_GPS],
+                                          const long long (&delta)[SGP_MAX_GPS], int g,
+                                          uint64_t xa_block, uint32_t dst, int lane,
+                                          uint32_t voff) {
+  const int nr = nride[g];
+  for (int f = 0; f < nr; ++f) {        // (wave-uniform)
+    const uint64_t src = xa_block + uint64_t(delta[g + 1 + f]) + 128u * D;
+    if (lane < 8) dma_1k(src, dst + uint32_t(16 * D + 16 + 16 * f) * 8u, voff);
   }
 }
 
@@ -471,16 +501,16 @@ __device__ __forceinline__ void row_epilogue(const PairParams& p, RowState& rs,
 
 // The persistent stage loop of one wave; H = its half of the pair (compile time:
 // the two halves run the phases of a stage in opposite order).
-template <int D, int MODE, bool SINGLE, int H>
+template <int D, int MODE, bool SINGLE, int H, int R>
 __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
                                           const int lane, const int wave) {
-  typedef LayP<D> L;
+  typedef LayP<D, R> L;
   constexpr bool conf = MODE == MODE_CONF;
   constexpr bool kMultFirst = PGP_ORDER == 0 ? H == 0 : PGP_ORDER == 1;
   // (32 more live registers across the evaluation: instances that would spill for
   // it -- d >= 6, product kernels -- do without)
   constexpr int kOpsEarly =
-      PGP_OPS_EARLY >= 0 ? PGP_OPS_EARLY : ((SINGLE && D <= 4) ? 2 : 0);
+      PGP_OPS_EARLY >= 0 ? PGP_OPS_EARLY : ((SINGLE && D <= 4 && R == 0) ? 2 : 0);
   // (only where the B operands are fetched in front of the evaluation does the place
   // of the stage-table fetch matter -- and elsewhere the registers are not there)
   constexpr int kStageLate = kOpsEarly != 0 ? PGP_STAGE_LATE : 0;
@@ -500,7 +530,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   int left = 0;                        // stages of the current item still to go
 
   double* kbp = lds + L::kKbOff + pr * (2 * L::kKbBuf);   // the pair's B buffers
-  double* exch = lds + L::kExOff + pr * 64;                // ... exchange [2][32]
+  double* exch = lds + L::kExOff + pr * (2 * L::kExRow);   // ... exchange [2][kExRow]
   double* qst = lds + L::kQOff + pr * L::kQCap;            // ... staged Q rows
   const uint32_t lds_a = lds_addr_of(lds);
   const uint32_t lds_xa = lds_addr_of(lds + L::kXOff);
@@ -526,6 +556,12 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   // covariances of one stage: this wave's half (training points 8 H .. 8 H + 7 of
   // the j-block) -> the pair's B buffer, [k][q pair][point][2]
   double mean = 0.0;
+  // riders of the GP being evaluated (R > 0): their alpha . k, formed from the
+  // leader's covariances
+  double mean_r[R > 0 ? R : 1];
+#pragma unroll
+  for (int f = 0; f < (R > 0 ? R : 1); ++f) mean_r[f] = 0.0;
+  int nr_e = 0;
   // the wave's two training rows (8 H + k4 and 4 further) and alpha entries of a
   // staged j-block: read FIRST in a stage, so that the evaluation does not queue
   // behind the operand reads of the matrix phase
@@ -549,6 +585,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   auto evaluate = [&](uint32_t w1, const Rows& r, const double* xa, double* kbw) {
     if (__builtin_expect((w1 & PW_GP_FIRST) != 0, 0)) {
       kf.load_const(&p.gps[int(w1 >> PW_G_SHIFT) & 7].kern);
+      if (R > 0) nr_e = p.nride[int(w1 >> PW_G_SHIFT) & 7];
       kf.template prep_t<SINGLE>(x_raw, xs_e);
       if (w1 & PW_LAST_GP) {
         tile_e += tstep;
@@ -575,6 +612,16 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
         mean = fma(al[4], kv[1], mean);
       }
     }
+    if (R > 0 && (w1 & PW_MEAN)) {
+#pragma unroll
+      for (int f = 0; f < R; ++f) {
+        if (f < nr_e) {
+          const double* al = xa + kJC * D + kJC * (1 + f) + 8 * H + k4;
+          mean_r[f] = fma(al[0], kv[0], mean_r[f]);
+          mean_r[f] = fma(al[4], kv[1], mean_r[f]);
+        }
+      }
+    }
     *reinterpret_cast<double2_t*>(kbw + k4 * kKbRow + H * 32 + c16 * 2) =
         double2_t{kv[0], kv[1]};
   };
@@ -596,6 +643,9 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   constexpr int kFin = PGP_FIN_HALF;
   RowState rs;                       // (H == kFin: the finishing wave)
   double keep_ssq = 0.0, keep_mu = 0.0;
+  double keep_mu_r[R > 0 ? R : 1];
+#pragma unroll
+  for (int f = 0; f < (R > 0 ? R : 1); ++f) keep_mu_r[f] = 0.0;
   uint32_t pend_w = 0;               // GP-end word waiting for its epilogue
   int pend_tile = 0;
 
@@ -692,7 +742,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
 
   double ssq_lead = 0.0;             // |L^-1 k|^2 of the last GP with a factor of its own
   auto finish = [&](int par_prev) {
-    const double* ex = exch + par_prev * 32;
+    const double* ex = exch + par_prev * L::kExRow;
     double ssq = keep_ssq + ex[c16];
     if (pend_w & PW_SHARED)
       ssq = ssq_lead;
@@ -702,7 +752,25 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     const int g = int(pend_w >> PW_G_SHIFT) & 7;
     const double kdiag = gpc[g].kern.kdiag;
     const double var = fmax(kdiag - ssq, 1e-15);  // GPy clip
-    row_epilogue<D, MODE>(p, rs, pend_w, pend_tile, pr, lane, mu, var, qst);
+    const int nr = R > 0 ? p.nride[g] : 0;
+    // (the tile ends behind the last rider)
+    row_epilogue<D, MODE>(p, rs, nr > 0 ? pend_w & ~uint32_t(PW_TILE_END) : pend_w, pend_tile,
+                          pr, lane, mu, var, qst);
+    if (R > 0) {
+#pragma unroll
+      for (int f = 0; f < R; ++f) {
+        if (f < nr) {
+          // a rider: the leader's |L^-1 k|^2, its own alpha . k and prior variance
+          const int gf = g + 1 + f;
+          const double mu_f = keep_mu_r[f] + ex[16 * (2 + f) + c16];
+          const double var_f = fmax(gpc[gf].kern.kdiag - ssq, 1e-15);
+          uint32_t wf = (pend_w & ~uint32_t((7u << PW_G_SHIFT) | PW_TILE_END)) |
+                        (uint32_t(gf) << PW_G_SHIFT);
+          if (f == nr - 1) wf |= pend_w & PW_TILE_END;
+          row_epilogue<D, MODE>(p, rs, wf, pend_tile, pr, lane, mu_f, var_f, qst);
+        }
+      }
+    }
     pend_w = 0;
   };
 
@@ -735,10 +803,13 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   // the same bits wherever an item begins).  Only the training block of the first
   // stage has to be in LDS before it.
   par = 0;
-  e1 = load_pstage(stages, s_lo);
+  e1 = load_pstage<(R > 0)>(stages, s_lo);
   if (wave == 7) {
-    const PStage el = load_pstage(stages, (s_lo == 0 ? nstages : s_lo) - 1);
+    const PStage el = load_pstage<(R > 0)>(stages, (s_lo == 0 ? nstages : s_lo) - 1);
     xa_dma<D>(el.xa_next, lds_xa + L::kXBuf * 8, lane, voff);   // block of the first stage
+    if (R > 0)
+      rider_dma<D>(p.nride, p.ride_delta, int(el.g_next), el.xa_next, lds_xa + L::kXBuf * 8,
+                   lane, voff);
   }
   wcur = 0;
   ++left;
@@ -748,6 +819,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   if (!(e1.word & PW_GP_FIRST)) {
     // the item begins inside a GP (a run of chunks of a remainder tile)
     kf.load_const(&p.gps[int(e1.word >> PW_G_SHIFT) & 7].kern);
+    if (R > 0) nr_e = p.nride[int(e1.word >> PW_G_SHIFT) & 7];
     kf.template prep_t<SINGLE>(x_raw, xs_e);
   }
   wait_dma();
@@ -766,8 +838,12 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       if (more && !PGP_ABL(2)) {
         if (PGP_DMA_MODE == 0)
           a_dma(e1, lds_a + uint32_t(par ^ 1) * (L::kATile * 8), wave, voff);
-        if (wave == 7)
+        if (wave == 7) {
           xa_dma<D>(e1.xa_next, lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
+          if (R > 0)
+            rider_dma<D>(p.nride, p.ride_delta, int(e1.g_next), e1.xa_next,
+                         lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
+        }
       }
     };
     if (!(PGP_DMA_LATE && kMultFirst)) prefetch();
@@ -789,7 +865,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     // load in flight turns every LDS wait into a wait for everything, and the
     // evaluation would stand behind the operand reads issued in front of it)
     StageAhead sa{stages, si2, kStageLate == 2 && left > 2, e1};
-    if (kStageLate == 0 && left > 2) sa.e = load_pstage(stages, si2);
+    if (kStageLate == 0 && left > 2) sa.e = load_pstage<(R > 0)>(stages, si2);
 
     const double* abuf = lds + par * L::kATile;
     const double* kbr = kbp + par * L::kKbBuf;
@@ -816,19 +892,44 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     if (__builtin_expect((wcur & PW_GP_END) != 0, 0)) {
       // alpha . k of the GP that ends here (the evaluation below may already belong
       // to the next one): half 0 hands its share over, half 1 keeps it
+      const int g_end = int(wcur >> PW_G_SHIFT) & 7;
+      const int nr = R > 0 ? p.nride[g_end] : 0;
       if (p.split_parts > 0 && tile >= p.split_tile0) {
         // (a run of a remainder tile: per lane, summed by k_pair_split_finish)
-        p.split_m[(size_t(tile - p.split_tile0) * p.geff + (int(wcur >> PW_G_SHIFT) & 7)) * 512 +
-                  wave * 64 + lane] = mean;
+        double* sm = p.split_m + (size_t(tile - p.split_tile0) * p.geff + g_end) * 512 +
+                     wave * 64 + lane;
+        sm[0] = mean;
+        if (R > 0) {
+#pragma unroll
+          for (int f = 0; f < R; ++f)
+            if (f < nr) sm[size_t(1 + f) * 512] = mean_r[f];
+        }
       } else {
         const double mu = sum_lane_groups(mean);
         if (H != kFin) {
-          if (lane < 16) exch[par * 32 + 16 + lane] = mu;
+          if (lane < 16) exch[par * L::kExRow + 16 + lane] = mu;
         } else {
           keep_mu = mu;
         }
+        if (R > 0) {
+#pragma unroll
+          for (int f = 0; f < R; ++f) {
+            if (f < nr) {
+              const double mu_f = sum_lane_groups(mean_r[f]);
+              if (H != kFin) {
+                if (lane < 16) exch[par * L::kExRow + 16 * (2 + f) + lane] = mu_f;
+              } else {
+                keep_mu_r[f] = mu_f;
+              }
+            }
+          }
+        }
       }
       mean = 0.0;
+      if (R > 0) {
+#pragma unroll
+        for (int f = 0; f < R; ++f) mean_r[f] = 0.0;
+      }
     }
     if (PGP_EVAL_PRIO && !PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(PGP_EVAL_PRIO);
     if (kRowsFirst && kMultFirst && more) load_rows(xa, rows);
@@ -851,7 +952,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
         double ssq;
         gp_partials(ssq);
         if (H != kFin) {
-          if (lane < 16) exch[par * 32 + lane] = ssq;
+          if (lane < 16) exch[par * L::kExRow + lane] = ssq;
         } else {
           keep_ssq = ssq;
           pend_w = wcur;
@@ -891,17 +992,17 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   }
 }
 
-template <int D, int MODE, bool SINGLE>
+template <int D, int MODE, bool SINGLE, int R = 0>
 __global__ __launch_bounds__(512, 1) void k_sweep_pair(PairParams p) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  exp_tab_init(lds + LayP<D>::kTabOff);   // visible after the first barrier
+  exp_tab_init(lds + LayP<D, R>::kTabOff);   // visible after the first barrier
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (PGP_ADJ ? (wave & 1) == 0 : wave < 4)
-    pair_loop<D, MODE, SINGLE, 0>(p, lds, lane, wave);
+    pair_loop<D, MODE, SINGLE, 0, R>(p, lds, lane, wave);
   else
-    pair_loop<D, MODE, SINGLE, 1>(p, lds, lane, wave);
+    pair_loop<D, MODE, SINGLE, 1, R>(p, lds, lane, wave);
 }
 
 // Remainder tiles that were cut into runs of chunks (PairParams::split_*): the
@@ -959,13 +1060,17 @@ __global__ __launch_bounds__(512) void k_pair_split_finish(PairParams p) {
 // of L^-1, the j-blocks 0 .. bend-1.  Entries hold absolute addresses, so the
 // table is rebuilt when a block count OR a buffer address changes (buffers are
 // sized for the pitch of L^-1: one-row appends keep their addresses).
-int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d,
+int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, const bool* rides,
                      const PStage** dev, int* nstages) {
   std::vector<uint64_t> sig(1, uint64_t(Geff));
   sig.push_back(uint64_t(d));
+  int last_staged = 0;
+  for (int g = 0; g < Geff; ++g)
+    if (!rides[g]) last_staged = g;
   for (int g = 0; g < Geff; ++g) {
     sig.push_back(uint64_t(gh[g].nblk));
-    sig.push_back(uint64_t(gh[g].narrow) | (uint64_t(gh[g].share >= 0) << 8));
+    sig.push_back(uint64_t(gh[g].narrow) | (uint64_t(gh[g].share >= 0) << 8) |
+                  (uint64_t(rides[g]) << 9));
     sig.push_back(reinterpret_cast<uint64_t>(gh[g].Apack));
     sig.push_back(reinterpret_cast<uint64_t>(gh[g].XA));
   }
@@ -976,6 +1081,7 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d,
   }
   std::vector<PStage> tab;
   std::vector<uint64_t> xa;
+  std::vector<uint32_t> gof;      // GP of every stage
   std::vector<int> chunk_start;
   const uint64_t xa_block = uint64_t(16 * d + 16) * sizeof(double);
   for (int g = 0; g < Geff; ++g) {
@@ -983,6 +1089,7 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d,
     const int nchunks = (nblk + kPairSlots - 1) / kPairSlots;
     const uint64_t apack = reinterpret_cast<uint64_t>(gh[g].Apack);
     ctx->pstage_chunk_off[g] = int(chunk_start.size());
+    if (rides[g]) continue;       // (its alpha . k is formed in its leader's stages)
     if (gh[g].share >= 0) {
       // same factor as the GP in front: one "chunk" without rows -- every j-block
       // once, for alpha . k
@@ -995,13 +1102,14 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d,
         e.word = (uint32_t(g) << PW_G_SHIFT) | ((chunk_id & 63u) << PW_CHUNK_SHIFT) |
                  PW_MEAN | PW_SHARED;
         if (jb == 0) e.word |= PW_GP_FIRST;
-        if (g == Geff - 1) e.word |= PW_LAST_GP;
+        if (g == last_staged) e.word |= PW_LAST_GP;
         if (jb == nblk - 1) {
           e.word |= PW_CHUNK_END | PW_GP_END;
-          if (g == Geff - 1) e.word |= PW_TILE_END;
+          if (g == last_staged) e.word |= PW_TILE_END;
         }
         tab.push_back(e);
         xa.push_back(reinterpret_cast<uint64_t>(gh[g].XA) + uint64_t(jb) * xa_block);
+        gof.push_back(uint32_t(g));
       }
       continue;
     }
@@ -1020,17 +1128,21 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d,
         if (c == nchunks - 1) e.word |= PW_MEAN;
         if (c == nchunks - 1 && gh[g].narrow) e.word |= PW_NARROW;
         if (c == 0 && jb == 0) e.word |= PW_GP_FIRST;
-        if (g == Geff - 1) e.word |= PW_LAST_GP;
+        if (g == last_staged) e.word |= PW_LAST_GP;
         if (c == nchunks - 1 && jb == bend - 1) {
           e.word |= PW_GP_END;
-          if (g == Geff - 1) e.word |= PW_TILE_END;
+          if (g == last_staged) e.word |= PW_TILE_END;
         }
         tab.push_back(e);
         xa.push_back(reinterpret_cast<uint64_t>(gh[g].XA) + uint64_t(jb) * xa_block);
+        gof.push_back(uint32_t(g));
       }
     }
   }
-  for (size_t i = 0; i < tab.size(); ++i) tab[i].xa_next = xa[(i + 1) % tab.size()];
+  for (size_t i = 0; i < tab.size(); ++i) {
+    tab[i].xa_next = xa[(i + 1) % tab.size()];
+    tab[i].g_next = gof[(i + 1) % tab.size()];
+  }
   ctx->pstage_chunk_off[Geff] = int(chunk_start.size());
   chunk_start.push_back(int(tab.size()));
   ctx->pstage_chunk_start = chunk_start;
@@ -1121,14 +1233,14 @@ PairPlan pair_plan(const sgp_ctx* ctx, int64_t N) {
   return pl;
 }
 
-template <int D, int MODE, bool SINGLE>
+template <int D, int MODE, bool SINGLE, int R = 0>
 int launch_pair_v(sgp_ctx* ctx, const PairParams& p, double flops) {
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep_pair<D, MODE, SINGLE>),
+                     reinterpret_cast<const void*>(&k_sweep_pair<D, MODE, SINGLE, R>),
                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                     int(LayP<D>::bytes())));
+                     int(LayP<D, R>::bytes())));
     attr_set = true;
   }
   const PairPlan pl = pair_plan(ctx, p.pts.N);
@@ -1160,8 +1272,8 @@ int launch_pair_v(sgp_ctx* ctx, const PairParams& p, double flops) {
   if (!stamps_dev) SGP_HIP(ctx, hipMalloc(&stamps_dev, size_t(4096) * 64 * 8));
   pp.stamps = stamps_dev;
 #endif
-  hipLaunchKernelGGL((k_sweep_pair<D, MODE, SINGLE>), dim3(nblocks), dim3(512),
-                     LayP<D>::bytes(), ctx->stream, pp);
+  hipLaunchKernelGGL((k_sweep_pair<D, MODE, SINGLE, R>), dim3(nblocks), dim3(512),
+                     (LayP<D, R>::bytes()), ctx->stream, pp);
   if (pl.parts > 0)
     hipLaunchKernelGGL((k_pair_split_finish<MODE>), dim3(pl.count), dim3(512), 0,
                        ctx->stream, pp);
@@ -1190,10 +1302,36 @@ int launch_pair_v(sgp_ctx* ctx, const PairParams& p, double flops) {
   return timer.end(ctx);
 }
 
+// (riders: single-part kernels up to d = 4 -- pair_riders)
 template <int D>
-int launch_pair_d(sgp_ctx* ctx, const PairParams& p, bool single, double flops) {
+int launch_pair_d(sgp_ctx* ctx, const PairParams& p, bool single, bool riders, double flops) {
+  if constexpr (D <= 4) {
+    if (riders) return launch_pair_v<D, MODE_CONF, true, kMaxRide>(ctx, p, flops);
+  }
   return single ? launch_pair_v<D, MODE_CONF, true>(ctx, p, flops)
                 : launch_pair_v<D, MODE_CONF, false>(ctx, p, flops);
+}
+
+// Which GPs ride with the GP in front (kMaxRide): a follower (GpDev::share >= 0) of a
+// launch whose kernels are all single-part, d <= 4, among the first kMaxRide behind
+// its leader.
+bool pair_riders(const GpDev* gh, int Geff, int d, bool single, bool* rides, int* nride) {
+  bool any = false;
+  int leader = 0;
+  for (int g = 0; g < Geff; ++g) {
+    rides[g] = false;
+    nride[g] = 0;
+    if (gh[g].share < 0) {
+      leader = g;
+      continue;
+    }
+    if (single && d <= 4 && g - leader <= kMaxRide && nride[leader] == g - leader - 1) {
+      rides[g] = true;
+      ++nride[leader];
+      any = true;
+    }
+  }
+  return any;
 }
 
 }  // namespace
@@ -1230,19 +1368,39 @@ int launch_sweep_pair(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d,
   for (int g = 0; g < Geff; ++g)
     if (gh[g].share >= 0) p.shared_mask |= 1u << g;
   // (a.mode is MODE_CONF: launch_sweep turns a fitness call into posterior + shaping)
-  SGP_TRY(pair_stage_table(ctx, gh, Geff, d, &p.stages, &p.nstages));
   bool single = true;
   for (int g = 0; g < Geff; ++g) single = single && gh[g].kern.n_parts == 1;
+  bool rides[SGP_MAX_GPS] = {};
+  static const bool no_ride = getenv("SGP_PAIR_RIDE") && atoi(getenv("SGP_PAIR_RIDE")) == 0;
+  for (int g = 0; g < SGP_MAX_GPS; ++g) {
+    p.nride[g] = 0;
+    p.ride_delta[g] = 0;
+  }
+  const bool riders = !no_ride && pair_riders(gh, Geff, d, single, rides, p.nride);
+  if (!riders)
+    for (int g = 0; g < Geff; ++g) {
+      rides[g] = false;
+      p.nride[g] = 0;
+    }
+  for (int g = 0, leader = 0; g < Geff; ++g) {
+    if (!rides[g]) {
+      leader = g;
+      continue;
+    }
+    p.ride_delta[g] = (long long)(reinterpret_cast<intptr_t>(gh[g].XA) -
+                                  reinterpret_cast<intptr_t>(gh[leader].XA));
+  }
+  SGP_TRY(pair_stage_table(ctx, gh, Geff, d, rides, &p.stages, &p.nstages));
   int rc = -2;
   switch (d) {
-    case 1: rc = launch_pair_d<1>(ctx, p, single, flops); break;
-    case 2: rc = launch_pair_d<2>(ctx, p, single, flops); break;
-    case 3: rc = launch_pair_d<3>(ctx, p, single, flops); break;
-    case 4: rc = launch_pair_d<4>(ctx, p, single, flops); break;
-    case 5: rc = launch_pair_d<5>(ctx, p, single, flops); break;
-    case 6: rc = launch_pair_d<6>(ctx, p, single, flops); break;
-    case 7: rc = launch_pair_d<7>(ctx, p, single, flops); break;
-    case 8: rc = launch_pair_d<8>(ctx, p, single, flops); break;
+    case 1: rc = launch_pair_d<1>(ctx, p, single, riders, flops); break;
+    case 2: rc = launch_pair_d<2>(ctx, p, single, riders, flops); break;
+    case 3: rc = launch_pair_d<3>(ctx, p, single, riders, flops); break;
+    case 4: rc = launch_pair_d<4>(ctx, p, single, riders, flops); break;
+    case 5: rc = launch_pair_d<5>(ctx, p, single, riders, flops); break;
+    case 6: rc = launch_pair_d<6>(ctx, p, single, riders, flops); break;
+    case 7: rc = launch_pair_d<7>(ctx, p, single, riders, flops); break;
+    case 8: rc = launch_pair_d<8>(ctx, p, single, riders, flops); break;
     default:
       sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
       return -2;

@@ -395,7 +395,12 @@ def test_split_remainder_tiles_same_bits(mods, kind, d, ns, N):
 
 
 @pytest.mark.parametrize("n,N,layout", [(300, 5000, "aaa"), (530, 3000, "aab"), (400, 20000, "abb"),
-                                        (1100, 2500, "aa")])
+                                        (1100, 2500, "aa"),
+                                        # riders (up to 2 per leader form alpha . k in the leader's
+                                        # stages), a third follower with stages of its own, two
+                                        # groups, a rider as the LAST GP, cut remainder tiles
+                                        (300, 3000, "aaaa"), (520, 2000, "aabbb"), (280, 999, "abbba"),
+                                        (500, 64 * 256 + 64 * 40, "aaa"), (1000, 64 * 300 + 7, "baa")])
 def test_shared_factor_same_bits(mods, n, N, layout):
     """BASELINE.json config 3 is a multi-output GP: its GPs have the same inputs,
     kernel and noise, hence the same L^-1.  The paired sweep then takes |L^-1 k|^2
