@@ -48,59 +48,11 @@ constexpr int kPairs = 4;              // pairs per workgroup (64 rows per tile)
 constexpr int kTileRows = 16 * kPairs;
 constexpr int kKbRow = 80;             // doubles between the k-rows of a B buffer
 
-// experiment switches (scripts/dev/build_variant.sh; defaults = the kept kernel)
-#ifndef PGP_ORDER
-#define PGP_ORDER 2     // 0: half 0 multiplies first, half 1 evaluates first
-#endif                  // 1: both multiply first   2: both evaluate first
-#ifndef PGP_ADJ
-#define PGP_ADJ 0       // 1: pairs are adjacent waves (2p, 2p+1) instead of (p, p+4)
-#endif
-#ifndef PGP_DMA_LATE
-#define PGP_DMA_LATE 0  // 1: waves that multiply first issue their LDS-DMA after it
-#endif
-#ifndef PGP_DMA_MODE
-#define PGP_DMA_MODE 2  // 0: every wave issues its share of the next A chunk at the top
-#endif                  //    of the stage (slots w, w+8, ..)
-                        // 1: every wave, interleaved with its own slot sequence
-                        // 2: the waves of half 0 only (slots w, w+4, ..), interleaved
-#ifndef PGP_DMA_EARLY
-#define PGP_DMA_EARLY 0 // 1: (mode 2) one group behind each of the first 8 slots instead
-#endif                  //    of every second slot
-#ifndef PGP_EVAL_PRIO
-#define PGP_EVAL_PRIO 0 // s_setprio level of the evaluation (VALU) phase
-#endif
-#ifndef PGP_OPS_EARLY
-#define PGP_OPS_EARLY -1 // waves that evaluate first fetch the operands of their matrix
-#endif                   // phase BEFORE the evaluation (their latency passes under the
-                         // VALU burst): 0 no, 1 all of them, 2 the B operands only;
-                         // -1: 2 in the instances that have the registers for it
-#ifndef PGP_PRIO_ALL
-#define PGP_PRIO_ALL 0  // 1: everything outside the slot sequence runs at priority 3
-#endif
-#ifndef PGP_H1_PRIO
-#ifndef PGP_STAGE_LATE
-#define PGP_STAGE_LATE 0   // stage-table prefetch: 0 in front of the evaluation, 1 behind it,
-                           // 2 at the start of the wave's second slot.  (0: the scalar load in
-                           // flight makes the evaluation wait for the B operand reads as well --
-                           // and that is FASTER, +1..2 % for 1 and 2: the waves of a SIMD then
-                           // start their VALU bursts together; experiments.txt section 10)
-#endif
-#ifndef PGP_FIN_HALF
-#define PGP_FIN_HALF 1     // which half finishes the rows of a pair
-#endif
-#ifndef PGP_NOP_ALL
-#define PGP_NOP_ALL 1      // 1: every slot opens with s_nop 1; 0: slot 0 only (-0.1..0.6 %, but the
-                           // padding is what covers register copies the compiler may place at a join:
-                           // kept, experiments.txt section 10)
-#endif
-#ifndef PGP_EVAL_BARRIER
-#define PGP_EVAL_BARRIER 0
-#endif
-#ifndef PGP_ROWS_WAIT
-#define PGP_ROWS_WAIT 0    // 1: the training rows are waited for BEFORE the B operand reads go out
-#endif
-#define PGP_H1_PRIO 0   // s_setprio level of half 1 outside its evaluation phase
-#endif
+// The structure below is what survived the round-3 experiments (phase orders, pairs
+// on adjacent waves, where and by whom the LDS-DMA is issued, priorities, a second
+// barrier, ...: profiles/r03/experiments.txt; the switches they were built with are
+// in the history of this file up to commit d1566ec).  Debug builds: -DSGP_INSTRUMENT
+// (ablation mask, PGP_ABL) and -DPGP_STAMPS (cycle stamps per phase).
 
 // One stage (GP, chunk, j-block) of a tile.  Global slot t of the staged chunk
 // holds row block bend-1-t, k-steps 4 jb .. 4 jb + 3; its source is
@@ -234,26 +186,6 @@ __device__ __forceinline__ PStage load_pstage(pstage_ptr_t t, int i) {
 
 // (dma_2k / dma_1k / wait_dma / lds_addr_of: sweep_shared.h)
 
-// A chunk of stage `e` -> LDS image [global slot][k-step][lane] (2 KB per slot):
-// wave w copies the global slots w, w + 8, w + 16, w + 24 below nact.
-__device__ __forceinline__ void a_dma(const PStage& e, uint32_t dst0, int wave,
-                                      uint32_t voff) {
-  const int left = int(e.word & PW_NACT_MASK) - wave;
-  const uint64_t step = uint64_t(e.rs_bytes) * 8;
-  uint64_t src = e.a_src - uint64_t(uint32_t(wave)) * e.rs_bytes;
-  uint32_t dst = dst0 + uint32_t(wave) * 2048u;
-  if (left > 0) {
-    dma_2k(src, dst, voff);
-    if (left > 8) {
-      dma_2k(src - step, dst + 8 * 2048, voff);
-      if (left > 16) {
-        dma_2k(src - 2 * step, dst + 16 * 2048, voff);
-        if (left > 24) dma_2k(src - 3 * step, dst + 24 * 2048, voff);
-      }
-    }
-  }
-}
-
 // [16 D training rows | 16 alpha] of one j-block: 128 D + 128 bytes, one wave.
 template <int D>
 __device__ __forceinline__ void xa_dma(uint64_t src, uint32_t dst, int lane,
@@ -279,9 +211,10 @@ __device__ __forceinline__ void rider_dma(const int (&nride)[SGP_MAX_GPS],
   }
 }
 
-// The share of one wave in the copy of the next A chunk, issued piecewise between
-// the slots of the running stage (PGP_DMA_MODE 1, 2): group i is the global slot
-// w + kStride i, wanted when left > kStride i.
+// The share of one wave of half 0 in the copy of the next A chunk (LDS image
+// [global slot][k-step][lane], 2 KB per slot), issued piecewise between the slots of
+// the running stage: group i is the global slot w + kStride i, wanted when
+// left > kStride i.
 struct DmaPlan {
   uint64_t src0;     // source of the wave's first slot
   uint64_t step;     // bytes between its consecutive slots (kStride row blocks)
@@ -310,16 +243,6 @@ __device__ __forceinline__ void dma_group(const DmaPlan& d, int i) {
 // MFMA (needs 9 wait states, gets 0 -- scripts/dev/check_mfma_hazards.py finds
 // such code): the instances for d >= 6, the ones that run out of registers, use the
 // builtin instead (a few register copies at the joins of the slot sequence).
-//
-// The stage-table entry after the next one is fetched at the start of local slot 1
-// (StageAhead): a scalar load in flight turns the next LDS wait into a wait for
-// everything, and here that wait is a whole slot away.
-struct StageAhead {
-  pstage_ptr_t stages;
-  int index;
-  bool want;       // (false as well in instances that fetch the entry elsewhere)
-  PStage e;
-};
 template <int S, bool NARROW_OK, int kGroups, bool ASM_MFMA>
 __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
                                            double (&acc)[kWaveSlots][4], double& accx,
@@ -327,14 +250,13 @@ __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
                                            const double (&kb)[4][4],
                                            const double (&kvn)[4],
                                            double (&cur)[4], double (&nxt)[4],
-                                           const DmaPlan& dma, StageAhead& sa) {
+                                           const DmaPlan& dma) {
   if constexpr (S < kWaveSlots) {
     if (S < nw) {
       if (S + 1 < kWaveSlots) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) nxt[q] = aT[((S + 1) * 2 * kSteps + q) * 64];
       }
-      if (S == 1 && sa.want) sa.e = load_pstage(sa.stages, sa.index);
       __builtin_amdgcn_sched_barrier(0);
       // The matrix instructions are inline asm: the compiler's hazard recogniser
       // does not see them.  A register copy it places at the join in front of a
@@ -363,11 +285,8 @@ __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
           asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
                        : "+v"(accx) : "v"(cur[q]), "v"(kvn[q]));
       } else {
-        if (PGP_NOP_ALL || S == 0)
-          asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0"
-                       : "+v"(acc[S][0]) : "v"(cur[0]), "v"(kb[0][0]));
-        else
-          mfma_acc(acc[S][0], cur[0], kb[0][0]);
+        asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0"
+                     : "+v"(acc[S][0]) : "v"(cur[0]), "v"(kb[0][0]));
 #pragma unroll
         for (int m = 1; m < 4; ++m) mfma_acc(acc[S][m], cur[0], kb[m][0]);
 #pragma unroll
@@ -379,11 +298,11 @@ __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
       if (S + 1 < kWaveSlots)
         asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
       if constexpr (kGroups > 0) {
-        constexpr int kEvery = PGP_DMA_EARLY ? 1 : kWaveSlots / kGroups;
+        constexpr int kEvery = kWaveSlots / kGroups;
         if (S % kEvery == 0 && S / kEvery < kGroups) dma_group<kGroups>(dma, S / kEvery);
       }
       pair_slots<S + 1, false, kGroups, ASM_MFMA>(nw, false, acc, accx, aT, kb, kvn, nxt,
-                                                  cur, dma, sa);
+                                                  cur, dma);
     }
   }
 }
@@ -499,22 +418,19 @@ __device__ __forceinline__ void row_epilogue(const PairParams& p, RowState& rs,
   }
 }
 
-// The persistent stage loop of one wave; H = its half of the pair (compile time:
-// the two halves run the phases of a stage in opposite order).
+// The persistent stage loop of one wave; H = its half of the pair (compile time: half 0
+// copies the A chunks and owns the narrow slot, half 1 finishes the pair's rows),
+// R = riders per leader the instance can carry (0 or kMaxRide).
 template <int D, int MODE, bool SINGLE, int H, int R>
 __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
                                           const int lane, const int wave) {
   typedef LayP<D, R> L;
   constexpr bool conf = MODE == MODE_CONF;
-  constexpr bool kMultFirst = PGP_ORDER == 0 ? H == 0 : PGP_ORDER == 1;
   // (32 more live registers across the evaluation: instances that would spill for
   // it -- d >= 6, product kernels -- do without)
   constexpr int kOpsEarly =
-      PGP_OPS_EARLY >= 0 ? PGP_OPS_EARLY : ((SINGLE && D <= 4 && R == 0) ? 2 : 0);
-  // (only where the B operands are fetched in front of the evaluation does the place
-  // of the stage-table fetch matter -- and elsewhere the registers are not there)
-  constexpr int kStageLate = kOpsEarly != 0 ? PGP_STAGE_LATE : 0;
-  const int pr = PGP_ADJ ? wave >> 1 : wave & 3;
+      (SINGLE && D <= 4 && R == 0) ? 2 : 0;
+  const int pr = wave & 3;
   const int k4 = lane >> 4, c16 = lane & 15;
   const double* tab = lds + L::kTabOff;
   const pstage_ptr_t stages = (pstage_ptr_t)(p.stages);
@@ -640,7 +556,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     for (int m = 0; m < 4; ++m) acc[b][m] = 0.0;
   // the half whose wave finishes a pair's rows (sums the two partial |L^-1 k|^2 and
   // alpha . k, runs the row epilogue one stage later); the other hands its share over
-  constexpr int kFin = PGP_FIN_HALF;
+  constexpr int kFin = 1;
   RowState rs;                       // (H == kFin: the finishing wave)
   double keep_ssq = 0.0, keep_mu = 0.0;
   double keep_mu_r[R > 0 ? R : 1];
@@ -649,7 +565,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   uint32_t pend_w = 0;               // GP-end word waiting for its epilogue
   int pend_tile = 0;
 
-  constexpr int kDmaGroups = PGP_DMA_MODE == 1 ? 4 : (PGP_DMA_MODE == 2 && H == 0 ? 8 : 0);
+  constexpr int kDmaGroups = H == 0 ? 8 : 0;     // (the waves of half 0 copy the A chunks)
   // B operands of a stage (operand (q, m) of lane (k, a, j) = value of training
   // point 4 q + k at row 4 m + j), the plain covariance register for a narrow slot
   // 0, and the A operands of the wave's first slot
@@ -682,23 +598,18 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
 #pragma unroll
     for (int q = 0; q < 4; ++q) o.a0[q] = aT[q * 64];
   };
-  auto multiply = [&](uint32_t w, const double* abuf, Ops& o, const DmaPlan& dma,
-                      StageAhead& sa) {
+  auto multiply = [&](uint32_t w, const double* abuf, Ops& o, const DmaPlan& dma) {
     const int nw = (int(w & PW_NACT_MASK) - H + 1) >> 1;   // this wave's active slots
-    if (sa.want && !(nw > 1 && !PGP_ABL(8)))
-      sa.e = load_pstage(sa.stages, sa.index);
     if (nw > 0 && !PGP_ABL(8)) {
       const bool narrow0 = H == 0 && (w & PW_NARROW) != 0;
       const double* aT = abuf + H * (kSteps * 64) + lane;
       double opsB[4];
-      if (PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(0);
       pair_slots<0, H == 0, kDmaGroups, (D <= 5)>(nw, narrow0, acc, accx, aT, o.kb,
-                                                  o.kvn, o.a0, opsB, dma, sa);
-      if (PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(3);
+                                                  o.kvn, o.a0, opsB, dma);
     }
     if constexpr (kDmaGroups > 0) {
       // groups whose slot was not active (the hook sits behind slot kEvery * i)
-      constexpr int kEvery = PGP_DMA_EARLY ? 1 : kWaveSlots / (kDmaGroups > 0 ? kDmaGroups : 1);
+      constexpr int kEvery = kWaveSlots / (kDmaGroups > 0 ? kDmaGroups : 1);
 #pragma unroll
       for (int i = 0; i < kDmaGroups; ++i)
         if (!(nw > kEvery * i && !PGP_ABL(8))) dma_group<kDmaGroups>(dma, i);
@@ -779,8 +690,6 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
   int par = 0;
-  if (H == 1 && PGP_H1_PRIO) __builtin_amdgcn_s_setprio(PGP_H1_PRIO);
-  if (PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
   for (int item = 0; item < 2; ++item) {
   int s_lo = 0;                        // first stage of the item
@@ -833,24 +742,17 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     if (H == kFin && pend_w != 0 && !PGP_ABL(32)) finish(par ^ 1);
     PGP_STAMP(0);   // deferred row epilogue
 
-    // ---- prefetch: A chunk of the next stage, training block of the one after it
-    auto prefetch = [&]() {
-      if (more && !PGP_ABL(2)) {
-        if (PGP_DMA_MODE == 0)
-          a_dma(e1, lds_a + uint32_t(par ^ 1) * (L::kATile * 8), wave, voff);
-        if (wave == 7) {
-          xa_dma<D>(e1.xa_next, lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
-          if (R > 0)
-            rider_dma<D>(p.nride, p.ride_delta, int(e1.g_next), e1.xa_next,
-                         lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
-        }
-      }
-    };
-    if (!(PGP_DMA_LATE && kMultFirst)) prefetch();
+    // ---- prefetch: the training block of the stage after the next one (its A chunk
+    // goes out piecewise between the slots of half 0, DmaPlan)
+    if (more && !PGP_ABL(2) && wave == 7) {
+      xa_dma<D>(e1.xa_next, lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
+      if (R > 0)
+        rider_dma<D>(p.nride, p.ride_delta, int(e1.g_next), e1.xa_next,
+                     lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
+    }
     DmaPlan plan{};
     if constexpr (kDmaGroups > 0) {
-      // first global slot of this wave in the copy: w (all waves) or w of 0..3
-      const int w0 = PGP_DMA_MODE == 1 ? wave : (PGP_ADJ ? wave >> 1 : wave & 3);
+      const int w0 = wave & 3;     // first global slot of this wave in the copy
       plan.src0 = e1.a_src - uint64_t(uint32_t(w0)) * e1.rs_bytes;
       plan.step = uint64_t(e1.rs_bytes) * (32 / (kDmaGroups > 0 ? kDmaGroups : 1));
       plan.dst0 = lds_a + uint32_t(par ^ 1) * (L::kATile * 8) + uint32_t(w0) * 2048u;
@@ -861,11 +763,12 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     PGP_STAMP(1);   // LDS-DMA issue
     int si2 = si1 + 1;
     if (si2 == nstages) si2 = 0;    // (a run of chunks ends before it would wrap)
-    // (the table entry after the next one is fetched BEHIND the evaluation: a scalar
-    // load in flight turns every LDS wait into a wait for everything, and the
-    // evaluation would stand behind the operand reads issued in front of it)
-    StageAhead sa{stages, si2, kStageLate == 2 && left > 2, e1};
-    if (kStageLate == 0 && left > 2) sa.e = load_pstage<(R > 0)>(stages, si2);
+    // (the table entry after the next one: a scalar load in flight here makes the
+    // evaluation below wait for the B operand reads as well -- which is FASTER than
+    // letting it start early, the waves of a SIMD then run their VALU bursts
+    // together; experiments.txt section 10)
+    PStage e2 = e1;
+    if (left > 2) e2 = load_pstage<(R > 0)>(stages, si2);
 
     const double* abuf = lds + par * L::kATile;
     const double* kbr = kbp + par * L::kKbBuf;
@@ -874,21 +777,11 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
 
     Ops ops;
     Rows rows;
-    if (kRowsFirst && !kMultFirst && more) {
-      load_rows(xa, rows);
-      if (PGP_ROWS_WAIT) {
-        // (in-order LDS returns: with nothing else in flight this waits for the rows)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-    }
-    if (kMultFirst) {
-      fetch_ops(abuf, kbr, ops, 3);
-      multiply(wcur, abuf, ops, plan, sa);
-      PGP_STAMP(2);   // matrix phase (B operand reads, slots, chunk fold)
-    } else if (kOpsEarly) {
-      fetch_ops(abuf, kbr, ops, kOpsEarly == 2 ? 1 : 3);
-    }
-    if (PGP_DMA_LATE && kMultFirst) prefetch();
+    // both halves evaluate first (the barrier starts the VALU bursts of a SIMD's two
+    // waves together), then multiply; where the registers are there, the training rows
+    // and the B operands of the matrix phase are fetched in front of the evaluation
+    if (kRowsFirst && more) load_rows(xa, rows);
+    if (kOpsEarly) fetch_ops(abuf, kbr, ops, 1);
     if (__builtin_expect((wcur & PW_GP_END) != 0, 0)) {
       // alpha . k of the GP that ends here (the evaluation below may already belong
       // to the next one): half 0 hands its share over, half 1 keeps it
@@ -931,21 +824,11 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
         for (int f = 0; f < R; ++f) mean_r[f] = 0.0;
       }
     }
-    if (PGP_EVAL_PRIO && !PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(PGP_EVAL_PRIO);
-    if (kRowsFirst && kMultFirst && more) load_rows(xa, rows);
     if (more) evaluate(wnext, rows, xa, kbw);
-    if (PGP_EVAL_PRIO && !PGP_PRIO_ALL) __builtin_amdgcn_s_setprio(H == 1 ? PGP_H1_PRIO : 0);
-    // (a second, bare barrier: no wave of the workgroup starts its matrix instructions
-    // while another still evaluates -- VALU under a partner's MFMA stream gets one
-    // issue slot in 45..72 cycles)
-    if (PGP_EVAL_BARRIER && !kMultFirst && more) __builtin_amdgcn_s_barrier();
     PGP_STAMP(3);     // covariance evaluation
-    if (kStageLate == 1 && left > 2) sa.e = load_pstage(stages, si2);
-    if (!kMultFirst) {
-      if (kOpsEarly != 1) fetch_ops(abuf, kbr, ops, kOpsEarly == 2 ? 2 : 3);
-      multiply(wcur, abuf, ops, plan, sa);
-      PGP_STAMP(2);
-    }
+    fetch_ops(abuf, kbr, ops, kOpsEarly ? 2 : 3);
+    multiply(wcur, abuf, ops, plan);
+    PGP_STAMP(2);     // matrix phase (operand reads, slots, chunk fold)
 
     if (__builtin_expect((wcur & PW_GP_END) != 0, 0)) {
       if (!(p.split_parts > 0 && tile >= p.split_tile0)) {
@@ -970,7 +853,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     PGP_STAMP(6);     // barrier
     par ^= 1;
     wcur = wnext;
-    e1 = sa.e;
+    e1 = e2;
     si1 = si2;
     --left;
   }
@@ -999,7 +882,7 @@ __global__ __launch_bounds__(512, 1) void k_sweep_pair(PairParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (PGP_ADJ ? (wave & 1) == 0 : wave < 4)
+  if (wave < 4)
     pair_loop<D, MODE, SINGLE, 0, R>(p, lds, lane, wave);
   else
     pair_loop<D, MODE, SINGLE, 1, R>(p, lds, lane, wave);
@@ -1017,8 +900,8 @@ __global__ __launch_bounds__(512) void k_pair_split_finish(PairParams p) {
   __shared__ double sh_ex[kPairs][32];
   __shared__ __attribute__((aligned(16))) double sh_q[kPairs][LayP<1>::kQCap];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pr = PGP_ADJ ? wave >> 1 : wave & 3;
-  const int half = PGP_ADJ ? wave & 1 : wave >> 2;
+  const int pr = wave & 3;
+  const int half = wave >> 2;
   const int c16 = lane & 15;
   const int pt = int(blockIdx.x);
   const int tile = p.split_tile0 + pt;
