@@ -2,8 +2,8 @@
 // rows (BASELINE.json configs 3, 4, 5).
 //
 // Same mathematics as sweep.hip (gp.predict_noiseless + the Q update of
-// SafeOpt.update_confidence_intervals, safeopt/gp_opt.py:453-481, and
-// SafeOptSwarm._compute_particle_fitness, :901-1013): for every candidate row
+// SafeOpt.update_confidence_intervals, safeopt/gp_opt.py:453-481; the posterior
+// half of SafeOptSwarm._compute_particle_fitness, :901-1013): for every candidate row
 //     v = L^-1 k(X, x),  var = k(x,x) - |v|^2,  mean = alpha . k(X, x)
 // with k(X, x) evaluated on the fly and L^-1 k on the fp64 matrix cores.
 //
@@ -22,9 +22,17 @@
 //     there.  The exchange is software pipelined: the values of stage s + 1 are
 //     evaluated during stage s, so the one barrier per stage that the staged
 //     L^-1 chunk needs anyway also orders the exchange;
-//   * wave 0 of a pair multiplies first and evaluates afterwards, wave 1 the
-//     other way round: the SIMD they share always has one MFMA stream to issue
-//     while the other wave is in its VALU phase.
+//   * BOTH waves of a pair evaluate first, right behind the stage barrier, then
+//     both multiply: fp64 VALU and fp64 MFMA instructions do not overlap on a
+//     SIMD (a VALU instruction under the partner's MFMA stream gets one issue slot
+//     in 45..72 cycles), so the two VALU bursts run together at full rate and the
+//     two MFMA streams after them (profiles/r03/experiments.txt, sections 3, 5);
+//   * the waves of half 0 copy the next L^-1 chunk by LDS-DMA piecewise between
+//     their accumulator slots; half 1 finishes the pair's rows (adds the two
+//     partial |v|^2 and alpha . k, runs the row epilogue one stage later);
+//   * GPs with the factor of the GP in front of them (the outputs of a multi-
+//     output GP) ride in its stages: their alpha . k comes from the covariances
+//     the leader evaluates anyway (kMaxRide).
 // The stage sequence comes from a host-built table with ABSOLUTE source
 // addresses (one scalar load per stage, no pointer arithmetic on the device);
 // the training rows and alpha of a j-block are one contiguous block
