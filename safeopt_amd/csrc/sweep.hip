@@ -2,8 +2,11 @@
 //
 // Replaces gp.predict_noiseless(self.inputs) + the Q update of
 // SafeOpt.update_confidence_intervals (safeopt/gp_opt.py:453-476), the safe-set
-// test (:478-481), SafeOptSwarm._compute_particle_fitness (:901-1013) and the
-// per-candidate re-prediction of the expander loop (:579-606).
+// test (:478-481), the posterior half of SafeOptSwarm._compute_particle_fitness
+// (:901-1013; the shaping is k_fitness_small on the sweep's mean / var, launch_sweep
+// below) and the per-candidate re-prediction of the expander loop (:579-606).
+// This file: the 4-wave kernel for factors up to 256 rows (config 2), the dispatch
+// to the paired-wave kernel above that (sweep_pair.hip), the expander / rank-1 kernels.
 //
 // For a tile of candidate rows the kernel forms the covariance tile
 // K[j, pt] = k(X_j, x_pt) ON THE FLY in registers and contracts it with
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   for (int b = 0; b < kIB; ++b)
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[b][m] = 0.0;
-  // per-tile state of the row epilogue (confidence sweep / swarm fitness)
+  // per-tile state of the row epilogue
   bool safe = true;
   double l0 = 0.0;
   double lmax = -INFINITY;   // max l0 over the safe rows this wave has seen
