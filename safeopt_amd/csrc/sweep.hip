@@ -70,11 +70,12 @@ constexpr int kSteps = kJC / 4;        // MFMA k-steps per stage
 // between them doubles as the staging area of the wave's Q rows (kQCap doubles):
 // 48 doubles per k-row up to d = 4 (Q rows of up to 6 GPs), 16 beyond (2 GPs) --
 // what keeps two workgroups per CU inside 160 KB of LDS.
-template <int SL, int D>
+// R: alpha chunks of up to R riders behind the leader's (kSweepRide, see launch_posterior)
+template <int SL, int D, int R = 0>
 struct Lay {
   static constexpr int kATile = SL * kSteps * 64;           // doubles
   static constexpr int kXTile = kJC * D;
-  static constexpr int kBuf = kATile + kXTile + kJC;        // + alpha chunk
+  static constexpr int kBuf = kATile + kXTile + kJC * (1 + R);   // + alpha chunk(s)
   static constexpr int kTabOff = 2 * kBuf;                  // exp table
   static constexpr int kKbOff = kTabOff + kExpTabSize;
   static constexpr int kKbRow = D <= 4 ? 112 : 80;
@@ -133,6 +134,9 @@ struct SweepParams {
   const StageEnt* stages;   // [nstages] one tile's stage sequence (all GPs)
   int nstages;
   int single;               // every GP has a one-part kernel (pre-scaled inputs)
+  int nride[SGP_MAX_GPS];   // riders of GP g: the GPs g + 1 .. g + nride[g] share its
+                            // factor AND its covariances (GpDev::share) and have no stages
+                            // of their own -- their alpha . k is formed in g's stages
   int slots;                // accumulator slots per wave: 16 or 32 (host only)
 };
 
@@ -169,6 +173,17 @@ struct GpView {
     Apack = uniform(gp.Apack);
     Xs = uniform(gp.Xs);
     alpha = uniform(gp.alpha);
+  }
+};
+constexpr int kSweepRide = 2;      // riders per leader (what two workgroups' LDS holds)
+struct RiderView {
+  gptr_t alpha[kSweepRide];
+  int nr;
+  __device__ __forceinline__ void load(const GpDev* gps, int g, int n) {
+    nr = n;
+#pragma unroll
+    for (int f = 0; f < kSweepRide; ++f)
+      alpha[f] = GpView::uniform(gps[g + (f < n ? 1 + f : 0)].alpha);
   }
 };
 
@@ -217,17 +232,30 @@ __device__ __forceinline__ void stage_dma(const GpView& gp, const StageEnt& e,
 // 16 D and 16 doubles in GpDev::Xs / alpha -- wave 0 moves the rows (8 D lanes x
 // 16 B), the last wave the alpha run (8 lanes x 16 B); the other lanes are
 // masked off and write nothing.
-template <int D, int NW, int SL>
-__device__ __forceinline__ void stage_x_dma(const GpView& gp, const StageEnt& e,
-                                            double* buf, int wave, int lane) {
+// With riders (R > 0) the lanes 8 (1 + f) .. 8 (1 + f) + 7 of that instruction fetch
+// the same run of rider f's alpha: the LDS side of an LDS-DMA is contiguous in the
+// lane number, so the riders' chunks land right behind the leader's.
+template <int D, int NW, int SL, int R>
+__device__ __forceinline__ void stage_x_dma(const GpView& gp, const RiderView& rv,
+                                            const StageEnt& e, double* buf, int wave,
+                                            int lane) {
+  typedef Lay<SL, D, R> L;
   if (wave == 0) {
     if (lane < 8 * D)
-      lds_dma16(gp.Xs + int64_t(e.jb) * (kJC * D) + unsigned(lane) * 2u,
-                buf + Lay<SL, D>::kATile, 0);
+      lds_dma16(gp.Xs + int64_t(e.jb) * (kJC * D) + unsigned(lane) * 2u, buf + L::kATile, 0);
   } else if (wave == NW - 1) {
-    if (lane < 8)
-      lds_dma16(gp.alpha + int64_t(e.jb) * kJC + unsigned(lane) * 2u,
-                buf + Lay<SL, D>::kATile + Lay<SL, D>::kXTile, 0);
+    if (R == 0) {
+      if (lane < 8)
+        lds_dma16(gp.alpha + int64_t(e.jb) * kJC + unsigned(lane) * 2u,
+                  buf + L::kATile + L::kXTile, 0);
+    } else if (lane < 8 * (1 + rv.nr)) {
+      gptr_t src = gp.alpha;
+#pragma unroll
+      for (int f = 0; f < R; ++f)
+        if ((lane >> 3) == 1 + f) src = rv.alpha[f];
+      lds_dma16(src + int64_t(e.jb) * kJC + unsigned(lane & 7) * 2u,
+                buf + L::kATile + L::kXTile, 0);
+    }
   }
 }
 
@@ -371,12 +399,12 @@ __device__ __forceinline__ void mfma_jblock(int nact, bool narrow0,
   }
 }
 
-template <int D, int NW, int SL, int MODE, bool SINGLE>
+template <int D, int NW, int SL, int MODE, bool SINGLE, int R = 0>
 __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   constexpr int kTilePts = 16 * NW;
   // (the instances that have the registers for it: the others would spill)
   constexpr bool kSpread = SGP_DMA_SPREAD && MODE == MODE_CONF && SINGLE;
-  typedef Lay<SL, D> L;
+  typedef Lay<SL, D, R> L;
   constexpr int kATile = L::kATile, kBuf = L::kBuf, kXTile = L::kXTile;
   constexpr int kTabOff = L::kTabOff, kKbOff = L::kKbOff, kKbBuf = L::kKbBuf;
   constexpr int kIB = SL;
@@ -422,11 +450,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   GpView gv;               // GP of the stage being prefetched
   int gv_g = 0;
   gv.load(p.gps[0]);
+  RiderView rv;            // ... and its riders
+  rv.load(p.gps, 0, R > 0 ? p.nride[0] : 0);
   KernFast<D> kf(p.gps[0].kern);
   double kdiag = p.gps[0].kern.kdiag;
   StageEnt e1 = load_stage(stages, 0);
   stage_dma<NW, SL>(gv, e1, lds, wave, lane);
-  stage_x_dma<D, NW, SL>(gv, e1, lds, wave, lane);
+  stage_x_dma<D, NW, SL, R>(gv, rv, e1, lds, wave, lane);
   uint32_t wcur = e1.word;
   int si1 = 0, t1 = tile;
   advance(si1, t1);
@@ -438,6 +468,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   // per-GP state
   double xs[D];
   double sq[4] = {0.0, 0.0, 0.0, 0.0}, mean = 0.0;
+  double mean_r[R > 0 ? R : 1];      // alpha . k of the riders of the GP being swept
+#pragma unroll
+  for (int f = 0; f < (R > 0 ? R : 1); ++f) mean_r[f] = 0.0;
+  int nr_cur = R > 0 ? p.nride[0] : 0;
   double accx = 0.0, sqx = 0.0;     // narrow slot 0 (mfma_slots)
   double acc[kIB][4];
 #pragma unroll
@@ -464,11 +498,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       const int g_n = int(wnext >> SW_G_SHIFT) & 7;
       if (g_n != gv_g) {
         gv.load(p.gps[g_n]);
+        rv.load(p.gps, g_n, R > 0 ? p.nride[g_n] : 0);
         gv_g = g_n;
       }
       if (!SGP_ABL(2)) {
         if (!kSpread) stage_dma<NW, SL>(gv, e1, nbuf, wave, lane);
-        stage_x_dma<D, NW, SL>(gv, e1, nbuf, wave, lane);
+        stage_x_dma<D, NW, SL, R>(gv, rv, e1, nbuf, wave, lane);
       }
       if (next_tile) load_x(t1, xnext);
     }
@@ -507,6 +542,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         mean = fma(alT[q * 4 + (lane >> 4)], kv[q], mean);
+      if (R > 0) {
+#pragma unroll
+        for (int f = 0; f < R; ++f) {
+          if (f < nr_cur) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              mean_r[f] = fma(alT[kJC * (1 + f) + q * 4 + (lane >> 4)], kv[q], mean_r[f]);
+          }
+        }
+      }
     }
     double kb[4][4];
     if (!SGP_ABL(8)) broadcast_quads<L::kKbRow>(kv, kbw, lane, kb);
@@ -542,8 +587,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       double sumsq = (a1 ? v1 : v0) + __shfl_xor(a1 ? v0 : v1, 8, 64);
       sumsq = sum_lane_groups(sumsq + sqx);   // (sqx is per point l & 15 already)
       const double mu = sum_lane_groups(mean);
-      const double var = fmax(kdiag - sumsq, 1e-15);  // GPy clip
-      const double sd = sqrt(var);
       sq[0] = sq[1] = sq[2] = sq[3] = 0.0;
       sqx = 0.0;
       mean = 0.0;
@@ -551,17 +594,20 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       const int g = int(wcur >> SW_G_SHIFT) & 7;
       const int64_t row = int64_t(tile) * kTilePts + wave * 16 + (lane & 15);
       const bool writer = (row < p.pts.N) && (lane < 16);
-      if (conf) {
-        // update_confidence_intervals + compute_safe_set (gp_opt.py:453-481)
-        const double lo = mu - p.conf.beta * sd;
-        const double up = mu + p.conf.beta * sd;
-        if (g == 0) l0 = lo;
-        safe = safe && (lo > p.conf.fmin[g]);
+      // one GP's posterior at the wave's rows -> mean / var, its interval, the safe
+      // set (update_confidence_intervals + compute_safe_set, gp_opt.py:453-481)
+      auto emit = [&](int gi, double mu_i, double kdiag_i) {
+        const double var = fmax(kdiag_i - sumsq, 1e-15);  // GPy clip
+        const double sd = sqrt(var);
+        const double lo = mu_i - p.conf.beta * sd;
+        const double up = mu_i + p.conf.beta * sd;
+        if (gi == 0) l0 = lo;
+        safe = safe && (lo > p.conf.fmin[gi]);
         if (writer && !SGP_ABL(16)) {
           // streaming rows in / results out: non-temporal, so that they do not push
           // the L^-1 chunks every workgroup re-reads out of the 4 MB L2 of the XCD
-          __builtin_nontemporal_store(mu, p.conf.mean + int64_t(g) * p.pts.N + row);
-          __builtin_nontemporal_store(var, p.conf.var + int64_t(g) * p.pts.N + row);
+          __builtin_nontemporal_store(mu_i, p.conf.mean + int64_t(gi) * p.pts.N + row);
+          __builtin_nontemporal_store(var, p.conf.var + int64_t(gi) * p.pts.N + row);
         }
         // Q row = [l0, u0, l1, u1, ...] (gp_opt.py:375): the intervals of the G
         // passes are collected in the padding of the wave's broadcast buffer
@@ -570,11 +616,25 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
         // row from 16 lanes per GP
         if (p.conf.Q && lane < 16 && !SGP_ABL(16)) {
           if (p.G <= L::kQMaxG)
-            *reinterpret_cast<double2_t*>(kbw + L::qoff(lane * p.G + g)) =
+            *reinterpret_cast<double2_t*>(kbw + L::qoff(lane * p.G + gi)) =
                 double2_t{lo, up};
           else if (writer)
-            *reinterpret_cast<double2_t*>(p.conf.Q + (row * p.G + g) * 2) =
+            *reinterpret_cast<double2_t*>(p.conf.Q + (row * p.G + gi) * 2) =
                 double2_t{lo, up};
+        }
+      };
+      if (conf) {
+        emit(g, mu, kdiag);
+        if (R > 0) {
+          // riders: the leader's |L^-1 k|^2, their own alpha . k and prior variance
+#pragma unroll
+          for (int f = 0; f < R; ++f) {
+            if (f < nr_cur) {
+              const double mu_f = sum_lane_groups(mean_r[f]);
+              mean_r[f] = 0.0;
+              emit(g + 1 + f, mu_f, p.gps[g + 1 + f].kern.kdiag);
+            }
+          }
         }
       }
 
@@ -610,6 +670,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
           kf = KernFast<D>(p.gps[g_n].kern);
           kdiag = p.gps[g_n].kern.kdiag;
         }
+        if (R > 0) nr_cur = p.nride[g_n];
       }
       gp_start = true;
     }
@@ -987,13 +1048,15 @@ int sweep_waves() { return 4; }
 // of L^-1, the j-blocks 0 .. bend-1 (only the slots at or below the diagonal are
 // active).  Depends on the block counts only, so it is rebuilt (and uploaded)
 // when a GP crosses a multiple of 16 training points, not per launch.
-int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB,
+int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB, const bool* rides,
                 const StageEnt** dev, int* nstages) {
   std::vector<int> sig(1, Geff);
   sig.push_back(kIB);
+  int last_staged = 0;
   for (int g = 0; g < Geff; ++g) {
     sig.push_back(gh[g].nblk);
-    sig.push_back(gh[g].narrow);
+    sig.push_back(gh[g].narrow | (int(rides[g]) << 1));
+    if (!rides[g]) last_staged = g;
   }
   if (sig == ctx->stage_sig && ctx->stage_tab.p) {
     *dev = static_cast<const StageEnt*>(ctx->stage_tab.p);
@@ -1002,6 +1065,7 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB,
   }
   std::vector<StageEnt> tab;
   for (int g = 0; g < Geff; ++g) {
+    if (rides[g]) continue;       // (its alpha . k is formed in its leader's stages)
     const int nblk = gh[g].nblk, nsteps = gh[g].n_pad / 4;
     const int nchunks = (nblk + kIB - 1) / kIB;
     for (int c = 0; c < nchunks; ++c) {
@@ -1018,7 +1082,7 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB,
         if (c == nchunks - 1 && gh[g].narrow) e.word |= SW_NARROW;
         if (c == nchunks - 1 && jb == bend - 1) {
           e.word |= SW_GP_END;
-          if (g == Geff - 1) e.word |= SW_TILE_END;
+          if (g == last_staged) e.word |= SW_TILE_END;
         }
         tab.push_back(e);
       }
@@ -1042,14 +1106,14 @@ int sweep_grid_blocks(int num_cu, int64_t N, int nw, int slots) {
   return int(ntiles < resident ? ntiles : resident);
 }
 
-template <int D, int NW, int SL, int MODE, bool SINGLE>
+template <int D, int NW, int SL, int MODE, bool SINGLE, int R = 0>
 int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep<D, NW, SL, MODE, SINGLE>),
+                     reinterpret_cast<const void*>(&k_sweep<D, NW, SL, MODE, SINGLE, R>),
                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                     int(Lay<SL, D>::bytes(NW))));
+                     int(Lay<SL, D, R>::bytes(NW))));
     attr_set = true;
   }
   const int nblocks = sweep_grid_blocks(ctx->num_cu, p.pts.N, NW, SL);
@@ -1060,8 +1124,8 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
   pp.ablate = ablate;
 #endif
-  const size_t lds_bytes = Lay<SL, D>::bytes(NW);
-  hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE>), dim3(nblocks),
+  const size_t lds_bytes = Lay<SL, D, R>::bytes(NW);
+  hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE, R>), dim3(nblocks),
                      dim3(64 * NW), lds_bytes, ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
   return timer.end(ctx);
@@ -1069,6 +1133,11 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
 
 template <int D, int NW, int SL>
 int launch_sweep_w(sgp_ctx* ctx, const SweepParams& p, double flops) {
+  if constexpr (D <= 3) {       // (the d = 4 instance with riders would spill)
+    bool riders = false;
+    for (int g = 0; g < SGP_MAX_GPS; ++g) riders = riders || p.nride[g] > 0;
+    if (riders) return launch_sweep_v<D, NW, SL, MODE_CONF, true, kSweepRide>(ctx, p, flops);
+  }
   return p.single ? launch_sweep_v<D, NW, SL, MODE_CONF, true>(ctx, p, flops)
                   : launch_sweep_v<D, NW, SL, MODE_CONF, false>(ctx, p, flops);
 }
@@ -1124,9 +1193,18 @@ int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d,
                         sweep_waves();
   SweepParams q = p;
   q.slots = 16;            // accumulator slots per wave
-  SGP_TRY(stage_table(ctx, gh, Geff, q.slots, &q.stages, &q.nstages));
   q.single = 1;
   for (int g = 0; g < Geff; ++g) q.single = q.single && gh[g].kern.n_parts == 1;
+  // followers of a shared factor ride in their leader's stages (sweep_shared.h)
+  bool rides[SGP_MAX_GPS] = {};
+  static const bool no_ride = getenv("SGP_PAIR_RIDE") && atoi(getenv("SGP_PAIR_RIDE")) == 0;
+  for (int g = 0; g < SGP_MAX_GPS; ++g) q.nride[g] = 0;
+  if (no_ride || !sweep_riders(gh, Geff, d, q.single != 0, kSweepRide, 3, rides, q.nride))
+    for (int g = 0; g < SGP_MAX_GPS; ++g) {
+      rides[g] = false;
+      q.nride[g] = 0;
+    }
+  SGP_TRY(stage_table(ctx, gh, Geff, q.slots, rides, &q.stages, &q.nstages));
   switch (d) {
     case 1: return launch_sweep_d<1>(ctx, q, flops);
     case 2: return launch_sweep_d<2>(ctx, q, flops);

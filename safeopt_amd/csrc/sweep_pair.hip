@@ -1203,28 +1203,6 @@ int launch_pair_d(sgp_ctx* ctx, const PairParams& p, bool single, bool riders, d
                 : launch_pair_v<D, MODE_CONF, false>(ctx, p, flops);
 }
 
-// Which GPs ride with the GP in front (kMaxRide): a follower (GpDev::share >= 0) of a
-// launch whose kernels are all single-part, d <= 4, among the first kMaxRide behind
-// its leader.
-bool pair_riders(const GpDev* gh, int Geff, int d, bool single, bool* rides, int* nride) {
-  bool any = false;
-  int leader = 0;
-  for (int g = 0; g < Geff; ++g) {
-    rides[g] = false;
-    nride[g] = 0;
-    if (gh[g].share < 0) {
-      leader = g;
-      continue;
-    }
-    if (single && d <= 4 && g - leader <= kMaxRide && nride[leader] == g - leader - 1) {
-      rides[g] = true;
-      ++nride[leader];
-      any = true;
-    }
-  }
-  return any;
-}
-
 }  // namespace
 
 // The paired kernel pays off once a factor needs more than one pass of the
@@ -1267,7 +1245,7 @@ int launch_sweep_pair(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d,
     p.nride[g] = 0;
     p.ride_delta[g] = 0;
   }
-  const bool riders = !no_ride && pair_riders(gh, Geff, d, single, rides, p.nride);
+  const bool riders = !no_ride && sweep_riders(gh, Geff, d, single, kMaxRide, 4, rides, p.nride);
   if (!riders)
     for (int g = 0; g < Geff; ++g) {
       rides[g] = false;

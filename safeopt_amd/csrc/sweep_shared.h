@@ -72,6 +72,33 @@ __device__ __forceinline__ uint32_t lds_addr_of(const double* p) {
   return uint32_t(uintptr_t((const __attribute__((address_space(3))) void*)p));
 }
 
+// Which GPs of a launch RIDE with the GP in front of them: a follower (GpDev::share >= 0:
+// same inputs, kernel, noise and fitting history -- the outputs of a multi-output GP) has
+// the leader's L^-1 AND its covariances with every candidate, so its alpha . k is formed
+// in the leader's stages and it needs no stages of its own.  Single-part kernels, d <= max_d
+// (LDS room for the riders' alpha chunks, registers), the first `max_ride` followers of a
+// leader.
+// rides[g]: GP g rides; nride[g]: riders of leader g.  Returns whether any GP rides.
+inline bool sweep_riders(const GpDev* gh, int Geff, int d, bool single, int max_ride,
+                         int max_d, bool* rides, int* nride) {
+  bool any = false;
+  int leader = 0;
+  for (int g = 0; g < Geff; ++g) {
+    rides[g] = false;
+    nride[g] = 0;
+    if (gh[g].share < 0) {
+      leader = g;
+      continue;
+    }
+    if (single && d <= max_d && g - leader <= max_ride && nride[leader] == g - leader - 1) {
+      rides[g] = true;
+      ++nride[leader];
+      any = true;
+    }
+  }
+  return any;
+}
+
 // sweep_pair.hip
 bool pair_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff);
 int pair_sweep_partials(const sgp_ctx* ctx, int64_t N);

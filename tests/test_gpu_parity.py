@@ -400,7 +400,10 @@ def test_split_remainder_tiles_same_bits(mods, kind, d, ns, N):
                                         # stages), a third follower with stages of its own, two
                                         # groups, a rider as the LAST GP, cut remainder tiles
                                         (300, 3000, "aaaa"), (520, 2000, "aabbb"), (280, 999, "abbba"),
-                                        (500, 64 * 256 + 64 * 40, "aaa"), (1000, 64 * 300 + 7, "baa")])
+                                        (500, 64 * 256 + 64 * 40, "aaa"), (1000, 64 * 300 + 7, "baa"),
+                                        # the 4-wave kernel (n <= 256): riders only
+                                        (200, 5000, "aaa"), (40, 700, "aabbb"), (256, 3000, "abba"),
+                                        (130, 1200, "aaaa")])
 def test_shared_factor_same_bits(mods, n, N, layout):
     """BASELINE.json config 3 is a multi-output GP: its GPs have the same inputs,
     kernel and noise, hence the same L^-1.  The paired sweep then takes |L^-1 k|^2
