@@ -328,9 +328,12 @@ int sgp_ctx_set_sweep(sgp_ctx* ctx, int which);
 /* Multi-output case: consecutive GPs of a launch with bit-identical training
  * inputs, kernel, noise and fitting history have the same L^-1, so the variance
  * contraction of gp.predict_noiseless (safeopt/gp_opt.py:466-476 loops over the
- * GPs independently) is computed once and only alpha . k per GP (paired-wave
- * kernel; identical results, tests/test_gpu_parity.py).  on = 1 (default) / 0;
- * returns the previous setting.                                                  */
+ * GPs independently) is computed once and only alpha . k per GP: up to two such
+ * followers per leader take their alpha . k from the covariances the leader's
+ * sweep evaluates anyway (both sweep kernels; single-part kernels, d <= 4 / 3),
+ * further ones keep covariance-only stages in the paired-wave kernel.  Identical
+ * results bit for bit (tests/test_gpu_parity.py).  on = 1 (default) / 0; returns
+ * the previous setting.                                                         */
 int sgp_ctx_set_share(sgp_ctx* ctx, int on);
 
 #ifdef __cplusplus
