@@ -436,7 +436,7 @@ def main():
     # ---- the product's default: consecutive GPs with identical (X, kernel, noise)
     # share the variance contraction -- own timing, own flop count
     shared = None
-    if cfg["G"] > 1 and args.config != 5 and not args.no_shared_pass:
+    if cfg["G"] > 1 and not args.no_shared_pass:
         ctx.set_share(True)
         for _ in range(args.warmup):
             step()
@@ -522,10 +522,15 @@ def main():
     if shared:
         dts, s_ms, s_launches = shared
         sfl = (cfg["n"] ** 2 + 2.0 * G * cfg["n"]) * rows_rank
+        if args.config == 5:
+            # three sweeps per step: the greedy swarm takes GP 0 only (average per launch)
+            sfl = ((cfg["n"] ** 2 + 2.0 * cfg["n"]) + 2.0 * (cfg["n"] ** 2 + 2.0 * G * cfg["n"])) \
+                * rows_rank / 3.0
         res["shared_factor"] = {
             "note": "the product default (sgp_ctx_set_share): the GPs of this config have "
                     "identical inputs, kernel and noise, so |L^-1 k|^2 is formed once and "
-                    "alpha . k per GP; same Q/S/M/G bits (tests/test_gpu_parity.py)",
+                    "alpha . k per GP -- the followers ride in their leader's stages; same "
+                    "bits (tests/test_gpu_parity.py)",
             "value": units / (dts / args.steps), "unit": "candidates/s",
             "ms_per_step": dts * 1e3 / args.steps,
             "kernel_ms_avg": s_ms / max(s_launches, 1),
