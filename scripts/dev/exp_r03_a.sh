@@ -1,4 +1,6 @@
 #!/bin/bash
+# (record of a round-3 experiment: the -DPGP_* switches it builds with were removed from sweep_pair.hip after commit d1566ec;
+#  check that commit out to re-run it -- results in profiles/r03/experiments.txt)
 # round 3, experiment A: phase order / pair mapping / DMA placement of the paired sweep, and its ablation
 cd "$(dirname "$0")/../.."
 export AB_ONLY=pair

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (record of a round-3 experiment: the -DPGP_* switches it builds with were removed from sweep_pair.hip after commit d1566ec;
+#  check that commit out to re-run it -- results in profiles/r03/experiments.txt)
 # round 3, experiment E: priority 3 for everything outside the slot sequence
 cd "$(dirname "$0")/../.."
 export AB_ONLY=pair
