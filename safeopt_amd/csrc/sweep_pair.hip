@@ -752,11 +752,21 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
 
     // ---- prefetch: the training block of the stage after the next one (its A chunk
     // goes out piecewise between the slots of half 0, DmaPlan)
-    if (more && !PGP_ABL(2) && wave == 7) {
-      xa_dma<D>(e1.xa_next, lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
-      if (R > 0)
+    // Which wave copies it: without riders wave 7, at the top of the stage (14.77 vs
+    // 14.85 ms at config 3 for a wave of half 0); with riders -- three instructions --
+    // wave 0, the half with slack at the barrier, behind the VALU bursts and in front of
+    // its first slot (config 3 with the shared factor: 5.77 -> 5.65 ms).
+    // (d = 4 with riders: wave 7 again -- the other placement spills there)
+    constexpr bool kXaHalf0 = R > 0 && D <= 3;
+    if constexpr (R == 0) {
+      if (more && !PGP_ABL(2) && wave == 7)
+        xa_dma<D>(e1.xa_next, lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
+    } else if constexpr (!kXaHalf0) {
+      if (more && !PGP_ABL(2) && wave == 7) {
+        xa_dma<D>(e1.xa_next, lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
         rider_dma<D>(p.nride, p.ride_delta, int(e1.g_next), e1.xa_next,
                      lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
+      }
     }
     DmaPlan plan{};
     if constexpr (kDmaGroups > 0) {
@@ -835,6 +845,13 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     if (more) evaluate(wnext, rows, xa, kbw);
     PGP_STAMP(3);     // covariance evaluation
     fetch_ops(abuf, kbr, ops, kOpsEarly ? 2 : 3);
+    if constexpr (kXaHalf0 && H == 0) {
+      if (more && !PGP_ABL(2) && wave == 0) {
+        xa_dma<D>(e1.xa_next, lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
+        rider_dma<D>(p.nride, p.ride_delta, int(e1.g_next), e1.xa_next,
+                     lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
+      }
+    }
     multiply(wcur, abuf, ops, plan);
     PGP_STAMP(2);     // matrix phase (operand reads, slots, chunk fold)
 
