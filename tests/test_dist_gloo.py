@@ -171,6 +171,74 @@ def test_three_way_shard_single_process():
         assert np.array_equal(M, z["M"]) and np.array_equal(G, z["G"])
 
 
+def test_q_written_in_place_on_three_ranks():
+    """SPMD: every rank makes the same element-wise writes into ``opt.Q`` (the
+    reference mutates Q in place); the write-back uploads each rank's shard before the
+    next pass and the sets / query point equal the unsharded optimiser's."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import safeopt_amd
+    from oracle import gp_numpy as gpn
+    from _golden import load, make_kernel
+    from _oracle_backend import OracleGridBackend
+    import threading
+
+    class ThreadComm(object):
+        def __init__(self, rank, world, shared):
+            self.rank, self.world, self.sh = rank, world, shared
+
+        def _exchange(self, a):
+            self.sh["slots"][self.rank] = np.array(a, copy=True)
+            self.sh["bar"].wait()
+            out = [np.array(s, copy=True) for s in self.sh["slots"]]
+            self.sh["bar"].wait()
+            return out
+
+        def allreduce_max(self, a):
+            return np.max(np.stack(self._exchange(np.asarray(a, dtype=float))), axis=0)
+
+        def allgather(self, a):
+            return np.stack(self._exchange(np.asarray(a)))
+
+        def barrier(self):
+            self.sh["bar"].wait()
+
+    z, meta = load("sets_1d_seed7")
+
+    def scenario(comm):
+        gp = gpn.GPRegression(z["X0"], z["Y0"], make_kernel(gpn, meta["kernels"][0]),
+                              noise_var=meta["noise_vars"][0])
+        opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"],
+                                  comm=comm, _backend_factory=OracleGridBackend)
+        opt.update_confidence_intervals()
+        n = z["parameter_set"].shape[0]
+        opt.Q[n // 5:n // 2, 0] -= 0.2          # spans shard boundaries
+        opt.Q[[1, n - 2], 1] += 0.5
+        opt.compute_sets()
+        x = opt.get_new_query_point()
+        return x, opt.Q.copy(), opt.S.copy(), opt.M.copy(), opt.G.copy()
+
+    ref = scenario(None)
+    world = 3
+    shared = dict(slots=[None] * world, bar=threading.Barrier(world))
+    out = [None] * world
+    err = []
+
+    def run(rank):
+        try:
+            out[rank] = scenario(ThreadComm(rank, world, shared))
+        except Exception:                       # noqa: BLE001
+            import traceback
+            err.append(traceback.format_exc())
+            shared["bar"].abort()
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ths]; [t.join(120) for t in ths]
+    assert not err, err[0]
+    for r in range(world):
+        for a, b in zip(out[r], ref):
+            assert np.array_equal(a, b)
+
+
 # ---------------------------------------------------------------------------
 # the launcher: `python bench.py --gpus N` from a bare shell
 def test_bench_spawns_its_own_ranks():
