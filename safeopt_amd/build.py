@@ -19,12 +19,16 @@ CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libsafeopt_hip.so")
 SOURCES = ["api.hip", "sweep.hip", "sweep_pair.hip", "factor.hip", "sets.hip", "swarm.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "kern_eval.h", "fitness.h",
-                                            "small_path.h", "sweep_shared.h")] + \
+                                            "small_path.h", "sweep_shared.h",
+                                            "sweep_slots.h")] + \
           [os.path.join(REPO, "include", "safeopt_hip.h")]
 BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
         "-I", os.path.join(REPO, "include"), "-I", CSRC, "-Wall",
         "-Wno-unused-function"]
-EXTRA = {"sets.hip": ["-ffp-contract=off"], "swarm.hip": ["-ffp-contract=off"]}
+# sweep.hip: the accumulators of the 4-wave sweep live in hand-assigned AccVGPRs
+# (csrc/sweep_slots.h); the compiler must not park spilled VGPRs there.
+EXTRA = {"sets.hip": ["-ffp-contract=off"], "swarm.hip": ["-ffp-contract=off"],
+         "sweep.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-Wno-inline-asm"]}
 # e.g. SGP_HIPCC_FLAGS=-DSGP_INSTRUMENT for scripts/ablate.py (use --force)
 USER = os.environ.get("SGP_HIPCC_FLAGS", "").split()
 

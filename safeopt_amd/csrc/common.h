@@ -85,6 +85,9 @@ struct GpDev {
   int narrow;           // 1: the last row block has <= 4 real rows and Apack holds
                         // them in the "narrow" form (k_pack): the sweep then needs
                         // one MFMA per k-step for that block instead of four
+  int last_rows;        // real rows of the last row block (1..16): the 4-wave sweep
+                        // takes a last block of <= 12 rows as 1..3 narrow 4-row groups
+                        // (sweep.hip, narrow_groups)
   // record of the last one-row append (sgp_gp_append), consumed by the
   // rank-1 update of the resident posterior: w = Ky_old^-1 k(X_old, x*)
   // (zero padded to n_pad), upd[0] = (y* - mu(x*)) / s2, upd[1] = 1 / s2,

@@ -423,6 +423,7 @@ int publish_gp(sgp_gp* gp) {
   gp->dev.n_pad = np;
   gp->dev.nblk = nblk;
   gp->dev.narrow = narrow;
+  gp->dev.last_rows = n - 16 * (nblk - 1);
   gp->dev.share = -1;       // (only collect_gps, which sees the other GPs, may set it)
   gp->dev.Linv = Li;
   gp->dev.ld = gp->ld;

@@ -46,6 +46,7 @@
 
 #include "small_path.h"
 #include "sweep_shared.h"
+#include "sweep_slots.h"
 
 namespace {
 
@@ -107,8 +108,12 @@ enum : uint32_t {
   SW_GP_END = 1u << 7,      // last stage of a GP: row epilogue
   SW_TILE_END = 1u << 8,    // last stage of the tile
   SW_MEAN = 1u << 9,        // stage of the LAST chunk: accumulate alpha . k
-  SW_NARROW = 1u << 10,     // slot 0 holds a narrow row block (GpDev::narrow)
-  SW_G_SHIFT = 12           // GP index (3 bits)
+  SW_NARROW = 1u << 10,     // slot 0 is the last row block with <= 12 real rows: taken
+                            // as SW_NGRP narrow 4-row groups (narrow_groups)
+  SW_G_SHIFT = 12,          // GP index (3 bits)
+  SW_NGRP_SHIFT = 16,       // narrow groups of slot 0 (1..3)
+  SW_FIRST = 1u << 18,      // first stage (j-block 0) of an accumulator chunk
+  SW_NSL_SHIFT = 19         // slots of the stage's chunk (1..16; 5 bits)
 };
 
 // Timing experiments ("what does the kernel cost without X"; results are wrong
@@ -138,7 +143,24 @@ struct SweepParams {
                             // factor AND its covariances (GpDev::share) and have no stages
                             // of their own -- their alpha . k is formed in g's stages
   int slots;                // accumulator slots per wave: 16 or 32 (host only)
+#ifdef SGP_STAMPS
+  unsigned long long* stamps;   // [blocks][4 waves][8] cycles per phase (debug build)
+#endif
 };
+
+// Per-phase cycle stamps of the stage loop (-DSGP_STAMPS, scripts/dev): s_memtime at
+// the phase boundaries, summed per wave.  Perturbs the run (every stamp drains the
+// LDS / scalar-load counter); for attribution only.
+#ifdef SGP_STAMPS
+#define SGP_STAMP(i)                                                   \
+  do {                                                                 \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();        \
+    stamp_acc[i] += (unsigned int)(t_ - stamp_prev);                   \
+    stamp_prev = t_;                                                   \
+  } while (0)
+#else
+#define SGP_STAMP(i) do {} while (0)
+#endif
 
 typedef const __attribute__((address_space(1))) double* gptr_t;
 // the stage table is read-only for the whole launch: constant address space, so
@@ -320,10 +342,84 @@ __device__ __forceinline__ void load_slot(double (&ops)[4], const double* aT,
 // (mfma_acc: sweep_shared.h)
 
 //
-// Slot 0 of the last chunk may hold a NARROW row block (k_pack): its four MFMA
-// blocks carry the same <= 4 real rows, so the plain covariance register kv[q]
-// -- a different point quad per block -- is the B operand and one instruction
-// per k-step does the whole slot (accumulator accx: rows l >> 4, point l & 15).
+// Slot 0 of the last chunk is the LAST row block.  With <= 12 real rows it is taken as
+// 1..3 NARROW 4-row groups: the A operand of group g carries rows 4 g .. 4 g + 3 in
+// all four MFMA blocks -- read from the staged slot (standard layout, lane = 16 k +
+// row) with the lane address 16 k + 4 g + (lane & 3): the replication is a broadcast
+// read of LDS, no special packing -- so the plain covariance register kv[q], a
+// different point quad per block, is the B operand and ONE instruction per k-step
+// and group covers all 16 points (accumulator accx[g]: rows l >> 4 of the group,
+// point l & 15).  n = 200: 8 real rows in the 13th block, 8 MFMAs per stage instead
+// of 16 in the one slot that meets EVERY j-block.  The groups need kv only, not the
+// broadcast operands: they are issued in front of the LDS transpose, whose round
+// trip passes under them.
+#ifndef SGP_AN_EARLY
+#define SGP_AN_EARLY 0
+#endif
+#ifndef SGP_MAX_NG
+#define SGP_MAX_NG 3
+#endif
+constexpr int kMaxNg = SGP_MAX_NG;
+// ONE asm statement for all groups, the groups a GP does not have skipped by a scalar
+// branch INSIDE it: variants of the sequence at the source level, or a slot that is
+// narrow on one path and full on the other, make the register allocator duplicate
+// the 64 accumulators around the joins (400+ bytes of scratch).  Hence also: the
+// narrow groups are a region of their own in FRONT of the full slots (position 0 of
+// the staged chunk; the full slots then start at position 1) and touch no register
+// of theirs.
+// Per group four DEPENDENT MFMAs on one accumulator: the addend must not be read
+// before the previous result is written (4 wait states for this opcode; nothing pads
+// inside asm).  s_nop 1 in front: kv / the register copies the compiler may place
+// here are VALU writes, two wait states before an MFMA may read them -- the hazard
+// recogniser does not see into the asm.
+#define SGP_NARROW_GROUP(ACC, A0, A1, A2, A3)                       \
+  "v_mfma_f64_4x4x4_4b_f64 " ACC ", " A0 ", %[k0], " ACC "\n\ts_nop 4\n\t" \
+  "v_mfma_f64_4x4x4_4b_f64 " ACC ", " A1 ", %[k1], " ACC "\n\ts_nop 4\n\t" \
+  "v_mfma_f64_4x4x4_4b_f64 " ACC ", " A2 ", %[k2], " ACC "\n\ts_nop 4\n\t" \
+  "v_mfma_f64_4x4x4_4b_f64 " ACC ", " A3 ", %[k3], " ACC "\n\ts_nop 4\n\t"
+__device__ __forceinline__ void narrow_groups(int ngrp, double (&accx)[kMaxNg],
+                                              const double (&an)[kMaxNg][4],
+                                              const double (&kv)[4]) {
+  constexpr int g1 = kMaxNg > 1 ? 1 : 0, g2 = kMaxNg > 2 ? 2 : 0;
+  if constexpr (kMaxNg == 1) {
+    asm volatile("s_nop 1\n\t" SGP_NARROW_GROUP("%[c0]", "%[a00]", "%[a01]", "%[a02]", "%[a03]")
+                 : [c0] "+v"(accx[0])
+                 : [a00] "v"(an[0][0]), [a01] "v"(an[0][1]), [a02] "v"(an[0][2]),
+                   [a03] "v"(an[0][3]),
+                   [k0] "v"(kv[0]), [k1] "v"(kv[1]), [k2] "v"(kv[2]), [k3] "v"(kv[3]));
+  } else if constexpr (kMaxNg == 2) {
+    asm volatile("s_nop 1\n\t" SGP_NARROW_GROUP("%[c0]", "%[a00]", "%[a01]", "%[a02]", "%[a03]")
+                 "s_cmp_lt_u32 %[ng], 2\n\ts_cbranch_scc1 .Lsgp_narrow_end_%=\n\t"
+                 SGP_NARROW_GROUP("%[c1]", "%[a10]", "%[a11]", "%[a12]", "%[a13]")
+                 ".Lsgp_narrow_end_%=:"
+                 : [c0] "+v"(accx[0]), [c1] "+v"(accx[g1])
+                 : [a00] "v"(an[0][0]), [a01] "v"(an[0][1]), [a02] "v"(an[0][2]),
+                   [a03] "v"(an[0][3]),
+                   [a10] "v"(an[g1][0]), [a11] "v"(an[g1][1]), [a12] "v"(an[g1][2]),
+                   [a13] "v"(an[g1][3]),
+                   [k0] "v"(kv[0]), [k1] "v"(kv[1]), [k2] "v"(kv[2]), [k3] "v"(kv[3]),
+                   [ng] "s"(ngrp)
+                 : "scc");
+  } else {
+    asm volatile("s_nop 1\n\t" SGP_NARROW_GROUP("%[c0]", "%[a00]", "%[a01]", "%[a02]", "%[a03]")
+                 "s_cmp_lt_u32 %[ng], 2\n\ts_cbranch_scc1 .Lsgp_narrow_end_%=\n\t"
+                 SGP_NARROW_GROUP("%[c1]", "%[a10]", "%[a11]", "%[a12]", "%[a13]")
+                 "s_cmp_lt_u32 %[ng], 3\n\ts_cbranch_scc1 .Lsgp_narrow_end_%=\n\t"
+                 SGP_NARROW_GROUP("%[c2]", "%[a20]", "%[a21]", "%[a22]", "%[a23]")
+                 ".Lsgp_narrow_end_%=:"
+                 : [c0] "+v"(accx[0]), [c1] "+v"(accx[g1]), [c2] "+v"(accx[g2])
+                 : [a00] "v"(an[0][0]), [a01] "v"(an[0][1]), [a02] "v"(an[0][2]),
+                   [a03] "v"(an[0][3]),
+                   [a10] "v"(an[g1][0]), [a11] "v"(an[g1][1]), [a12] "v"(an[g1][2]),
+                   [a13] "v"(an[g1][3]),
+                   [a20] "v"(an[g2][0]), [a21] "v"(an[g2][1]), [a22] "v"(an[g2][2]),
+                   [a23] "v"(an[g2][3]),
+                   [k0] "v"(kv[0]), [k1] "v"(kv[1]), [k2] "v"(kv[2]), [k3] "v"(kv[3]),
+                   [ng] "s"(ngrp)
+                 : "scc");
+  }
+}
+#undef SGP_NARROW_GROUP
 // The wave's share of the copy of the NEXT stage's A chunk: group i is slot
 // w + NW i, wanted when left > NW i; issued behind slot NW i of the running stage.
 struct DmaShare {
@@ -338,65 +434,18 @@ __device__ __forceinline__ void dma_share_group(const DmaShare& d, int i) {
     dma_2k(d.src0 - uint64_t(i) * d.step, d.dst0 + uint32_t(i) * (NW * 2048u), d.voff);
 }
 
-template <int SL, int S, int NW, bool SPREAD>
-__device__ __forceinline__ void mfma_slots(int nact, bool narrow0,
-                                           double (&acc)[SL][4], double& accx,
-                                           const double* aT,
-                                           const double (&kb)[4][4],
-                                           const double (&kv)[4],
-                                           double (&cur)[4], double (&nxt)[4],
-                                           const DmaShare& dma) {
-  if constexpr (S < SL) {
-    if (S < nact) {
-      if (S + 1 < SL) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) nxt[q] = aT[((S + 1) * kSteps + q) * 64];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (S == 0 && narrow0) {
-        // four DEPENDENT MFMAs on one accumulator: the addend must not be read
-        // before the previous result is written (4 wait states for this opcode;
-        // nothing pads inside asm)
-        // (s_nop 1: the register copy of accx the compiler puts in front of this
-        // block is a VALU write, two wait states before an MFMA may read it -- the
-        // hazard recogniser does not see into the asm)
-        asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
-                     : "+v"(accx) : "v"(cur[0]), "v"(kv[0]));
-#pragma unroll
-        for (int q = 1; q < 4; ++q)
-          asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
-                       : "+v"(accx) : "v"(cur[q]), "v"(kv[q]));
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-          for (int m = 0; m < 4; ++m) mfma_acc(acc[S][m], cur[q], kb[m][q]);
-        }
-      }
-      if (S + 1 < SL)
-        asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
-      if (SPREAD && S % NW == 0) dma_share_group<NW>(dma, S / NW);
-      mfma_slots<SL, S + 1, NW, SPREAD>(nact, false, acc, accx, aT, kb, kv, nxt, cur, dma);
-    }
-  }
-}
-
+// The full slots of a stage: sweep_slots.h (hand-written, accumulators in a0..a127).
+// In front of them the wave's share of the next stage's A chunk goes out: all groups
+// at once (spread over the slot sequence they cost ~12 scalar instructions each).
 template <int SL, int NW, bool SPREAD>
-__device__ __forceinline__ void mfma_jblock(int nact, bool narrow0,
-                                            double (&acc)[SL][4], double& accx,
-                                            const double* aT,
-                                            const double (&kb)[4][4],
-                                            const double (&kv)[4], const DmaShare& dma) {
-  double opsA[4], opsB[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) opsA[q] = aT[q * 64];
-  mfma_slots<SL, 0, NW, SPREAD>(nact, narrow0, acc, accx, aT, kb, kv, opsA, opsB, dma);
+__device__ __forceinline__ void mfma_jblock(int nact, int first, unsigned abase,
+                                            const double (&kb)[4][4], const DmaShare& dma) {
+  static_assert(SL == 16, "sweep_slots.h is written out for 16 slots");
   if (SPREAD) {
-    // groups whose slot was not active (the hook sits behind slot NW i)
 #pragma unroll
-    for (int i = 0; i < SL / NW; ++i)
-      if (!(nact > NW * i)) dma_share_group<NW>(dma, i);
+    for (int i = 0; i < SL / NW; ++i) dma_share_group<NW>(dma, i);
   }
+  if (nact > 0) sgp_slots(__builtin_amdgcn_readfirstlane(nact), first, abase, kb);
 }
 
 template <int D, int NW, int SL, int MODE, bool SINGLE, int R = 0>
@@ -404,6 +453,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   constexpr int kTilePts = 16 * NW;
   // (the instances that have the registers for it: the others would spill)
   constexpr bool kSpread = SGP_DMA_SPREAD && MODE == MODE_CONF && SINGLE;
+  // (6 kMaxNg registers live across the evaluation: where they are to be had)
+  constexpr bool kAnEarly = SGP_AN_EARLY && D <= 2 && R == 0;
   typedef Lay<SL, D, R> L;
   constexpr int kATile = L::kATile, kBuf = L::kBuf, kXTile = L::kXTile;
   constexpr int kTabOff = L::kTabOff, kKbOff = L::kKbOff, kKbBuf = L::kKbBuf;
@@ -467,23 +518,24 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
 
   // per-GP state
   double xs[D];
-  double sq[4] = {0.0, 0.0, 0.0, 0.0}, mean = 0.0;
+  double ssq_run = 0.0, mean = 0.0;   // folded squares of the GP's finished chunks (per lane)
   double mean_r[R > 0 ? R : 1];      // alpha . k of the riders of the GP being swept
 #pragma unroll
   for (int f = 0; f < (R > 0 ? R : 1); ++f) mean_r[f] = 0.0;
   int nr_cur = R > 0 ? p.nride[0] : 0;
-  double accx = 0.0, sqx = 0.0;     // narrow slot 0 (mfma_slots)
-  double acc[kIB][4];
+  double accx[kMaxNg];              // narrow groups of slot 0 (narrow_groups)
 #pragma unroll
-  for (int b = 0; b < kIB; ++b)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) acc[b][m] = 0.0;
+  for (int g = 0; g < kMaxNg; ++g) accx[g] = 0.0;
   // per-tile state of the row epilogue
   bool safe = true;
   double l0 = 0.0;
   double lmax = -INFINITY;   // max l0 over the safe rows this wave has seen
   bool gp_start = true;
 
+#ifdef SGP_STAMPS
+  unsigned int stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
   int par = 0;
 #pragma unroll 1
   while (true) {
@@ -525,6 +577,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     StageEnt e2 = e1;
     if (have2) e2 = load_stage(stages, si2);
 
+    SGP_STAMP(0);   // prefetch issue, table entry
+#ifdef SGP_PAD_SALU      // issue-model experiment: extra scalar instructions per stage
+    asm volatile(".rept " SGP_STR(SGP_PAD_SALU) "\n\ts_mov_b32 s98, 0\n\t.endr" ::: "s98");
+#endif
+#ifdef SGP_PAD_VALU
+    asm volatile(".rept " SGP_STR(SGP_PAD_VALU) "\n\tv_mov_b32 v127, 0\n\t.endr" ::: "v127");
+#endif
     // ---- this stage: 16 training points against the active row blocks
     if (gp_start) {
       kf.template prep_t<SINGLE>(x, xs);
@@ -532,6 +591,20 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     }
     const double* xT = cbuf + kATile;
     const double* alT = cbuf + kATile + kXTile;
+    // A operands of the narrow groups (position 0 of the staged chunk), read FIRST in
+    // the stage: they arrive under the evaluation.  (All kMaxNg groups whether the GP
+    // has them or not: the reads stay inside the slot.)
+    const int ngrp = (wcur & SW_NARROW) ? int(wcur >> SW_NGRP_SHIFT) & 3 : 0;
+    double an[kMaxNg][4];
+    auto load_an = [&]() {
+      const double* aN = cbuf + (lane & 0x33);
+#pragma unroll
+      for (int g = 0; g < kMaxNg; ++g) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) an[g][q] = aN[q * 64 + 4 * g];
+      }
+    };
+    if (kAnEarly && ngrp > 0 && !SGP_ABL(8)) load_an();
     double kv[4];
     if (!SGP_ABL(4)) {
       kf.template many4_t<SINGLE>(xs, xT + (lane >> 4) * D, 4 * D, tab, kv);
@@ -553,42 +626,68 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
         }
       }
     }
+    // the narrow groups of the last row block (position 0 of the staged chunk): they
+    // need kv only -- issued in front of the LDS transpose, whose round trip passes
+    // under them
+    SGP_STAMP(1);   // covariance evaluation (+ alpha . k)
+    if (ngrp > 0 && !SGP_ABL(8)) {
+      if (!kAnEarly) load_an();
+      narrow_groups(ngrp, accx, an, kv);
+    }
+    SGP_STAMP(2);   // narrow groups
     double kb[4][4];
     if (!SGP_ABL(8)) broadcast_quads<L::kKbRow>(kv, kbw, lane, kb);
+#ifdef SGP_STAMPS
+    asm volatile("" : "+v"(kb[0][0]), "+v"(kb[1][0]), "+v"(kb[2][0]), "+v"(kb[3][0]));
+    asm volatile("" : "+v"(kb[0][3]), "+v"(kb[1][3]), "+v"(kb[2][3]), "+v"(kb[3][3]));
+#endif
+    SGP_STAMP(3);   // LDS transpose round trip
     if (!SGP_ABL(8)) {
-      mfma_jblock<SL, NW, kSpread>(int(wcur & SW_NACT_MASK), (wcur & SW_NARROW) != 0, acc, accx,
-                          cbuf + lane, kb, kv, share);
+      const int shift = ngrp > 0 ? 1 : 0;
+      mfma_jblock<SL, NW, kSpread>(int(wcur & SW_NACT_MASK) - shift,
+                                   int(wcur & SW_FIRST), lds_addr_of(cbuf) + uint32_t(lane) * 8u +
+                                       uint32_t(shift) * (kSteps * 512u),
+                                   kb, share);
     } else if (kSpread) {
 #pragma unroll
       for (int i = 0; i < SL / NW; ++i) dma_share_group<NW>(share, i);
     }
 
+    SGP_STAMP(4);   // full slots
     if (wcur & SW_CHUNK_END) {
-#pragma unroll
-      for (int b = 0; b < kIB; ++b) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          sq[m] = fma(acc[b][m], acc[b][m], sq[m]);
-          acc[b][m] = 0.0;
-        }
-      }
-      sqx = fma(accx, accx, sqx);
-      accx = 0.0;
-    }
-
-    if ((wcur & SW_GP_END) && !SGP_ABL(32)) {
+      // squares of the chunk's accumulators, folded at once to this lane's share of
+      // |L^-1 k|^2 for its point (lane l: point l & 15): ONE register survives the chunk
+      // (the chunk's slots: what its LAST stage -- this one -- has active is the
+      // diagonal block only; the table carries the chunk's slot count)
+      double sq[4] = {0.0, 0.0, 0.0, 0.0};
+      const int nsl = __builtin_amdgcn_readfirstlane(int(wcur >> SW_NSL_SHIFT) & 31) -
+                      (ngrp > 0 ? 1 : 0);
+      if (nsl > 0 && !SGP_ABL(8)) sgp_fold_slots(nsl, sq);
+      // lane 16 i' + 4 blk + j' of sq[m]: the squares for point 4 m + j' of row group
+      // blk on the DIAGONAL lanes i' = j' only (cross terms elsewhere)
+      if ((lane >> 4) != (lane & 3)) sq[0] = sq[1] = sq[2] = sq[3] = 0.0;
       // sq[m]: partial sums for column 4m + (lane & 3) over this lane's rows.
       // Transposing fold over the lanes that share (lane & 3): after the xor-4
       // and xor-8 exchanges each lane holds the quad of its OWN column
-      // (lane & 15) = 4 ((lane >> 2) & 3) + (lane & 3); then the 4 k-rows.
+      // (lane & 15) = 4 ((lane >> 2) & 3) + (lane & 3).
       const bool a0 = (lane & 4) != 0, a1 = (lane & 8) != 0;
-      double v0 = (a0 ? sq[1] : sq[0]) + __shfl_xor(a0 ? sq[0] : sq[1], 4, 64);
-      double v1 = (a0 ? sq[3] : sq[2]) + __shfl_xor(a0 ? sq[2] : sq[3], 4, 64);
-      double sumsq = (a1 ? v1 : v0) + __shfl_xor(a1 ? v0 : v1, 8, 64);
-      sumsq = sum_lane_groups(sumsq + sqx);   // (sqx is per point l & 15 already)
+      const double v0 = (a0 ? sq[1] : sq[0]) + __shfl_xor(a0 ? sq[0] : sq[1], 4, 64);
+      const double v1 = (a0 ? sq[3] : sq[2]) + __shfl_xor(a0 ? sq[2] : sq[3], 4, 64);
+      double t = (a1 ? v1 : v0) + __shfl_xor(a1 ? v0 : v1, 8, 64);
+      // (the narrow groups: rows l >> 4 of the group, point l & 15 already)
+#pragma unroll
+      for (int g = 0; g < kMaxNg; ++g) {
+        t = fma(accx[g], accx[g], t);
+        accx[g] = 0.0;
+      }
+      ssq_run += t;
+    }
+
+    if ((wcur & SW_GP_END) && !SGP_ABL(32)) {
+      // ... then the 4 k-rows
+      const double sumsq = sum_lane_groups(ssq_run);
       const double mu = sum_lane_groups(mean);
-      sq[0] = sq[1] = sq[2] = sq[3] = 0.0;
-      sqx = 0.0;
+      ssq_run = 0.0;
       mean = 0.0;
 
       const int g = int(wcur >> SW_G_SHIFT) & 7;
@@ -675,9 +774,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       gp_start = true;
     }
 
+    SGP_STAMP(5);   // chunk fold, row epilogue
     if (!more) break;
     if (kSpread) wait_dma();       // (asm copies: the compiler does not count them)
+    SGP_STAMP(6);   // wait for this wave's LDS-DMA
     if (!SGP_ABL(1)) __syncthreads();
+    SGP_STAMP(7);   // barrier
     par ^= 1;
     wcur = wnext;
     e1 = e2;
@@ -685,6 +787,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     t1 = t2;
     have1 = have2;
   }
+#ifdef SGP_STAMPS
+  if (lane == 0) {
+    unsigned long long* o = p.stamps + (size_t(blockIdx.x) * NW + wave) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = stamp_acc[i];
+  }
+#endif
   if (conf && p.conf.S) {
     lmax = wave_max(lmax);
     if (lane == 0) p.conf.partial[int(blockIdx.x) * NW + wave] = lmax;
@@ -1048,6 +1156,16 @@ int sweep_waves() { return 4; }
 // of L^-1, the j-blocks 0 .. bend-1 (only the slots at or below the diagonal are
 // active).  Depends on the block counts only, so it is rebuilt (and uploaded)
 // when a GP crosses a multiple of 16 training points, not per launch.
+// Narrow 4-row groups the last row block of a GP is taken as (0: a full block).
+// SGP_NO_NARROW=1: never (A/B runs); =2: only the one-group form of round 3.
+int narrow_groups_of(const GpDev& gp) {
+  static const int mode = getenv("SGP_NO_NARROW") ? atoi(getenv("SGP_NO_NARROW")) : 0;
+  const int ng = (gp.last_rows + 3) / 4;
+  if (mode == 1 || ng > kMaxNg) return 0;
+  if (mode == 2 && ng > 1) return 0;
+  return ng;
+}
+
 int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB, const bool* rides,
                 const StageEnt** dev, int* nstages) {
   std::vector<int> sig(1, Geff);
@@ -1055,7 +1173,7 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB, const bool* ri
   int last_staged = 0;
   for (int g = 0; g < Geff; ++g) {
     sig.push_back(gh[g].nblk);
-    sig.push_back(gh[g].narrow | (int(rides[g]) << 1));
+    sig.push_back(narrow_groups_of(gh[g]) | (int(rides[g]) << 2));
     if (!rides[g]) last_staged = g;
   }
   if (sig == ctx->stage_sig && ctx->stage_tab.p) {
@@ -1076,10 +1194,13 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB, const bool* ri
         e.row_stride = uint32_t(nsteps);
         e.jb = uint32_t(jb);
         e.word = uint32_t(std::min(nib, bend - jb)) | (uint32_t(g) << SW_G_SHIFT);
+        if (jb == 0) e.word |= SW_FIRST;
+        e.word |= uint32_t(nib) << SW_NSL_SHIFT;
         if (jb == bend - 1) e.word |= SW_CHUNK_END;
         if (c == nchunks - 1) e.word |= SW_MEAN;
         // slot 0 of the last chunk = the last row block
-        if (c == nchunks - 1 && gh[g].narrow) e.word |= SW_NARROW;
+        if (c == nchunks - 1 && narrow_groups_of(gh[g]) > 0)
+          e.word |= SW_NARROW | (uint32_t(narrow_groups_of(gh[g])) << SW_NGRP_SHIFT);
         if (c == nchunks - 1 && jb == bend - 1) {
           e.word |= SW_GP_END;
           if (g == last_staged) e.word |= SW_TILE_END;
@@ -1125,9 +1246,32 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   pp.ablate = ablate;
 #endif
   const size_t lds_bytes = Lay<SL, D, R>::bytes(NW);
+#ifdef SGP_STAMPS
+  static unsigned long long* stamps_dev = nullptr;
+  if (!stamps_dev) SGP_HIP(ctx, hipMalloc(&stamps_dev, size_t(4096) * NW * 8 * 8));
+  pp.stamps = stamps_dev;
+#endif
   hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE, R>), dim3(nblocks),
                      dim3(64 * NW), lds_bytes, ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
+#ifdef SGP_STAMPS
+  {
+    std::vector<unsigned long long> h(size_t(nblocks) * NW * 8);
+    SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SGP_HIP(ctx, hipMemcpy(h.data(), stamps_dev, h.size() * 8, hipMemcpyDeviceToHost));
+    static const char* names[8] = {"prefetch", "evaluate", "narrow", "transpose", "slots",
+                                   "fold+epilogue", "dma-wait", "barrier"};
+    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
+    for (size_t w = 0; w < size_t(nblocks) * NW; ++w)
+      for (int i = 0; i < 8; ++i) sum[i] += double(h[w * 8 + i]);
+    for (int i = 0; i < 8; ++i) tot += sum[i];
+    fprintf(stderr, "stamps (ticks per wave, %% of loop):");
+    for (int i = 0; i < 8; ++i)
+      fprintf(stderr, "  %s %.0f (%.1f%%)", names[i], sum[i] / (double(NW) * nblocks),
+              100.0 * sum[i] / tot);
+    fprintf(stderr, "  | loop %.0f\n", tot / (double(NW) * nblocks));
+  }
+#endif
   return timer.end(ctx);
 }
 
@@ -1206,14 +1350,18 @@ int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d,
     }
   SGP_TRY(stage_table(ctx, gh, Geff, q.slots, rides, &q.stages, &q.nstages));
   switch (d) {
+#ifndef SGP_ONLY_D2      // (compile-time experiments: one instance set)
     case 1: return launch_sweep_d<1>(ctx, q, flops);
+#endif
     case 2: return launch_sweep_d<2>(ctx, q, flops);
+#ifndef SGP_ONLY_D2
     case 3: return launch_sweep_d<3>(ctx, q, flops);
     case 4: return launch_sweep_d<4>(ctx, q, flops);
     case 5: return launch_sweep_d<5>(ctx, q, flops);
     case 6: return launch_sweep_d<6>(ctx, q, flops);
     case 7: return launch_sweep_d<7>(ctx, q, flops);
     case 8: return launch_sweep_d<8>(ctx, q, flops);
+#endif
   }
   sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
   return -2;

@@ -49,6 +49,12 @@ struct SweepTimer {
 __device__ __forceinline__ void mfma_acc(double& c, double a, double b) {
   asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
+// ... with the accumulator in an ACCUMULATION register (the AccVGPR half of the
+// unified register file, gfx90a+): the 128 registers of a wave's 16 slots then do not
+// compete with anything the compiler allocates among the architectural VGPRs.
+__device__ __forceinline__ void mfma_acc_a(double& c, double a, double b) {
+  asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
 
 // global -> LDS without a VGPR round trip: "scalar base + 32-bit lane offset"
 // (the builtin only produces the 64-bit-VGPR-address form, one VALU add per

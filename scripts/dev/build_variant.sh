@@ -8,7 +8,7 @@ NAME=$1; FLAGS=$2
 C=safeopt_amd/csrc; O=/tmp/variant_$NAME; mkdir -p $O scripts/dev/ab
 BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -I $C -Wall -Wno-unused-function -Wno-inline-asm"
 /opt/rocm/bin/hipcc $BASE $FLAGS -c $C/sweep_pair.hip -o $O/sweep_pair.o &
-/opt/rocm/bin/hipcc $BASE $FLAGS -c $C/sweep.hip -o $O/sweep.o &
+/opt/rocm/bin/hipcc $BASE $FLAGS -mllvm -amdgpu-spill-vgpr-to-agpr=0 -c $C/sweep.hip -o $O/sweep.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scripts/dev/ab/$NAME.so \
   $C/api.o $O/sweep.o $O/sweep_pair.o $C/factor.o $C/sets.o $C/swarm.o -ldl

@@ -9,6 +9,8 @@ go unpadded (wait states as in LLVM's GCNHazardRecognizer for gfx90a+ DGEMM 4x4)
   R3  MFMA write of a VGPR -> VMEM / LDS / FLAT reads it needs 9  (e.g. a SPILL of
       an accumulator right behind the slot sequence)
   R4  MFMA write -> MFMA reads it as SrcC                needs 4
+  A1  (k_sweep only) an AccVGPR named by an instruction outside the inline asm
+      blocks: the accumulators live in hand-assigned AccVGPRs (csrc/sweep_slots.h)
 
     python scripts/dev/check_mfma_hazards.py [extra hipcc flags ...]
 
@@ -22,24 +24,63 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "safeopt_amd", "csrc")
-NEED = {"R1": 2, "R2": 6, "R3": 9, "R4": 4}
+NEED = {"R1": 2, "R2": 6, "R3": 9, "R4": 4, "A1": 0}
+COUNT = {}
 HORIZON = 10
 
 
+_ARITH = re.compile(r"^[0-9+\-*() ]+$")
+
+
+def _num(expr):
+    """Register indices in hand-written asm are assembler expressions (8*(15)+2*0)."""
+    expr = expr.strip()
+    if not _ARITH.match(expr):
+        raise ValueError(expr)
+    return int(eval(expr, {"__builtins__": {}}, {}))
+
+
 def regs(tok):
+    """VGPRs / AccVGPRs an operand names, as ('v' | 'a', index) pairs."""
     tok = tok.strip(",")
-    m = re.match(r"-?\|?v\[(\d+):(\d+)\]", tok)
+    m = re.match(r"-?\|?([va])\[([^:\]]+):([^\]]+)\]", tok)
     if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.match(r"-?\|?v(\d+)\b", tok)
-    return {int(m.group(1))} if m else set()
+        try:
+            return {(m.group(1), i) for i in range(_num(m.group(2)), _num(m.group(3)) + 1)}
+        except ValueError:
+            return set()
+    m = re.match(r"-?\|?([va])(\d+)\b", tok)
+    return {(m.group(1), int(m.group(2)))} if m else set()
+
+
+def split_args(rest):
+    """Operands of one instruction: commas outside brackets separate them."""
+    out, depth, cur = [], 0, ""
+    for ch in rest:
+        if ch == "[":
+            depth += 1
+        elif ch == "]":
+            depth -= 1
+        if (ch == "," or ch.isspace()) and depth == 0:
+            if cur:
+                out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur:
+        out.append(cur)
+    return out
 
 
 def isa(path, flags):
-    return subprocess.run(
+    extra = ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"] if path.endswith("sweep.hip") else []
+    r = subprocess.run(
         ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I",
          os.path.join(ROOT, "include"), "-I", CSRC, "-S", "--cuda-device-only", "-o", "-",
-         path] + flags, capture_output=True, text=True).stdout
+         path] + extra + flags, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on %s:\n%s" % (path, r.stderr[-2000:]))
+    return r.stdout
 
 
 def scan(asm, verbose=True):
@@ -61,8 +102,16 @@ def scan(asm, verbose=True):
             continue
         if t.startswith("."):
             continue
-        toks = t.split()
-        op, args = toks[0], toks[1:]
+        toks = t.split(None, 1)
+        op, args = toks[0], split_args(toks[1] if len(toks) > 1 else "")
+        if op.startswith("v_mfma") and in_asm:
+            COUNT["asm_mfma"] = COUNT.get("asm_mfma", 0) + 1
+        # A1: the accumulators of the 4-wave sweep are hand-assigned AccVGPRs
+        # (csrc/sweep_slots.h): in its instances no instruction of the COMPILER's may
+        # name an AccVGPR (as spill space, as a copy target, as a load destination)
+        if not in_asm and "k_sweepI" in func and (
+                "accvgpr" in op or any(r[0] == "a" for a in args for r in regs(a))):
+            bad.append((func, "A1", 0, "(compiler-generated)", t))
         is_mfma = op.startswith("v_mfma") and in_asm
         is_valu = op.startswith("v_") and not op.startswith("v_mfma")
         is_mem = op.startswith(("ds_", "global_", "scratch_", "flat_", "buffer_"))
@@ -115,7 +164,14 @@ def scan(asm, verbose=True):
 def main(flags):
     total = 0
     for f in ("sweep.hip", "sweep_pair.hip"):
+        COUNT.clear()
         total += len(scan(isa(os.path.join(CSRC, f), flags)))
+        # (an empty or truncated listing must not pass as "0 hazards")
+        n = COUNT.get("asm_mfma", 0)
+        print("%s: %d inline-asm MFMAs scanned" % (f, n))
+        if n < 1000:
+            print("too few matrix instructions in the ISA of %s: scan is void" % f)
+            total += 1
     print("hazards found: %d" % total)
     return total
 

@@ -118,7 +118,7 @@ def test_predict_noiseless(mods, kind, n, d):
 # through both sweep kernels: the 4-wave kernel (csrc/sweep.hip) and the
 # paired-wave kernel (csrc/sweep_pair.hip), each FORCED on every shape -- one
 # j-block, ragged tiles, accumulator-chunk boundaries of both (256 / 512 rows),
-# narrow last row blocks (n = 16 k + 1..4), up to 8 GPs (more than the 6 whose Q
+# narrow last row blocks (n = 16 k + 1..12: one to three 4-row groups), up to 8 GPs (more than the 6 whose Q
 # rows are staged in LDS), GPs of different sizes in one launch, d up to 8.
 SWEEP_CASES = [
     # kind, d, [n per GP], N
@@ -130,6 +130,8 @@ SWEEP_CASES = [
     ("RBF", 4, [2000, 2000], 300), ("RBF", 2, [33] * 8, 500),
     ("Matern52", 5, [300] * 7, 321), ("RBF", 8, [130, 290], 450),
     ("Matern32", 6, [600], 200), ("RBF", 7, [64, 1, 270], 260),
+    # last row blocks of 6 / 11 / 9 rows: two and three narrow groups (sweep.hip)
+    ("Matern32", 2, [22, 43, 201], 333),
 ]
 
 
