@@ -103,6 +103,20 @@ int sgp_grid_create(sgp_ctx* ctx, const double* base, int64_t N, int d,
 void sgp_grid_destroy(sgp_grid* grid);
 /* SafeOpt.context setter (gp_opt.py:439-451): fill the last nc columns       */
 int sgp_grid_set_context(sgp_grid* grid, const double* c, int nc);
+/* Declares the rows a TENSOR grid, which is what SafeOpt's parameter_set is
+ * (linearly_spaced_combinations, utilities.py:21-54, followed by constant context
+ * columns, gp_opt.py:439-451): global row i has column k equal to
+ * values_k[(i / stride[k]) % count[k]], values = the d axes concatenated (count[k]
+ * doubles each; count 1 = a constant column).  The declaration is checked against the
+ * resident rows bit for bit; *ok = 1 when it holds, 0 when it does not (nothing
+ * changes then).  On a verified tensor grid the sweeps of GPs whose kernels are
+ * products of RBF parts -- k(X_j, x) is then a product of one factor per axis -- read
+ * per-axis factor tables instead of evaluating the covariance (same results within
+ * rounding; sgp_ctx_set_sweep(... + 8) switches it off).  Replaces nothing in the
+ * reference: gp.predict_noiseless(self.inputs) (gp_opt.py:469) evaluates every
+ * covariance of the grid in full.                                               */
+int sgp_grid_set_axes(sgp_grid* grid, int d, const int64_t* count,
+                      const int64_t* stride, const double* values, int* ok);
 /* update_confidence_intervals + compute_safe_set (gp_opt.py:453-481), fused:
  * for every GP mean/var over all rows, Q[:,2i] = mean - beta*std,
  * Q[:,2i+1] = mean + beta*std, S = all(Q[:, ::2] > fmin).
@@ -320,7 +334,8 @@ int64_t sgp_ctx_alloc_count(sgp_ctx* ctx);
  * a GP has more than 256 training rows, csrc/sweep_pair.hip), 1 = always the
  * 4-wave kernel (csrc/sweep.hip), 2 = always the paired-wave kernel; + 4: the
  * paired-wave kernel does not cut remainder tiles into runs of chunks (same bits
- * either way, tests/test_gpu_parity.py).  Same results within rounding between
+ * either way, tests/test_gpu_parity.py); + 8: no factor tables on tensor grids
+ * (sgp_grid_set_axes).  Same results within rounding between
  * the two kernels; the switch exists for A/B measurements and tests.  Returns
  * the previous setting.                                                        */
 int sgp_ctx_set_sweep(sgp_ctx* ctx, int which);

@@ -54,6 +54,8 @@ PROTOTYPES = {
                                   vpp]),
     "sgp_grid_destroy": (None, [vp]),
     "sgp_grid_set_context": (C.c_int, [vp, c_double_p, C.c_int]),
+    "sgp_grid_set_axes": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                    c_double_p, c_int_p]),
     "sgp_grid_confidence": (C.c_int, [vp, vpp, C.c_int, C.c_double,
                                       c_double_p, c_double_p]),
     "sgp_grid_posterior": (C.c_int, [vp, vpp, C.c_int]),
@@ -278,10 +280,16 @@ class Context(object):
     def set_sweep(self, which):
         """Posterior-sweep kernel: 'auto' | 'classic' (4 waves) | 'pair' (paired
         waves), '-nosplit' appended: remainder tiles are not cut into runs of
-        chunks; returns the previous setting."""
+        chunks, '-notables': no factor tables on tensor grids (set_axes); or the
+        integer of sgp_ctx_set_sweep.  Returns the previous setting (a name)."""
         names = ("auto", "classic", "pair", None, "auto-nosplit", "classic-nosplit",
-                 "pair-nosplit")
-        return names[int(lib().sgp_ctx_set_sweep(self.h, names.index(which)))]
+                 "pair-nosplit", None)
+        names = names + tuple(n + "-notables" if n else None for n in names)
+
+        def code(w):          # a name, or the integer of sgp_ctx_set_sweep
+            return int(w) if isinstance(w, (int, np.integer)) else names.index(w)
+
+        return names[int(lib().sgp_ctx_set_sweep(self.h, code(which)))]
 
     # -- RCCL
     @staticmethod
@@ -422,6 +430,40 @@ class DeviceGP(object):
         return Linv, alpha
 
 
+def tensor_grid_axes(points):
+    """``(counts, strides, axis values)`` of an (N, d) array whose rows are a tensor
+    grid -- row ``i`` has column ``k`` equal to ``values[k][(i // strides[k]) % counts[k]]``,
+    as ``linearly_spaced_combinations`` builds it (safeopt/utilities.py:21-54), constant
+    columns (contexts) having one point -- or None.  Necessary conditions only (run
+    lengths, periods, the chain of the strides): the device compares every row
+    (``DeviceGrid.set_axes``)."""
+    points = np.asarray(points)
+    if points.ndim != 2 or points.shape[0] < 1:
+        return None
+    N, d = points.shape
+    counts, strides, values = [], [], []
+    for k in range(d):
+        col = points[:, k]
+        change = np.flatnonzero(col[1:] != col[:-1])
+        if change.size == 0:
+            counts.append(1); strides.append(1); values.append(col[:1].copy())
+            continue
+        run = int(change[0]) + 1
+        firsts = col[::run]
+        again = np.flatnonzero(firsts[1:] == firsts[0])
+        cnt = int(again[0]) + 1 if again.size else int(firsts.size)
+        counts.append(cnt); strides.append(run); values.append(firsts[:cnt].copy())
+    total, expect = 1, 1
+    for k in sorted((k for k in range(d) if counts[k] > 1), key=lambda k: strides[k]):
+        if strides[k] != expect:
+            return None
+        expect *= counts[k]
+        total *= counts[k]
+    if total != N or N >= 2 ** 31:
+        return None
+    return counts, strides, values
+
+
 class DeviceGrid(object):
     """This rank's shard of SafeOpt.inputs resident in HBM, with Q/S/M/G."""
 
@@ -451,6 +493,23 @@ class DeviceGrid(object):
     def set_context(self, c):
         c = f64(c).reshape(-1)
         self.ctx.check(lib().sgp_grid_set_context(self.h, dptr(c), c.size))
+
+    def set_axes(self, axes):
+        """Declare the rows a tensor grid (``axes`` from ``tensor_grid_axes`` of the
+        WHOLE grid, this shard's rows being its rows ``goff .. goff + N``); the device
+        checks the declaration against the resident rows.  True when it holds: RBF
+        kernels are then swept through per-axis factor tables."""
+        if axes is None:
+            return False
+        counts, strides, values = axes
+        cnt = np.ascontiguousarray(counts, dtype=np.int64)
+        stv = np.ascontiguousarray(strides, dtype=np.int64)
+        vals = f64(np.concatenate([np.asarray(v, dtype=np.float64) for v in values]))
+        ok = C.c_int(0)
+        self.ctx.check(lib().sgp_grid_set_axes(
+            self.h, int(cnt.size), cnt.ctypes.data_as(C.POINTER(C.c_int64)),
+            stv.ctypes.data_as(C.POINTER(C.c_int64)), dptr(vals), C.byref(ok)))
+        return bool(ok.value)
 
     def confidence(self, gps, beta, fmin, defer=False):
         """``defer``: enqueue only; ``max l0[S]`` stays on the device and comes

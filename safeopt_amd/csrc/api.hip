@@ -278,6 +278,8 @@ int sgp_gp_create(sgp_ctx* ctx, int d, int n_parts, const int* kinds,
   sgp_gp* gp = new (std::nothrow) sgp_gp();
   SGP_CHECK(ctx, gp != nullptr, "out of host memory");
   gp->ctx = ctx;
+  static uint64_t next_serial = 1;
+  gp->serial = next_serial++;
   gp->kern = kd;
   gp->noise_var = noise_var;
   *out = gp;
@@ -304,6 +306,7 @@ int sgp_gp_set_data(sgp_gp* gp, const double* X, const double* Y, int64_t n,
   SGP_CHECK(ctx, n >= 1 && n <= 16384, "n = %lld training points unsupported",
             (long long)n);
   const int d = gp->kern.d;
+  ++gp->data_version;
   gp->n = n;
   gp->n_pad = int((n + 15) / 16) * 16;
   gp->n_f = int((n + 31) / 32) * 32;
@@ -359,6 +362,7 @@ int sgp_gp_append(sgp_gp* gp, const double* x, double y, int* info) {
   SGP_TRY(sgp_h2d(ctx, X + size_t(gp->n) * d, x, size_t(d) * sizeof(double)));
   SGP_TRY(sgp_h2d(ctx, Y + gp->n, &y, sizeof(double)));
   const int64_t n0 = gp->n;
+  ++gp->data_version;
   SGP_TRY(append_gp(gp, y, info));
   if (gp->n == n0 + 1) {
     gp->xhash.resize(size_t(n0));
@@ -373,6 +377,7 @@ int sgp_gp_pop(sgp_gp* gp) {
   sgp_ctx* ctx = gp->ctx;
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   SGP_CHECK(ctx, gp->n > 1, "cannot remove the only training point");
+  ++gp->data_version;
   SGP_TRY(pop_gp(gp));
   gp->xhash.resize(size_t(gp->n));
   gp->prov = gp->prov * 1099511628211ull + 3;
@@ -558,6 +563,9 @@ void sgp_grid_destroy(sgp_grid* g) {
                   g->Gm,  g->cand, g->w,    g->partial, g->gpdev, g->scal};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (g->ax_vals.p) (void)hipFree(g->ax_vals.p);
+  for (DevBuf& b : g->sep_tab)
+    if (b.p) (void)hipFree(b.p);
   delete g;
 }
 
@@ -567,7 +575,133 @@ int sgp_grid_set_context(sgp_grid* g, const double* c, int nc) {
   SGP_CHECK(ctx, nc >= 0 && nc <= g->d && nc <= SGP_MAX_GPS,
             "bad number of context columns %d", nc);
   if (nc == 0) return 0;
+  if (g->axes_valid) {
+    // the context columns are constant columns of the tensor grid: new axis values
+    for (int i = 0; i < nc; ++i) {
+      const int k = g->d - nc + i;
+      if (g->ax_count[k] != 1) {
+        g->axes_valid = false;      // (declared otherwise: the declaration is void)
+        break;
+      }
+      g->ax_host[size_t(g->ax_off[k])] = c[i];
+    }
+    if (g->axes_valid) {
+      SGP_TRY(sgp_h2d(ctx, g->ax_vals.p, g->ax_host.data(), g->ax_host.size() * sizeof(double)));
+      ++g->ax_version;
+    }
+  }
   return launch_fill_cols(g, c, nc);
+}
+
+// SafeOpt's parameter_set is a tensor grid (linearly_spaced_combinations,
+// utilities.py:21-54) followed by constant context columns (gp_opt.py:439-451): global
+// row i has column k equal to values_k[(i / stride[k]) % count[k]].  The declaration is
+// checked against the resident rows bit for bit; *ok = 1 when it holds (the sweeps
+// then take per-axis factor tables for RBF kernels), 0 when not (nothing changes).
+int sgp_grid_set_axes(sgp_grid* g, int d, const int64_t* count, const int64_t* stride,
+                      const double* values, int* ok) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  *ok = 0;
+  g->axes_valid = false;
+  SGP_CHECK(ctx, d == g->d, "grid has %d columns, %d axes declared", g->d, d);
+  int64_t total = 1, nvals = 0;
+  for (int k = 0; k < d; ++k) {
+    SGP_CHECK(ctx, count[k] >= 1 && stride[k] >= 1, "axis %d: count %lld, stride %lld", k,
+              (long long)count[k], (long long)stride[k]);
+    if (count[k] > 1) total *= count[k];
+    nvals += count[k];
+    if (total >= (int64_t(1) << 31) || count[k] * stride[k] >= (int64_t(1) << 31)) return 0;
+  }
+  // (32-bit index arithmetic in the sweep)
+  if (g->goff + g->N > total || g->goff + g->N >= (int64_t(1) << 31)) return 0;
+  g->ax_host.assign(values, values + nvals);
+  int off = 0;
+  for (int k = 0; k < d; ++k) {
+    g->ax_count[k] = uint32_t(count[k]);
+    g->ax_stride[k] = uint32_t(stride[k]);
+    g->ax_off[k] = off;
+    off += int(count[k]);
+  }
+  SGP_TRY(sgp_reserve(ctx, &g->ax_vals, size_t(nvals) * sizeof(double)));
+  SGP_TRY(sgp_h2d(ctx, g->ax_vals.p, g->ax_host.data(), size_t(nvals) * sizeof(double)));
+  int* mism = static_cast<int*>(sgp_scratch(ctx, 2, 256));
+  SGP_CHECK(ctx, mism, "device allocation failed: %s", ctx->err.c_str());
+  SGP_HIP(ctx, hipMemsetAsync(mism, 0, sizeof(int), ctx->stream));
+  SGP_TRY(launch_verify_axes(g, mism));
+  int bad = 0;
+  SGP_TRY(sgp_d2h(ctx, &bad, mism, sizeof(int)));
+  if (bad != 0) return 0;
+  // the strides must chain: sorted by stride, each is the product of the counts below
+  {
+    int ord[SGP_MAX_D], na = 0;
+    for (int k = 0; k < d; ++k)
+      if (count[k] > 1) ord[na++] = k;
+    std::sort(ord, ord + na, [&](int a, int b) { return stride[a] < stride[b]; });
+    int64_t expect = 1;
+    for (int i = 0; i < na; ++i) {
+      if (stride[ord[i]] != expect) return 0;
+      expect *= count[ord[i]];
+    }
+  }
+  g->axes_valid = true;
+  ++g->ax_version;
+  *ok = 1;
+  return 0;
+}
+
+// The tensor-grid description of a sweep over grid g with the GPs of `host`, or
+// nullptr when the grid is not one / a kernel is not a product of RBF parts / the
+// switch is off.  Builds (or reuses) the factor tables of every GP.
+static const SepLaunch* sep_launch(sgp_grid* g, sgp_gp* const* gps, const GpDev* host, int G,
+                                   SepLaunch* sl) {
+  sgp_ctx* ctx = g->ctx;
+  static const bool off = getenv("SGP_NO_SEP") != nullptr;
+  if (off || !g->axes_valid || (ctx->sweep_choice & 8)) return nullptr;
+  for (int i = 0; i < G; ++i)
+    for (int p = 0; p < host[i].kern.n_parts; ++p)
+      if (host[i].kern.kind[p] != SGP_RBF) return nullptr;
+  int cols[SGP_MAX_D], na = 0;
+  for (int k = 0; k < g->d; ++k)
+    if (g->ax_count[k] > 1) cols[na++] = k;
+  if (na < 1 || na > 4) return nullptr;
+  std::sort(cols, cols + na, [&](int a, int b) { return g->ax_stride[a] < g->ax_stride[b]; });
+  sl->naxes = na;
+  sl->goff = g->goff;
+  for (int a = 0; a < na; ++a) sl->count[a] = g->ax_count[cols[a]];
+  for (int i = 0; i < G; ++i) {
+    // (a follower of a shared factor has its leader's inputs and kernel: same tables)
+    const int src = host[i].share >= 0 ? host[i].share : i;
+    if (src != i) {
+      for (int a = 0; a < na; ++a) sl->tab[i][a] = sl->tab[src][a];
+      continue;
+    }
+    size_t need = 0, offa[4];
+    for (int a = 0; a < na; ++a) {
+      offa[a] = need;
+      need += sep_table_doubles(host[i], sl->count[a]);
+    }
+    const uint64_t key[3] = {gps[i]->serial, gps[i]->data_version, g->ax_version};
+    const bool fresh = g->sep_tab[i].p && g->sep_tab[i].cap >= need * sizeof(double) &&
+                       memcmp(g->sep_key[i], key, sizeof(key)) == 0;
+    // (room for the appends to come: a growing table must not reallocate every step)
+    if (!g->sep_tab[i].p || g->sep_tab[i].cap < need * sizeof(double))
+      if (sgp_reserve(ctx, &g->sep_tab[i], (need + need / 4) * sizeof(double)) != 0)
+        return nullptr;
+    double* out[4];
+    for (int a = 0; a < na; ++a) {
+      out[a] = static_cast<double*>(g->sep_tab[i].p) + offa[a];
+      sl->tab[i][a] = out[a];
+    }
+    if (!fresh) {
+      if (launch_sep_tables(ctx, host[i], g->d, g->ax_count,
+                            static_cast<const double*>(g->ax_vals.p), g->ax_off, na, cols,
+                            out) != 0)
+        return nullptr;
+      memcpy(g->sep_key[i], key, sizeof(key));
+    }
+  }
+  return sl;
 }
 
 // max l0 over S ends up in g->scal[0]; out2 == nullptr defers the read-back
@@ -634,7 +768,9 @@ int sgp_grid_confidence(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   co.partial = g->partial;
   co.beta = beta;
   for (int i = 0; i < SGP_MAX_GPS; ++i) co.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
-  SGP_TRY(launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co));
+  SepLaunch sl;
+  SGP_TRY(launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co,
+                            sep_launch(g, gps, host, G, &sl)));
   return finish_safe_partials(g, sweep_num_partials(ctx, g->N), out2);
 }
 
@@ -651,7 +787,9 @@ int sgp_grid_posterior(sgp_grid* g, sgp_gp* const* gps, int G) {
   co.var = g->var;
   co.beta = 0.0;
   for (int i = 0; i < SGP_MAX_GPS; ++i) co.fmin[i] = -INFINITY;
-  return launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co);
+  SepLaunch sl;
+  return launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co,
+                           sep_launch(g, gps, host, G, &sl));
 }
 
 int sgp_grid_rank1_update(sgp_grid* g, sgp_gp* const* gps, int G,
@@ -1535,7 +1673,7 @@ int sgp_ctx_set_share(sgp_ctx* ctx, int on) {
 int sgp_ctx_set_sweep(sgp_ctx* ctx, int which) {
   if (!ctx) return -1;
   const int old = ctx->sweep_choice;
-  if (which >= 0 && (which & 3) <= 2 && which < 8) ctx->sweep_choice = which;
+  if (which >= 0 && (which & 3) <= 2 && which < 16) ctx->sweep_choice = which;
   return old;
 }
 

@@ -102,6 +102,23 @@ struct GpDev {
   KernDesc kern;
 };
 
+// A candidate grid that is a TENSOR grid (linearly_spaced_combinations,
+// safeopt/utilities.py:21-54: global row i has column k equal to
+// axis_k[(i / stride_k) % count_k]), declared with sgp_grid_set_axes and verified on
+// the device, together with per-axis factor tables of every GP whose kernel is a
+// product of RBF parts: k(X_j, x) = prod_k E_k[idx_k(x)][j].  The sweep then reads d
+// table entries per covariance instead of evaluating an exponential (sweep.hip, SEP).
+struct SepLaunch {
+  int naxes;                  // axes with more than one point (1..4), in order of their
+                              // stride in the flat index; constant columns (contexts)
+                              // are folded into the tables of axis 0
+  uint32_t count[4];          // points of axis a
+  int64_t goff;               // global index of the shard's first row
+  // per GP and axis: [n_pad / 16][count][16] doubles, entry 4 k4 + q of a block of 16
+  // = training point 16 jb + 4 q + k4 (the four values of a lane side by side)
+  const double* tab[SGP_MAX_GPS][4];
+};
+
 // ---- host-side objects ------------------------------------------------------
 struct DevBuf {
   void* p = nullptr;
@@ -126,7 +143,7 @@ struct sgp_ctx {
   double prof_flops = 0.0;
   // stage table of the posterior sweep (sweep.hip: stage_table)
   DevBuf stage_tab;
-  std::vector<int> stage_sig;
+  std::vector<uint64_t> stage_sig;
   int stage_count = 0;
   // ... and of the paired sweep (sweep_pair.hip: pair_stage_table)
   DevBuf pstage_tab;
@@ -156,6 +173,8 @@ struct sgp_gp {
   int n_pad = 0;  // multiple of 16 (sweep blocks)
   int n_f = 0;    // multiple of 32 (factorisation leaves)
   int ld = 0;     // leading dimension / row capacity of Linv, Kmat, work
+  uint64_t serial = 0;           // unique per sgp_gp_create
+  uint64_t data_version = 0;     // bumped by every fit / append / removal
   std::vector<uint64_t> xhash;   // xhash[i]: hash of the first i + 1 training rows
   uint64_t prov = 0;             // hash of the operations that led to this factor
                                  // (fit at n, appends, removals): two GPs with equal
@@ -188,6 +207,16 @@ struct sgp_grid {
   double* scal = nullptr;    // [8] resident scalars: [0] = max l0 over S
   int l0_pending = 0;        // > 0: scal[0] is still spread over that many
                              // entries of `partial` (deferred confidence pass)
+  // tensor-grid structure (sgp_grid_set_axes; SepLaunch)
+  bool axes_valid = false;
+  uint32_t ax_count[SGP_MAX_D] = {0};
+  uint32_t ax_stride[SGP_MAX_D] = {0};
+  int ax_off[SGP_MAX_D] = {0};          // first entry of column k's axis in ax_vals
+  std::vector<double> ax_host;          // axis values, concatenated
+  DevBuf ax_vals;                       // ... on the device
+  uint64_t ax_version = 0;              // bumped when an axis value changes (context)
+  DevBuf sep_tab[SGP_MAX_GPS];          // factor tables of the GP in slot g
+  uint64_t sep_key[SGP_MAX_GPS][3] = {{0}};   // (gp serial, data version, axes version)
 };
 
 // ---- helpers (api.hip) ------------------------------------------------------
@@ -248,7 +277,17 @@ struct FitnessArgs {
 };
 int sweep_num_partials(const sgp_ctx* ctx, int64_t N);
 int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
-                      int G, int d, SweepPoints pts, ConfOut out);
+                      int G, int d, SweepPoints pts, ConfOut out,
+                      const SepLaunch* sep = nullptr);
+// per-axis factor tables of one GP (SepLaunch::tab): out[a] = table of axis a =
+// column cols[a] (count[cols[a]] points); the columns with one point are folded into
+// out[0]
+int launch_sep_tables(sgp_ctx* ctx, const GpDev& gp, int d, const uint32_t* count,
+                      const double* axis_vals, const int* axis_off, int naxes,
+                      const int* cols, double* const* out);
+size_t sep_table_doubles(const GpDev& gp, uint32_t count);
+// rows == the declared tensor grid?  *mismatch (device int) counts the differences
+int launch_verify_axes(sgp_grid* g, int* mismatch_dev);
 int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,
                          const GpDev* gps_host, int G, int d, SweepPoints pts,
                          FitnessArgs fa);

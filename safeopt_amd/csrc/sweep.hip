@@ -53,9 +53,6 @@ namespace {
 // 1: a wave's share of the next A chunk (slots w, w + 4, ..) is copied piecewise
 // between the slots of the running stage instead of in one burst behind the barrier
 // (the paired kernel's finding, profiles/r03/experiments.txt section 4)
-#ifndef SGP_DMA_SPREAD
-#define SGP_DMA_SPREAD 1
-#endif
 
 constexpr int kJC = 16;                // training points per stage (one j-block)
 constexpr int kSteps = kJC / 4;        // MFMA k-steps per stage
@@ -93,14 +90,18 @@ struct Lay {
 };
 
 // One stage of the flattened (GP, chunk, j-block) sequence of a tile, built on
-// the host (build_stage_table).  Slot s of the staged A chunk holds row block
-// bend-1-s of the chunk, k-steps 4 jb .. 4 jb + 3; its source is
-// Apack + (a_off - s * row_stride) * 64 doubles.
+// the host (stage_table) with ABSOLUTE device addresses: no pointer arithmetic per
+// stage on the device, one scalar load per entry.  Position t of the staged A chunk
+// holds row block bend-1-t of the chunk, k-steps 4 jb .. 4 jb + 3; its source is
+// a_src - t * rs_bytes.
 struct StageEnt {
-  uint32_t a_off;       // (bend - 1) * nsteps_total + 4 jb       [units of 64 doubles]
-  uint32_t row_stride;  // nsteps_total = n_pad / 4               [units of 64 doubles]
-  uint32_t jb;          // j-block: training points 16 jb .. 16 jb + 15
-  uint32_t word;        // see SW_*
+  uint64_t a_src;      // device address of position 0's 2 KB
+  uint64_t xa;         // device address of the j-block's [16 d rows | 16 alpha] (GpDev::XA);
+                       // launches on factor tables (SEP): of its 16 alpha
+  uint32_t rs_bytes;   // bytes between consecutive row blocks in Apack
+  uint32_t jb;         // j-block: training points 16 jb .. 16 jb + 15
+  uint32_t word;       // see SW_*
+  uint32_t pad;
 };
 enum : uint32_t {
   SW_NACT_MASK = 63u,       // active slots 0 .. nact-1 (1..32)
@@ -139,10 +140,12 @@ struct SweepParams {
   const StageEnt* stages;   // [nstages] one tile's stage sequence (all GPs)
   int nstages;
   int single;               // every GP has a one-part kernel (pre-scaled inputs)
+  long long ride_delta[SGP_MAX_GPS];   // rider g: bytes from its leader's XA to its own
   int nride[SGP_MAX_GPS];   // riders of GP g: the GPs g + 1 .. g + nride[g] share its
                             // factor AND its covariances (GpDev::share) and have no stages
                             // of their own -- their alpha . k is formed in g's stages
   int slots;                // accumulator slots per wave: 16 or 32 (host only)
+  SepLaunch sep;            // tensor grid + factor tables (instances with SEP > 0)
 #ifdef SGP_STAMPS
   unsigned long long* stamps;   // [blocks][4 waves][8] cycles per phase (debug build)
 #endif
@@ -168,118 +171,27 @@ typedef const __attribute__((address_space(1))) double* gptr_t;
 // with a full memory wait, since the kernel also stores to global memory)
 typedef const __attribute__((address_space(4))) StageEnt* stage_ptr_t;
 __device__ __forceinline__ StageEnt load_stage(stage_ptr_t t, int i) {
-  StageEnt e;      // member-wise: one s_load_dwordx4
-  e.a_off = t[i].a_off;
-  e.row_stride = t[i].row_stride;
+  StageEnt e;      // member-wise: scalar loads
+  e.a_src = t[i].a_src;
+  e.xa = t[i].xa;
+  e.rs_bytes = t[i].rs_bytes;
   e.jb = t[i].jb;
   e.word = t[i].word;
+  e.pad = 0;
   return e;
 }
+typedef const __attribute__((address_space(4))) GpDev* gpdev_cptr_t;
 
-// Wave-uniform view of one GP's operands: SGPR-resident base pointers.  (They
-// come out of a descriptor in memory, so the compiler would emit FLAT loads for
-// them; a FLAT load also counts on lgkmcnt, and every LDS wait of the stage
-// would then sit out a global-memory latency.  Hence the explicit global
-// address space.)
-struct GpView {
-  gptr_t Apack;
-  gptr_t Xs;
-  gptr_t alpha;
-  static __device__ __forceinline__ gptr_t uniform(const double* q) {
-    const uint64_t v = reinterpret_cast<uint64_t>(q);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v));
-    const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
-    return (gptr_t)reinterpret_cast<const double*>((uint64_t(hi) << 32) | lo);
-  }
-  __device__ __forceinline__ void load(const GpDev& gp) {
-    Apack = uniform(gp.Apack);
-    Xs = uniform(gp.Xs);
-    alpha = uniform(gp.alpha);
-  }
-};
+// a wave-uniform pointer, pinned to scalar registers
+template <typename T>
+__device__ __forceinline__ const T* uniform_ptr(const T* q) {
+  const uint64_t v = reinterpret_cast<uint64_t>(q);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
+  return reinterpret_cast<const T*>((uint64_t(hi) << 32) | lo);
+}
+
 constexpr int kSweepRide = 2;      // riders per leader (what two workgroups' LDS holds)
-struct RiderView {
-  gptr_t alpha[kSweepRide];
-  int nr;
-  __device__ __forceinline__ void load(const GpDev* gps, int g, int n) {
-    nr = n;
-#pragma unroll
-    for (int f = 0; f < kSweepRide; ++f)
-      alpha[f] = GpView::uniform(gps[g + (f < n ? 1 + f : 0)].alpha);
-  }
-};
-
-__device__ __forceinline__ void lds_dma16(gptr_t src, double* dst, int off) {
-  // global -> LDS, 16 bytes per lane, no VGPR round trip; `off` (an immediate)
-  // applies to the global and the LDS address alike
-  if (off == 0)
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)src,
-        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  else
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)src,
-        (__attribute__((address_space(3))) void*)dst, 16, 1024, 0);
-}
-
-// (src is wave-uniform and stays in SGPRs; the lane offset is added at the call
-// so every copy is "scalar base + 32-bit lane offset", no 64-bit VALU adds)
-template <int NW, int SL, int K>
-__device__ __forceinline__ void dma_slots(gptr_t src, double* dst, int64_t rs,
-                                          int left, unsigned lane2) {
-  if constexpr (K < SL / NW) {
-    if (left > NW * K) {          // slot wave + NW K is active (prefix: nested)
-      lds_dma16(src + lane2, dst, 0);
-      lds_dma16(src + lane2, dst, 1024);
-      dma_slots<NW, SL, K + 1>(src - NW * rs, dst + NW * (kSteps * 64), rs, left,
-                               lane2);
-    }
-  }
-}
-
-// Asynchronous global -> LDS copy of the active slots of one stage.  LDS image:
-// slot-major A[slot][k-step][lane] (2 KB per slot = two 1 KB instructions);
-// wave w copies slots w, w + NW, ... below nact.
-template <int NW, int SL>
-__device__ __forceinline__ void stage_dma(const GpView& gp, const StageEnt& e,
-                                          double* buf, int wave, int lane) {
-  const int nact = int(e.word & SW_NACT_MASK);
-  const int64_t rs = int64_t(e.row_stride) * 64;            // doubles / row block
-  gptr_t src = gp.Apack + (int64_t(e.a_off) * 64 - wave * rs);   // wave-uniform
-  double* dst = buf + wave * (kSteps * 64);                       // wave-uniform
-  dma_slots<NW, SL, 0>(src, dst, rs, nact - wave, unsigned(lane) * 2u);
-}
-
-// Training rows (pre-scaled) and alpha entries of the stage's j-block: runs of
-// 16 D and 16 doubles in GpDev::Xs / alpha -- wave 0 moves the rows (8 D lanes x
-// 16 B), the last wave the alpha run (8 lanes x 16 B); the other lanes are
-// masked off and write nothing.
-// With riders (R > 0) the lanes 8 (1 + f) .. 8 (1 + f) + 7 of that instruction fetch
-// the same run of rider f's alpha: the LDS side of an LDS-DMA is contiguous in the
-// lane number, so the riders' chunks land right behind the leader's.
-template <int D, int NW, int SL, int R>
-__device__ __forceinline__ void stage_x_dma(const GpView& gp, const RiderView& rv,
-                                            const StageEnt& e, double* buf, int wave,
-                                            int lane) {
-  typedef Lay<SL, D, R> L;
-  if (wave == 0) {
-    if (lane < 8 * D)
-      lds_dma16(gp.Xs + int64_t(e.jb) * (kJC * D) + unsigned(lane) * 2u, buf + L::kATile, 0);
-  } else if (wave == NW - 1) {
-    if (R == 0) {
-      if (lane < 8)
-        lds_dma16(gp.alpha + int64_t(e.jb) * kJC + unsigned(lane) * 2u,
-                  buf + L::kATile + L::kXTile, 0);
-    } else if (lane < 8 * (1 + rv.nr)) {
-      gptr_t src = gp.alpha;
-#pragma unroll
-      for (int f = 0; f < R; ++f)
-        if ((lane >> 3) == 1 + f) src = rv.alpha[f];
-      lds_dma16(src + int64_t(e.jb) * kJC + unsigned(lane & 7) * 2u,
-                buf + L::kATile + L::kXTile, 0);
-    }
-  }
-}
 
 // ---- matrix part ------------------------------------------------------------------
 // v_mfma_f64_4x4x4_4b_f64 is the fp64 matrix instruction that reaches the chip's
@@ -353,11 +265,14 @@ __device__ __forceinline__ void load_slot(double (&ops)[4], const double* aT,
 // of 16 in the one slot that meets EVERY j-block.  The groups need kv only, not the
 // broadcast operands: they are issued in front of the LDS transpose, whose round
 // trip passes under them.
+#ifndef SGP_AN_EARLY_SEP
+#define SGP_AN_EARLY_SEP 1
+#endif
 #ifndef SGP_AN_EARLY
 #define SGP_AN_EARLY 0
 #endif
 #ifndef SGP_MAX_NG
-#define SGP_MAX_NG 3
+#define SGP_MAX_NG 2
 #endif
 constexpr int kMaxNg = SGP_MAX_NG;
 // ONE asm statement for all groups, the groups a GP does not have skipped by a scalar
@@ -420,45 +335,22 @@ __device__ __forceinline__ void narrow_groups(int ngrp, double (&accx)[kMaxNg],
   }
 }
 #undef SGP_NARROW_GROUP
-// The wave's share of the copy of the NEXT stage's A chunk: group i is slot
-// w + NW i, wanted when left > NW i; issued behind slot NW i of the running stage.
-struct DmaShare {
-  uint64_t src0, step;
-  uint32_t dst0, voff;
-  int left;
-  bool on;
-};
-template <int NW>
-__device__ __forceinline__ void dma_share_group(const DmaShare& d, int i) {
-  if (d.on && d.left > NW * i)
-    dma_2k(d.src0 - uint64_t(i) * d.step, d.dst0 + uint32_t(i) * (NW * 2048u), d.voff);
-}
-
-// The full slots of a stage: sweep_slots.h (hand-written, accumulators in a0..a127).
-// In front of them the wave's share of the next stage's A chunk goes out: all groups
-// at once (spread over the slot sequence they cost ~12 scalar instructions each).
-template <int SL, int NW, bool SPREAD>
-__device__ __forceinline__ void mfma_jblock(int nact, int first, unsigned abase,
-                                            const double (&kb)[4][4], const DmaShare& dma) {
-  static_assert(SL == 16, "sweep_slots.h is written out for 16 slots");
-  if (SPREAD) {
-#pragma unroll
-    for (int i = 0; i < SL / NW; ++i) dma_share_group<NW>(dma, i);
-  }
-  if (nact > 0) sgp_slots(__builtin_amdgcn_readfirstlane(nact), first, abase, kb);
-}
-
-template <int D, int NW, int SL, int MODE, bool SINGLE, int R = 0>
+// SEP > 0: the rows are a tensor grid with SEP axes and every kernel is a product of
+// RBF parts (SepLaunch): a covariance is the product of SEP table entries -- two
+// 16-byte loads per axis, lane and stage, issued one stage ahead, instead of ~22 fp64
+// instructions per value.  (Instantiated with D = 1: the rows themselves are not read.)
+template <int D, int NW, int SL, int MODE, bool SINGLE, int R = 0, int SEP = 0>
 __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   constexpr int kTilePts = 16 * NW;
-  // (the instances that have the registers for it: the others would spill)
-  constexpr bool kSpread = SGP_DMA_SPREAD && MODE == MODE_CONF && SINGLE;
-  // (6 kMaxNg registers live across the evaluation: where they are to be had)
-  constexpr bool kAnEarly = SGP_AN_EARLY && D <= 2 && R == 0;
+  // (2 kMaxNg doubles live across the evaluation: where the registers are to be had)
+  constexpr bool kAnEarly = (SGP_AN_EARLY && D <= 2 && R == 0) || (SGP_AN_EARLY_SEP && SEP > 0);
+  // where the LDS-DMA of the next stage is issued: at the top of the stage, or in front
+  // of the full slots (measured per variant: with factor tables the table loads want
+  // the head of the queue)
+  constexpr bool kDmaLate = SEP > 0;
   typedef Lay<SL, D, R> L;
   constexpr int kATile = L::kATile, kBuf = L::kBuf, kXTile = L::kXTile;
   constexpr int kTabOff = L::kTabOff, kKbOff = L::kKbOff, kKbBuf = L::kKbBuf;
-  constexpr int kIB = SL;
   constexpr bool conf = MODE == MODE_CONF;   // compile-time: no dead state
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const double* tab = lds + kTabOff;
@@ -470,11 +362,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   double* kbw = lds + kKbOff + wave * kKbBuf;
   const int ntiles = int((p.pts.N + kTilePts - 1) / kTilePts);
   const stage_ptr_t stages = (stage_ptr_t)(p.stages);
+  const gpdev_cptr_t gpc = (gpdev_cptr_t)(p.gps);
   const int nstages = p.nstages;
   const int tstep = int(gridDim.x);
+  const uint32_t lds0 = lds_addr_of(lds);
+  const uint32_t voff = uint32_t(lane) * 16u;
 
-  int tile = int(blockIdx.x);
+  int tile = int(blockIdx.x);          // tile of the stage being multiplied
   if (tile >= ntiles) return;
+  int left = ((ntiles - tile + tstep - 1) / tstep) * nstages;   // stages still to go
+  int tile_p = tile;                   // tile of the stage being prefetched
 
   // candidate rows of the current tile (and, prefetched, of the next one)
   auto load_x = [&](int t, double (&xo)[D]) {
@@ -485,35 +382,116 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       xo[k] = __builtin_nontemporal_load(p.pts.base + r * p.pts.stride_row + k * p.pts.stride_col);
   };
   double x[D], xnext[D];
-  load_x(tile, x);
+  if (SEP == 0) load_x(tile, x);
 #pragma unroll
-  for (int k = 0; k < D; ++k) xnext[k] = x[k];
-
-  // Stage cursors: the stage being multiplied (its entry word in wcur), the
-  // stage being prefetched (entry e1, one ahead) and the stage whose entry is
-  // being loaded (two ahead: a scalar load issued a whole stage before its use).
-  auto advance = [&](int& si, int& t) {
-    if (++si == nstages) {
-      si = 0;
-      t += tstep;
+  for (int k = 0; k < D; ++k) xnext[k] = SEP == 0 ? x[k] : 0.0;
+  // SEP: byte offsets of this lane's row (lane & 15) and training points (4 (lane >> 4)
+  // .. + 3 of a block of 16) in the tables of the tile being PREFETCHED; axis a's index
+  // = (global row / stride_a) % count_a with stride_a = count_0 .. count_{a-1}
+  constexpr int kAx = SEP > 0 ? SEP : 1;
+  uint32_t soff[kAx];
+  auto sep_offsets = [&](int t) {
+    int64_t r = int64_t(t) * kTilePts + wave * 16 + (lane & 15);
+    r = r < p.pts.N ? r : p.pts.N - 1;
+    uint32_t q = uint32_t(p.sep.goff + r);
+#pragma unroll
+    for (int a = 0; a < kAx; ++a) {
+      uint32_t idx = q;
+      if (a + 1 < kAx) {
+        const uint32_t c = p.sep.count[a];
+        const uint32_t qn = q / c;
+        idx = q - qn * c;
+        q = qn;
+      }
+      soff[a] = idx * 128u + uint32_t(lane >> 4) * 32u;
     }
   };
-  GpView gv;               // GP of the stage being prefetched
-  int gv_g = 0;
-  gv.load(p.gps[0]);
-  RiderView rv;            // ... and its riders
-  rv.load(p.gps, 0, R > 0 ? p.nride[0] : 0);
-  KernFast<D> kf(p.gps[0].kern);
-  double kdiag = p.gps[0].kern.kdiag;
+  // the factors of the stage about to be multiplied (loaded one stage ahead); the
+  // tables of the GP being prefetched stay in scalar registers
+  double4_t efn[kAx];
+  const char* sep_tab[kAx];
+  uint32_t sep_pitch[kAx];
+  int sep_g = -1;
+  auto sep_fetch = [&](const StageEnt& e) {
+    const int g = int(e.word >> SW_G_SHIFT) & 7;
+    if (g != sep_g) {
+      sep_g = g;
+#pragma unroll
+      for (int a = 0; a < kAx; ++a) {
+        sep_tab[a] = reinterpret_cast<const char*>(uniform_ptr(p.sep.tab[g][a]));
+        sep_pitch[a] = __builtin_amdgcn_readfirstlane(p.sep.count[a] * 128u);
+      }
+    }
+    // (explicitly GLOBAL loads: a flat load also counts on lgkmcnt, and every LDS wait
+    // of the stage would sit out its latency)
+    typedef const __attribute__((address_space(1))) double4_t* gvec_t;
+#pragma unroll
+    for (int a = 0; a < kAx; ++a) {
+      const char* src = sep_tab[a] + e.jb * sep_pitch[a];      // (tables below 4 GB)
+      efn[a] = *(gvec_t)(reinterpret_cast<const double4_t*>(src + soff[a]));
+    }
+  };
+
+  // What a stage needs besides its table entry comes by LDS-DMA from absolute
+  // addresses of the entry: the A chunk (position t = row block bend-1-t, 2 KB each;
+  // wave w copies positions w, w + NW, ..) and the block [16 d rows | 16 alpha] of the
+  // j-block (one instruction of one wave; SEP: the 16 alpha only), + the alpha
+  // blocks of the riders behind it.
+  auto prefetch = [&](const StageEnt& e, int buf) {
+    const uint32_t a_dst = lds0 + uint32_t(buf) * (kBuf * 8u);
+    const int nact = int(e.word & SW_NACT_MASK);
+    const uint64_t src0 = e.a_src - uint64_t(uint32_t(wave)) * e.rs_bytes;
+    const uint64_t step = uint64_t(e.rs_bytes) * NW;
+#pragma unroll
+    for (int i = 0; i < SL / NW; ++i)
+      if (nact > wave + NW * i)
+        dma_2k(src0 - uint64_t(i) * step, a_dst + uint32_t(wave + NW * i) * 2048u, voff);
+    if (wave == NW - 1) {
+      const uint32_t x_dst = a_dst + kATile * 8u;
+      if (SEP > 0) {
+        if (lane < 8) dma_1k(e.xa, x_dst + kXTile * 8u, voff);
+      } else {
+        constexpr int kLanes = 8 * D + 8;              // 16 bytes each
+        if (lane < (kLanes < 64 ? kLanes : 64)) dma_1k(e.xa, x_dst, voff);
+        if (kLanes > 64) {
+          if (lane < kLanes - 64) dma_1k(e.xa + 1024, x_dst + 1024, voff);
+        }
+      }
+      if (R > 0) {
+        const int g = int(e.word >> SW_G_SHIFT) & 7;
+        const int nr = p.nride[g];
+        const uint64_t al = SEP > 0 ? e.xa : e.xa + 128u * D;
+        for (int f = 0; f < nr; ++f)       // (wave-uniform)
+          if (lane < 8)
+            dma_1k(al + uint64_t(p.ride_delta[g + 1 + f]),
+                   x_dst + uint32_t(kXTile + kJC * (1 + f)) * 8u, voff);
+      }
+    }
+  };
+
+  // Stage cursors: the stage being multiplied (its entry word in wcur), the stage
+  // being prefetched (entry e1, one ahead) and the stage whose entry is being loaded
+  // (two ahead: a scalar load issued a whole stage before its use).
+  KernFast<D> kf;
+  double kdiag;
+  int nr_cur = 0;
+  auto load_gp = [&](int g) {
+    if (SEP == 0) kf.load_const(&p.gps[g].kern);
+    kdiag = gpc[g].kern.kdiag;
+    if (R > 0) nr_cur = p.nride[g];
+  };
   StageEnt e1 = load_stage(stages, 0);
-  stage_dma<NW, SL>(gv, e1, lds, wave, lane);
-  stage_x_dma<D, NW, SL, R>(gv, rv, e1, lds, wave, lane);
+  load_gp(int(e1.word >> SW_G_SHIFT) & 7);
+  prefetch(e1, 0);
+  if (SEP > 0) {
+    sep_offsets(tile);
+    sep_fetch(e1);
+  }
   uint32_t wcur = e1.word;
-  int si1 = 0, t1 = tile;
-  advance(si1, t1);
-  bool have1 = t1 < ntiles;
-  if (have1) e1 = load_stage(stages, si1);
-  int si2 = si1, t2 = t1;
+  int si1 = nstages > 1 ? 1 : 0;       // index of the stage being prefetched
+  if (si1 == 0) tile_p += tstep;
+  if (left > 1) e1 = load_stage(stages, si1);
+  wait_dma();
   __syncthreads();
 
   // per-GP state
@@ -522,7 +500,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   double mean_r[R > 0 ? R : 1];      // alpha . k of the riders of the GP being swept
 #pragma unroll
   for (int f = 0; f < (R > 0 ? R : 1); ++f) mean_r[f] = 0.0;
-  int nr_cur = R > 0 ? p.nride[0] : 0;
   double accx[kMaxNg];              // narrow groups of slot 0 (narrow_groups)
 #pragma unroll
   for (int g = 0; g < kMaxNg; ++g) accx[g] = 0.0;
@@ -540,42 +517,43 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
 #pragma unroll 1
   while (true) {
     double* cbuf = lds + par * kBuf;
-    double* nbuf = lds + (par ^ 1) * kBuf;
 
+    // SEP: the covariances of THIS stage from the factors fetched a stage ago (their
+    // registers take the next stage's right below)
+    double kv[4];
+    if (SEP > 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        kv[q] = efn[0][q];
+#pragma unroll
+        for (int a = 1; a < kAx; ++a) kv[q] *= efn[a][q];
+      }
+      // (... BEFORE the next stage's factors are requested: loads complete in order, so a
+      // wait for these values placed behind the new requests would sit out THEIR latency)
+      asm volatile("" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- prefetch: the stage after this one (possibly of the next tile)
-    const bool more = have1;
+    const bool more = left > 1;
     const uint32_t wnext = e1.word;
-    const bool next_tile = more && si1 == 0;
     if (more) {
-      const int g_n = int(wnext >> SW_G_SHIFT) & 7;
-      if (g_n != gv_g) {
-        gv.load(p.gps[g_n]);
-        rv.load(p.gps, g_n, R > 0 ? p.nride[g_n] : 0);
-        gv_g = g_n;
+      if (!kDmaLate && !SGP_ABL(2)) prefetch(e1, par ^ 1);
+      const bool next_tile = si1 == 0;
+      if (SEP == 0) {
+        if (next_tile) load_x(tile_p, xnext);
+      } else {
+        if (next_tile) sep_offsets(tile_p);
+        sep_fetch(e1);
       }
-      if (!SGP_ABL(2)) {
-        if (!kSpread) stage_dma<NW, SL>(gv, e1, nbuf, wave, lane);
-        stage_x_dma<D, NW, SL, R>(gv, rv, e1, nbuf, wave, lane);
-      }
-      if (next_tile) load_x(t1, xnext);
     }
-    DmaShare share{};
-    if (kSpread) {
-      const uint64_t rs_bytes = uint64_t(e1.row_stride) * 512u;
-      share.src0 = reinterpret_cast<uint64_t>((const double*)gv.Apack) +
-                   uint64_t(e1.a_off) * 512u - uint64_t(uint32_t(wave)) * rs_bytes;
-      share.step = rs_bytes * NW;
-      share.dst0 = lds_addr_of(nbuf) + uint32_t(wave) * 2048u;
-      share.voff = uint32_t(lane) * 16u;
-      share.left = int(wnext & SW_NACT_MASK) - wave;
-      share.on = more && !SGP_ABL(2);
-    }
-    const int tile_after = t1;
     // the entry after that: loaded now, first used at the top of the next stage
-    advance(si2, t2);
-    const bool have2 = more && t2 < ntiles;
+    int si2 = si1 + 1;
+    if (si2 == nstages) {
+      si2 = 0;
+      tile_p += tstep;
+    }
     StageEnt e2 = e1;
-    if (have2) e2 = load_stage(stages, si2);
+    if (left > 2) e2 = load_stage(stages, si2);
 
     SGP_STAMP(0);   // prefetch issue, table entry
 #ifdef SGP_PAD_SALU      // issue-model experiment: extra scalar instructions per stage
@@ -585,7 +563,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     asm volatile(".rept " SGP_STR(SGP_PAD_VALU) "\n\tv_mov_b32 v127, 0\n\t.endr" ::: "v127");
 #endif
     // ---- this stage: 16 training points against the active row blocks
-    if (gp_start) {
+    if (SEP == 0 && gp_start) {
       kf.template prep_t<SINGLE>(x, xs);
       gp_start = false;
     }
@@ -605,8 +583,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       }
     };
     if (kAnEarly && ngrp > 0 && !SGP_ABL(8)) load_an();
-    double kv[4];
-    if (!SGP_ABL(4)) {
+    if (SEP > 0) {
+      // (done at the top of the stage)
+    } else if (!SGP_ABL(4)) {
       kf.template many4_t<SINGLE>(xs, xT + (lane >> 4) * D, 4 * D, tab, kv);
     } else {
       kv[0] = xs[0]; kv[1] = xs[0] + 1.0; kv[2] = xs[0] + 2.0; kv[3] = xs[0] + 3.0;
@@ -642,15 +621,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     asm volatile("" : "+v"(kb[0][3]), "+v"(kb[1][3]), "+v"(kb[2][3]), "+v"(kb[3][3]));
 #endif
     SGP_STAMP(3);   // LDS transpose round trip
+    if (kDmaLate && more && !SGP_ABL(2)) prefetch(e1, par ^ 1);
     if (!SGP_ABL(8)) {
+      // the full slots: sweep_slots.h (hand-written, accumulators in a0..a127)
       const int shift = ngrp > 0 ? 1 : 0;
-      mfma_jblock<SL, NW, kSpread>(int(wcur & SW_NACT_MASK) - shift,
-                                   int(wcur & SW_FIRST), lds_addr_of(cbuf) + uint32_t(lane) * 8u +
-                                       uint32_t(shift) * (kSteps * 512u),
-                                   kb, share);
-    } else if (kSpread) {
-#pragma unroll
-      for (int i = 0; i < SL / NW; ++i) dma_share_group<NW>(share, i);
+      const int nfull = int(wcur & SW_NACT_MASK) - shift;
+      if (nfull > 0)
+        sgp_slots(nfull, int(wcur & SW_FIRST),
+                  lds0 + uint32_t(par) * (kBuf * 8u) + uint32_t(lane) * 8u +
+                      uint32_t(shift) * (kSteps * 512u),
+                  kb);
     }
 
     SGP_STAMP(4);   // full slots
@@ -660,8 +640,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       // (the chunk's slots: what its LAST stage -- this one -- has active is the
       // diagonal block only; the table carries the chunk's slot count)
       double sq[4] = {0.0, 0.0, 0.0, 0.0};
-      const int nsl = __builtin_amdgcn_readfirstlane(int(wcur >> SW_NSL_SHIFT) & 31) -
-                      (ngrp > 0 ? 1 : 0);
+      const int nsl = (int(wcur >> SW_NSL_SHIFT) & 31) - (ngrp > 0 ? 1 : 0);
       if (nsl > 0 && !SGP_ABL(8)) sgp_fold_slots(nsl, sq);
       // lane 16 i' + 4 blk + j' of sq[m]: the squares for point 4 m + j' of row group
       // blk on the DIAGONAL lanes i' = j' only (cross terms elsewhere)
@@ -731,7 +710,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
             if (f < nr_cur) {
               const double mu_f = sum_lane_groups(mean_r[f]);
               mean_r[f] = 0.0;
-              emit(g + 1 + f, mu_f, p.gps[g + 1 + f].kern.kdiag);
+              emit(g + 1 + f, mu_f, gpc[g + 1 + f].kern.kdiag);
             }
           }
         }
@@ -741,8 +720,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
         if (conf) {
           if (p.conf.Q && p.G <= L::kQMaxG && !SGP_ABL(16)) {
             const int64_t row0 = int64_t(tile) * kTilePts + wave * 16;
-            const int64_t left = p.pts.N - row0;
-            const int nq = (left >= 16 ? 16 : (left > 0 ? int(left) : 0)) * p.G;
+            const int64_t rows_left = p.pts.N - row0;
+            const int nq = (rows_left >= 16 ? 16 : (rows_left > 0 ? int(rows_left) : 0)) * p.G;
             __builtin_amdgcn_wave_barrier();
             double2_t* dst = reinterpret_cast<double2_t*>(p.conf.Q) + row0 * p.G;
             for (int i = lane; i < nq; i += 64)
@@ -761,22 +740,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
         l0 = 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) x[k] = xnext[k];
-        tile = tile_after;
+        tile += tstep;
       }
       if (more) {   // hyper-parameters of the next GP
         const int g_n = int(wnext >> SW_G_SHIFT) & 7;
-        if (g_n != g) {
-          kf = KernFast<D>(p.gps[g_n].kern);
-          kdiag = p.gps[g_n].kern.kdiag;
-        }
-        if (R > 0) nr_cur = p.nride[g_n];
+        if (g_n != g || R > 0) load_gp(g_n);
       }
       gp_start = true;
     }
 
     SGP_STAMP(5);   // chunk fold, row epilogue
     if (!more) break;
-    if (kSpread) wait_dma();       // (asm copies: the compiler does not count them)
+    wait_dma();       // (asm copies: the compiler does not count them)
     SGP_STAMP(6);   // wait for this wave's LDS-DMA
     if (!SGP_ABL(1)) __syncthreads();
     SGP_STAMP(7);   // barrier
@@ -784,8 +759,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     wcur = wnext;
     e1 = e2;
     si1 = si2;
-    t1 = t2;
-    have1 = have2;
+    --left;
   }
 #ifdef SGP_STAMPS
   if (lane == 0) {
@@ -1166,14 +1140,18 @@ int narrow_groups_of(const GpDev& gp) {
   return ng;
 }
 
-int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB, const bool* rides,
-                const StageEnt** dev, int* nstages) {
-  std::vector<int> sig(1, Geff);
-  sig.push_back(kIB);
+int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, bool sep, int kIB,
+                const bool* rides, const StageEnt** dev, int* nstages) {
+  // (entries hold absolute addresses: rebuilt when a block count OR a buffer address
+  // changes; the buffers are sized for the pitch of L^-1, so one-row appends keep them)
+  std::vector<uint64_t> sig(1, uint64_t(Geff));
+  sig.push_back(uint64_t(kIB) | (uint64_t(d) << 8) | (uint64_t(sep) << 16));
   int last_staged = 0;
   for (int g = 0; g < Geff; ++g) {
-    sig.push_back(gh[g].nblk);
-    sig.push_back(narrow_groups_of(gh[g]) | (int(rides[g]) << 2));
+    sig.push_back(uint64_t(gh[g].nblk));
+    sig.push_back(uint64_t(narrow_groups_of(gh[g])) | (uint64_t(rides[g]) << 2));
+    sig.push_back(reinterpret_cast<uint64_t>(gh[g].Apack));
+    sig.push_back(reinterpret_cast<uint64_t>(gh[g].XA));
     if (!rides[g]) last_staged = g;
   }
   if (sig == ctx->stage_sig && ctx->stage_tab.p) {
@@ -1182,16 +1160,20 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int kIB, const bool* ri
     return 0;
   }
   std::vector<StageEnt> tab;
+  const uint64_t xa_block = uint64_t(16 * d + 16) * sizeof(double);
   for (int g = 0; g < Geff; ++g) {
     if (rides[g]) continue;       // (its alpha . k is formed in its leader's stages)
     const int nblk = gh[g].nblk, nsteps = gh[g].n_pad / 4;
     const int nchunks = (nblk + kIB - 1) / kIB;
+    const uint64_t apack = reinterpret_cast<uint64_t>(gh[g].Apack);
+    const uint64_t xa = reinterpret_cast<uint64_t>(gh[g].XA) + (sep ? 128u * uint64_t(d) : 0u);
     for (int c = 0; c < nchunks; ++c) {
       const int b0 = c * kIB, nib = std::min(kIB, nblk - b0), bend = b0 + nib;
       for (int jb = 0; jb < bend; ++jb) {
-        StageEnt e;
-        e.a_off = uint32_t((bend - 1) * nsteps + 4 * jb);
-        e.row_stride = uint32_t(nsteps);
+        StageEnt e{};
+        e.a_src = apack + (uint64_t(bend - 1) * nsteps + 4 * uint64_t(jb)) * 512;
+        e.xa = xa + uint64_t(jb) * xa_block;
+        e.rs_bytes = uint32_t(nsteps) * 512u;
         e.jb = uint32_t(jb);
         e.word = uint32_t(std::min(nib, bend - jb)) | (uint32_t(g) << SW_G_SHIFT);
         if (jb == 0) e.word |= SW_FIRST;
@@ -1227,12 +1209,12 @@ int sweep_grid_blocks(int num_cu, int64_t N, int nw, int slots) {
   return int(ntiles < resident ? ntiles : resident);
 }
 
-template <int D, int NW, int SL, int MODE, bool SINGLE, int R = 0>
+template <int D, int NW, int SL, int MODE, bool SINGLE, int R = 0, int SEP = 0>
 int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep<D, NW, SL, MODE, SINGLE, R>),
+                     reinterpret_cast<const void*>(&k_sweep<D, NW, SL, MODE, SINGLE, R, SEP>),
                      hipFuncAttributeMaxDynamicSharedMemorySize,
                      int(Lay<SL, D, R>::bytes(NW))));
     attr_set = true;
@@ -1251,7 +1233,7 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   if (!stamps_dev) SGP_HIP(ctx, hipMalloc(&stamps_dev, size_t(4096) * NW * 8 * 8));
   pp.stamps = stamps_dev;
 #endif
-  hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE, R>), dim3(nblocks),
+  hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE, R, SEP>), dim3(nblocks),
                      dim3(64 * NW), lds_bytes, ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
 #ifdef SGP_STAMPS
@@ -1291,10 +1273,21 @@ int launch_sweep_d(sgp_ctx* ctx, const SweepParams& p, double flops) {
   return launch_sweep_w<D, 4, 16>(ctx, p, flops);
 }
 
-int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d, int Geff,
-                     double flops);
+// tensor grid + RBF kernels: the instances that read factor tables (SEP axes; D = 1:
+// they do not read the rows).  Riders as in the generic instances.
+template <int SEP>
+int launch_sweep_sep(sgp_ctx* ctx, const SweepParams& p, double flops) {
+  bool riders = false;
+  for (int g = 0; g < SGP_MAX_GPS; ++g) riders = riders || p.nride[g] > 0;
+  if (riders) return launch_sweep_v<1, 4, 16, MODE_CONF, true, kSweepRide, SEP>(ctx, p, flops);
+  return launch_sweep_v<1, 4, 16, MODE_CONF, true, 0, SEP>(ctx, p, flops);
+}
 
-int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
+int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d, int Geff,
+                     double flops, const SepLaunch* sep);
+
+int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d,
+                 const SepLaunch* sep = nullptr) {
   // algorithmic flops: G * (n^2 + 2n) per row
   double flops = 0.0;
   const int Geff =
@@ -1320,7 +1313,7 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
     q.G = Geff;
     for (int i = 0; i < SGP_MAX_GPS; ++i) q.conf.fmin[i] = -INFINITY;
   }
-  int rc = launch_posterior(ctx, q, gh, d, Geff, flops);
+  int rc = launch_posterior(ctx, q, gh, d, Geff, flops, sep);
   if (rc != 0 || !fitness) return rc;
   return launch_fitness_small(ctx, p.G, p.pts.N, q.conf.mean, q.conf.var, p.fit);
 }
@@ -1328,7 +1321,7 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d) {
 // The confidence sweep proper: the paired-wave kernel from 257 rows of L^-1 on,
 // the 4-wave kernel below.
 int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d, int Geff,
-                     double flops) {
+                     double flops, const SepLaunch* sep) {
   if (pair_sweep_wanted(ctx, gh, Geff)) {
     SweepArgs a{p.gps, p.G, p.mode, p.pts, p.conf, p.fit};
     return launch_sweep_pair(ctx, a, gh, d, Geff, flops);   // (sets ctx->sweep_partials)
@@ -1343,12 +1336,34 @@ int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d,
   bool rides[SGP_MAX_GPS] = {};
   static const bool no_ride = getenv("SGP_PAIR_RIDE") && atoi(getenv("SGP_PAIR_RIDE")) == 0;
   for (int g = 0; g < SGP_MAX_GPS; ++g) q.nride[g] = 0;
-  if (no_ride || !sweep_riders(gh, Geff, d, q.single != 0, kSweepRide, 3, rides, q.nride))
+  // (tensor-grid instances: one set of tables per leader, whatever the input dimension)
+  if (no_ride || !sweep_riders(gh, Geff, sep ? 1 : d, q.single != 0 || sep != nullptr,
+                               kSweepRide, 3, rides, q.nride))
     for (int g = 0; g < SGP_MAX_GPS; ++g) {
       rides[g] = false;
       q.nride[g] = 0;
     }
-  SGP_TRY(stage_table(ctx, gh, Geff, q.slots, rides, &q.stages, &q.nstages));
+  for (int g = 0, leader = 0; g < Geff; ++g) {
+    q.ride_delta[g] = 0;
+    if (!rides[g]) {
+      leader = g;
+      continue;
+    }
+    q.ride_delta[g] = (long long)(reinterpret_cast<intptr_t>(gh[g].XA) -
+                                  reinterpret_cast<intptr_t>(gh[leader].XA));
+  }
+  SGP_TRY(stage_table(ctx, gh, Geff, d, sep != nullptr, q.slots, rides, &q.stages, &q.nstages));
+  if (sep) {
+    q.sep = *sep;
+    switch (sep->naxes) {
+      case 1: return launch_sweep_sep<1>(ctx, q, flops);
+      case 2: return launch_sweep_sep<2>(ctx, q, flops);
+#ifndef SGP_ONLY_D2
+      case 3: return launch_sweep_sep<3>(ctx, q, flops);
+      case 4: return launch_sweep_sep<4>(ctx, q, flops);
+#endif
+    }
+  }
   switch (d) {
 #ifndef SGP_ONLY_D2      // (compile-time experiments: one instance set)
     case 1: return launch_sweep_d<1>(ctx, q, flops);
@@ -1377,7 +1392,7 @@ int sweep_num_partials(const sgp_ctx* ctx, int64_t N) {
 }
 
 int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
-                      int G, int d, SweepPoints pts, ConfOut out) {
+                      int G, int d, SweepPoints pts, ConfOut out, const SepLaunch* sep) {
   SweepParams p{};
   p.gps = gps_dev;
   p.G = G;
@@ -1385,7 +1400,7 @@ int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
   p.pts = pts;
   p.conf = out;
   p.fit = FitnessArgs{};
-  return launch_sweep(ctx, p, gps_host, d);
+  return launch_sweep(ctx, p, gps_host, d, sep);
 }
 
 int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,
@@ -1443,6 +1458,105 @@ int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
   return 0;
 }
 
+
+// ---- tensor grids: per-axis factor tables (SepLaunch) -------------------------------
+// E_a[jb][i][4 k4 + q] = 2^(-W_k (axis_k[i] - X_{j k})^2 / 32), k = column of axis a,
+// j = 16 jb + 4 q + k4, W_k = sum over the parts of their squared weights on column k
+// (KernDesc::wsq: the exponents of RBF parts add).  Axis 0's table also carries the
+// product of the variances and the factors of the constant columns (contexts).
+struct SepCols {
+  int naxes, d;
+  int cols[4];
+  uint32_t count[SGP_MAX_D];
+  int off[SGP_MAX_D];
+};
+__global__ __launch_bounds__(256) void k_sep_table(GpDev gp, SepCols sc, int a,
+                                                   const double* vals, double* out) {
+  const int k = sc.cols[a];
+  const uint32_t count = sc.count[k];
+  const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t total = int64_t(gp.nblk) * count * 16;
+  if (e >= total) return;
+  const int pos = int(e & 15);
+  const uint32_t i = uint32_t((e >> 4) % count);
+  const int jb = int((e >> 4) / count);
+  const int j = 16 * jb + 4 * (pos & 3) + (pos >> 2);
+  const double* xj = gp.Xpad + int64_t(j) * sc.d;
+  auto weight = [&](int col) {
+    double W = 0.0;
+    for (int p = 0; p < gp.kern.n_parts; ++p) W += gp.kern.wsq[p][col];
+    return W;
+  };
+  double dx = vals[sc.off[k] + i] - xj[k];
+  double u = weight(k) * dx * dx;
+  double scale = 1.0;
+  if (a == 0) {
+    scale = gp.kern.kdiag;
+    for (int c = 0; c < sc.d; ++c) {
+      if (sc.count[c] != 1) continue;
+      dx = vals[sc.off[c]] - xj[c];
+      u += weight(c) * dx * dx;
+    }
+  }
+  out[e] = scale * exp2(-u * (1.0 / 32.0));
+}
+
+size_t sep_table_doubles(const GpDev& gp, uint32_t count) {
+  return size_t(gp.nblk) * count * 16;
+}
+
+int launch_sep_tables(sgp_ctx* ctx, const GpDev& gp, int d, const uint32_t* count,
+                      const double* axis_vals, const int* axis_off, int naxes,
+                      const int* cols, double* const* out) {
+  SepCols sc{};
+  sc.naxes = naxes;
+  sc.d = d;
+  for (int a = 0; a < naxes; ++a) sc.cols[a] = cols[a];
+  for (int k = 0; k < d; ++k) {
+    sc.count[k] = count[k];
+    sc.off[k] = axis_off[k];
+  }
+  for (int a = 0; a < naxes; ++a) {
+    const int64_t total = int64_t(sep_table_doubles(gp, count[cols[a]]));
+    hipLaunchKernelGGL(k_sep_table, dim3(unsigned((total + 255) / 256)), dim3(256), 0,
+                       ctx->stream, gp, sc, a, axis_vals, out[a]);
+  }
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// rows of the grid against the declared axes, bit for bit
+__global__ __launch_bounds__(256) void k_verify_axes(const double* pts, int64_t N, int d,
+                                                     int64_t goff, const double* vals,
+                                                     const uint32_t* meta, int* mismatch) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= N) return;
+  const uint32_t gi = uint32_t(goff + i);
+  int bad = 0;
+  for (int k = 0; k < d; ++k) {
+    const uint32_t cnt = meta[3 * k], str = meta[3 * k + 1], off = meta[3 * k + 2];
+    const double want = vals[off + (gi / str) % cnt];
+    bad |= __double_as_longlong(want) != __double_as_longlong(pts[int64_t(k) * N + i]);
+  }
+  if (bad) atomicAdd(mismatch, 1);
+}
+
+int launch_verify_axes(sgp_grid* g, int* mismatch_dev) {
+  sgp_ctx* ctx = g->ctx;
+  uint32_t meta[3 * SGP_MAX_D];
+  for (int k = 0; k < g->d; ++k) {
+    meta[3 * k] = g->ax_count[k];
+    meta[3 * k + 1] = g->ax_stride[k];
+    meta[3 * k + 2] = uint32_t(g->ax_off[k]);
+  }
+  uint32_t* meta_dev = reinterpret_cast<uint32_t*>(mismatch_dev + 4);   // (same scratch slot)
+  SGP_TRY(sgp_h2d(ctx, meta_dev, meta, sizeof(uint32_t) * 3 * g->d));
+  hipLaunchKernelGGL(k_verify_axes, dim3(unsigned((g->N + 255) / 256)), dim3(256), 0,
+                     ctx->stream, g->pts, g->N, g->d, g->goff,
+                     static_cast<const double*>(g->ax_vals.p), meta_dev, mismatch_dev);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
 
 int rank1_num_blocks(int64_t N) { return int((N + 63) / 64); }
 

@@ -186,7 +186,7 @@ class _HipGridBackend(object):
     HBM plus the GP handles.  (Tests drive the same phase interface with a
     NumPy stand-in to exercise the sharded host logic without a GPU.)"""
 
-    def __init__(self, gps, inputs_shard, global_offset, ctx=None):
+    def __init__(self, gps, inputs_shard, global_offset, ctx=None, axes=None):
         # the grid must live in the context of its GPs (stream ordering, device
         # pointers) and of the communicator (in-stream collectives)
         gp_ctx = getattr(gps[0], '_ctx', None)
@@ -198,6 +198,9 @@ class _HipGridBackend(object):
         self.gps = gps
         self.grid = _hip.DeviceGrid(self.ctx, inputs_shard, len(gps),
                                     global_offset)
+        #: the rows are a tensor grid (what linearly_spaced_combinations builds): RBF
+        #: kernels are swept through per-axis factor tables
+        self.tensor_grid = self.grid.set_axes(axes)
         self.lo = int(global_offset)
         self.hi = self.lo + self.grid.N
         # which data version of every GP the resident mean/var reflect
@@ -390,7 +393,8 @@ class SafeOpt(GaussianProcessOptimization):
             self._backend = _backend_factory(self.gps, self.inputs[lo:hi], lo)
         else:
             self._backend = _HipGridBackend(self.gps, self.inputs[lo:hi], lo,
-                                            ctx=getattr(self._comm, 'ctx', None))
+                                            ctx=getattr(self._comm, 'ctx', None),
+                                            axes=_hip.tensor_grid_axes(self.inputs))
         self._any_safe = False
         self._max_l = -np.inf
         self._ci_fresh = False

@@ -44,6 +44,10 @@ def run(k, reps):
         if k == 4:
             pts = pts[4000000:5000000]       # one rank's share of the 200^3 grid
         grid = _hip.DeviceGrid(ctx, pts, G)
+        if os.environ.get("AB_SEP", "1") == "1":        # tensor grid: factor tables (RBF)
+            lo = 4000000 if k == 4 else 0
+            grid = _hip.DeviceGrid(ctx, pts, G, lo)
+            grid.set_axes(_hip.tensor_grid_axes(cfg["grid"]))
         for which in ((ONLY,) if ONLY else ("classic", "pair")):
             ctx.set_sweep(which)
             grid.confidence(devs, 2.0, fmin)

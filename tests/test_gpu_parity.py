@@ -358,6 +358,85 @@ def test_grid_sweep_product_kernels(mods, which, d, gpspec, N):
         assert_allclose(Q[:, 2 * i + 1], mo[:, 0] + 2.0 * sd, rtol=0, atol=2e-8)
 
 
+# Tensor grids (what linearly_spaced_combinations builds, utilities.py:21-54) with RBF
+# kernels are swept through per-axis factor tables (sgp_grid_set_axes): same posterior
+# as the generic evaluation within rounding, for 1..4 axes, constant context columns,
+# products of RBF parts, shards of the grid, GPs of different sizes; anything else
+# (other kernels, rows that are no tensor grid) silently takes the generic path.
+SEP_CASES = [
+    # sides, context columns, [n per GP], kernel spec, (lo, hi) shard or None
+    ([70], 0, [1], "RBF", None), ([37, 29], 0, [200], "RBF", None),
+    ([37, 29], 0, [17, 255], "RBF", (100, 1000)), ([9, 8, 11], 0, [130], "RBF", None),
+    ([5, 4, 6, 3], 0, [60, 60], "RBF", (7, 355)), ([31, 17], 1, [90], "RBF*RBF", None),
+    ([40, 25], 2, [33], "RBF", None), ([64, 3], 0, [256], "RBF", None),
+]
+
+
+@pytest.mark.parametrize("sides,nc,ns,spec,shard", SEP_CASES)
+def test_tensor_grid_tables_match_generic(mods, sides, nc, ns, spec, shard):
+    sa, gpy, gpn, son = mods
+    from safeopt_amd import _hip
+    dp = len(sides)
+    d = dp + nc
+    rng = np.random.default_rng(sum(ns) + 7 * d)
+    full = sa.linearly_spaced_combinations([(-3., 3.)] * dp, sides)
+    if nc:
+        full = np.hstack([full, np.tile(rng.uniform(-1, 1, size=nc), (full.shape[0], 1))])
+    axes = _hip.tensor_grid_axes(full)
+    assert axes is not None
+    lo, hi = shard or (0, full.shape[0])
+    gps = []
+    for i, n in enumerate(ns):
+        X = rng.uniform(-2, 2, size=(n, d)); Y = smooth(X, 3 + i) + 0.3
+        if spec == "RBF":
+            k = gpy.kern.RBF(d, 1.7, list(rng.uniform(0.6, 1.5, size=d)), ARD=True)
+        else:
+            k = (gpy.kern.RBF(dp, 1.3, list(rng.uniform(0.6, 1.5, size=dp)), ARD=True,
+                              active_dims=list(range(dp))) *
+                 gpy.kern.RBF(nc, 0.9, 0.8, active_dims=list(range(dp, d))))
+        gps.append(gpy.models.GPRegression(X, Y, k, noise_var=0.05 ** 2))
+    devs = [g._fitted() for g in gps]
+    ctx = devs[0].ctx
+    G = len(ns)
+    fmin = np.full(G, 0.1)
+    grid = _hip.DeviceGrid(ctx, full[lo:hi], G, lo)
+    assert grid.set_axes(axes)
+    out = {}
+    for which in (8, 0):                 # 8: no factor tables
+        old = ctx.set_sweep(which)
+        try:
+            grid.confidence(devs, 2.0, fmin)
+            out[which] = [grid.download(a) for a in (_hip.Q, _hip.MEAN, _hip.VAR, _hip.S)]
+        finally:
+            ctx.set_sweep(old)
+    kd = max(float(g.kern.Kdiag(np.zeros((1, d)))[0]) for g in gps)
+    assert_allclose(out[0][1], out[8][1], rtol=0, atol=1e-11 * max(1.0, np.abs(out[8][1]).max()))
+    assert_allclose(out[0][2], out[8][2], rtol=0, atol=1e-11 * kd)
+    assert_allclose(out[0][0], out[8][0], rtol=0, atol=2e-9)
+    assert np.mean(out[0][3] != out[8][3]) < 1e-3
+    if nc:
+        # a new context: new axis values, new tables
+        c = rng.uniform(-1, 1, size=nc)
+        grid.set_context(c)
+        full[:, dp:] = c
+        grid.confidence(devs, 2.0, fmin)
+        m1 = grid.download(_hip.MEAN)
+        ref = _hip.DeviceGrid(ctx, full[lo:hi], G, lo)
+        old = ctx.set_sweep(8)
+        try:
+            ref.confidence(devs, 2.0, fmin)
+        finally:
+            ctx.set_sweep(old)
+        assert_allclose(m1, ref.download(_hip.MEAN), rtol=0,
+                        atol=1e-11 * max(1.0, np.abs(m1).max()))
+    # rows that are no tensor grid are refused (and swept as before)
+    perm = full[lo:hi].copy()
+    if perm.shape[0] > 3:
+        perm[[1, 2]] = perm[[2, 1]]
+        g2 = _hip.DeviceGrid(ctx, perm, G, lo)
+        assert not g2.set_axes(axes)
+
+
 @pytest.mark.parametrize("kind,d,ns,N", [("Matern52", 2, [500, 500, 500], 2000 + 64 * 256),
                                         ("RBF", 3, [1000], 3000),
                                         ("RBF", 4, [2000, 1500], 64 * 300 + 5),
