@@ -224,7 +224,8 @@ class Context(object):
             world = int(os.environ.get("LOCAL_WORLD_SIZE",
                                        os.environ.get("WORLD_SIZE", "1")))
             if n > 0 and device >= n:
-                if world > 1 and "SAFEOPT_HIP_DEVICE" not in os.environ:
+                shared = os.environ.get("SAFEOPT_COMM", "rccl") == "socket"
+                if world > 1 and "SAFEOPT_HIP_DEVICE" not in os.environ and not shared:
                     # two ranks on one GPU: RCCL would fail or hang in
                     # ncclCommInitRank -- say what is wrong instead
                     raise HipError(

@@ -303,10 +303,20 @@ __device__ __forceinline__ void narrow_groups(int ngrp, double (&accx)[kMaxNg],
                    [a03] "v"(an[0][3]),
                    [k0] "v"(kv[0]), [k1] "v"(kv[1]), [k2] "v"(kv[2]), [k3] "v"(kv[3]));
   } else if constexpr (kMaxNg == 2) {
-    asm volatile("s_nop 1\n\t" SGP_NARROW_GROUP("%[c0]", "%[a00]", "%[a01]", "%[a02]", "%[a03]")
-                 "s_cmp_lt_u32 %[ng], 2\n\ts_cbranch_scc1 .Lsgp_narrow_end_%=\n\t"
-                 SGP_NARROW_GROUP("%[c1]", "%[a10]", "%[a11]", "%[a12]", "%[a13]")
-                 ".Lsgp_narrow_end_%=:"
+    // two groups: their chains interleaved (the partner's instruction and s_nop 2 make
+    // the 4 wait states of a dependent pair), the second group's half skipped by a branch
+    // per k-step when the GP has one group only
+#define SGP_NARROW_STEP(Q, A0, A1, K)                                                  \
+  "v_mfma_f64_4x4x4_4b_f64 %[c0], " A0 ", " K ", %[c0]\n\t"                             \
+  "s_cbranch_scc1 .Lsgp_n1_" #Q "_%=\n\t"                                               \
+  "v_mfma_f64_4x4x4_4b_f64 %[c1], " A1 ", " K ", %[c1]\n\t"                             \
+  ".Lsgp_n1_" #Q "_%=:\n\ts_nop 3\n\t"
+    asm volatile("s_cmp_lt_u32 %[ng], 2\n\ts_nop 0\n\t"
+                 SGP_NARROW_STEP(0, "%[a00]", "%[a10]", "%[k0]")
+                 SGP_NARROW_STEP(1, "%[a01]", "%[a11]", "%[k1]")
+                 SGP_NARROW_STEP(2, "%[a02]", "%[a12]", "%[k2]")
+                 SGP_NARROW_STEP(3, "%[a03]", "%[a13]", "%[k3]")
+                 "s_nop 2"      // (a VALU instruction may read the results next: 6 wait states)
                  : [c0] "+v"(accx[0]), [c1] "+v"(accx[g1])
                  : [a00] "v"(an[0][0]), [a01] "v"(an[0][1]), [a02] "v"(an[0][2]),
                    [a03] "v"(an[0][3]),
@@ -315,6 +325,7 @@ __device__ __forceinline__ void narrow_groups(int ngrp, double (&accx)[kMaxNg],
                    [k0] "v"(kv[0]), [k1] "v"(kv[1]), [k2] "v"(kv[2]), [k3] "v"(kv[3]),
                    [ng] "s"(ngrp)
                  : "scc");
+#undef SGP_NARROW_STEP
   } else {
     asm volatile("s_nop 1\n\t" SGP_NARROW_GROUP("%[c0]", "%[a00]", "%[a01]", "%[a02]", "%[a03]")
                  "s_cmp_lt_u32 %[ng], 2\n\ts_cbranch_scc1 .Lsgp_narrow_end_%=\n\t"

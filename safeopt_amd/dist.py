@@ -22,7 +22,7 @@ import time
 
 import numpy as np
 
-__all__ = ["shard_range", "LocalComm", "RcclComm", "init_from_env",
+__all__ = ["shard_range", "LocalComm", "RcclComm", "SocketComm", "init_from_env",
            "merge_topk", "merge_argmax", "launch_check"]
 
 
@@ -74,6 +74,119 @@ class RcclComm(object):
 
     def barrier(self):
         self.ctx.barrier()
+
+
+class SocketComm(object):
+    """The collectives of ``RcclComm`` over TCP, through rank 0 (a star).
+
+    RCCL wants one GPU per rank; this communicator does not care where the ranks'
+    kernels run, so N processes -- each with its own HIP context and its TRUE shard
+    of the grid -- can share one GPU (``SAFEOPT_COMM=socket``; how the N-rank product
+    is tested on a one-GPU box, tests/test_gpu_parity.py), or sit on machines without
+    xGMI.  The payloads of the path are a few dozen bytes per collective
+    (SURVEY.md section 8e), latency is all that matters.  Not in stream: the library's
+    fused N-rank step (``sgp_grid_sets_fused_comm``) needs device-side collectives, the
+    host driver then takes the packed host collectives (``sets_front`` / ``sets_back``).
+    """
+    in_stream = False
+
+    def __init__(self, rank, world, addr="127.0.0.1", port=29517, timeout=300.0, ctx=None):
+        self.rank, self.world, self.ctx = int(rank), int(world), ctx
+        self._peers = []          # rank 0: sockets of ranks 1 .. world - 1
+        self._up = None           # other ranks: socket to rank 0
+        if self.world <= 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            peers = {}
+            try:
+                while len(peers) < self.world - 1:
+                    c, _a = srv.accept()
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    c.settimeout(timeout)
+                    r = struct.unpack("<I", self._recv_exact(c, 4))[0]
+                    if not 0 < r < self.world or r in peers:
+                        raise RuntimeError("rendezvous: unexpected rank %d" % r)
+                    peers[r] = c
+            finally:
+                srv.close()
+            self._peers = [peers[r] for r in range(1, self.world)]
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    c = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            c.settimeout(timeout)
+            c.sendall(struct.pack("<I", self.rank))
+            self._up = c
+
+    @staticmethod
+    def _recv_exact(c, n):
+        buf = bytearray()
+        while len(buf) < n:
+            chunk = c.recv(n - len(buf))
+            if not chunk:
+                raise RuntimeError("peer closed the connection")
+            buf += chunk
+        return bytes(buf)
+
+    def _gather_bytes(self, raw):
+        """Every rank's bytes, in rank order, on every rank."""
+        if self.world <= 1:
+            return [raw]
+        if self.rank == 0:
+            parts = [raw]
+            for c in self._peers:
+                n = struct.unpack("<Q", self._recv_exact(c, 8))[0]
+                parts.append(self._recv_exact(c, n))
+            blob = b"".join(struct.pack("<Q", len(x)) + x for x in parts)
+            for c in self._peers:
+                c.sendall(struct.pack("<Q", len(blob)) + blob)
+            return parts
+        self._up.sendall(struct.pack("<Q", len(raw)) + raw)
+        n = struct.unpack("<Q", self._recv_exact(self._up, 8))[0]
+        blob = self._recv_exact(self._up, n)
+        parts, at = [], 0
+        for _ in range(self.world):
+            m = struct.unpack_from("<Q", blob, at)[0]
+            parts.append(blob[at + 8:at + 8 + m])
+            at += 8 + m
+        return parts
+
+    def allreduce_max(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        parts = self._gather_bytes(a.tobytes())
+        out = np.frombuffer(parts[0], dtype=np.float64).copy()
+        for x in parts[1:]:
+            # (max as RCCL's ncclMax: NaN-free operands on this path)
+            np.maximum(out, np.frombuffer(x, dtype=np.float64), out=out)
+        return out.reshape(a.shape)
+
+    def allgather(self, a):
+        a = np.ascontiguousarray(a)
+        parts = self._gather_bytes(a.tobytes())
+        return np.stack([np.frombuffer(x, dtype=a.dtype).reshape(a.shape) for x in parts])
+
+    def barrier(self):
+        self._gather_bytes(b"")
+
+    def close(self):
+        for c in self._peers + ([self._up] if self._up else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self._peers, self._up = [], None
 
 
 def _serve_uid(addr, port, uid, world, timeout):
@@ -212,7 +325,9 @@ def init_from_env(ctx=None, timeout=300.0):
 
     Returns ``(ctx, comm)``; with ``WORLD_SIZE`` unset or 1 it is a
     ``LocalComm`` and no RCCL call is made (``SAFEOPT_FORCE_RCCL=1`` builds a
-    one-rank RCCL communicator instead, to exercise that path).  The
+    one-rank RCCL communicator instead, to exercise that path);
+    ``SAFEOPT_COMM=socket`` takes host-side collectives over TCP (``SocketComm``:
+    ranks that share a GPU, or no xGMI between them) instead of RCCL.  The
     ncclUniqueId travels through a file in /tmp when MASTER_ADDR is local
     (one node -- the supported topology), otherwise over a TCP socket on
     MASTER_PORT+17 (``SAFEOPT_RDZV=tcp|file`` overrides).
@@ -227,6 +342,12 @@ def init_from_env(ctx=None, timeout=300.0):
         return ctx, LocalComm()
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     mport = int(os.environ.get("MASTER_PORT", "29500"))
+    if os.environ.get("SAFEOPT_COMM", "rccl") == "socket":
+        # host-side collectives: the ranks need not have a GPU each
+        comm = SocketComm(rank, world, addr, int(os.environ.get("SAFEOPT_RDZV_PORT", mport + 17)),
+                          timeout, ctx=ctx)
+        comm.barrier()
+        return ctx, comm
     mode = os.environ.get("SAFEOPT_RDZV",
                           "file" if addr in ("127.0.0.1", "localhost", "::1")
                           else "tcp")
