@@ -288,6 +288,134 @@ def full_grid_check(cfg, opt, chosen_index):
                 q_linf=float(np.max(np.abs(opt.Q - Q))))
 
 
+def bo_iteration(cfg, gpy, safeopt_amd, ctx, iters=12):
+    """What a user of the drop-in pays per sequential BO iteration with the product
+    defaults (shared factor, bordered factor update + closed-form rank-1 refresh of the
+    resident posterior, safeopt/gp_opt.py:230-255 then :651-675): median ms of
+    ``add_new_data_point`` + ``optimize`` over ``iters`` iterations, candidates/s, and
+    whether the query points equal those of the full-refit path.  Also the hipEvent
+    time of the rank-1 refresh alone (``rank1_roofline``)."""
+    out = {}
+    old_share = ctx.set_share(True)
+    try:
+        runs = {}
+        for incremental in (False, True):
+            gps = build_gps(cfg, gpy)
+            for g in gps:
+                g.incremental = incremental
+            G = cfg["G"]
+            opt = safeopt_amd.SafeOpt(gps if G > 1 else gps[0], cfg["grid"],
+                                      cfg["fmin"] if G > 1 else 0., threshold=cfg["threshold"])
+            opt._backend.incremental = incremental
+            opt._backend.refresh_every = 1 << 30
+            xs, t_add, t_opt, t_r1 = [], [], [], []
+            x = opt.optimize()
+            for it in range(iters):
+                y = np.array([[_bumps(np.atleast_2d(x), 100 + cfg["k"] - 1 + g)[0] + 1.0
+                               for g in range(G)]])
+                ctx.sync(); t0 = time.perf_counter()
+                opt.add_new_data_point(x, y)
+                ctx.sync(); t1 = time.perf_counter()
+                x = opt.optimize()
+                ctx.sync(); t2 = time.perf_counter()
+                t_add.append(t1 - t0); t_opt.append(t2 - t1); xs.append(np.array(x))
+            if incremental:
+                # the refresh of the resident posterior alone (k_rank1 + Q / S), between
+                # two events on the library's stream (its own iterations: the explicit
+                # update takes the pending append, optimize() then sweeps in full)
+                for it in range(6):
+                    y = np.array([[_bumps(np.atleast_2d(x), 100 + cfg["k"] - 1 + g)[0] + 1.0
+                                   for g in range(G)]])
+                    opt.add_new_data_point(x, y)
+                    ctx.sync()
+                    ctx.timer_start()
+                    opt.update_confidence_intervals()
+                    t_r1.append(ctx.timer_stop())
+                    x = opt.optimize()
+            runs[incremental] = (np.array(xs), float(np.median(t_add[2:]) * 1e3),
+                                 float(np.median(t_opt[2:]) * 1e3),
+                                 float(np.median(t_r1[1:])) if t_r1 else None)
+        xf, addf, optf, _ = runs[False]
+        xi, addi, opti, r1 = runs[True]
+        rows = cfg["grid"].shape[0]
+        out = {
+            "note": "product defaults: shared factor + one-row factor update + rank-1 refresh "
+                    "of the resident posterior (sgp_gp_append, sgp_grid_rank1_update); "
+                    "median of iterations 3..%d from n = %d" % (iters, cfg["n"]),
+            "ms": addi + opti, "add_new_data_point_ms": addi, "optimize_ms": opti,
+            "value": rows / ((addi + opti) * 1e-3), "unit": "candidates/s",
+            "full_refit_ms": addf + optf,
+            "same_query_points": bool(np.array_equal(xf, xi)),
+        }
+        if r1:
+            # VALU-bound: n covariance evaluations + 1 FMA per row and updated GP;
+            # roof = the chip's fp64 vector rate in lane-operations (256 CUs x 4 SIMDs
+            # x 16 lanes at 2.4 GHz); ~22 instructions per RBF / 30 per Matern value
+            per = 22 if cfg["kernels"][0][0]["kind"] == "RBF" else 30
+            ops = float(rows) * cfg["G"] * (cfg["n"] + iters // 2) * per
+            out["rank1_roofline"] = {
+                "bound": "fp64 valu", "kernel": "k_rank1 (+ Q / S epilogue)",
+                "ms": r1, "achieved": ops / (r1 * 1e-3) / 1e12,
+                "peak": 39.3, "unit": "T lane-ops/s",
+                "frac": ops / (r1 * 1e-3) / 1e12 / 39.3,
+                "ops_note": "%d instructions per covariance value x n x G x rows" % per}
+    finally:
+        ctx.set_share(old_share)
+    return out
+
+
+def sets_roofline(opt, ctx, cfg, rows, steps=20):
+    """The set passes of one step (compute_sets + get_new_query_point,
+    gp_opt.py:483-649) between two events on the library's stream, after a fresh
+    confidence pass: HBM-bound chain of masked passes over Q / masks / widths."""
+    G, d = cfg["G"], cfg["d"]
+    ms = []
+    for _ in range(steps):
+        opt.update_confidence_intervals()
+        ctx.sync()
+        ctx.timer_start()
+        opt.compute_sets()
+        opt.get_new_query_point()
+        ms.append(ctx.timer_stop())
+    ms.sort()
+    t = ms[len(ms) // 2]
+    # bytes a row costs: maximisers (l0, u0, S -> M), candidates (Q, S, M -> mask, width),
+    # expander pre-filter of one candidate (S, the row, mean / var of the active GPs),
+    # arg-max (Q, M, G)
+    per_row = (16 + 2) + (16 * G + 2 + 9) + (1 + 8 * d + 16 * G) + (16 * G + 2)
+    gbs = per_row * rows / (t * 1e-3) / 1e9
+    return {"bound": "hbm", "kernels": "set passes of one step (sets.hip + expander scan)",
+            "ms": t, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_row": per_row,
+            "note": "event-to-event on the library's stream: kernels + launch gaps + the one "
+                    "host round trip of the step"}
+
+
+def config4_strong(gpy, safeopt_amd, dist, ctx, comm, rank, world, steps=4, warmup=2):
+    """BASELINE.json's 8-GPU config (3-D RBF, n = 1000, the fixed 200^3 grid,
+    row-sharded in contiguous blocks of the flat index): ms per SafeOpt.optimize() and
+    candidates/s at THIS number of ranks -- strong scaling, whatever --config the line
+    itself is for."""
+    cfg = make_config(4)
+    gps = build_gps(cfg, gpy)
+    opt = safeopt_amd.SafeOpt(gps[0], cfg["grid"], 0.0, threshold=cfg["threshold"], comm=comm)
+    for _ in range(warmup):
+        x = opt.optimize()
+    comm.barrier(); ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        x = opt.optimize()
+    ctx.sync(); comm.barrier()
+    dt = float(comm.allreduce_max(np.array([time.perf_counter() - t0]))[0])
+    rows = cfg["grid"].shape[0]
+    lo, hi = dist.shard_range(rows, rank, world)
+    return {"workload": "config4: 3-D RBF, G=1, n=1000, grid 200x200x200 = 8000000 rows, "
+                        "%d per GPU (contiguous blocks of the flat index)" % (hi - lo),
+            "scaling": "strong", "n_gpus": world, "steps": steps,
+            "ms_per_step": dt * 1e3 / steps, "value": rows / (dt / steps),
+            "unit": "candidates/s", "chosen_x": [float(v) for v in np.atleast_1d(x)]}
+
+
 def spawn_ranks(n, argv):
     """``python bench.py --gpus N`` from a bare shell: start the N ranks (one
     process per GPU, torchrun-style environment) and pass rank 0's line on."""
@@ -320,7 +448,11 @@ def main():
                     help="timed steps (default: enough for a timed region >= 0.5 s: "
                          "40 at configs 3 and 5, 500 at config 2, 6 at config 4)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5])
+    ap.add_argument("--config", type=int, default=None, choices=[2, 3, 4, 5],
+                    help="BASELINE.json config (default: 3, the north-star config, plus "
+                         "the key config4_strong: the 8-GPU config at this number of ranks)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip bo_iteration / sets_roofline / config4_strong")
     ap.add_argument("--side", type=int, default=None,
                     help="grid points per dimension (default: the config's)")
     ap.add_argument("--cpu-rows", type=int, default=None,
@@ -339,6 +471,9 @@ def main():
     ap.add_argument("--launch-check", action="store_true",
                     help="only rendezvous the ranks (no device): launcher self-test")
     args = ap.parse_args()
+    default_run = args.config is None
+    if default_run:
+        args.config = 3
     if args.steps is None:
         args.steps = {2: 500, 3: 40, 4: 6, 5: 40}[args.config]
     if args.check_chosen is None:
@@ -385,11 +520,15 @@ def main():
         units = parts.shape[0]
         rows_rank = units
 
+        # P / t of ONE _compute_particle_fitness call over all G GPs
         def step():
+            opt._compute_particle_fitness("maximizers", parts)
+
+        def step3():
             for st in ("greedy", "maximizers", "expanders"):
                 opt._compute_particle_fitness(st, parts)
-        workload = ("config5: SafeOptSwarm fitness, 4-D RBF, G=2, n=2000, "
-                    "P=%d particles, greedy+maximizers+expanders" % units)
+        workload = ("config5: ONE SafeOptSwarm._compute_particle_fitness call "
+                    "('maximizers': both GPs), 4-D RBF, G=2, n=2000, P=%d particles" % units)
     else:
         grid = cfg["grid"]
         opt = safeopt_amd.SafeOpt(gps if cfg["G"] > 1 else gps[0], grid,
@@ -408,6 +547,12 @@ def main():
                      cfg["G"], cfg["n"], "x".join(map(str, cfg["sides"])),
                      units, rows_rank))
 
+    # (the clocks ramp up over the first ~30 ms of load -- profiles/r04/clock_ramp.txt:
+    # a kernel is ~10 % slower in the first launches of a process -- so a short run of
+    # untimed steps comes in front of the W warm-up steps)
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.1:
+        step()
     for _ in range(args.warmup):
         step()
     # ---- the timed region: K steps, nothing but the path
@@ -456,6 +601,33 @@ def main():
         ctx.profile_enable(False)
         ctx.set_share(False)
         shared = (dts, s_ms, s_launches)
+
+    # ---- config 5: the step of three calls a swarm iteration makes (extra key)
+    three = None
+    if args.config == 5:
+        for _ in range(2):
+            step3()
+        ctx.sync(); t3 = time.perf_counter()
+        for _ in range(max(4, args.steps // 4)):
+            step3()
+        ctx.sync()
+        three = (time.perf_counter() - t3) / max(4, args.steps // 4)
+
+    # ---- extra keys (never inside the timed region above)
+    extras = {}
+    if not args.no_extras and args.config != 5 and args.side is None:
+        if world == 1:
+            try:
+                extras["sets_roofline"] = sets_roofline(opt, ctx, cfg, rows_rank)
+                extras["bo_iteration"] = bo_iteration(cfg, gpy, safeopt_amd, ctx)
+            except Exception as e:      # noqa -- an extra must never break the line
+                extras["extras_error"] = repr(e)
+        if default_run:
+            try:
+                extras["config4_strong"] = config4_strong(gpy, safeopt_amd, dist, ctx, comm,
+                                                          rank, world)
+            except Exception as e:      # noqa
+                extras["config4_strong"] = {"error": repr(e)}
 
     # ---- what the ranks did, for the N-rank line
     per_rank_ms = comm.allgather(np.array([prof_ms / max(launches, 1)]))[:, 0]
@@ -522,10 +694,6 @@ def main():
     if shared:
         dts, s_ms, s_launches = shared
         sfl = (cfg["n"] ** 2 + 2.0 * G * cfg["n"]) * rows_rank
-        if args.config == 5:
-            # three sweeps per step: the greedy swarm takes GP 0 only (average per launch)
-            sfl = ((cfg["n"] ** 2 + 2.0 * cfg["n"]) + 2.0 * (cfg["n"] ** 2 + 2.0 * G * cfg["n"])) \
-                * rows_rank / 3.0
         res["shared_factor"] = {
             "note": "the product default (sgp_ctx_set_share): the GPs of this config have "
                     "identical inputs, kernel and noise, so |L^-1 k|^2 is formed once and "
@@ -538,6 +706,12 @@ def main():
             "achieved": sfl / (s_ms / max(s_launches, 1) * 1e-3) / 1e12 if s_ms > 0 else 0.0,
         }
         res["shared_factor"]["frac"] = res["shared_factor"]["achieved"] / FP64_MFMA_PEAK_TFLOPS
+    res.update(extras)
+    if three is not None:
+        res["three_call_step"] = {
+            "note": "greedy + maximizers + expanders: the three fitness calls of one swarm "
+                    "iteration of SafeOptSwarm.optimize (gp_opt.py:1136-1177)",
+            "ms": three * 1e3, "value": units / three, "unit": "particles/s"}
     if args.config != 5:
         x = np.atleast_1d(last["x"])
         res["chosen_x"] = [float(v) for v in x]

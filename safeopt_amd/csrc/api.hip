@@ -119,7 +119,11 @@ int collect_gps(sgp_ctx* ctx, sgp_gp* const* gps, int G, int d, GpDev* host) {
           b->xhash.size() == size_t(b->n) && a->xhash.back() == b->xhash.back() &&
           a->prov == b->prov &&
           memcmp(&a->kern, &b->kern, sizeof(KernDesc)) == 0 &&
-          a->noise_var == b->noise_var && a->jitter == b->jitter)
+          a->noise_var == b->noise_var && a->jitter == b->jitter &&
+          // (the hashes only nominate: a collision must not hand one GP the other's
+          // |L^-1 k|^2 -- the rows themselves decide, a few KB of memcmp per launch)
+          a->xhost.size() == b->xhost.size() &&
+          memcmp(a->xhost.data(), b->xhost.data(), a->xhost.size() * sizeof(double)) == 0)
         host[g].share = host[g - 1].share >= 0 ? host[g - 1].share : g - 1;
     }
   }
@@ -316,6 +320,7 @@ int sgp_gp_set_data(sgp_gp* gp, const double* X, const double* Y, int64_t n,
   SGP_TRY(sgp_reserve(ctx, &gp->Y, size_t(gp->ld) * sizeof(double)));
   SGP_TRY(sgp_h2d(ctx, gp->X.p, X, size_t(n) * d * sizeof(double)));
   SGP_TRY(sgp_h2d(ctx, gp->Y.p, Y, size_t(n) * sizeof(double)));
+  gp->xhost.assign(X, X + size_t(n) * d);
   gp->xhash.resize(size_t(n));
   {
     uint64_t h = 14695981039346656037ull;
@@ -365,6 +370,8 @@ int sgp_gp_append(sgp_gp* gp, const double* x, double y, int* info) {
   ++gp->data_version;
   SGP_TRY(append_gp(gp, y, info));
   if (gp->n == n0 + 1) {
+    gp->xhost.resize(size_t(n0) * d);
+    gp->xhost.insert(gp->xhost.end(), x, x + d);
     gp->xhash.resize(size_t(n0));
     gp->xhash.push_back(hash_rows(n0 > 0 ? gp->xhash.back() : 14695981039346656037ull, x,
                                   size_t(d)));
@@ -379,6 +386,7 @@ int sgp_gp_pop(sgp_gp* gp) {
   SGP_CHECK(ctx, gp->n > 1, "cannot remove the only training point");
   ++gp->data_version;
   SGP_TRY(pop_gp(gp));
+  gp->xhost.resize(size_t(gp->n) * gp->kern.d);
   gp->xhash.resize(size_t(gp->n));
   gp->prov = gp->prov * 1099511628211ull + 3;
   return 0;

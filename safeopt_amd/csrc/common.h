@@ -175,6 +175,8 @@ struct sgp_gp {
   int ld = 0;     // leading dimension / row capacity of Linv, Kmat, work
   uint64_t serial = 0;           // unique per sgp_gp_create
   uint64_t data_version = 0;     // bumped by every fit / append / removal
+  std::vector<double> xhost;     // host copy of the training rows (n x d): the EXACT
+                                 // check behind a hash match of two GPs' inputs
   std::vector<uint64_t> xhash;   // xhash[i]: hash of the first i + 1 training rows
   uint64_t prov = 0;             // hash of the operations that led to this factor
                                  // (fit at n, appends, removals): two GPs with equal

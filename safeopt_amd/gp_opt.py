@@ -161,6 +161,12 @@ class GaussianProcessOptimization(object):
         self._x, self._y = self._x[:-1, :], self._y[:-1, :]
 
 
+#: Hook of the CPU test-suite (tests/_oracle_backend.py): a callable ``(gps, rows of
+#: this rank, global offset) -> backend`` that stands in for ``_HipGridBackend`` so the
+#: sharded host logic can run without a GPU.  None in the product.
+_BACKEND_FACTORY = None
+
+
 class _WriteBackView(np.ndarray):
     """View of the host mirror of ``Q`` that remembers element-wise writes: the
     reference mutates ``opt.Q`` in place (``gp_opt.py:374-390, 475-476``) and user
@@ -175,10 +181,17 @@ class _WriteBackView(np.ndarray):
         self._owner = getattr(obj, '_owner', None)
 
     def __setitem__(self, key, value):
-        np.ndarray.__setitem__(self, key, value)
         owner = self._owner() if self._owner is not None else None
-        if owner is not None:
+        # only writes that land IN the mirror count: a copy of opt.Q, or an array
+        # computed from it, inherits this class but not the memory
+        if owner is not None and np.may_share_memory(self, owner._Q):
+            # the mirror may lag behind the device (a sweep since this view was
+            # taken): bring it up to date first -- in the reference the array is live
+            owner._mirror('Q', _hip.Q)
+            np.ndarray.__setitem__(self, key, value)
             owner._q_written = True
+        else:
+            np.ndarray.__setitem__(self, key, value)
 
 
 class _HipGridBackend(object):
@@ -357,7 +370,7 @@ class SafeOpt(GaussianProcessOptimization):
 
     def __init__(self, gp, parameter_set, fmin, lipschitz=None, beta=2,
                  num_contexts=0, threshold=0, scaling='auto', comm=None,
-                 _backend_factory=None):
+                 ):
         super(SafeOpt, self).__init__(gp, fmin=fmin, beta=beta,
                                       num_contexts=num_contexts,
                                       threshold=threshold, scaling=scaling)
@@ -389,8 +402,8 @@ class SafeOpt(GaussianProcessOptimization):
         self._comm = comm if comm is not None else LocalComm()
         self._shard = shard_range(N, self._comm.rank, self._comm.world)
         lo, hi = self._shard
-        if _backend_factory is not None:          # tests: NumPy stand-in
-            self._backend = _backend_factory(self.gps, self.inputs[lo:hi], lo)
+        if _BACKEND_FACTORY is not None:          # CPU tests: NumPy stand-in
+            self._backend = _BACKEND_FACTORY(self.gps, self.inputs[lo:hi], lo)
         else:
             self._backend = _HipGridBackend(self.gps, self.inputs[lo:hi], lo,
                                             ctx=getattr(self._comm, 'ctx', None),

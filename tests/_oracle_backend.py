@@ -168,3 +168,16 @@ class OracleGridBackend(object):
 
     def download(self, what):
         return {Q_: self.Q, S_: self.S, M_: self.M, G_: self.G}[what]
+
+
+def use_oracle_backend():
+    """Install the NumPy stand-in as SafeOpt's grid backend (the product's hook for the
+    CPU test-suite, ``safeopt_amd.gp_opt._BACKEND_FACTORY``); ``reset_backend`` undoes it
+    (tests/conftest.py does so after every test)."""
+    import safeopt_amd.gp_opt as go
+    go._BACKEND_FACTORY = OracleGridBackend
+
+
+def reset_backend():
+    import safeopt_amd.gp_opt as go
+    go._BACKEND_FACTORY = None

@@ -28,3 +28,15 @@ def hip_device():
     n = _hip.device_count()
     assert n > 0, "gpu-marked test needs a HIP device and libsafeopt_hip.so"
     return 0
+
+
+@pytest.fixture(autouse=True)
+def _product_backend_after_each_test():
+    """CPU tests may install the NumPy stand-in for the grid backend
+    (``_oracle_backend.use_oracle_backend``); no test inherits it."""
+    yield
+    try:
+        import safeopt_amd.gp_opt as go
+        go._BACKEND_FACTORY = None
+    except Exception:
+        pass

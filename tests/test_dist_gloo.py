@@ -53,7 +53,8 @@ def _worker(rank, world, port, names, q):
         import safeopt_amd
         from oracle import gp_numpy as gpn
         from _golden import load, make_kernel
-        from _oracle_backend import OracleGridBackend
+        from _oracle_backend import OracleGridBackend, use_oracle_backend
+        use_oracle_backend()
         comm = TorchComm()
         report = []
         for name in names:
@@ -76,7 +77,7 @@ def _worker(rank, world, port, names, q):
                     gps if G > 1 else gps[0], z["parameter_set"],
                     meta["fmin"] if G > 1 else meta["fmin"][0], lipschitz=lip, beta=beta,
                     threshold=meta["threshold"], num_contexts=meta.get("num_contexts", 0),
-                    comm=comm, _backend_factory=OracleGridBackend)
+                    comm=comm)
                 lo, hi = opt._shard
                 assert hi - lo < z["parameter_set"].shape[0]        # really sharded
                 ctx = z[pre + "context"] if meta.get("num_contexts") else None
@@ -125,7 +126,8 @@ def test_three_way_shard_single_process():
     import safeopt_amd
     from oracle import gp_numpy as gpn
     from _golden import load, make_kernel
-    from _oracle_backend import OracleGridBackend
+    from _oracle_backend import OracleGridBackend, use_oracle_backend
+    use_oracle_backend()
     import threading
 
     class ThreadComm(object):
@@ -158,8 +160,7 @@ def test_three_way_shard_single_process():
         gp = gpn.GPRegression(z["X0"], z["Y0"], make_kernel(gpn, meta["kernels"][0]),
                               noise_var=meta["noise_vars"][0])
         opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"],
-                                  comm=ThreadComm(rank, world, shared),
-                                  _backend_factory=OracleGridBackend)
+                                  comm=ThreadComm(rank, world, shared))
         x = opt.optimize()
         out[rank] = (x, opt.S.copy(), opt.M.copy(), opt.G.copy())
 
@@ -179,7 +180,8 @@ def test_q_written_in_place_on_three_ranks():
     import safeopt_amd
     from oracle import gp_numpy as gpn
     from _golden import load, make_kernel
-    from _oracle_backend import OracleGridBackend
+    from _oracle_backend import OracleGridBackend, use_oracle_backend
+    use_oracle_backend()
     import threading
 
     class ThreadComm(object):
@@ -208,7 +210,7 @@ def test_q_written_in_place_on_three_ranks():
         gp = gpn.GPRegression(z["X0"], z["Y0"], make_kernel(gpn, meta["kernels"][0]),
                               noise_var=meta["noise_vars"][0])
         opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"],
-                                  comm=comm, _backend_factory=OracleGridBackend)
+                                  comm=comm)
         opt.update_confidence_intervals()
         n = z["parameter_set"].shape[0]
         opt.Q[n // 5:n // 2, 0] -= 0.2          # spans shard boundaries

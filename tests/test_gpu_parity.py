@@ -737,8 +737,14 @@ def test_tied_widths_golden(mods, seed):
     assert_array_equal(x, z["parameter_set"][son.query_index(z["Q"], So, Mo, Go, meta["scaling"])])
     # which tied candidate argsort()[::-1] visits first is NumPy's choice: with the
     # NumPy that wrote the fixture the REFERENCE's own G / x_next must come out
-    if meta.get("numpy_version") == np.__version__ or np.array_equal(Go, z["G"]):
+    same_numpy = meta.get("numpy_version") == np.__version__
+    if same_numpy or np.array_equal(Go, z["G"]):
         assert_array_equal(opt.G, z["G"]); assert_array_equal(x, z["x_next"])
+        print("ties seed %d: asserted the REFERENCE's G / x_next (NumPy here %s, fixture %s)"
+              % (seed, np.__version__, meta.get("numpy_version")))
+    else:
+        print("ties seed %d: NumPy here %s sorts ties unlike the fixture's %s: asserted the "
+              "LOCAL oracle only" % (seed, np.__version__, meta.get("numpy_version")))
     # the whole step in one call gives the same sets (Q is recomputed: no ties then,
     # but the path through sets_fused with its tie count must still agree)
     assert_array_equal(opt.S, z["S"]); assert_array_equal(opt.M, z["M"])
@@ -1152,6 +1158,41 @@ def test_full_size_config5_fitness(mods):
     assert_array_equal(out["maximizers"][1], out["expanders"][1])
     assert_array_equal(out["maximizers"][1], out["safe_set"][1])
     assert out["safe_set"][1].any() and not out["safe_set"][1].all()
+
+
+@pytest.mark.timeout(900)
+def test_config4_whole_shard_against_oracle(mods):
+    """BASELINE.json config 4, rank 4's TRUE shard (rows [4e6, 5e6) of the 200^3 grid,
+    n = 1000): every one of its 1e6 rows against the oracle -- Q, S, the safe maximum
+    (the other full-size tests check spot rows + properties; ~30 s of host work)."""
+    import bench
+    sa, gpy, gpn, son = mods
+    from safeopt_amd import _hip
+    cfg = bench.make_config(4)
+    lo, hi = 4000000, 5000000
+    gps = bench.build_gps(cfg, gpy)
+    gos = bench.build_gps(cfg, gpn)
+    devs = [g._fitted() for g in gps]
+    ctx = devs[0].ctx
+    grid = _hip.DeviceGrid(ctx, cfg["grid"][lo:hi], 1, lo)
+    assert grid.set_axes(_hip.tensor_grid_axes(cfg["grid"]))
+    fmin = np.zeros(1)
+    max_l, any_safe = grid.confidence(devs, 2.0, fmin)
+    Q = grid.download(_hip.Q); S = grid.download(_hip.S)
+    Qo = np.empty_like(Q)
+    for a in range(lo, hi, 50000):
+        m, v = gos[0].predict_noiseless(cfg["grid"][a:a + 50000])
+        sd = np.sqrt(v[:, 0])
+        Qo[a - lo:a - lo + 50000, 0] = m[:, 0] - 2.0 * sd
+        Qo[a - lo:a - lo + 50000, 1] = m[:, 0] + 2.0 * sd
+    assert_allclose(Q, Qo, rtol=0, atol=5e-8)
+    So = Qo[:, 0] > 0.0
+    # (rows whose lower bound sits within the posterior tolerance of fmin may differ)
+    edge = np.abs(Qo[:, 0]) < 1e-7
+    assert_array_equal(S[~edge].astype(bool), So[~edge])
+    assert any_safe == bool(S.any())
+    if S.any():
+        assert max_l == Q[S.astype(bool), 0].max()
 
 
 @pytest.mark.parametrize("k,side", [(2, 250), (3, 120), (4, 30)])

@@ -175,12 +175,12 @@ def test_tie_settlement_matches_reference(seed):
     import safeopt_amd
     from oracle import gp_numpy as gpn
     from _golden import load, make_kernel
-    from _oracle_backend import OracleGridBackend
+    from _oracle_backend import OracleGridBackend, use_oracle_backend
+    use_oracle_backend()
     z, meta = load("ties_1d_seed%d" % seed)
     gp = gpn.GPRegression(z["X0"], z["Y0"], make_kernel(gpn, meta["kernels"][0]),
                           noise_var=meta["noise_vars"][0])
-    opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"],
-                              _backend_factory=OracleGridBackend)
+    opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"])
     opt.Q = z["Q"]
     be = opt._backend
     for i, g in enumerate(be.gps):      # the stand-in predicts from the GP; Q is assigned
@@ -235,14 +235,14 @@ def test_q_mirror_writes_reach_the_device_and_the_setter_uploads():
     import safeopt_amd
     from oracle import gp_numpy as gpn
     from _golden import load, make_kernel
-    from _oracle_backend import OracleGridBackend
+    from _oracle_backend import OracleGridBackend, use_oracle_backend
+    use_oracle_backend()
     z, meta = load("ties_1d_seed0")
 
     def make():
         gp = gpn.GPRegression(z["X0"], z["Y0"], make_kernel(gpn, meta["kernels"][0]),
                               noise_var=meta["noise_vars"][0])
-        opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"],
-                                  _backend_factory=OracleGridBackend)
+        opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"])
         opt.update_confidence_intervals()
         return opt
     opt = make()
@@ -271,3 +271,39 @@ def test_q_mirror_writes_reach_the_device_and_the_setter_uploads():
     a.Q[:, 0] = -9.0
     a.update_confidence_intervals()
     assert np.array_equal(a.Q, make().Q)
+
+
+def test_q_writes_into_copies_and_stale_views():
+    """  Only writes that land in the mirror of ``Q`` may be flushed
+    to the device: a copy of ``opt.Q`` or an array computed from it inherits the view
+    class, not the memory; and a view taken BEFORE a sweep is live like the
+    reference's array -- a write through it lands on the fresh intervals."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import safeopt_amd
+    from oracle import gp_numpy as gpn
+    from _oracle_backend import use_oracle_backend
+    use_oracle_backend()
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-2, 2, size=(6, 1)); Y = np.cos(X) + 1.0
+    grid = safeopt_amd.linearly_spaced_combinations([(-3., 3.)], 50)
+    gp = gpn.GPRegression(X, Y, gpn.RBF(1, 2., 1.), noise_var=0.05 ** 2)
+    opt = safeopt_amd.SafeOpt(gp, grid, 0., threshold=0.1)
+    opt.optimize()
+    w = opt.Q[:, 1] - opt.Q[:, 0]            # derived array
+    c = opt.Q.copy()                         # copy
+    held = opt.Q                             # a view of the mirror itself
+    opt.add_new_data_point(np.array([[0.5]]), np.array([[1.7]]))
+    opt.update_confidence_intervals()
+    fresh = np.array(opt._backend.download(safeopt_amd._hip.Q) if False else opt.Q)
+    w[...] = 0.0; c[...] = -1.0
+    assert not opt._q_written                # neither touched the mirror
+    opt.compute_sets()
+    assert np.array_equal(np.asarray(opt.Q), fresh)
+    # a write through the view held from before the sweep: lands on the FRESH intervals
+    held[3, 0] = -5.0
+    assert opt._q_written
+    expect = fresh.copy(); expect[3, 0] = -5.0
+    opt.compute_sets()
+    assert np.array_equal(np.asarray(opt.Q), expect)
+    assert not opt.S[3]
