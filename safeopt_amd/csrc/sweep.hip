@@ -487,7 +487,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   double kdiag;
   int nr_cur = 0;
   auto load_gp = [&](int g) {
+#ifdef SGP_KF_CTOR
+    if (SEP == 0) kf = KernFast<D>(p.gps[g].kern);
+#else
     if (SEP == 0) kf.load_const(&p.gps[g].kern);
+#endif
     kdiag = gpc[g].kern.kdiag;
     if (R > 0) nr_cur = p.nride[g];
   };
@@ -584,6 +588,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     // the stage: they arrive under the evaluation.  (All kMaxNg groups whether the GP
     // has them or not: the reads stay inside the slot.)
     const int ngrp = (wcur & SW_NARROW) ? int(wcur >> SW_NGRP_SHIFT) & 3 : 0;
+    // the full slots of this stage (sweep_slots.h): the operands of the first one are
+    // requested now
+    const int nfull = int(wcur & SW_NACT_MASK) - (ngrp > 0 ? 1 : 0);
+    const uint32_t abase = lds0 + uint32_t(par) * (kBuf * 8u) + uint32_t(lane) * 8u +
+                           (ngrp > 0 ? kSteps * 512u : 0u);
+    SgpEntryOps entry;
+    if (nfull > 0 && !SGP_ABL(8))
+      sgp_slots_prefetch(nfull, cbuf + lane + (ngrp > 0 ? kSteps * 64 : 0), entry);
     double an[kMaxNg][4];
     auto load_an = [&]() {
       const double* aN = cbuf + (lane & 0x33);
@@ -635,13 +647,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     if (kDmaLate && more && !SGP_ABL(2)) prefetch(e1, par ^ 1);
     if (!SGP_ABL(8)) {
       // the full slots: sweep_slots.h (hand-written, accumulators in a0..a127)
-      const int shift = ngrp > 0 ? 1 : 0;
-      const int nfull = int(wcur & SW_NACT_MASK) - shift;
-      if (nfull > 0)
-        sgp_slots(nfull, int(wcur & SW_FIRST),
-                  lds0 + uint32_t(par) * (kBuf * 8u) + uint32_t(lane) * 8u +
-                      uint32_t(shift) * (kSteps * 512u),
-                  kb);
+      if (nfull > 0) sgp_slots(nfull, int(wcur & SW_FIRST), abase, kb, entry);
     }
 
     SGP_STAMP(4);   // full slots

@@ -73,7 +73,8 @@ def split_args(rest):
 
 
 def isa(path, flags):
-    extra = ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"] if path.endswith("sweep.hip") else []
+    extra = ["-Wno-inline-asm"] + (["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]
+                                   if path.endswith("sweep.hip") else [])
     r = subprocess.run(
         ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I",
          os.path.join(ROOT, "include"), "-I", CSRC, "-S", "--cuda-device-only", "-o", "-",
