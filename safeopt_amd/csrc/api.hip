@@ -672,7 +672,7 @@ static const SepLaunch* sep_launch(sgp_grid* g, sgp_gp* const* gps, const GpDev*
   int cols[SGP_MAX_D], na = 0;
   for (int k = 0; k < g->d; ++k)
     if (g->ax_count[k] > 1) cols[na++] = k;
-  if (na < 1 || na > 4) return nullptr;
+  if (na < 1 || na > 3) return nullptr;      // (4 axes: evaluated, launch_posterior)
   std::sort(cols, cols + na, [&](int a, int b) { return g->ax_stride[a] < g->ax_stride[b]; });
   sl->naxes = na;
   sl->goff = g->goff;

@@ -182,15 +182,6 @@ __device__ __forceinline__ StageEnt load_stage(stage_ptr_t t, int i) {
 }
 typedef const __attribute__((address_space(4))) GpDev* gpdev_cptr_t;
 
-// a wave-uniform pointer, pinned to scalar registers
-template <typename T>
-__device__ __forceinline__ const T* uniform_ptr(const T* q) {
-  const uint64_t v = reinterpret_cast<uint64_t>(q);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v));
-  const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
-  return reinterpret_cast<const T*>((uint64_t(hi) << 32) | lo);
-}
-
 constexpr int kSweepRide = 2;      // riders per leader (what two workgroups' LDS holds)
 
 // ---- matrix part ------------------------------------------------------------------
@@ -354,7 +345,14 @@ template <int D, int NW, int SL, int MODE, bool SINGLE, int R = 0, int SEP = 0>
 __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   constexpr int kTilePts = 16 * NW;
   // (2 kMaxNg doubles live across the evaluation: where the registers are to be had)
-  constexpr bool kAnEarly = (SGP_AN_EARLY && D <= 2 && R == 0) || (SGP_AN_EARLY_SEP && SEP > 0);
+  constexpr bool kAnEarly = (SGP_AN_EARLY && D <= 2 && R == 0) ||
+                            (SGP_AN_EARLY_SEP && SEP > 0 && SEP <= 2 && !(SEP == 2 && R > 0));
+  // d >= 5 (and products at d = 4): no registers for the raw row of this tile and of
+  // the next one -- the row is read (an L2 hit) where a GP's scaled row is formed
+  constexpr bool kLeanX = SEP == 0 && (D >= 5 || (D == 4 && !SINGLE));
+  // the entry operands of the slot sequence: requested at the top of the stage (8
+  // registers across the evaluation) or, where those are not to be had, in front of it
+  constexpr bool kEntryEarly = D <= 5;
   // where the LDS-DMA of the next stage is issued: at the top of the stage, or in front
   // of the full slots (measured per variant: with factor tables the table loads want
   // the head of the queue)
@@ -392,10 +390,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     for (int k = 0; k < D; ++k)
       xo[k] = __builtin_nontemporal_load(p.pts.base + r * p.pts.stride_row + k * p.pts.stride_col);
   };
-  double x[D], xnext[D];
-  if (SEP == 0) load_x(tile, x);
+  double x[kLeanX ? 1 : D], xnext[kLeanX ? 1 : D];
+  if constexpr (!kLeanX) {
+    if (SEP == 0) load_x(tile, x);
 #pragma unroll
-  for (int k = 0; k < D; ++k) xnext[k] = SEP == 0 ? x[k] : 0.0;
+    for (int k = 0; k < D; ++k) xnext[k] = SEP == 0 ? x[k] : 0.0;
+  }
   // SEP: byte offsets of this lane's row (lane & 15) and training points (4 (lane >> 4)
   // .. + 3 of a block of 16) in the tables of the tile being PREFETCHED; axis a's index
   // = (global row / stride_a) % count_a with stride_a = count_0 .. count_{a-1}
@@ -555,7 +555,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       if (!kDmaLate && !SGP_ABL(2)) prefetch(e1, par ^ 1);
       const bool next_tile = si1 == 0;
       if (SEP == 0) {
-        if (next_tile) load_x(tile_p, xnext);
+        if constexpr (!kLeanX) {
+          if (next_tile) load_x(tile_p, xnext);
+        }
       } else {
         if (next_tile) sep_offsets(tile_p);
         sep_fetch(e1);
@@ -579,7 +581,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
 #endif
     // ---- this stage: 16 training points against the active row blocks
     if (SEP == 0 && gp_start) {
-      kf.template prep_t<SINGLE>(x, xs);
+      if constexpr (kLeanX) {
+        double xr[D];
+        load_x(tile, xr);
+        kf.template prep_t<SINGLE>(xr, xs);
+      } else {
+        kf.template prep_t<SINGLE>(x, xs);
+      }
       gp_start = false;
     }
     const double* xT = cbuf + kATile;
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     const uint32_t abase = lds0 + uint32_t(par) * (kBuf * 8u) + uint32_t(lane) * 8u +
                            (ngrp > 0 ? kSteps * 512u : 0u);
     SgpEntryOps entry;
-    if (nfull > 0 && !SGP_ABL(8))
+    if (kEntryEarly && nfull > 0 && !SGP_ABL(8))
       sgp_slots_prefetch(nfull, cbuf + lane + (ngrp > 0 ? kSteps * 64 : 0), entry);
     double an[kMaxNg][4];
     auto load_an = [&]() {
@@ -647,6 +655,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     if (kDmaLate && more && !SGP_ABL(2)) prefetch(e1, par ^ 1);
     if (!SGP_ABL(8)) {
       // the full slots: sweep_slots.h (hand-written, accumulators in a0..a127)
+      if (!kEntryEarly && nfull > 0)
+        sgp_slots_prefetch(nfull, cbuf + lane + (ngrp > 0 ? kSteps * 64 : 0), entry);
       if (nfull > 0) sgp_slots(nfull, int(wcur & SW_FIRST), abase, kb, entry);
     }
 
@@ -755,8 +765,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
         }
         safe = true;
         l0 = 0.0;
+        if constexpr (!kLeanX) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) x[k] = xnext[k];
+          for (int k = 0; k < D; ++k) x[k] = xnext[k];
+        }
         tile += tstep;
       }
       if (more) {   // hyper-parameters of the next GP
@@ -1341,7 +1353,7 @@ int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d,
                      double flops, const SepLaunch* sep) {
   if (pair_sweep_wanted(ctx, gh, Geff)) {
     SweepArgs a{p.gps, p.G, p.mode, p.pts, p.conf, p.fit};
-    return launch_sweep_pair(ctx, a, gh, d, Geff, flops);   // (sets ctx->sweep_partials)
+    return launch_sweep_pair(ctx, a, gh, d, Geff, flops, sep);   // (sets ctx->sweep_partials)
   }
   ctx->sweep_partials = sweep_grid_blocks(ctx->num_cu, p.pts.N, sweep_waves(), 16) *
                         sweep_waves();
@@ -1377,8 +1389,9 @@ int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d,
       case 2: return launch_sweep_sep<2>(ctx, q, flops);
 #ifndef SGP_ONLY_D2
       case 3: return launch_sweep_sep<3>(ctx, q, flops);
-      case 4: return launch_sweep_sep<4>(ctx, q, flops);
 #endif
+      // (4 axes: 32 registers of factors in flight -- the instance would spill; the
+      // covariances are evaluated, below)
     }
   }
   switch (d) {

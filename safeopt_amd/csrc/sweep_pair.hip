@@ -72,7 +72,7 @@ struct PStage {
   uint32_t rs_bytes;   // bytes between consecutive row blocks in Apack
   uint32_t word;       // PW_*
   uint32_t g_next;     // GP of the NEXT stage (whose riders' alpha blocks go with xa_next)
-  uint32_t pad1;
+  uint32_t jb;         // j-block of THIS stage (factor tables: row [jb] of every axis)
 };
 enum : uint32_t {
   PW_NACT_MASK = 63u,       // active global slots 0 .. nact-1 (1..32)
@@ -149,6 +149,7 @@ struct PairParams {
   double* split_t;        // [split_count][nchunks][512]
   double* split_m;        // [split_count][geff][512]
   int split_partial0;     // first slot of the finish kernel in ConfOut::partial
+  SepLaunch sep;          // tensor grid + factor tables (instances with SEP > 0)
 #ifdef SGP_INSTRUMENT
   int ablate;
 #endif
@@ -187,8 +188,8 @@ __device__ __forceinline__ PStage load_pstage(pstage_ptr_t t, int i) {
   e.xa_next = t[i].xa_next;
   e.rs_bytes = t[i].rs_bytes;
   e.word = t[i].word;
+  e.jb = t[i].jb;
   e.g_next = RIDE ? t[i].g_next : 0;
-  e.pad1 = 0;
   return e;
 }
 
@@ -249,8 +250,10 @@ __device__ __forceinline__ void dma_group(const DmaPlan& d, int i) {
 // sweep_shared.h).  The compiler cannot pad hazards around instructions it does not
 // see, and in instances that SPILL it stores accumulators right behind their last
 // MFMA (needs 9 wait states, gets 0 -- scripts/dev/check_mfma_hazards.py finds
-// such code): the instances for d >= 6, the ones that run out of registers, use the
-// builtin instead (a few register copies at the joins of the slot sequence).
+// such code).  Until round 4 the instances for d >= 6 spilled and used the builtin
+// instead (a few register copies at the joins of the slot sequence); since no
+// instance has scratch any more (d >= 7 without registers for the raw rows, kLeanX)
+// all of them take the asm path, and the scanner runs over every one of them.
 template <int S, bool NARROW_OK, int kGroups, bool ASM_MFMA>
 __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
                                            double (&acc)[kWaveSlots][4], double& accx,
@@ -429,7 +432,11 @@ __device__ __forceinline__ void row_epilogue(const PairParams& p, RowState& rs,
 // The persistent stage loop of one wave; H = its half of the pair (compile time: half 0
 // copies the A chunks and owns the narrow slot, half 1 finishes the pair's rows),
 // R = riders per leader the instance can carry (0 or kMaxRide).
-template <int D, int MODE, bool SINGLE, int H, int R>
+// SEP > 0: the rows are a tensor grid with SEP axes and every kernel a product of RBF
+// parts (SepLaunch, sweep.hip): a covariance is the product of SEP table entries -- one
+// 16-byte load per axis, lane and stage, requested a stage ahead -- instead of ~20 fp64
+// instructions per value.  (Instantiated with D = 1: the rows themselves are not read.)
+template <int D, int MODE, bool SINGLE, int H, int R, int SEP>
 __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
                                           const int lane, const int wave) {
   typedef LayP<D, R> L;
@@ -473,9 +480,57 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   // x_raw: raw rows of the tile being evaluated -- until the scaled rows of its
   // LAST GP are formed, from then on already the rows of the next tile (the load
   // has a whole GP's stages to arrive)
-  double x_raw[D], xs_e[D];
+  // (d >= 7: no registers for the raw row -- it is read, an L2 hit, where a GP's scaled
+  // row is formed)
+  constexpr bool kLeanX = D >= 7;
+  double x_raw[kLeanX ? 1 : D], xs_e[D];
   int tile_e = tile;
   KernFast<D> kf;
+  // SEP: byte offsets of this lane's row (c16) and training points (8 H + k4 and 4
+  // further: positions 4 k4 + 2 H, + 1 of a block of 16) in the tables, for the tile of
+  // the stage whose factors are being REQUESTED (tile_f); axis a's index =
+  // (global row / stride_a) % count_a with stride_a = count_0 .. count_{a-1}
+  constexpr int kAx = SEP > 0 ? SEP : 1;
+  uint32_t soff[kAx];
+  int tile_f = tile;
+  auto sep_offsets = [&](int t) {
+    int64_t r = int64_t(t) * kTileRows + pr * 16 + c16;
+    r = r < p.pts.N ? r : p.pts.N - 1;
+    uint32_t q = uint32_t(p.sep.goff + r);
+#pragma unroll
+    for (int a = 0; a < kAx; ++a) {
+      uint32_t idx = q;
+      if (a + 1 < kAx) {
+        const uint32_t c = p.sep.count[a];
+        const uint32_t qn = q / c;
+        idx = q - qn * c;
+        q = qn;
+      }
+      soff[a] = idx * 128u + uint32_t(k4) * 32u + uint32_t(H) * 16u;
+    }
+  };
+  double2_t efn[kAx];
+  const char* sep_tab[kAx];
+  uint32_t sep_pitch[kAx];
+  int sep_g = -1;
+  auto sep_fetch = [&](const PStage& e) {
+    const int g = int(e.word >> PW_G_SHIFT) & 7;
+    if (g != sep_g) {
+      sep_g = g;
+#pragma unroll
+      for (int a = 0; a < kAx; ++a) {
+        sep_tab[a] = reinterpret_cast<const char*>(uniform_ptr(p.sep.tab[g][a]));
+        sep_pitch[a] = __builtin_amdgcn_readfirstlane(p.sep.count[a] * 128u);
+      }
+    }
+    // (explicitly GLOBAL loads: a flat load also counts on lgkmcnt)
+    typedef const __attribute__((address_space(1))) double2_t* gvec_t;
+#pragma unroll
+    for (int a = 0; a < kAx; ++a) {
+      const char* src = sep_tab[a] + e.jb * sep_pitch[a];      // (tables below 4 GB)
+      efn[a] = *(gvec_t)(reinterpret_cast<const double2_t*>(src + soff[a]));
+    }
+  };
 
   // covariances of one stage: this wave's half (training points 8 H .. 8 H + 7 of
   // the j-block) -> the pair's B buffer, [k][q pair][point][2]
@@ -507,17 +562,32 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   // reads its rows itself)
   constexpr bool kRowsFirst = kOpsEarly != 0 && SINGLE && D <= 2;
   auto evaluate = [&](uint32_t w1, const Rows& r, const double* xa, double* kbw) {
-    if (__builtin_expect((w1 & PW_GP_FIRST) != 0, 0)) {
+    if (SEP == 0 && __builtin_expect((w1 & PW_GP_FIRST) != 0, 0)) {
       kf.load_const(&p.gps[int(w1 >> PW_G_SHIFT) & 7].kern);
       if (R > 0) nr_e = p.nride[int(w1 >> PW_G_SHIFT) & 7];
-      kf.template prep_t<SINGLE>(x_raw, xs_e);
-      if (w1 & PW_LAST_GP) {
-        tile_e += tstep;
-        load_x(tile_e, x_raw);
+      if constexpr (kLeanX) {
+        double xr[D];
+        load_x(tile_e, xr);
+        kf.template prep_t<SINGLE>(xr, xs_e);
+        if (w1 & PW_LAST_GP) tile_e += tstep;
+      } else {
+        kf.template prep_t<SINGLE>(x_raw, xs_e);
+        if (w1 & PW_LAST_GP) {
+          tile_e += tstep;
+          load_x(tile_e, x_raw);
+        }
       }
     }
     double kv[2];
-    if (!PGP_ABL(4)) {
+    if constexpr (SEP > 0) {
+      kv[0] = efn[0].x;
+      kv[1] = efn[0].y;
+#pragma unroll
+      for (int a = 1; a < kAx; ++a) {
+        kv[0] *= efn[a].x;
+        kv[1] *= efn[a].y;
+      }
+    } else if (!PGP_ABL(4)) {
       if (kRowsFirst)
         kf.template manyn_t<2, SINGLE>(xs_e, r.y, D, tab, kv);
       else
@@ -612,7 +682,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       const bool narrow0 = H == 0 && (w & PW_NARROW) != 0;
       const double* aT = abuf + H * (kSteps * 64) + lane;
       double opsB[4];
-      pair_slots<0, H == 0, kDmaGroups, (D <= 5)>(nw, narrow0, acc, accx, aT, o.kb,
+      pair_slots<0, H == 0, kDmaGroups, true>(nw, narrow0, acc, accx, aT, o.kb,
                                                   o.kvn, o.a0, opsB, dma);
     }
     if constexpr (kDmaGroups > 0) {
@@ -732,12 +802,23 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   ++left;
   si1 = s_lo;
   tile_e = tile;
-  load_x(tile_e, x_raw);
-  if (!(e1.word & PW_GP_FIRST)) {
+  if constexpr (SEP > 0) {
+    tile_f = tile;
+    sep_offsets(tile_f);
+    sep_fetch(e1);
+  }
+  if constexpr (!kLeanX && SEP == 0) load_x(tile_e, x_raw);
+  if (SEP == 0 && !(e1.word & PW_GP_FIRST)) {
     // the item begins inside a GP (a run of chunks of a remainder tile)
     kf.load_const(&p.gps[int(e1.word >> PW_G_SHIFT) & 7].kern);
     if (R > 0) nr_e = p.nride[int(e1.word >> PW_G_SHIFT) & 7];
-    kf.template prep_t<SINGLE>(x_raw, xs_e);
+    if constexpr (kLeanX) {
+      double xr[D];
+      load_x(tile_e, xr);
+      kf.template prep_t<SINGLE>(xr, xs_e);
+    } else {
+      kf.template prep_t<SINGLE>(x_raw, xs_e);
+    }
   }
   wait_dma();
   __syncthreads();
@@ -843,6 +924,18 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       }
     }
     if (more) evaluate(wnext, rows, xa, kbw);
+    if constexpr (SEP > 0) {
+      // the factors of the stage after the next one (its entry, e2, was requested
+      // above: it has arrived under the evaluation); they have the matrix phase to come
+      if (left > 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (si2 == 0) {
+          tile_f += tstep;
+          sep_offsets(tile_f);
+        }
+        sep_fetch(e2);
+      }
+    }
     PGP_STAMP(3);     // covariance evaluation
     fetch_ops(abuf, kbr, ops, kOpsEarly ? 2 : 3);
     if constexpr (kXaHalf0 && H == 0) {
@@ -900,7 +993,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   }
 }
 
-template <int D, int MODE, bool SINGLE, int R = 0>
+template <int D, int MODE, bool SINGLE, int R = 0, int SEP = 0>
 __global__ __launch_bounds__(512, 1) void k_sweep_pair(PairParams p) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   exp_tab_init(lds + LayP<D, R>::kTabOff);   // visible after the first barrier
@@ -908,9 +1001,9 @@ __global__ __launch_bounds__(512, 1) void k_sweep_pair(PairParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (wave < 4)
-    pair_loop<D, MODE, SINGLE, 0, R>(p, lds, lane, wave);
+    pair_loop<D, MODE, SINGLE, 0, R, SEP>(p, lds, lane, wave);
   else
-    pair_loop<D, MODE, SINGLE, 1, R>(p, lds, lane, wave);
+    pair_loop<D, MODE, SINGLE, 1, R, SEP>(p, lds, lane, wave);
 }
 
 // Remainder tiles that were cut into runs of chunks (PairParams::split_*): the
@@ -968,10 +1061,12 @@ __global__ __launch_bounds__(512) void k_pair_split_finish(PairParams p) {
 // of L^-1, the j-blocks 0 .. bend-1.  Entries hold absolute addresses, so the
 // table is rebuilt when a block count OR a buffer address changes (buffers are
 // sized for the pitch of L^-1: one-row appends keep their addresses).
-int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, const bool* rides,
+// sep: the launch reads factor tables -- the training block of a stage is its 16 alpha
+// only (the D = 1 instance copies 256 bytes: the address is that of alpha - 128).
+int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, bool sep, const bool* rides,
                      const PStage** dev, int* nstages) {
   std::vector<uint64_t> sig(1, uint64_t(Geff));
-  sig.push_back(uint64_t(d));
+  sig.push_back(uint64_t(d) | (uint64_t(sep) << 8));
   int last_staged = 0;
   for (int g = 0; g < Geff; ++g)
     if (!rides[g]) last_staged = g;
@@ -992,6 +1087,7 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, const bool*
   std::vector<uint32_t> gof;      // GP of every stage
   std::vector<int> chunk_start;
   const uint64_t xa_block = uint64_t(16 * d + 16) * sizeof(double);
+  const uint64_t xa_skip = sep ? uint64_t(16 * d - 16) * sizeof(double) : 0;
   for (int g = 0; g < Geff; ++g) {
     const int nblk = gh[g].nblk, nsteps = gh[g].n_pad / 4;
     const int nchunks = (nblk + kPairSlots - 1) / kPairSlots;
@@ -1009,6 +1105,7 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, const bool*
         e.rs_bytes = uint32_t(nsteps) * 512u;
         e.word = (uint32_t(g) << PW_G_SHIFT) | ((chunk_id & 63u) << PW_CHUNK_SHIFT) |
                  PW_MEAN | PW_SHARED;
+        e.jb = uint32_t(jb);
         if (jb == 0) e.word |= PW_GP_FIRST;
         if (g == last_staged) e.word |= PW_LAST_GP;
         if (jb == nblk - 1) {
@@ -1016,7 +1113,7 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, const bool*
           if (g == last_staged) e.word |= PW_TILE_END;
         }
         tab.push_back(e);
-        xa.push_back(reinterpret_cast<uint64_t>(gh[g].XA) + uint64_t(jb) * xa_block);
+        xa.push_back(reinterpret_cast<uint64_t>(gh[g].XA) + uint64_t(jb) * xa_block + xa_skip);
         gof.push_back(uint32_t(g));
       }
       continue;
@@ -1032,6 +1129,7 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, const bool*
         e.rs_bytes = uint32_t(nsteps) * 512u;
         e.word = uint32_t(std::min(nib, bend - jb)) | (uint32_t(g) << PW_G_SHIFT) |
                  ((chunk_id & 63u) << PW_CHUNK_SHIFT);
+        e.jb = uint32_t(jb);
         if (jb == bend - 1) e.word |= PW_CHUNK_END;
         if (c == nchunks - 1) e.word |= PW_MEAN;
         if (c == nchunks - 1 && gh[g].narrow) e.word |= PW_NARROW;
@@ -1042,7 +1140,7 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, const bool*
           if (g == last_staged) e.word |= PW_TILE_END;
         }
         tab.push_back(e);
-        xa.push_back(reinterpret_cast<uint64_t>(gh[g].XA) + uint64_t(jb) * xa_block);
+        xa.push_back(reinterpret_cast<uint64_t>(gh[g].XA) + uint64_t(jb) * xa_block + xa_skip);
         gof.push_back(uint32_t(g));
       }
     }
@@ -1141,12 +1239,12 @@ PairPlan pair_plan(const sgp_ctx* ctx, int64_t N) {
   return pl;
 }
 
-template <int D, int MODE, bool SINGLE, int R = 0>
+template <int D, int MODE, bool SINGLE, int R = 0, int SEP = 0>
 int launch_pair_v(sgp_ctx* ctx, const PairParams& p, double flops) {
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep_pair<D, MODE, SINGLE, R>),
+                     reinterpret_cast<const void*>(&k_sweep_pair<D, MODE, SINGLE, R, SEP>),
                      hipFuncAttributeMaxDynamicSharedMemorySize,
                      int(LayP<D, R>::bytes())));
     attr_set = true;
@@ -1180,7 +1278,7 @@ int launch_pair_v(sgp_ctx* ctx, const PairParams& p, double flops) {
   if (!stamps_dev) SGP_HIP(ctx, hipMalloc(&stamps_dev, size_t(4096) * 64 * 8));
   pp.stamps = stamps_dev;
 #endif
-  hipLaunchKernelGGL((k_sweep_pair<D, MODE, SINGLE, R>), dim3(nblocks), dim3(512),
+  hipLaunchKernelGGL((k_sweep_pair<D, MODE, SINGLE, R, SEP>), dim3(nblocks), dim3(512),
                      (LayP<D, R>::bytes()), ctx->stream, pp);
   if (pl.parts > 0)
     hipLaunchKernelGGL((k_pair_split_finish<MODE>), dim3(pl.count), dim3(512), 0,
@@ -1242,7 +1340,7 @@ int pair_sweep_partials(const sgp_ctx* ctx, int64_t N) {
 }
 
 int launch_sweep_pair(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d,
-                      int Geff, double flops) {
+                      int Geff, double flops, const SepLaunch* sep) {
   PairParams p{};
   p.gps = a.gps;
   p.G = a.G;
@@ -1263,6 +1361,8 @@ int launch_sweep_pair(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d,
     p.ride_delta[g] = 0;
   }
   const bool riders = !no_ride && sweep_riders(gh, Geff, d, single, kMaxRide, 4, rides, p.nride);
+  // (factor tables: the instances without riders; a launch with riders evaluates)
+  if (riders) sep = nullptr;
   if (!riders)
     for (int g = 0; g < Geff; ++g) {
       rides[g] = false;
@@ -1276,7 +1376,17 @@ int launch_sweep_pair(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d,
     p.ride_delta[g] = (long long)(reinterpret_cast<intptr_t>(gh[g].XA) -
                                   reinterpret_cast<intptr_t>(gh[leader].XA));
   }
-  SGP_TRY(pair_stage_table(ctx, gh, Geff, d, rides, &p.stages, &p.nstages));
+  SGP_TRY(pair_stage_table(ctx, gh, Geff, d, sep != nullptr, rides, &p.stages, &p.nstages));
+  if (sep) {
+    p.sep = *sep;
+    switch (sep->naxes) {
+      case 1: return launch_pair_v<1, MODE_CONF, true, 0, 1>(ctx, p, flops);
+      case 2: return launch_pair_v<1, MODE_CONF, true, 0, 2>(ctx, p, flops);
+      case 3: return launch_pair_v<1, MODE_CONF, true, 0, 3>(ctx, p, flops);
+    }
+    sgp_set_error(ctx, "factor tables with %d axes", sep->naxes);
+    return -2;
+  }
   int rc = -2;
   switch (d) {
     case 1: rc = launch_pair_d<1>(ctx, p, single, riders, flops); break;

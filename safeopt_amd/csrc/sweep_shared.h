@@ -105,8 +105,17 @@ inline bool sweep_riders(const GpDev* gh, int Geff, int d, bool single, int max_
   return any;
 }
 
+// a wave-uniform pointer, pinned to scalar registers
+template <typename T>
+__device__ __forceinline__ const T* uniform_ptr(const T* q) {
+  const uint64_t v = reinterpret_cast<uint64_t>(q);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
+  return reinterpret_cast<const T*>((uint64_t(hi) << 32) | lo);
+}
+
 // sweep_pair.hip
 bool pair_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff);
 int pair_sweep_partials(const sgp_ctx* ctx, int64_t N);
 int launch_sweep_pair(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d,
-                      int Geff, double flops);
+                      int Geff, double flops, const SepLaunch* sep);

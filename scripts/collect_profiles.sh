@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): rocprofv3 evidence for profiles/<tag>/.
-#   scripts/collect_profiles.sh r03 [configs...]      (default configs: 3 2 4 5)
+#   scripts/collect_profiles.sh r04 [configs...]      (default configs: 3 2 4 5)
 # Per config: the bench JSON line, kernel stats of the same command, and three
 # separate PMC passes (MFMA busy + clock; FETCH_SIZE; WRITE_SIZE) -- never
 # combined with trace domains other than --kernel-trace, as the MI355X guide
@@ -9,21 +9,29 @@
 # stamps of the paired kernel (variant builds under scripts/dev/ab/, made by
 # scripts/dev/build_variant.sh before the call), hardware probes, BO-loop and
 # small-swarm timings.
-TAG=${1:-r03}; shift
+TAG=${1:-r04}; shift
 CFGS=${@:-3 2 4 5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd $R
-[ -z "$ONLY_PMC" ] && for c in $CFGS; do
-  extra=""; [ $c = 4 ] && extra="--warmup 2 --profile-steps 3"
-  python bench.py --config $c $extra > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err
-done
+if [ -z "$ONLY_PMC" ]; then
+  # the driver's command (config 3 + bo_iteration / sets_roofline / rank1_roofline /
+  # config4_strong / shared_factor keys), then every config on its own
+  python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+  for c in $CFGS; do
+    extra=""; [ $c = 4 ] && extra="--warmup 2 --profile-steps 3"
+    python bench.py --config $c $extra > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err
+  done
+fi
 cd /tmp && export TMPDIR=/tmp
-SHORT="--steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-check-chosen --no-shared-pass"
+SHORT="--steps 3 --warmup 1 --profile-steps 1 --no-extras --no-cpu-baseline --no-check-chosen --no-shared-pass"
+# (kernel stats: enough steps that the launches of the clock ramp -- the first ~30 ms of
+# load run ~10 % slower, profiles/r04/clock_ramp.txt -- are a small part of the average)
+declare -A STEPS=([2]="--steps 300 --warmup 20 --profile-steps 100" [3]="--steps 40 --warmup 5 --profile-steps 20" [4]="--steps 5 --warmup 2 --profile-steps 3" [5]="--steps 30 --warmup 5 --profile-steps 20")
 for c in $CFGS; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg$c -- \
-    python $R/bench.py --config $c --steps 5 --warmup 2 --profile-steps 2 --no-cpu-baseline --no-check-chosen --no-shared-pass > $OUT/stats_cfg$c.log 2>&1
+    python $R/bench.py --config $c ${STEPS[$c]} --no-extras --no-cpu-baseline --no-check-chosen --no-shared-pass > $OUT/stats_cfg$c.log 2>&1
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES \
     --output-format csv -d $OUT/pmc_mfma_cfg$c -- python $R/bench.py --config $c $SHORT > $OUT/pmc_mfma_cfg$c.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_cfg$c -- \
@@ -31,14 +39,14 @@ for c in $CFGS; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_cfg$c -- \
     python $R/bench.py --config $c $SHORT > $OUT/pmc_write_cfg$c.log 2>&1
 done
-if echo " $CFGS " | grep -q " 3 "; then
+for c in 3 2; do echo " $CFGS " | grep -q " $c " || continue
   rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM \
-    --output-format csv -d $OUT/pmc_insts_cfg3 -- python $R/bench.py --config 3 $SHORT > $OUT/pmc_insts_cfg3.log 2>&1
+    --output-format csv -d $OUT/pmc_insts_cfg$c -- python $R/bench.py --config $c $SHORT > $OUT/pmc_insts_cfg$c.log 2>&1
   rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH \
-    --output-format csv -d $OUT/pmc_issue_cfg3 -- python $R/bench.py --config 3 $SHORT > $OUT/pmc_issue_cfg3.log 2>&1
-  rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2_cfg3 -- \
-    python $R/bench.py --config 3 $SHORT > $OUT/pmc_l2_cfg3.log 2>&1
-fi
+    --output-format csv -d $OUT/pmc_issue_cfg$c -- python $R/bench.py --config $c $SHORT > $OUT/pmc_issue_cfg$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2_cfg$c -- \
+    python $R/bench.py --config $c $SHORT > $OUT/pmc_l2_cfg$c.log 2>&1
+done
 cd $R
 if [ -n "$ONLY_PMC" ]; then python scripts/profiles_digest.py $OUT > $OUT/SUMMARY.txt 2>&1; cat $OUT/SUMMARY.txt; exit 0; fi
 # the two sweep kernels side by side (same process, same box), un-shared path
@@ -53,13 +61,29 @@ if [ -f scripts/dev/ab/stamps.so ]; then
   for c in 3 4 5; do
     SAFEOPT_HIP_LIB=scripts/dev/ab/stamps.so AB_ONLY=pair AB_TAG=stamps timeout 200 python scripts/dev/ab_sweep.py $c 2>&1 | tail -3
   done > $OUT/stamps.txt
+  # the 4-wave kernel at config 2: factor tables / evaluated covariances
+  { SAFEOPT_HIP_LIB=scripts/dev/ab/stamps.so AB_ONLY=classic AB_TAG="stamps, factor tables" timeout 200 python scripts/dev/ab_sweep.py 2 2>&1 | tail -3
+    SAFEOPT_HIP_LIB=scripts/dev/ab/stamps.so AB_SEP=0 AB_ONLY=classic AB_TAG="stamps, evaluated" timeout 200 python scripts/dev/ab_sweep.py 2 2>&1 | tail -3
+    SAFEOPT_HIP_LIB=scripts/dev/ab/stamps.so timeout 300 python scripts/dev/small_n.py 8 20 64 2>&1
+  } > $OUT/stamps_cfg2.txt
 fi
-# hardware probes behind the design decisions (standalone HIP programs)
+if [ -f scripts/dev/ab/instr.so ]; then
+  for sep in 1 0; do for m in 0 1 2 4 8 16 32; do
+    SAFEOPT_HIP_LIB=scripts/dev/ab/instr.so SGP_ABLATE=$m AB_SEP=$sep AB_ONLY=classic AB_TAG="tables=$sep ablate $m" timeout 200 python scripts/dev/ab_sweep.py 2 2>&1 | tail -1
+  done; done > $OUT/ablation_cfg2.txt
+fi
+# the reference's own regime (n <= 256) and SafeOptSwarm's input dimensions
+python scripts/dev/small_n.py > $OUT/small_n.txt 2>&1
+python scripts/dev/high_d.py > $OUT/high_d_times.txt 2>&1
+# hipEvent vs rocprof on identical launches, and the clock ramp
 {
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/probe1 scripts/dev/probe_r02.hip && /tmp/probe1 | grep -v "^[ABD][0-9]*:"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/probe2 scripts/dev/probe_coexec.hip && /tmp/probe2
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/probe3 scripts/dev/probe_interleave.hip && /tmp/probe3
-} > $OUT/probes.txt 2>&1
+  for mult in 1 8; do python scripts/dev/clock_reconcile.py $mult 40; done
+  for mult in 1 8; do
+    ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rp_x$mult -- python $R/scripts/dev/clock_reconcile.py $mult 40 2>&1 | tail -1 )
+    f=$(find $OUT/rp_x$mult -name "*kernel_stats.csv" | head -1); echo "  rocprofv3 kernel stats of the same process:"; grep -i "k_sweep" $f | head -2
+  done
+} > $OUT/reconcile.txt 2>&1
+# (hardware probes behind the design decisions: profiles/r02/probes.txt, profiles/r03/probes.txt)
 # product kernels (the reference's context example) on both sweep kernels; cost of the
 # N-rank control flow on one GPU (one-rank RCCL communicator posing as world 2)
 python scripts/dev/ab_product.py 64 200 256 > $OUT/product_kernels.txt 2>&1

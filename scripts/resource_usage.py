@@ -22,7 +22,10 @@ def demangle(names):
 
 
 def usage(src):
-    extra = ["-ffp-contract=off"] if os.path.basename(src) in ("sets.hip", "swarm.hip") else []
+    # the flags of the product build (safeopt_amd/build.py)
+    sys.path.insert(0, ROOT)
+    from safeopt_amd import build as _b
+    extra = list(_b.EXTRA.get(os.path.basename(src), []))
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "--cuda-device-only", "-c",
            "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null", src] + extra

@@ -369,6 +369,11 @@ SEP_CASES = [
     ([37, 29], 0, [17, 255], "RBF", (100, 1000)), ([9, 8, 11], 0, [130], "RBF", None),
     ([5, 4, 6, 3], 0, [60, 60], "RBF", (7, 355)), ([31, 17], 1, [90], "RBF*RBF", None),
     ([40, 25], 2, [33], "RBF", None), ([64, 3], 0, [256], "RBF", None),
+    # more than 256 rows: the paired-wave sweep (whole tiles, cut remainder tiles, a
+    # shard that starts inside a grid row, several chunks of 512 rows)
+    ([37, 29], 0, [300], "RBF", None), ([23, 19, 7], 0, [600, 257], "RBF", (50, 3000)),
+    ([31, 17], 1, [400], "RBF*RBF", None), ([200, 40], 0, [520], "RBF", (1000, 7900)),
+    ([200, 100], 0, [300], "RBF", None), ([13, 11, 9], 1, [1100], "RBF", None),
 ]
 
 
