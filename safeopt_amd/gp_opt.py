@@ -400,6 +400,10 @@ class SafeOpt(GaussianProcessOptimization):
 
         # this rank's contiguous block of rows, resident on its GPU
         self._comm = comm if comm is not None else LocalComm()
+        if N < self._comm.world:
+            # every rank owns at least one row (a shard without rows has no resident
+            # state to launch on; raised on ALL ranks, before any collective)
+            raise ValueError("parameter_set has %d rows for %d ranks" % (N, self._comm.world))
         self._shard = shard_range(N, self._comm.rank, self._comm.world)
         lo, hi = self._shard
         if _BACKEND_FACTORY is not None:          # CPU tests: NumPy stand-in

@@ -74,7 +74,7 @@ if [ -f scripts/dev/ab/instr.so ]; then
 fi
 # the reference's own regime (n <= 256) and SafeOptSwarm's input dimensions
 python scripts/dev/small_n.py > $OUT/small_n.txt 2>&1
-python scripts/dev/high_d.py > $OUT/high_d_times.txt 2>&1
+python scripts/dev/high_d.py > $OUT/high_d.txt 2>&1
 # hipEvent vs rocprof on identical launches, and the clock ramp
 {
   for mult in 1 8; do python scripts/dev/clock_reconcile.py $mult 40; done

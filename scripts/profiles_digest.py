@@ -70,7 +70,7 @@ def digest(d):
                 out.append("bench_cfg%d.json: no JSON (%s)" % (c, e))
         st = kernel_stats(d, c)
         if st:
-            out.append("   rocprofv3 --kernel-trace --stats (same command, 5+2+2 steps):")
+            out.append("   rocprofv3 --kernel-trace --stats (same config; step counts: scripts/collect_profiles.sh):")
             tot = sum(float(r["TotalDurationNs"]) for r in st)
             for r in st[:8]:
                 out.append("     %-34s calls %5s  avg %10.2f us  %5.1f%%" % (
@@ -128,14 +128,16 @@ def digest(d):
                          "doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md "
                          "section HBM)")
         out.append("")
-    for sub in ("pmc_insts_cfg3", "pmc_issue_cfg3", "pmc_l2_cfg3"):
-        for k, v in pmc(d, sub).items():
-            if "k_sweep" in k:
-                cm = {n: mean(vals) for n, vals in sorted(v.items())}
-                out.append("PMC %s %s: %s" % (sub, k, {n: "%.4g" % x for n, x in cm.items()}))
-                for n, val in cm.items():
-                    rows[3].append((sub, k, n, val))
-    for name in ("ab_kernels.txt", "ablation.txt", "stamps.txt", "probes.txt"):
+    for c in (3, 2):
+        for sub in ("pmc_insts_cfg%d" % c, "pmc_issue_cfg%d" % c, "pmc_l2_cfg%d" % c):
+            for k, v in pmc(d, sub).items():
+                if "k_sweep" in k:
+                    cm = {n: mean(vals) for n, vals in sorted(v.items())}
+                    out.append("PMC %s %s: %s" % (sub, k, {n: "%.4g" % x for n, x in cm.items()}))
+                    for n, val in cm.items():
+                        rows[c].append((sub, k, n, val))
+    for name in ("ab_kernels.txt", "ablation.txt", "ablation_cfg2.txt", "stamps.txt",
+                 "stamps_cfg2.txt", "reconcile.txt", "probes.txt"):
         p = os.path.join(d, name)
         if os.path.exists(p):
             out.append("\n== %s\n%s" % (name, open(p).read()))
@@ -163,16 +165,34 @@ def main(argv):
                     w = csv.writer(fh)
                     w.writerow(["pass", "kernel", "counter", "avg_value_per_dispatch"])
                     w.writerows(rows[c])
-        for name in ("ab_kernels.txt", "ablation.txt", "stamps.txt", "probes.txt", "bo_loop.json",
-                     "swarm_small.txt", "product_kernels.txt", "multirank_path_cost.txt"):
+        for name in ("ab_kernels.txt", "ablation.txt", "ablation_cfg2.txt", "stamps.txt",
+                     "stamps_cfg2.txt", "reconcile.txt", "probes.txt", "bo_loop.json",
+                     "swarm_small.txt", "product_kernels.txt", "multirank_path_cost.txt",
+                     "bench_default.json", "small_n.txt", "high_d.txt"):
             if os.path.exists(os.path.join(d, name)):
                 shutil.copy(os.path.join(d, name), os.path.join(dst, name))
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         cur = {}
         if os.path.exists(tj):
             cur = json.load(open(tj))
+        # where the bytes beyond the algorithmic ones come from (scripts/dev/probe_mall.hip,
+        # profiles/<tag>/served_by.txt): average outstanding time of the L2's read requests
+        sb = os.path.join(dst, "served_by.json")
+        served = json.load(open(sb)) if os.path.exists(sb) else None
         for k, v in traffic.items():
             v["note"] += "; source profiles/%s/pmc_%s.csv" % (tag, k.replace("config", "cfg"))
+            c = k.replace("config", "cfg")
+            if served and c in served["sweeps"]:
+                lat = served["sweeps"][c]
+                v["served_by"] = dict(
+                    level="infinity cache" if lat < 0.5 * (served["hbm_reference_cycles"] +
+                                                          served["infinity_cache_reference_cycles"])
+                    else "hbm",
+                    fabric_read_latency_cycles=lat,
+                    hbm_reference_cycles=served["hbm_reference_cycles"],
+                    infinity_cache_reference_cycles=served["infinity_cache_reference_cycles"],
+                    source="profiles/%s/served_by.txt (TCC_EA0_RDREQ_LEVEL_sum / TCC_EA0_RDREQ_sum "
+                           "against one-load-in-flight reference kernels)" % tag)
             cur[k] = v
         json.dump(cur, open(tj, "w"), indent=1)
         print("published", sorted(os.listdir(dst)), file=sys.stderr)

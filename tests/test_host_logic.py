@@ -128,6 +128,13 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_fewer_rows_than_ranks_is_refused_on_every_rank(gps):
+    class Comm(dist.LocalComm):
+        rank, world = 1, 4
+    with pytest.raises(ValueError, match="3 rows for 4 ranks"):
+        safeopt_amd.SafeOpt(gps[0], np.array([[0.], [1.], [2.]]), 0., comm=Comm())
+
+
 def test_merge_topk_and_argmax():
     w, i = dist.merge_topk([[3., 1., -np.inf], [3., 2., 2.]], [[5, 9, -1], [7, 4, 8]], 4)
     assert_array_equal(i, [7, 5, 8, 4]); assert_allclose(w, [3., 3., 2., 2.])
