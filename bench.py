@@ -620,6 +620,9 @@ def main():
             try:
                 extras["sets_roofline"] = sets_roofline(opt, ctx, cfg, rows_rank)
                 extras["bo_iteration"] = bo_iteration(cfg, gpy, safeopt_amd, ctx)
+                # (also at the top level, next to sets_roofline)
+                if "rank1_roofline" in extras["bo_iteration"]:
+                    extras["rank1_roofline"] = extras["bo_iteration"]["rank1_roofline"]
             except Exception as e:      # noqa -- an extra must never break the line
                 extras["extras_error"] = repr(e)
         if default_run:

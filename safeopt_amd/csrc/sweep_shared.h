@@ -59,11 +59,15 @@ __device__ __forceinline__ void mfma_acc_a(double& c, double a, double b) {
 // global -> LDS without a VGPR round trip: "scalar base + 32-bit lane offset"
 // (the builtin only produces the 64-bit-VGPR-address form, one VALU add per
 // copy).  M0 carries the wave-uniform LDS byte address.
+// (cache policy of the A-chunk copies: experiment switch, profiles/r04/experiments.txt)
+#ifndef SGP_DMA_POLICY
+#define SGP_DMA_POLICY ""
+#endif
 __device__ __forceinline__ void dma_2k(uint64_t src, uint32_t lds_addr, uint32_t voff) {
   asm volatile(
       "s_mov_b32 m0, %0\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "global_load_lds_dwordx4 %1, %2 offset:1024"
+      "global_load_lds_dwordx4 %1, %2" SGP_DMA_POLICY "\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:1024" SGP_DMA_POLICY
       :: "s"(lds_addr), "v"(voff), "s"(src) : "memory", "m0");
 }
 __device__ __forceinline__ void dma_1k(uint64_t src, uint32_t lds_addr, uint32_t voff) {

@@ -51,6 +51,12 @@ cd $R
 if [ -n "$ONLY_PMC" ]; then python scripts/profiles_digest.py $OUT > $OUT/SUMMARY.txt 2>&1; cat $OUT/SUMMARY.txt; exit 0; fi
 # the two sweep kernels side by side (same process, same box), un-shared path
 python scripts/dev/ab_sweep.py 3 2 4 5 > $OUT/ab_kernels.txt 2>&1
+# factor tables (tensor grids, RBF) against evaluated covariances: configs 2 and 4
+{ for c in 2 4; do
+    which=pair; [ $c = 2 ] && which=classic
+    AB_ONLY=$which AB_TAG="  [factor tables]" python scripts/dev/ab_sweep.py $c 2>&1 | tail -1
+    AB_ONLY=$which AB_SEP=0 AB_TAG="  [evaluated]" python scripts/dev/ab_sweep.py $c 2>&1 | tail -1
+  done; } > $OUT/ab_tables.txt 2>&1
 # ablation ("what does the paired sweep cost without X") and per-phase cycle stamps
 if [ -f scripts/dev/ab/instr.so ]; then
   for c in 3 4; do for m in 0 1 2 4 8 16 32 6 7 15; do
@@ -92,5 +98,8 @@ python scripts/dev/multirank_path_cost.py 2>&1 | tail -6 > $OUT/multirank_path_c
 # SafeOptSwarm.optimize() with the default swarm
 { python scripts/bench_bo_loop.py --config 2; python scripts/bench_bo_loop.py --config 3; } > $OUT/bo_loop.json 2>$OUT/bo_loop.err
 python scripts/dev/swarm_small.py > $OUT/swarm_small.txt 2>&1
+# where the L2 misses are served (fabric read latency against reference kernels)
+cp profiles/r04/scripts/exp_r04_r.sh /tmp/served_by.sh
+bash /tmp/served_by.sh > $OUT/served_by.log 2>&1
 python scripts/profiles_digest.py $OUT > $OUT/SUMMARY.txt 2>&1
 cat $OUT/SUMMARY.txt

@@ -137,7 +137,7 @@ def digest(d):
                     for n, val in cm.items():
                         rows[c].append((sub, k, n, val))
     for name in ("ab_kernels.txt", "ablation.txt", "ablation_cfg2.txt", "stamps.txt",
-                 "stamps_cfg2.txt", "reconcile.txt", "probes.txt"):
+                 "stamps_cfg2.txt", "reconcile.txt", "ab_tables.txt", "probes.txt"):
         p = os.path.join(d, name)
         if os.path.exists(p):
             out.append("\n== %s\n%s" % (name, open(p).read()))
@@ -168,7 +168,7 @@ def main(argv):
         for name in ("ab_kernels.txt", "ablation.txt", "ablation_cfg2.txt", "stamps.txt",
                      "stamps_cfg2.txt", "reconcile.txt", "probes.txt", "bo_loop.json",
                      "swarm_small.txt", "product_kernels.txt", "multirank_path_cost.txt",
-                     "bench_default.json", "small_n.txt", "high_d.txt"):
+                     "bench_default.json", "small_n.txt", "high_d.txt", "ab_tables.txt"):
             if os.path.exists(os.path.join(d, name)):
                 shutil.copy(os.path.join(d, name), os.path.join(dst, name))
         tj = os.path.join(ROOT, "profiles", "traffic.json")
