@@ -335,10 +335,18 @@ int64_t sgp_ctx_alloc_count(sgp_ctx* ctx);
  * 4-wave kernel (csrc/sweep.hip), 2 = always the paired-wave kernel; + 4: the
  * paired-wave kernel does not cut remainder tiles into runs of chunks (same bits
  * either way, tests/test_gpu_parity.py); + 8: no factor tables on tensor grids
- * (sgp_grid_set_axes).  Same results within rounding between
+ * (sgp_grid_set_axes); + 16: the 4-wave kernel streams small factors through its
+ * double buffer instead of keeping them in LDS for the launch (same bits either
+ * way).  Same results within rounding between
  * the two kernels; the switch exists for A/B measurements and tests.  Returns
  * the previous setting.                                                        */
 int sgp_ctx_set_sweep(sgp_ctx* ctx, int which);
+/* Which kernel ran the LAST posterior sweep of this context (tests of the selection,
+ * A/B scripts): 0 = none yet, 1 = the 4-wave kernel (n <= 256, csrc/sweep.hip),
+ * 2 = the paired-wave kernel (csrc/sweep_pair.hip), 3 = the VALU kernel for GPs with
+ * at most 48 observations (csrc/sweep_tiny.hip -- the regime of the reference's own
+ * examples), 4 = the few-points path (csrc/factor.hip).                            */
+int sgp_ctx_last_sweep(sgp_ctx* ctx);
 
 /* Multi-output case: consecutive GPs of a launch with bit-identical training
  * inputs, kernel, noise and fitting history have the same L^-1, so the variance

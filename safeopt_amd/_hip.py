@@ -126,6 +126,7 @@ PROTOTYPES = {
     "sgp_ctx_alloc_count": (C.c_int64, [vp]),
     "sgp_comm_count": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "sgp_ctx_set_sweep": (C.c_int, [vp, C.c_int]),
+    "sgp_ctx_last_sweep": (C.c_int, [vp]),
     "sgp_ctx_set_share": (C.c_int, [vp, C.c_int]),
 
 }
@@ -281,16 +282,23 @@ class Context(object):
     def set_sweep(self, which):
         """Posterior-sweep kernel: 'auto' | 'classic' (4 waves) | 'pair' (paired
         waves), '-nosplit' appended: remainder tiles are not cut into runs of
-        chunks, '-notables': no factor tables on tensor grids (set_axes); or the
-        integer of sgp_ctx_set_sweep.  Returns the previous setting (a name)."""
+        chunks, '-notables': no factor tables on tensor grids (set_axes), '-streamed':
+        small factors go through the 4-wave kernel's double buffer instead of staying
+        in LDS for the launch; or the integer of sgp_ctx_set_sweep.  Returns the
+        previous setting (a name)."""
         names = ("auto", "classic", "pair", None, "auto-nosplit", "classic-nosplit",
                  "pair-nosplit", None)
         names = names + tuple(n + "-notables" if n else None for n in names)
+        names = names + tuple(n + "-streamed" if n else None for n in names)
 
         def code(w):          # a name, or the integer of sgp_ctx_set_sweep
             return int(w) if isinstance(w, (int, np.integer)) else names.index(w)
 
         return names[int(lib().sgp_ctx_set_sweep(self.h, code(which)))]
+
+    def last_sweep(self):
+        """Kernel of the last posterior sweep: 'classic' | 'pair' | 'tiny' | 'few-points'."""
+        return (None, "classic", "pair", "tiny", "few-points")[int(lib().sgp_ctx_last_sweep(self.h))]
 
     # -- RCCL
     @staticmethod

@@ -145,6 +145,7 @@ struct sgp_ctx {
   DevBuf stage_tab;
   std::vector<uint64_t> stage_sig;
   int stage_count = 0;
+  int stage_slots = 0;       // 2-KB positions of all stages of that table
   // ... and of the paired sweep (sweep_pair.hip: pair_stage_table)
   DevBuf pstage_tab;
   std::vector<uint64_t> pstage_sig;
@@ -156,6 +157,7 @@ struct sgp_ctx {
   DevBuf pair_post;                      // [G][P] mean | var of a swarm (sweep_pair.hip)
   int sweep_partials = 0;     // partials of max l0[S] the last confidence sweep left
   int sweep_choice = 0;       // sgp_ctx_set_sweep: 0 auto, 1 4-wave, 2 paired
+  int last_sweep = 0;         // kernel of the last posterior sweep (sgp_ctx_last_sweep)
   int share_factors = 1;      // sgp_ctx_set_share: GPs with identical (X, kernel, noise)
                               // share the variance contraction (paired sweep)
   // RCCL

@@ -999,6 +999,7 @@ int posterior_small_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_hos
                         int G, const double* pts_rowmajor, int P, const SmallBufs& sb,
                         double* mean, double* var) {
   const int d = gps_host[0].kern.d;
+  ctx->last_sweep = 4;
 #define SMALL_CASE(DD)                                                         \
   case DD:                                                                     \
     hipLaunchKernelGGL(k_small_kb<DD>,                                         \

@@ -357,9 +357,9 @@ struct KernFast {
           out[q] = fma(u[q], fma(u[q], m2, m1), var0) * e[q];
       }
     } else {
-      // (two values at a time: the 4-wave sweep runs at the register limit; d = 8:
+      // (two values at a time: the 4-wave sweep runs at the register limit; d >= 7:
       // one -- the 8 squared differences of a value are 16 registers)
-      constexpr int kStep = NV > 2 ? (D >= 8 ? 1 : 2) : NV;
+      constexpr int kStep = NV > 2 ? (D >= 7 ? 1 : 2) : NV;
 #pragma unroll
       for (int q0 = 0; q0 < NV; q0 += kStep) {
         double o[kStep];

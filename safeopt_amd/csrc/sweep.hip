@@ -101,7 +101,7 @@ struct StageEnt {
   uint32_t rs_bytes;   // bytes between consecutive row blocks in Apack
   uint32_t jb;         // j-block: training points 16 jb .. 16 jb + 15
   uint32_t word;       // see SW_*
-  uint32_t pad;
+  uint32_t slot0;      // 2-KB positions of the stages in front of this one (resident mode)
 };
 enum : uint32_t {
   SW_NACT_MASK = 63u,       // active slots 0 .. nact-1 (1..32)
@@ -139,6 +139,12 @@ struct SweepParams {
   FitnessArgs fit;
   const StageEnt* stages;   // [nstages] one tile's stage sequence (all GPs)
   int nstages;
+  // Small factors stay in LDS for the whole launch (n <= ~112 rows in all GPs together):
+  // every stage's positions are copied ONCE, packed back to back, the [rows | alpha]
+  // blocks behind them from byte res_xbase on -- no LDS-DMA, no wait and no barrier per
+  // stage, the waves of a workgroup run free.  0: the chunks are streamed (double buffer).
+  int resident;
+  unsigned res_xbase;
   int single;               // every GP has a one-part kernel (pre-scaled inputs)
   long long ride_delta[SGP_MAX_GPS];   // rider g: bytes from its leader's XA to its own
   int nride[SGP_MAX_GPS];   // riders of GP g: the GPs g + 1 .. g + nride[g] share its
@@ -177,7 +183,7 @@ __device__ __forceinline__ StageEnt load_stage(stage_ptr_t t, int i) {
   e.rs_bytes = t[i].rs_bytes;
   e.jb = t[i].jb;
   e.word = t[i].word;
-  e.pad = 0;
+  e.slot0 = t[i].slot0;
   return e;
 }
 typedef const __attribute__((address_space(4))) GpDev* gpdev_cptr_t;
@@ -448,8 +454,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   // wave w copies positions w, w + NW, ..) and the block [16 d rows | 16 alpha] of the
   // j-block (one instruction of one wave; SEP: the 16 alpha only), + the alpha
   // blocks of the riders behind it.
-  auto prefetch = [&](const StageEnt& e, int buf) {
-    const uint32_t a_dst = lds0 + uint32_t(buf) * (kBuf * 8u);
+  auto prefetch_to = [&](const StageEnt& e, uint32_t a_dst, uint32_t x_dst) {
     const int nact = int(e.word & SW_NACT_MASK);
     const uint64_t src0 = e.a_src - uint64_t(uint32_t(wave)) * e.rs_bytes;
     const uint64_t step = uint64_t(e.rs_bytes) * NW;
@@ -458,7 +463,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       if (nact > wave + NW * i)
         dma_2k(src0 - uint64_t(i) * step, a_dst + uint32_t(wave + NW * i) * 2048u, voff);
     if (wave == NW - 1) {
-      const uint32_t x_dst = a_dst + kATile * 8u;
       if (SEP > 0) {
         if (lane < 8) dma_1k(e.xa, x_dst + kXTile * 8u, voff);
       } else {
@@ -479,6 +483,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       }
     }
   };
+  auto prefetch = [&](const StageEnt& e, int buf) {
+    const uint32_t a_dst = lds0 + uint32_t(buf) * (kBuf * 8u);
+    prefetch_to(e, a_dst, a_dst + kATile * 8u);
+  };
+  // resident mode: where stage si of the sequence lives (bytes from lds0)
+  constexpr uint32_t kXBlk = uint32_t(kXTile + kJC * (1 + R)) * 8u;
+  const bool resident = p.resident != 0;
 
   // Stage cursors: the stage being multiplied (its entry word in wcur), the stage
   // being prefetched (entry e1, one ahead) and the stage whose entry is being loaded
@@ -497,12 +508,22 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   };
   StageEnt e1 = load_stage(stages, 0);
   load_gp(int(e1.word >> SW_G_SHIFT) & 7);
-  prefetch(e1, 0);
+  if (resident) {
+#pragma unroll 1
+    for (int si = 0; si < nstages; ++si) {
+      const StageEnt es = load_stage(stages, si);
+      prefetch_to(es, lds0 + es.slot0 * 2048u, lds0 + p.res_xbase + uint32_t(si) * kXBlk);
+    }
+  } else {
+    prefetch(e1, 0);
+  }
   if (SEP > 0) {
     sep_offsets(tile);
     sep_fetch(e1);
   }
   uint32_t wcur = e1.word;
+  uint32_t s0cur = e1.slot0;           // (resident mode: position 0 / index of the stage
+  int sicur = 0;                       //  being multiplied)
   int si1 = nstages > 1 ? 1 : 0;       // index of the stage being prefetched
   if (si1 == 0) tile_p += tstep;
   if (left > 1) e1 = load_stage(stages, si1);
@@ -531,7 +552,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   int par = 0;
 #pragma unroll 1
   while (true) {
-    double* cbuf = lds + par * kBuf;
+    // the stage's positions and its [rows | alpha] block: the buffer of this parity, or
+    // (resident mode) where the stage was copied to at the start
+    const uint32_t a_off = resident ? s0cur * 2048u : uint32_t(par) * (kBuf * 8u);
+    const uint32_t x_off = resident ? p.res_xbase + uint32_t(sicur) * kXBlk
+                                    : a_off + kATile * 8u;
+    double* cbuf = lds + (a_off >> 3);
 
     // SEP: the covariances of THIS stage from the factors fetched a stage ago (their
     // registers take the next stage's right below)
@@ -551,8 +577,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     // ---- prefetch: the stage after this one (possibly of the next tile)
     const bool more = left > 1;
     const uint32_t wnext = e1.word;
+    const uint32_t s0next = e1.slot0;
     if (more) {
-      if (!kDmaLate && !SGP_ABL(2)) prefetch(e1, par ^ 1);
+      if (!kDmaLate && !resident && !SGP_ABL(2)) prefetch(e1, par ^ 1);
       const bool next_tile = si1 == 0;
       if (SEP == 0) {
         if constexpr (!kLeanX) {
@@ -590,8 +617,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       }
       gp_start = false;
     }
-    const double* xT = cbuf + kATile;
-    const double* alT = cbuf + kATile + kXTile;
+    const double* xT = lds + (x_off >> 3);
+    const double* alT = xT + kXTile;
     // A operands of the narrow groups (position 0 of the staged chunk), read FIRST in
     // the stage: they arrive under the evaluation.  (All kMaxNg groups whether the GP
     // has them or not: the reads stay inside the slot.)
@@ -599,7 +626,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     // the full slots of this stage (sweep_slots.h): the operands of the first one are
     // requested now
     const int nfull = int(wcur & SW_NACT_MASK) - (ngrp > 0 ? 1 : 0);
-    const uint32_t abase = lds0 + uint32_t(par) * (kBuf * 8u) + uint32_t(lane) * 8u +
+    const uint32_t abase = lds0 + a_off + uint32_t(lane) * 8u +
                            (ngrp > 0 ? kSteps * 512u : 0u);
     SgpEntryOps entry;
     if (kEntryEarly && nfull > 0 && !SGP_ABL(8))
@@ -652,7 +679,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     asm volatile("" : "+v"(kb[0][3]), "+v"(kb[1][3]), "+v"(kb[2][3]), "+v"(kb[3][3]));
 #endif
     SGP_STAMP(3);   // LDS transpose round trip
-    if (kDmaLate && more && !SGP_ABL(2)) prefetch(e1, par ^ 1);
+    if (kDmaLate && more && !resident && !SGP_ABL(2)) prefetch(e1, par ^ 1);
     if (!SGP_ABL(8)) {
       // the full slots: sweep_slots.h (hand-written, accumulators in a0..a127)
       if (!kEntryEarly && nfull > 0)
@@ -780,12 +807,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
 
     SGP_STAMP(5);   // chunk fold, row epilogue
     if (!more) break;
-    wait_dma();       // (asm copies: the compiler does not count them)
-    SGP_STAMP(6);   // wait for this wave's LDS-DMA
-    if (!SGP_ABL(1)) __syncthreads();
-    SGP_STAMP(7);   // barrier
+    if (!resident) {
+      wait_dma();       // (asm copies: the compiler does not count them)
+      SGP_STAMP(6);   // wait for this wave's LDS-DMA
+      if (!SGP_ABL(1)) __syncthreads();
+      SGP_STAMP(7);   // barrier
+    }
     par ^= 1;
     wcur = wnext;
+    s0cur = s0next;
+    sicur = si1;
     e1 = e2;
     si1 = si2;
     --left;
@@ -1190,6 +1221,7 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, bool sep, int kI
   }
   std::vector<StageEnt> tab;
   const uint64_t xa_block = uint64_t(16 * d + 16) * sizeof(double);
+  uint32_t slots_total = 0;       // 2-KB positions of all stages (resident mode)
   for (int g = 0; g < Geff; ++g) {
     if (rides[g]) continue;       // (its alpha . k is formed in its leader's stages)
     const int nblk = gh[g].nblk, nsteps = gh[g].n_pad / 4;
@@ -1205,6 +1237,8 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, bool sep, int kI
         e.rs_bytes = uint32_t(nsteps) * 512u;
         e.jb = uint32_t(jb);
         e.word = uint32_t(std::min(nib, bend - jb)) | (uint32_t(g) << SW_G_SHIFT);
+        e.slot0 = slots_total;
+        slots_total += uint32_t(std::min(nib, bend - jb));
         if (jb == 0) e.word |= SW_FIRST;
         e.word |= uint32_t(nib) << SW_NSL_SHIFT;
         if (jb == bend - 1) e.word |= SW_CHUNK_END;
@@ -1224,6 +1258,7 @@ int stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, bool sep, int kI
   SGP_TRY(sgp_h2d(ctx, ctx->stage_tab.p, tab.data(), tab.size() * sizeof(StageEnt)));
   ctx->stage_sig = sig;
   ctx->stage_count = int(tab.size());
+  ctx->stage_slots = int(slots_total);
   *dev = static_cast<const StageEnt*>(ctx->stage_tab.p);
   *nstages = ctx->stage_count;
   return 0;
@@ -1252,6 +1287,16 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   SweepTimer timer;
   SGP_TRY(timer.begin(ctx, flops));
   SweepParams pp = p;
+  {
+    // small factors: every stage's positions stay in LDS for the whole launch
+    // (SGP_NO_RESIDENT=1 / sgp_ctx_set_sweep(+ 16): stream them, A/B runs)
+    typedef Lay<SL, D, R> L;
+    static const bool off = getenv("SGP_NO_RESIDENT") != nullptr;
+    const size_t xblk = size_t(L::kXTile + kJC * (1 + R)) * 8;
+    const size_t need = size_t(ctx->stage_slots) * 2048 + size_t(p.nstages) * xblk;
+    pp.resident = (!off && !(ctx->sweep_choice & 16) && need <= size_t(2 * L::kBuf) * 8) ? 1 : 0;
+    pp.res_xbase = unsigned(ctx->stage_slots) * 2048u;
+  }
 #ifdef SGP_INSTRUMENT
   static const int ablate = getenv("SGP_ABLATE") ? atoi(getenv("SGP_ABLATE")) : 0;
   pp.ablate = ablate;
@@ -1348,13 +1393,20 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d,
 }
 
 // The confidence sweep proper: the paired-wave kernel from 257 rows of L^-1 on,
-// the 4-wave kernel below.
+// the 4-wave kernel below, the VALU kernel (sweep_tiny.hip) up to 32 observations.
 int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d, int Geff,
                      double flops, const SepLaunch* sep) {
+  if (tiny_sweep_wanted(ctx, gh, Geff)) {
+    ctx->last_sweep = 3;
+    SweepArgs a{p.gps, p.G, p.mode, p.pts, p.conf, p.fit};
+    return launch_sweep_tiny(ctx, a, gh, d, Geff, flops);    // (sets ctx->sweep_partials)
+  }
   if (pair_sweep_wanted(ctx, gh, Geff)) {
+    ctx->last_sweep = 2;
     SweepArgs a{p.gps, p.G, p.mode, p.pts, p.conf, p.fit};
     return launch_sweep_pair(ctx, a, gh, d, Geff, flops, sep);   // (sets ctx->sweep_partials)
   }
+  ctx->last_sweep = 1;
   ctx->sweep_partials = sweep_grid_blocks(ctx->num_cu, p.pts.N, sweep_waves(), 16) *
                         sweep_waves();
   SweepParams q = p;

@@ -118,6 +118,12 @@ __device__ __forceinline__ const T* uniform_ptr(const T* q) {
   return reinterpret_cast<const T*>((uint64_t(hi) << 32) | lo);
 }
 
+// sweep_tiny.hip: every GP of the launch has at most kTinyMaxN observations
+constexpr int kTinyMaxN = 48;
+bool tiny_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff);
+int launch_sweep_tiny(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d, int Geff,
+                      double flops);
+
 // sweep_pair.hip
 bool pair_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff);
 int pair_sweep_partials(const sgp_ctx* ctx, int64_t N);

@@ -1,0 +1,196 @@
+// The posterior sweep for FEW observations (every GP of the launch has n <= 48 rows --
+// the regime of the reference's own examples and tests, which run n <= 20): one thread
+// per candidate row, fp64 VALU only.
+//
+//   v = L^-1 k(X, x),  var = k(x,x) - |v|^2,  mean = alpha . k(X, x)
+//   (gp.predict_noiseless, safeopt/gp_opt.py:469; update_confidence_intervals +
+//    compute_safe_set, gp_opt.py:453-481)
+//
+// Why not the matrix-core kernels (sweep.hip): a 16-row tile of theirs walks through a
+// chain of LDS round trips, cross-lane folds and a barrier per stage with two waves per
+// SIMD to hide it -- at n = 20 a million rows take 0.09 ms, 5 % of either roof
+// (profiles/r04/small_n.txt).  On gfx950 the fp64 VALU peak EQUALS the fp64 MFMA peak
+// (78.6 TFLOP/s), so for a factor that fits the scalar registers' reach nothing is lost
+// by staying on the VALU: the thread keeps its n covariances in registers, the entries
+// of L^-1, alpha and the training rows are wave-uniform and come through SCALAR loads
+// from constant address space (one s_load_dwordx16 feeds 8 FMAs; a v_fma_f64 takes one
+// scalar operand), there is no LDS traffic, no cross-lane operation and no barrier, and
+// 3-7 waves per SIMD hide what latency is left.  NP = 8 / 16 / 32 / 48 (compile time):
+// the triangular product is fully unrolled, NP (NP + 1) / 2 FMAs.  Measured on 1e6 rows
+// (profiles/r04/small_n.txt): n = 8 0.020 ms against 0.060-0.076 for the 4-wave kernel,
+// n = 20 0.037 / 0.091-0.117, n = 48 0.094 / 0.141-0.177; at n = 56-64 the 64 + covariance
+// registers leave two waves per SIMD and the kernels meet (0.157-0.200 / 0.175-0.231):
+// the VALU kernel runs up to 48 observations.
+//
+// Padding: k_j = 0 for j >= n (the padding block of the dense L^-1 is the identity,
+// factor.hip), alpha is zero padded.  Results differ from the matrix-core kernels in the
+// last bits (another summation order); which kernel runs depends on the sizes of the GPs
+// only, so every rank and every shard of a launch takes the same one.
+#include "kern_eval.h"
+#include "sweep_shared.h"
+
+namespace {
+
+typedef const __attribute__((address_space(4))) double* cdbl_t;
+typedef const __attribute__((address_space(4))) GpDev* gpdev_c_t;
+
+struct TinyParams {
+  const GpDev* gps;
+  int G;
+  SweepPoints pts;
+  ConfOut conf;
+};
+
+template <int D, int NP, bool SINGLE>
+__global__ __launch_bounds__(256) void k_sweep_tiny(TinyParams p) {
+  __shared__ double tab[kExpTabSize];
+  __shared__ double sh_max[4];
+  exp_tab_init(tab);
+  __syncthreads();
+  const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const bool valid = row < p.pts.N;
+  const int64_t r = valid ? row : p.pts.N - 1;
+  double x[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+    x[k] = __builtin_nontemporal_load(p.pts.base + r * p.pts.stride_row + k * p.pts.stride_col);
+  const gpdev_c_t gpc = (gpdev_c_t)(p.gps);
+  bool safe = true;
+  double l0 = 0.0;
+  for (int g = 0; g < p.G; ++g) {        // (wave-uniform)
+    KernFast<D> kf;
+    kf.load_const(&p.gps[g].kern);
+    const int n = gpc[g].n;
+    const cdbl_t X = (cdbl_t)(gpc[g].Xs);
+    const cdbl_t al = (cdbl_t)(gpc[g].alpha);
+    const cdbl_t Li = (cdbl_t)(gpc[g].Linv);
+    const int64_t ld = gpc[g].ld;
+    double xs[D];
+    kf.template prep_t<SINGLE>(x, xs);
+    // the n covariances of this row, four at a time (training rows: scalar loads)
+    double k[NP];
+    double mean = 0.0;
+#pragma unroll
+    for (int j0 = 0; j0 < NP; j0 += 4) {
+      if (j0 < n) {                      // (uniform)
+        double y[4][D];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < D; ++i) y[q][i] = (j0 + q < n) ? X[(j0 + q) * D + i] : 0.0;
+        double kv[4];
+        kf.template manyn_t<4, SINGLE>(xs, &y[0][0], D, tab, kv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          k[j0 + q] = (j0 + q < n) ? kv[q] : 0.0;
+          mean = fma(al[j0 + q], k[j0 + q], mean);      // (alpha: zero padded to 16)
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k[j0 + q] = 0.0;
+      }
+    }
+    // |L^-1 k|^2, row by row (the entries of L^-1 are scalar operands)
+    double ssq = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (i < n) {                       // (uniform)
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) v = fma(Li[int64_t(i) * ld + j], k[j], v);
+        ssq = fma(v, v, ssq);
+      }
+    }
+    {
+      // (no contraction: mu -+ beta sd is rounded as the reference rounds it -- multiply,
+      // then add)
+#pragma clang fp contract(off)
+      const double var = fmax(gpc[g].kern.kdiag - ssq, 1e-15);   // GPy clip
+      const double sd = sqrt(var);
+      const double lo = mean - p.conf.beta * sd;
+      const double up = mean + p.conf.beta * sd;
+      if (g == 0) l0 = lo;
+      safe = safe && (lo > p.conf.fmin[g]);
+      if (valid) {
+        __builtin_nontemporal_store(mean, p.conf.mean + int64_t(g) * p.pts.N + row);
+        __builtin_nontemporal_store(var, p.conf.var + int64_t(g) * p.pts.N + row);
+        if (p.conf.Q)
+          *reinterpret_cast<double2_t*>(p.conf.Q + (row * p.G + g) * 2) = double2_t{lo, up};
+      }
+    }
+  }
+  if (p.conf.S) {
+    if (valid) p.conf.S[row] = safe ? 1 : 0;
+    // max l0 over the safe rows of the workgroup (folded by the consumer, sets.hip)
+    double m = wave_max((valid && safe) ? l0 : -INFINITY);
+    if ((threadIdx.x & 63) == 0) sh_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      p.conf.partial[blockIdx.x] = fmax(fmax(sh_max[0], sh_max[1]), fmax(sh_max[2], sh_max[3]));
+  }
+}
+
+template <int D, int NP>
+int launch_tiny_np(sgp_ctx* ctx, const TinyParams& p, bool single, unsigned nblocks) {
+  if (single)
+    hipLaunchKernelGGL((k_sweep_tiny<D, NP, true>), dim3(nblocks), dim3(256), 0, ctx->stream, p);
+  else
+    hipLaunchKernelGGL((k_sweep_tiny<D, NP, false>), dim3(nblocks), dim3(256), 0, ctx->stream, p);
+  return 0;
+}
+
+template <int D>
+int launch_tiny_d(sgp_ctx* ctx, const TinyParams& p, int np, bool single, unsigned nblocks) {
+  if (np <= 8) return launch_tiny_np<D, 8>(ctx, p, single, nblocks);
+  if (np <= 16) return launch_tiny_np<D, 16>(ctx, p, single, nblocks);
+  if (np <= 32) return launch_tiny_np<D, 32>(ctx, p, single, nblocks);
+  return launch_tiny_np<D, 48>(ctx, p, single, nblocks);
+}
+
+}  // namespace
+
+// Few observations in every GP of the launch: the VALU kernel (SGP_NO_TINY=1 /
+// sgp_ctx_set_sweep(1 or 2) keep the matrix-core kernels, A/B runs and tests).
+bool tiny_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff) {
+  static const bool off = getenv("SGP_NO_TINY") != nullptr;
+  if (off || (ctx->sweep_choice & 3) != 0) return false;
+  for (int g = 0; g < Geff; ++g)
+    if (gh[g].n > kTinyMaxN) return false;
+  return true;
+}
+
+int launch_sweep_tiny(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d, int Geff,
+                      double flops) {
+  TinyParams p{};
+  p.gps = a.gps;
+  p.G = Geff;
+  p.pts = a.pts;
+  p.conf = a.conf;
+  int np = 1;
+  bool single = true;
+  for (int g = 0; g < Geff; ++g) {
+    np = std::max(np, gh[g].n);
+    single = single && gh[g].kern.n_parts == 1;
+  }
+  const unsigned nblocks = unsigned((a.pts.N + 255) / 256);
+  ctx->sweep_partials = int(nblocks);
+  SweepTimer timer;
+  SGP_TRY(timer.begin(ctx, flops));
+  int rc = -2;
+  switch (d) {
+    case 1: rc = launch_tiny_d<1>(ctx, p, np, single, nblocks); break;
+    case 2: rc = launch_tiny_d<2>(ctx, p, np, single, nblocks); break;
+    case 3: rc = launch_tiny_d<3>(ctx, p, np, single, nblocks); break;
+    case 4: rc = launch_tiny_d<4>(ctx, p, np, single, nblocks); break;
+    case 5: rc = launch_tiny_d<5>(ctx, p, np, single, nblocks); break;
+    case 6: rc = launch_tiny_d<6>(ctx, p, np, single, nblocks); break;
+    case 7: rc = launch_tiny_d<7>(ctx, p, np, single, nblocks); break;
+    case 8: rc = launch_tiny_d<8>(ctx, p, np, single, nblocks); break;
+    default:
+      sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
+      return -2;
+  }
+  if (rc != 0) return rc;
+  SGP_HIP(ctx, hipGetLastError());
+  return timer.end(ctx);
+}

@@ -11,5 +11,5 @@ BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -I $C -Wall -Wno-unu
 /opt/rocm/bin/hipcc $BASE $FLAGS -mllvm -amdgpu-spill-vgpr-to-agpr=0 -c $C/sweep.hip -o $O/sweep.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scripts/dev/ab/$NAME.so \
-  $C/api.o $O/sweep.o $O/sweep_pair.o $C/factor.o $C/sets.o $C/swarm.o -ldl
+  $C/api.o $O/sweep.o $O/sweep_pair.o $C/sweep_tiny.o $C/factor.o $C/sets.o $C/swarm.o -ldl
 echo built scripts/dev/ab/$NAME.so

@@ -20,19 +20,24 @@ import bench  # noqa: E402
 import safeopt_amd.gpy as gpy  # noqa: E402
 from safeopt_amd import _hip  # noqa: E402
 
-ns = [int(a) for a in sys.argv[1:]] or [8, 20, 64, 128, 200, 256]
+ns = [int(a) for a in sys.argv[1:]] or [8, 20, 32, 64, 128, 200, 256]
 ctx = _hip.Context.default()
 ctx.set_share(False)
 cfg = bench.make_config(2)
 grid_pts = cfg["grid"]
 N = grid_pts.shape[0]
 axes = _hip.tensor_grid_axes(grid_pts)
-print("%-5s %-22s %9s %9s %9s %9s" % ("n", "kernel / evaluation", "ms", "TFLOP/s", "of 78.6", "VALU roof"))
+print("%-5s %-34s %9s %9s %9s %9s" % ("n", "covariances [sweep kernel]", "ms", "TFLOP/s", "of 78.6", "VALU roof"))
 for n in ns:
     rng = np.random.default_rng(n)
     X = rng.uniform(-2, 2, size=(n, 2))
     Y = (bench._bumps(X, 3) - bench._bumps(X, 3).min() + 0.5)[:, None]
-    for kind, tables in (("RBF", True), ("RBF", False), ("Matern52", False)):
+    cases = [("RBF", True, "auto"), ("RBF", False, "auto"), ("Matern52", False, "auto")]
+    if n <= 48:      # auto = the VALU kernel (sweep_tiny.hip); the matrix-core kernel next to it
+        cases = [("RBF", False, "auto"), ("Matern52", False, "auto"), ("RBF", True, "classic"),
+                 ("RBF", False, "classic"), ("Matern52", False, "classic")]
+    for kind, tables, which in cases:
+        ctx.set_sweep(which)
         k = getattr(gpy.kern, kind)(2, variance=2.0, lengthscale=[1.0, 1.0], ARD=True)
         gp = gpy.models.GPRegression(X, Y, k, noise_var=0.05 ** 2)
         dev = gp._fitted()
@@ -53,6 +58,10 @@ for n in ns:
         tf = fl / ms / 1e9
         per = 2 if tables else (22 if kind == "RBF" else 30)
         valu = per * n * N / (t * 1e-3) / 1e12 / 39.3
-        print("%-5d %-22s %9.4f %9.2f %9.3f %9.3f" %
-              (n, kind + (" factor tables" if tables else " evaluated"), t, tf, tf / 78.6, valu),
-              flush=True)
+        # VALU kernel: n evaluations + n (n + 1) / 2 + n FMAs per row
+        if ctx.last_sweep() == "tiny":
+            valu = ((22 if kind == "RBF" else 30) * n + n * (n + 1) / 2 + n) * N / (t * 1e-3) / 1e12 / 39.3
+        print("%-5d %-34s %9.4f %9.2f %9.3f %9.3f" %
+              (n, kind + (" factor tables" if tables else " evaluated") + " [" + ctx.last_sweep() + "]",
+               t, tf, tf / 78.6, valu), flush=True)
+ctx.set_sweep("auto")

@@ -47,7 +47,7 @@ def usage(src):
 
 def main():
     files = sys.argv[1:] or [os.path.join(CSRC, f) for f in
-                             ("sweep.hip", "sweep_pair.hip", "sets.hip", "swarm.hip",
+                             ("sweep.hip", "sweep_pair.hip", "sweep_tiny.hip", "sets.hip", "swarm.hip",
                               "factor.hip")]
     print("%-88s %5s %5s %5s %8s %5s %8s" % ("kernel", "VGPR", "AGPR", "SGPR", "scratch",
                                             "occ", "LDS"))

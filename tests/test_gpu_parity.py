@@ -480,6 +480,133 @@ def test_split_remainder_tiles_same_bits(mods, kind, d, ns, N):
         assert_array_equal(x, y)
 
 
+TINY_CASES = [
+    # kernel, d, [n per GP], rows
+    ("RBF", 1, [1], 300), ("RBF", 2, [5], 1000), ("Matern52", 2, [8], 5000), ("Matern32", 3, [9], 777),
+    ("RBF", 2, [16], 4096), ("Matern52", 1, [17], 1000), ("RBF", 2, [20], 50000), ("Matern32", 4, [32], 3000),
+    ("RBF", 8, [31], 900), ("Matern52", 5, [13, 2, 32], 2000), ("RBF", 2, [3] * 8, 1500),
+    ("RBF*RBF", 4, [24], 2500), ("RBF*RBF", 4, [7, 30], 700), ("Matern52", 7, [19], 256), ("RBF", 6, [32, 32], 257),
+    ("Matern52", 2, [33], 3000), ("RBF", 3, [48, 40], 1200), ("RBF*RBF", 4, [47], 600), ("Matern32", 8, [48], 300),
+]
+
+
+@pytest.mark.parametrize("kind,d,ns,N", TINY_CASES)
+def test_few_observations_valu_kernel(mods, kind, d, ns, N):
+    """Every GP of the launch has <= 48 observations (all examples of the reference): the
+    sweep runs on the fp64 VALU, one thread per row (csrc/sweep_tiny.hip).  Against the
+    oracle, against the 4-wave matrix-core kernel on the same rows, and the structural
+    properties: Q = mean -+ beta sqrt(var) bit for bit, S from Q, max l0 over S."""
+    sa, gpy, gpn, son = mods
+    from safeopt_amd import _hip
+    rng = np.random.default_rng(sum(ns) + 31 * d + N)
+
+    def kern(ns_):
+        if kind == "RBF*RBF":
+            return (ns_.RBF(2, 1.3, [0.8, 1.1], ARD=True, active_dims=[0, 1]) *
+                    ns_.RBF(2, 0.9, [1.2, 0.7], ARD=True, active_dims=[2, 3]))
+        return kernels(ns_, kind, d)
+    gps, gos = [], []
+    for i, n in enumerate(ns):
+        X = rng.uniform(-2, 2, size=(n, d)); Y = smooth(X, 5 + i) + 0.3
+        gps.append(gpy.models.GPRegression(X, Y, kern(gpy.kern), noise_var=0.05 ** 2))
+        gos.append(gpn.GPRegression(X, Y, kern(gpn), noise_var=0.05 ** 2))
+    pts = rng.uniform(-3, 3, size=(N, d))
+    G = len(ns)
+    fmin = np.where(np.arange(G) % 3 == 2, -np.inf, 0.1)
+    ctx = gps[0]._fitted().ctx
+    out = {}
+    old = ctx.set_sweep("auto")
+    try:
+        for which in ("auto", "classic"):
+            ctx.set_sweep(which)
+            grid = _hip.DeviceGrid(ctx, pts, G)
+            ml = grid.confidence([g._fitted() for g in gps], 2.0, fmin)
+            assert ctx.last_sweep() == ("tiny" if which == "auto" else "classic")
+            out[which] = (ml, grid.download(_hip.Q), grid.download(_hip.S),
+                          grid.download(_hip.MEAN), grid.download(_hip.VAR))
+    finally:
+        ctx.set_sweep(old)
+    (max_l, any_safe), Q, S, mean, var = out["auto"]
+    kd = float(gps[0].kern.Kdiag(np.zeros((1, d)))[0])
+    for i, go in enumerate(gos):
+        mo, vo = go.predict_noiseless(pts)
+        check_posterior(mean[i][:, None], var[i][:, None], mo, vo, kd)
+        sd = np.sqrt(var[i])
+        assert_array_equal(Q[:, 2 * i], mean[i] - 2.0 * sd)
+        assert_array_equal(Q[:, 2 * i + 1], mean[i] + 2.0 * sd)
+        # the matrix-core kernel on the same rows: another summation order, same posterior
+        assert_allclose(mean[i], out["classic"][3][i], rtol=0, atol=1e-12 * max(1.0, np.abs(mo).max()))
+        assert_allclose(var[i], out["classic"][4][i], rtol=0, atol=1e-12 * kd)
+    assert_array_equal(S, np.all(Q[:, ::2] > fmin, axis=1))
+    assert any_safe == bool(S.any())
+    if S.any():
+        assert max_l == Q[S, 0].max()
+    # from 49 observations on the matrix-core kernels take over
+    X = rng.uniform(-2, 2, size=(49, d)); Y = smooth(X, 3) + 0.3
+    big = gpy.models.GPRegression(X, Y, kern(gpy.kern), noise_var=0.05 ** 2)
+    g1 = _hip.DeviceGrid(ctx, pts, 1)
+    g1.confidence([big._fitted()], 2.0, np.zeros(1))
+    assert ctx.last_sweep() == "classic"
+
+
+@pytest.mark.parametrize("kind,d,ns,N,grid", [("RBF", 2, [1], 700, False), ("Matern52", 2, [20], 40000, False),
+                                              ("RBF", 2, [64], 64 * 520 + 3, True),
+                                              ("Matern32", 3, [17, 33, 5], 9000, False),
+                                              ("RBF", 1, [100], 3000, True), ("RBF", 5, [48, 48], 5000, False),
+                                              # the largest that stays (28 positions), one too many
+                                              ("RBF", 2, [112], 20000, True), ("RBF", 2, [113], 20000, True),
+                                              ("RBF*RBF", 4, [40], 2500, False)])
+def test_resident_factor_same_bits(mods, kind, d, ns, N, grid):
+    """Small factors (every example of the reference: n <= 20) stay in LDS for the whole
+    launch of the 4-wave kernel -- no LDS-DMA, wait or barrier per stage, the waves of a
+    workgroup run free: mean, var, Q and S must be the SAME BITS as when the very same
+    stages are streamed through the double buffer."""
+    sa, gpy, gpn, son = mods
+    from safeopt_amd import _hip
+    rng = np.random.default_rng(N + d + sum(ns))
+    def kern(ns_):
+        if kind == "RBF*RBF":
+            return (ns_.RBF(2, 1.3, [0.8, 1.1], ARD=True, active_dims=[0, 1]) *
+                    ns_.RBF(2, 0.9, [1.2, 0.7], ARD=True, active_dims=[2, 3]))
+        return kernels(ns_, kind, d)
+    gps, gos = [], []
+    for i, n in enumerate(ns):
+        X = rng.uniform(-2, 2, size=(n, d)); Y = smooth(X, 5 + i) + 0.3
+        gps.append(gpy.models.GPRegression(X, Y, kern(gpy.kern), noise_var=0.05 ** 2))
+        gos.append(gpn.GPRegression(X, Y, kern(gpn), noise_var=0.05 ** 2))
+    if grid:
+        side = max(2, int(round(N ** (1.0 / d))))
+        pts = sa.linearly_spaced_combinations([(-3., 3.)] * d, [side + k for k in range(d)])
+    else:
+        pts = rng.uniform(-3, 3, size=(N, d))
+    G = len(ns)
+    fmin = np.full(G, 0.1)
+    ctx = gps[0]._fitted().ctx
+    out = {}
+    old = ctx.set_sweep("classic")
+    try:
+        for which in ("classic", "classic-streamed"):
+            ctx.set_sweep(which)
+            g = _hip.DeviceGrid(ctx, pts, G)
+            if grid:
+                assert g.set_axes(_hip.tensor_grid_axes(pts))
+            ml = g.confidence([gp._fitted() for gp in gps], 2.0, fmin)
+            out[which] = (ml, g.download(_hip.Q), g.download(_hip.S),
+                          g.download(_hip.MEAN), g.download(_hip.VAR))
+    finally:
+        ctx.set_sweep(old)
+    a, b = out["classic"], out["classic-streamed"]
+    assert a[0] == b[0]
+    for x, y in zip(a[1:], b[1:]):
+        assert_array_equal(x, y)
+    # ... and the oracle, on a sample of rows
+    sel = rng.choice(pts.shape[0], size=min(300, pts.shape[0]), replace=False)
+    for i, go in enumerate(gos):
+        mo, vo = go.predict_noiseless(pts[sel])
+        kd = float(gps[i].kern.Kdiag(np.zeros((1, d)))[0])
+        check_posterior(a[3][i][sel, None], a[4][i][sel, None], mo, vo, kd)
+
+
 @pytest.mark.parametrize("n,N,layout", [(300, 5000, "aaa"), (530, 3000, "aab"), (400, 20000, "abb"),
                                         (1100, 2500, "aa"),
                                         # riders (up to 2 per leader form alpha . k in the leader's
