@@ -347,7 +347,9 @@ __device__ __forceinline__ void narrow_groups(int ngrp, double (&accx)[kMaxNg],
 // RBF parts (SepLaunch): a covariance is the product of SEP table entries -- two
 // 16-byte loads per axis, lane and stage, issued one stage ahead, instead of ~22 fp64
 // instructions per value.  (Instantiated with D = 1: the rows themselves are not read.)
-template <int D, int NW, int SL, int MODE, bool SINGLE, int R = 0, int SEP = 0>
+// RES: the factors are small enough to stay in LDS for the whole launch (SweepParams::
+// res_xbase) -- instances of their own, so that the streaming instances carry none of it.
+template <int D, int NW, int SL, int MODE, bool SINGLE, int R = 0, int SEP = 0, bool RES = false>
 __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   constexpr int kTilePts = 16 * NW;
   // (2 kMaxNg doubles live across the evaluation: where the registers are to be had)
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   };
   // resident mode: where stage si of the sequence lives (bytes from lds0)
   constexpr uint32_t kXBlk = uint32_t(kXTile + kJC * (1 + R)) * 8u;
-  const bool resident = p.resident != 0;
+  constexpr bool resident = RES;
 
   // Stage cursors: the stage being multiplied (its entry word in wcur), the stage
   // being prefetched (entry e1, one ahead) and the stage whose entry is being loaded
@@ -1278,7 +1280,11 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep<D, NW, SL, MODE, SINGLE, R, SEP>),
+                     reinterpret_cast<const void*>(&k_sweep<D, NW, SL, MODE, SINGLE, R, SEP, false>),
+                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                     int(Lay<SL, D, R>::bytes(NW))));
+    SGP_HIP(ctx, hipFuncSetAttribute(
+                     reinterpret_cast<const void*>(&k_sweep<D, NW, SL, MODE, SINGLE, R, SEP, true>),
                      hipFuncAttributeMaxDynamicSharedMemorySize,
                      int(Lay<SL, D, R>::bytes(NW))));
     attr_set = true;
@@ -1307,8 +1313,12 @@ int launch_sweep_v(sgp_ctx* ctx, const SweepParams& p, double flops) {
   if (!stamps_dev) SGP_HIP(ctx, hipMalloc(&stamps_dev, size_t(4096) * NW * 8 * 8));
   pp.stamps = stamps_dev;
 #endif
-  hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE, R, SEP>), dim3(nblocks),
-                     dim3(64 * NW), lds_bytes, ctx->stream, pp);
+  if (pp.resident)
+    hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE, R, SEP, true>), dim3(nblocks),
+                       dim3(64 * NW), lds_bytes, ctx->stream, pp);
+  else
+    hipLaunchKernelGGL((k_sweep<D, NW, SL, MODE, SINGLE, R, SEP, false>), dim3(nblocks),
+                       dim3(64 * NW), lds_bytes, ctx->stream, pp);
   SGP_HIP(ctx, hipGetLastError());
 #ifdef SGP_STAMPS
   {
