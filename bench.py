@@ -391,6 +391,43 @@ def sets_roofline(opt, ctx, cfg, rows, steps=20):
                     "host round trip of the step"}
 
 
+def reference_regime(gpy, safeopt_amd, ctx, n=20, steps=200):
+    """The regime of the reference's own examples and tests -- a GP with ~20 observations
+    (2-D RBF here, on the 1000 x 1000 grid of config 2): ms per SafeOpt.optimize(), the
+    sweep launch alone (sweep_tiny.hip: one thread per row on the fp64 VALU), its
+    fraction of the fp64-VALU roof (22 instructions per covariance value, n (n + 1) / 2
+    + n FMAs per row) -- and the oracle on a block of the same rows."""
+    cfg = make_config(2)
+    rng = np.random.default_rng(n)
+    X = rng.uniform(-2, 2, size=(n, 2))
+    Y = (_bumps(X, 3) - _bumps(X, 3).min() + 0.5)[:, None]
+    gp = gpy.models.GPRegression(X, Y, gpy.kern.RBF(2, variance=2.0, lengthscale=[1.0, 1.0], ARD=True),
+                                 noise_var=0.05 ** 2)
+    opt = safeopt_amd.SafeOpt(gp, cfg["grid"], 0.0, threshold=cfg["threshold"])
+    for _ in range(20):
+        opt.optimize()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        opt.optimize()
+    ctx.sync()
+    step_ms = (time.perf_counter() - t0) * 1e3 / steps
+    ctx.profile_enable(True)
+    for _ in range(20):
+        opt.optimize()
+    ctx.sync()
+    ms, launches, _ = ctx.profile_read()
+    ctx.profile_enable(False)
+    t = ms / max(launches, 1)
+    N = cfg["grid"].shape[0]
+    ops = (22.0 * n + n * (n + 1) / 2.0 + n) * N
+    return {"workload": "2-D RBF, G=1, n=%d, grid 1000x1000, one SafeOpt.optimize()" % n,
+            "ms_per_step": step_ms, "value": N / (step_ms * 1e-3), "unit": "candidates/s",
+            "sweep_kernel": ctx.last_sweep(), "sweep_ms": t,
+            "roofline": {"bound": "fp64 valu", "achieved": ops / (t * 1e-3) / 1e12, "peak": 39.3,
+                         "unit": "T lane-ops/s", "frac": ops / (t * 1e-3) / 1e12 / 39.3}}
+
+
 def config4_strong(gpy, safeopt_amd, dist, ctx, comm, rank, world, steps=4, warmup=2):
     """BASELINE.json's 8-GPU config (3-D RBF, n = 1000, the fixed 200^3 grid,
     row-sharded in contiguous blocks of the flat index): ms per SafeOpt.optimize() and
@@ -625,6 +662,11 @@ def main():
                     extras["rank1_roofline"] = extras["bo_iteration"]["rank1_roofline"]
             except Exception as e:      # noqa -- an extra must never break the line
                 extras["extras_error"] = repr(e)
+        if default_run and world == 1:
+            try:
+                extras["reference_regime"] = reference_regime(gpy, safeopt_amd, ctx)
+            except Exception as e:      # noqa
+                extras["reference_regime"] = {"error": repr(e)}
         if default_run:
             try:
                 extras["config4_strong"] = config4_strong(gpy, safeopt_amd, dist, ctx, comm,

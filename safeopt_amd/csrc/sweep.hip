@@ -262,16 +262,7 @@ __device__ __forceinline__ void load_slot(double (&ops)[4], const double* aT,
 // of 16 in the one slot that meets EVERY j-block.  The groups need kv only, not the
 // broadcast operands: they are issued in front of the LDS transpose, whose round
 // trip passes under them.
-#ifndef SGP_AN_EARLY_SEP
-#define SGP_AN_EARLY_SEP 1
-#endif
-#ifndef SGP_AN_EARLY
-#define SGP_AN_EARLY 0
-#endif
-#ifndef SGP_MAX_NG
-#define SGP_MAX_NG 2
-#endif
-constexpr int kMaxNg = SGP_MAX_NG;
+constexpr int kMaxNg = 2;     // (three groups, 9..12 rows: measured, no gain over a full slot)
 // ONE asm statement for all groups, the groups a GP does not have skipped by a scalar
 // branch INSIDE it: variants of the sequence at the source level, or a slot that is
 // narrow on one path and full on the other, make the register allocator duplicate
@@ -353,8 +344,7 @@ template <int D, int NW, int SL, int MODE, bool SINGLE, int R = 0, int SEP = 0, 
 __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   constexpr int kTilePts = 16 * NW;
   // (2 kMaxNg doubles live across the evaluation: where the registers are to be had)
-  constexpr bool kAnEarly = (SGP_AN_EARLY && D <= 2 && R == 0) ||
-                            (SGP_AN_EARLY_SEP && SEP > 0 && SEP <= 2 && !(SEP == 2 && R > 0));
+  constexpr bool kAnEarly = SEP > 0 && SEP <= 2 && !(SEP == 2 && R > 0);
   // d >= 5 (and products at d = 4): no registers for the raw row of this tile and of
   // the next one -- the row is read (an L2 hit) where a GP's scaled row is formed
   constexpr bool kLeanX = SEP == 0 && (D >= 5 || (D == 4 && !SINGLE));
@@ -500,11 +490,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
   double kdiag;
   int nr_cur = 0;
   auto load_gp = [&](int g) {
-#ifdef SGP_KF_CTOR
-    if (SEP == 0) kf = KernFast<D>(p.gps[g].kern);
-#else
     if (SEP == 0) kf.load_const(&p.gps[g].kern);
-#endif
     kdiag = gpc[g].kern.kdiag;
     if (R > 0) nr_cur = p.nride[g];
   };
@@ -602,12 +588,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     if (left > 2) e2 = load_stage(stages, si2);
 
     SGP_STAMP(0);   // prefetch issue, table entry
-#ifdef SGP_PAD_SALU      // issue-model experiment: extra scalar instructions per stage
-    asm volatile(".rept " SGP_STR(SGP_PAD_SALU) "\n\ts_mov_b32 s98, 0\n\t.endr" ::: "s98");
-#endif
-#ifdef SGP_PAD_VALU
-    asm volatile(".rept " SGP_STR(SGP_PAD_VALU) "\n\tv_mov_b32 v127, 0\n\t.endr" ::: "v127");
-#endif
     // ---- this stage: 16 training points against the active row blocks
     if (SEP == 0 && gp_start) {
       if constexpr (kLeanX) {
@@ -1449,26 +1429,20 @@ int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d,
     switch (sep->naxes) {
       case 1: return launch_sweep_sep<1>(ctx, q, flops);
       case 2: return launch_sweep_sep<2>(ctx, q, flops);
-#ifndef SGP_ONLY_D2
       case 3: return launch_sweep_sep<3>(ctx, q, flops);
-#endif
       // (4 axes: 32 registers of factors in flight -- the instance would spill; the
       // covariances are evaluated, below)
     }
   }
   switch (d) {
-#ifndef SGP_ONLY_D2      // (compile-time experiments: one instance set)
     case 1: return launch_sweep_d<1>(ctx, q, flops);
-#endif
     case 2: return launch_sweep_d<2>(ctx, q, flops);
-#ifndef SGP_ONLY_D2
     case 3: return launch_sweep_d<3>(ctx, q, flops);
     case 4: return launch_sweep_d<4>(ctx, q, flops);
     case 5: return launch_sweep_d<5>(ctx, q, flops);
     case 6: return launch_sweep_d<6>(ctx, q, flops);
     case 7: return launch_sweep_d<7>(ctx, q, flops);
     case 8: return launch_sweep_d<8>(ctx, q, flops);
-#endif
   }
   sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
   return -2;
