@@ -11,19 +11,32 @@ from oracle import gp_numpy as gpn, safeopt_numpy as son
 KINDS = ["RBF", "Matern32", "Matern52"]
 
 
-def run(trials=150, dmax=4, Gmax=3, nmax=300, seed0=1000, verbose=True, products=False):
-  """(mismatches, max |Q_dev - Q_oracle|) over `trials` seeded random problems."""
+def run(trials=150, dmax=4, Gmax=3, nmax=300, seed0=1000, verbose=True, products=False,
+        grids=False):
+  """(mismatches, max |Q_dev - Q_oracle|) over `trials` seeded random problems.
+  grids: half of the parameter sets are tensor grids (linearly_spaced_combinations, plus
+  constant context columns now and then) with RBF kernels -- factor tables -- and the
+  kernel that swept each trial is counted."""
   bad = 0
   worst = 0.0
+  ran = {}
   for t in range(trials):
     rng = np.random.default_rng(seed0 + t)
     n, d, G = int(rng.integers(1, nmax)), int(rng.integers(1, dmax + 1)), int(rng.integers(1, Gmax + 1))
     N = int(rng.integers(1, 3000))
     X = rng.uniform(-2, 2, size=(n, d))
     grid = rng.uniform(-3, 3, size=(N, d))
+    on_grid = grids and rng.random() < 0.5
+    if on_grid:
+        nctx = int(rng.integers(0, 2)) if d >= 2 else 0
+        sides = [int(rng.integers(2, max(3, int(round(N ** (1.0 / (d - nctx)))) + 2))) for _ in range(d - nctx)]
+        grid = safeopt_amd.linearly_spaced_combinations([(-3., 3.)] * (d - nctx), sides)
+        if nctx:
+            grid = np.hstack([grid, np.tile(rng.uniform(-1, 1, size=nctx), (grid.shape[0], 1))])
+        N = grid.shape[0]
     gps, gos = [], []
     for g in range(G):
-        kind = KINDS[int(rng.integers(0, 3))]
+        kind = "RBF" if on_grid and rng.random() < 0.8 else KINDS[int(rng.integers(0, 3))]
         ls = list(rng.uniform(0.5, 2.0, size=d))
         var = float(rng.uniform(0.5, 3.0))
         y = (np.sin(X.sum(1) + g) + 1.0 + 0.3 * rng.normal(size=n))[:, None]
@@ -52,6 +65,13 @@ def run(trials=150, dmax=4, Gmax=3, nmax=300, seed0=1000, verbose=True, products
         empty = False
     except EnvironmentError:
         empty = True
+    def all_rbf(k):
+        return all(p.name == "rbf" for p in (k.parts if k.name == "mul" else [k]))
+    tables = (getattr(opt._backend, "tensor_grid", False) and all(all_rbf(g.kern) for g in gps)
+              and gps[0]._fitted().ctx.last_sweep() != "tiny" and
+              len([c for c in range(d) if np.unique(grid[:, c]).size > 1]) <= 3)
+    key = gps[0]._fitted().ctx.last_sweep() + (" + tables" if tables else "")
+    ran[key] = ran.get(key, 0) + 1
     try:
         idx, Q, S, M, Gm = son.optimize_grid(gos, grid, fmin, opt.scaling, thr, 2.)
         oempty = False
@@ -98,6 +118,7 @@ def run(trials=150, dmax=4, Gmax=3, nmax=300, seed0=1000, verbose=True, products
         bad += 1
   if verbose:
     print("%d trials, %d mismatches, max |Q_dev - Q_oracle| = %.3g" % (trials, bad, worst))
+    print("sweep kernels of the trials:", ran)
   return bad, worst
 
 
