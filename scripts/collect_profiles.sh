@@ -80,6 +80,7 @@ if [ -f scripts/dev/ab/instr.so ]; then
 fi
 # the reference's own regime (n <= 256) and SafeOptSwarm's input dimensions
 python scripts/dev/small_n.py > $OUT/small_n.txt 2>&1
+python scripts/dev/small_n.py 4 8 16 20 32 48 64 > $OUT/small_n_few.txt 2>&1
 python scripts/dev/high_d.py > $OUT/high_d.txt 2>&1
 # hipEvent vs rocprof on identical launches, and the clock ramp
 {
