@@ -777,8 +777,11 @@ int sgp_grid_confidence(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   co.beta = beta;
   for (int i = 0; i < SGP_MAX_GPS; ++i) co.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
   SepLaunch sl;
-  SGP_TRY(launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co,
-                            sep_launch(g, gps, host, G, &sl)));
+  const SepLaunch* sep = sep_launch(g, gps, host, G, &sl);
+  ctx->sweep_rows_sharded = true;     // (kernel choice by the GPs alone: same on every rank)
+  const int rc = launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co, sep);
+  ctx->sweep_rows_sharded = false;
+  SGP_TRY(rc);
   return finish_safe_partials(g, sweep_num_partials(ctx, g->N), out2);
 }
 
@@ -796,8 +799,11 @@ int sgp_grid_posterior(sgp_grid* g, sgp_gp* const* gps, int G) {
   co.beta = 0.0;
   for (int i = 0; i < SGP_MAX_GPS; ++i) co.fmin[i] = -INFINITY;
   SepLaunch sl;
-  return launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co,
-                           sep_launch(g, gps, host, G, &sl));
+  const SepLaunch* sep = sep_launch(g, gps, host, G, &sl);
+  ctx->sweep_rows_sharded = true;
+  const int rc = launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co, sep);
+  ctx->sweep_rows_sharded = false;
+  return rc;
 }
 
 int sgp_grid_rank1_update(sgp_grid* g, sgp_gp* const* gps, int G,
@@ -1561,16 +1567,30 @@ int sgp_swarm_run(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
   fa.safe = dsafe;
   const SweepPoints sp{dpos, P, d, 1};          // row-major (P, d) in place
   const bool few = P <= kSmallSwarm && small_path_pays_all(gps, G, P);
+  // a small swarm against GPs with few observations (SafeOptSwarm's defaults on the
+  // reference's own examples: 20 particles, n <= 20): the posterior is one sweep launch
+  // (sweep_tiny.hip up to 48 observations), everything else of the iteration the same ONE
+  // workgroup as on the few-points path -- two launches per iteration instead of five
+  const bool few_swept = P <= kSmallSwarm && !few;
   const double* r = drand;
   double inertia = inertia0;
-  if (few) {
+  if (few || few_swept) {
     // small swarm: three launches per iteration -- k(X, particles), the block
     // products on the matrix cores, and ONE workgroup for everything else
     // (fitness, bests, and the move that opens the next iteration)
     const int Geff = (swarm_type == SGP_SWARM_GREEDY) ? 1 : G;
-    SmallBufs sb;
-    SGP_CHECK(ctx, small_reserve(ctx, host, Geff, int(P), &sb) == 0,
-              "device allocation failed: %s", ctx->err.c_str());
+    SmallBufs sb{};
+    ConfOut post{};
+    if (few) {
+      SGP_CHECK(ctx, small_reserve(ctx, host, Geff, int(P), &sb) == 0,
+                "device allocation failed: %s", ctx->err.c_str());
+    } else {
+      const size_t np = size_t(Geff) * size_t(P);
+      SGP_TRY(sgp_reserve(ctx, &ctx->pair_post, 2 * np * sizeof(double)));
+      post.mean = static_cast<double*>(ctx->pair_post.p);
+      post.var = post.mean + np;
+      for (int i = 0; i < SGP_MAX_GPS; ++i) post.fmin[i] = -INFINITY;
+    }
     PsoSmallArgs ps{};
     ps.pos = dpos;
     ps.vel = dvel;
@@ -1583,14 +1603,18 @@ int sgp_swarm_run(sgp_ctx* ctx, sgp_gp* const* gps, int G, int swarm_type,
     ps.P = int(P);
     ps.d = d;
     auto step = [&](int is_init, int it_next) -> int {   // it_next < 0: no move
-      SGP_TRY(posterior_small_all(ctx, gdev, host, Geff, dpos, int(P), sb, nullptr,
-                                  nullptr));
+      if (few)
+        SGP_TRY(posterior_small_all(ctx, gdev, host, Geff, dpos, int(P), sb, nullptr,
+                                    nullptr));
+      else
+        SGP_TRY(launch_sweep_conf(ctx, gdev, host, Geff, d, sp, post));
       ps.init = is_init;
       ps.move = it_next >= 0;
       ps.rand = r;
       ps.draw = uint32_t(it_next + 1);
       ps.inertia = inertia;
-      SGP_TRY(launch_pso_small_step(ctx, gdev, G, sb, fa, ps));
+      SGP_TRY(launch_pso_small_step(ctx, gdev, G, sb, fa, ps, few ? nullptr : post.mean,
+                                    few ? nullptr : post.var));
       if (ps.move) {
         if (r) r += 2 * size_t(P) * d;
         inertia += step_size;

@@ -158,6 +158,9 @@ struct sgp_ctx {
   int sweep_partials = 0;     // partials of max l0[S] the last confidence sweep left
   int sweep_choice = 0;       // sgp_ctx_set_sweep: 0 auto, 1 4-wave, 2 paired
   int last_sweep = 0;         // kernel of the last posterior sweep (sgp_ctx_last_sweep)
+  bool sweep_rows_sharded = false;   // the rows of the sweep being launched are a rank's
+                              // shard of a grid (sgp_grid_*): the kernel is then chosen by
+                              // the GPs alone, never by the number of rows
   int share_factors = 1;      // sgp_ctx_set_share: GPs with identical (X, kernel, noise)
                               // share the variance contraction (paired sweep)
   // RCCL

@@ -60,5 +60,7 @@ struct PsoSmallArgs {
   int P, d, init, move;
 };
 // block sums + fitness + personal / global bests + (optionally) the next move
+// (post_mean / post_var: [G][P] posterior of a sweep instead of the block sums of sb)
 int launch_pso_small_step(sgp_ctx* ctx, const GpDev* gps_dev, int G, const SmallBufs& sb,
-                          FitnessArgs fa, PsoSmallArgs ps);
+                          FitnessArgs fa, PsoSmallArgs ps, const double* post_mean = nullptr,
+                          const double* post_var = nullptr);

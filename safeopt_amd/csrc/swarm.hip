@@ -269,16 +269,26 @@ __global__ void k_fitness_small(int G, int64_t P, const double* mean,
 // GP, fitness, personal bests, global best (first index on ties) and the move
 // that opens the next iteration.  Same arithmetic, statement for statement, as
 // k_small_post + k_fitness_small + k_pso_best + k_pso_gbest + k_pso_move.
+// post_mean != nullptr: the posterior comes from a sweep ([G][P] mean | var, the GPs with
+// fewer observations than the few-points path wants): no block sums, the rest as above.
 __global__ __launch_bounds__(1024) void k_pso_small_step(const GpDev* gps, int G,
                                                          SmallBufs sb, FitnessArgs f,
-                                                         PsoSmallArgs ps) {
+                                                         PsoSmallArgs ps,
+                                                         const double* post_mean,
+                                                         const double* post_var) {
   __shared__ double sh[4][16][16];
   __shared__ double smean[SGP_MAX_GPS][kSmallSwarm], svar[SGP_MAX_GPS][kSmallSwarm];
   __shared__ double sbv[kSmallSwarm];
   const int t = threadIdx.x, P = ps.P, d = ps.d;
   const int Geff = (f.swarm_type == SGP_SWARM_GREEDY) ? 1 : G;
   // block sums of (GP, pass) pairs, four pairs side by side
-  const int grp = t >> 8, tl = t & 255, npairs = Geff * sb.passes;
+  const int grp = t >> 8, tl = t & 255, npairs = post_mean ? 0 : Geff * sb.passes;
+  if (post_mean) {
+    for (int e = t; e < Geff * P; e += 1024) {
+      smean[e / P][e % P] = post_mean[e];
+      svar[e / P][e % P] = post_var[e];
+    }
+  }
   for (int base = 0; base < npairs; base += 4) {
     const int pair = base + grp;
     const bool valid = pair < npairs;
@@ -392,9 +402,10 @@ int launch_fitness_small(sgp_ctx* ctx, int G, int64_t P, const double* mean,
 }
 
 int launch_pso_small_step(sgp_ctx* ctx, const GpDev* gps_dev, int G, const SmallBufs& sb,
-                          FitnessArgs fa, PsoSmallArgs ps) {
+                          FitnessArgs fa, PsoSmallArgs ps, const double* post_mean,
+                          const double* post_var) {
   hipLaunchKernelGGL(k_pso_small_step, dim3(1), dim3(1024), 0, ctx->stream, gps_dev, G,
-                     sb, fa, ps);
+                     sb, fa, ps, post_mean, post_var);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

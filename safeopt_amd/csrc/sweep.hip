@@ -1386,7 +1386,7 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d,
 // the 4-wave kernel below, the VALU kernel (sweep_tiny.hip) up to 32 observations.
 int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d, int Geff,
                      double flops, const SepLaunch* sep) {
-  if (tiny_sweep_wanted(ctx, gh, Geff)) {
+  if (tiny_sweep_wanted(ctx, gh, Geff, p.pts.N)) {
     ctx->last_sweep = 3;
     SweepArgs a{p.gps, p.G, p.mode, p.pts, p.conf, p.fit};
     return launch_sweep_tiny(ctx, a, gh, d, Geff, flops);    // (sets ctx->sweep_partials)

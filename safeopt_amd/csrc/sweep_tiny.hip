@@ -90,15 +90,24 @@ __global__ __launch_bounds__(256) void k_sweep_tiny(TinyParams p) {
         for (int q = 0; q < 4; ++q) k[j0 + q] = 0.0;
       }
     }
-    // |L^-1 k|^2, row by row (the entries of L^-1 are scalar operands)
+    // |L^-1 k|^2 (the entries of L^-1 are scalar operands), four rows at a time: four
+    // independent chains, so that a launch with few rows (a swarm of 20 particles: one
+    // wave, nothing else to hide the FMA latency behind) is not a single dependent chain
+    // of n^2 / 2 instructions.  Rows n .. of the last group: identity rows of the padding
+    // times k = 0.  Every row is summed in the order j = 0 .. i.
     double ssq = 0.0;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      if (i < n) {                       // (uniform)
-        double v = 0.0;
+    for (int i0 = 0; i0 < NP; i0 += 4) {
+      if (i0 < n) {                      // (uniform)
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j <= i; ++j) v = fma(Li[int64_t(i) * ld + j], k[j], v);
-        ssq = fma(v, v, ssq);
+        for (int j = 0; j <= i0 + 3; ++j) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (j <= i0 + q) v[q] = fma(Li[int64_t(i0 + q) * ld + j], k[j], v[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ssq = fma(v[q], v[q], ssq);
       }
     }
     {
@@ -151,12 +160,20 @@ int launch_tiny_d(sgp_ctx* ctx, const TinyParams& p, int np, bool single, unsign
 
 // Few observations in every GP of the launch: the VALU kernel (SGP_NO_TINY=1 /
 // sgp_ctx_set_sweep(1 or 2) keep the matrix-core kernels, A/B runs and tests).
-bool tiny_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff) {
+// A grid (the rows are a rank's shard): by the sizes of the GPs alone, so that every rank
+// takes the same kernel.  A set of points handed over per call (swarm particles, predict):
+// the thread-per-row kernel needs rows to hide its dependent chains behind -- a swarm of
+// 20 particles is ONE wave -- and the 4-wave kernel, which spreads a row's training
+// points over lanes, is faster below ~1500 rows per observation (20 rows, n = 40: 9.4
+// against 15.2 us; crossover at 32 k rows for n = 20, 55 k for n = 40; from n <= 10 the
+// VALU kernel wins at any size: scripts/dev/tiny_crossover.py).
+bool tiny_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff, int64_t rows) {
   static const bool off = getenv("SGP_NO_TINY") != nullptr;
   if (off || (ctx->sweep_choice & 3) != 0) return false;
-  for (int g = 0; g < Geff; ++g)
-    if (gh[g].n > kTinyMaxN) return false;
-  return true;
+  int nmax = 0;
+  for (int g = 0; g < Geff; ++g) nmax = std::max(nmax, gh[g].n);
+  if (nmax > kTinyMaxN) return false;
+  return ctx->sweep_rows_sharded || nmax <= 10 || rows >= int64_t(1536) * nmax;
 }
 
 int launch_sweep_tiny(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d, int Geff,
