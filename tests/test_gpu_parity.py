@@ -541,6 +541,17 @@ def test_few_observations_valu_kernel(mods, kind, d, ns, N):
     assert any_safe == bool(S.any())
     if S.any():
         assert max_l == Q[S, 0].max()
+    # points handed over per call (predict, swarm particles): the thread-per-row kernel only
+    # with enough rows to hide its chains behind, or when the GP is tiny; same posterior
+    few = pts[:50]
+    m_few, v_few = gps[0].predict_noiseless(few)
+    assert ctx.last_sweep() == ("tiny" if ns[0] <= 10 else "classic")
+    assert_allclose(m_few[:, 0], mean[0][:50], rtol=0, atol=1e-12 * max(1.0, np.abs(mean[0]).max()))
+    assert_allclose(v_few[:, 0], var[0][:50], rtol=0, atol=1e-12 * kd)
+    if ns[0] <= 12:
+        many = rng.uniform(-3, 3, size=(1536 * ns[0], d))
+        gps[0].predict_noiseless(many)
+        assert ctx.last_sweep() == "tiny"
     # from 49 observations on the matrix-core kernels take over
     X = rng.uniform(-2, 2, size=(49, d)); Y = smooth(X, 3) + 0.3
     big = gpy.models.GPRegression(X, Y, kern(gpy.kern), noise_var=0.05 ** 2)
