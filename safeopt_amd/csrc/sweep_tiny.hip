@@ -93,8 +93,7 @@ __global__ __launch_bounds__(256) void k_sweep_tiny(TinyParams p) {
     // |L^-1 k|^2 (the entries of L^-1 are scalar operands), four rows at a time: four
     // independent chains, so that a launch with few rows (a swarm of 20 particles: one
     // wave, nothing else to hide the FMA latency behind) is not a single dependent chain
-    // of n^2 / 2 instructions.  Rows n .. of the last group: identity rows of the padding
-    // times k = 0.  Every row is summed in the order j = 0 .. i.
+    // of n^2 / 2 instructions.  Every row is summed in the order j = 0 .. i.
     double ssq = 0.0;
 #pragma unroll
     for (int i0 = 0; i0 < NP; i0 += 4) {
@@ -106,8 +105,12 @@ __global__ __launch_bounds__(256) void k_sweep_tiny(TinyParams p) {
           for (int q = 0; q < 4; ++q)
             if (j <= i0 + q) v[q] = fma(Li[int64_t(i0 + q) * ld + j], k[j], v[q]);
         }
+        // (rows n .. of the last group are NOT summed: after a pop / in a buffer with room
+        // for appends they hold whatever the factor left there -- only their reads are
+        // harmless)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ssq = fma(v[q], v[q], ssq);
+        for (int q = 0; q < 4; ++q)
+          if (i0 + q < n) ssq = fma(v[q], v[q], ssq);
       }
     }
     {
