@@ -777,11 +777,8 @@ int sgp_grid_confidence(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   co.beta = beta;
   for (int i = 0; i < SGP_MAX_GPS; ++i) co.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
   SepLaunch sl;
-  const SepLaunch* sep = sep_launch(g, gps, host, G, &sl);
-  ctx->sweep_rows_sharded = true;     // (kernel choice by the GPs alone: same on every rank)
-  const int rc = launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co, sep);
-  ctx->sweep_rows_sharded = false;
-  SGP_TRY(rc);
+  SGP_TRY(launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co,
+                            sep_launch(g, gps, host, G, &sl), /*rows_sharded=*/true));
   return finish_safe_partials(g, sweep_num_partials(ctx, g->N), out2);
 }
 
@@ -799,11 +796,8 @@ int sgp_grid_posterior(sgp_grid* g, sgp_gp* const* gps, int G) {
   co.beta = 0.0;
   for (int i = 0; i < SGP_MAX_GPS; ++i) co.fmin[i] = -INFINITY;
   SepLaunch sl;
-  const SepLaunch* sep = sep_launch(g, gps, host, G, &sl);
-  ctx->sweep_rows_sharded = true;
-  const int rc = launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co, sep);
-  ctx->sweep_rows_sharded = false;
-  return rc;
+  return launch_sweep_conf(ctx, g->gpdev, host, G, g->d, sp, co,
+                           sep_launch(g, gps, host, G, &sl), /*rows_sharded=*/true);
 }
 
 int sgp_grid_rank1_update(sgp_grid* g, sgp_gp* const* gps, int G,

@@ -158,9 +158,6 @@ struct sgp_ctx {
   int sweep_partials = 0;     // partials of max l0[S] the last confidence sweep left
   int sweep_choice = 0;       // sgp_ctx_set_sweep: 0 auto, 1 4-wave, 2 paired
   int last_sweep = 0;         // kernel of the last posterior sweep (sgp_ctx_last_sweep)
-  bool sweep_rows_sharded = false;   // the rows of the sweep being launched are a rank's
-                              // shard of a grid (sgp_grid_*): the kernel is then chosen by
-                              // the GPs alone, never by the number of rows
   int share_factors = 1;      // sgp_ctx_set_share: GPs with identical (X, kernel, noise)
                               // share the variance contraction (paired sweep)
   // RCCL
@@ -283,9 +280,11 @@ struct FitnessArgs {
   uint8_t* safe;
 };
 int sweep_num_partials(const sgp_ctx* ctx, int64_t N);
+// rows_sharded: the rows are a rank's shard of a grid -- the sweep kernel is then chosen
+// by the GPs alone (the same on every rank), never by the number of rows
 int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
                       int G, int d, SweepPoints pts, ConfOut out,
-                      const SepLaunch* sep = nullptr);
+                      const SepLaunch* sep = nullptr, bool rows_sharded = false);
 // per-axis factor tables of one GP (SepLaunch::tab): out[a] = table of axis a =
 // column cols[a] (count[cols[a]] points); the columns with one point are folded into
 // out[0]

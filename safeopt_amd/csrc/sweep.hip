@@ -1348,10 +1348,12 @@ int launch_sweep_sep(sgp_ctx* ctx, const SweepParams& p, double flops) {
 }
 
 int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d, int Geff,
-                     double flops, const SepLaunch* sep);
+                     double flops, const SepLaunch* sep, bool rows_sharded);
 
+// rows_sharded: the rows are a rank's shard of a grid (sgp_grid_*) -- the kernel is then
+// chosen by the GPs alone, never by the number of rows (same kernel on every rank)
 int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d,
-                 const SepLaunch* sep = nullptr) {
+                 const SepLaunch* sep = nullptr, bool rows_sharded = false) {
   // algorithmic flops: G * (n^2 + 2n) per row
   double flops = 0.0;
   const int Geff =
@@ -1377,7 +1379,7 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d,
     q.G = Geff;
     for (int i = 0; i < SGP_MAX_GPS; ++i) q.conf.fmin[i] = -INFINITY;
   }
-  int rc = launch_posterior(ctx, q, gh, d, Geff, flops, sep);
+  int rc = launch_posterior(ctx, q, gh, d, Geff, flops, sep, rows_sharded);
   if (rc != 0 || !fitness) return rc;
   return launch_fitness_small(ctx, p.G, p.pts.N, q.conf.mean, q.conf.var, p.fit);
 }
@@ -1385,8 +1387,8 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d,
 // The confidence sweep proper: the paired-wave kernel from 257 rows of L^-1 on,
 // the 4-wave kernel below, the VALU kernel (sweep_tiny.hip) up to 32 observations.
 int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d, int Geff,
-                     double flops, const SepLaunch* sep) {
-  if (tiny_sweep_wanted(ctx, gh, Geff, p.pts.N)) {
+                     double flops, const SepLaunch* sep, bool rows_sharded) {
+  if (tiny_sweep_wanted(ctx, gh, Geff, p.pts.N, rows_sharded)) {
     ctx->last_sweep = 3;
     SweepArgs a{p.gps, p.G, p.mode, p.pts, p.conf, p.fit};
     return launch_sweep_tiny(ctx, a, gh, d, Geff, flops);    // (sets ctx->sweep_partials)
@@ -1458,7 +1460,8 @@ int sweep_num_partials(const sgp_ctx* ctx, int64_t N) {
 }
 
 int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
-                      int G, int d, SweepPoints pts, ConfOut out, const SepLaunch* sep) {
+                      int G, int d, SweepPoints pts, ConfOut out, const SepLaunch* sep,
+                      bool rows_sharded) {
   SweepParams p{};
   p.gps = gps_dev;
   p.G = G;
@@ -1466,7 +1469,7 @@ int launch_sweep_conf(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
   p.pts = pts;
   p.conf = out;
   p.fit = FitnessArgs{};
-  return launch_sweep(ctx, p, gps_host, d, sep);
+  return launch_sweep(ctx, p, gps_host, d, sep, rows_sharded);
 }
 
 int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,

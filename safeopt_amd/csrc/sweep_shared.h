@@ -120,7 +120,8 @@ __device__ __forceinline__ const T* uniform_ptr(const T* q) {
 
 // sweep_tiny.hip: every GP of the launch has at most kTinyMaxN observations
 constexpr int kTinyMaxN = 48;
-bool tiny_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff, int64_t rows);
+bool tiny_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff, int64_t rows,
+                       bool rows_sharded);
 int launch_sweep_tiny(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d, int Geff,
                       double flops);
 

@@ -170,13 +170,14 @@ int launch_tiny_d(sgp_ctx* ctx, const TinyParams& p, int np, bool single, unsign
 // points over lanes, is faster below ~1500 rows per observation (20 rows, n = 40: 9.4
 // against 15.2 us; crossover at 32 k rows for n = 20, 55 k for n = 40; from n <= 10 the
 // VALU kernel wins at any size: scripts/dev/tiny_crossover.py).
-bool tiny_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff, int64_t rows) {
+bool tiny_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff, int64_t rows,
+                       bool rows_sharded) {
   static const bool off = getenv("SGP_NO_TINY") != nullptr;
   if (off || (ctx->sweep_choice & 3) != 0) return false;
   int nmax = 0;
   for (int g = 0; g < Geff; ++g) nmax = std::max(nmax, gh[g].n);
   if (nmax > kTinyMaxN) return false;
-  return ctx->sweep_rows_sharded || nmax <= 10 || rows >= int64_t(1536) * nmax;
+  return rows_sharded || nmax <= 10 || rows >= int64_t(1536) * nmax;
 }
 
 int launch_sweep_tiny(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d, int Geff,
