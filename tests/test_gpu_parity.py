@@ -627,7 +627,10 @@ def test_resident_factor_same_bits(mods, kind, d, ns, N, grid):
                                         (500, 64 * 256 + 64 * 40, "aaa"), (1000, 64 * 300 + 7, "baa"),
                                         # the 4-wave kernel (n <= 256): riders only
                                         (200, 5000, "aaa"), (40, 700, "aabbb"), (256, 3000, "abba"),
-                                        (130, 1200, "aaaa")])
+                                        (130, 1200, "aaaa"),
+                                        # ... with the factors resident in LDS (forced onto the 4-wave
+                                        # kernel below: up to 48 observations the VALU kernel would run)
+                                        (60, 2500, "aaa"), (30, 900, "aab"), (96, 4000, "aa")])
 def test_shared_factor_same_bits(mods, n, N, layout):
     """BASELINE.json config 3 is a multi-output GP: its GPs have the same inputs,
     kernel and noise, hence the same L^-1.  The paired sweep then takes |L^-1 k|^2
@@ -649,6 +652,8 @@ def test_shared_factor_same_bits(mods, n, N, layout):
     G = len(layout)
     fmin = np.full(G, 0.1)
     ctx = gps[0]._fitted().ctx
+    # (riders are a matter of the matrix-core kernels: keep small problems on the 4-wave one)
+    forced = ctx.set_sweep("classic") if n <= 112 else None
 
     def sweep():
         res = {}
@@ -657,6 +662,8 @@ def test_shared_factor_same_bits(mods, n, N, layout):
             try:
                 grid = _hip.DeviceGrid(ctx, pts, G)
                 ml = grid.confidence([g._fitted() for g in gps], 2.0, fmin)
+                assert ctx.last_sweep() == ("classic" if max(g.X.shape[0] for g in gps) <= 256
+                                            else "pair")
                 res[on] = (ml, grid.download(_hip.Q), grid.download(_hip.S),
                            grid.download(_hip.MEAN), grid.download(_hip.VAR))
             finally:
@@ -666,14 +673,18 @@ def test_shared_factor_same_bits(mods, n, N, layout):
             assert_array_equal(x, y)
         return res[True]
 
-    r = sweep()
-    if layout[0] == layout[1]:          # equal factors: equal variances
-        assert_array_equal(r[4][0], r[4][1])
-    # the same new observation point for every GP (SafeOpt.add_new_data_point)
-    xn = rng.uniform(-1, 1, size=(1, d))
-    for i, gp in enumerate(gps):
-        gp.set_XY(np.vstack([gp.X, xn]), np.vstack([gp.Y, [[0.4 + 0.1 * i]]]))
-    sweep()
+    try:
+        r = sweep()
+        if layout[0] == layout[1]:          # equal factors: equal variances
+            assert_array_equal(r[4][0], r[4][1])
+        # the same new observation point for every GP (SafeOpt.add_new_data_point)
+        xn = rng.uniform(-1, 1, size=(1, d))
+        for i, gp in enumerate(gps):
+            gp.set_XY(np.vstack([gp.X, xn]), np.vstack([gp.Y, [[0.4 + 0.1 * i]]]))
+        sweep()
+    finally:
+        if forced is not None:
+            ctx.set_sweep(forced)
 
 
 @pytest.mark.parametrize("which", ["classic", "pair"])
