@@ -1104,10 +1104,24 @@ __global__ __launch_bounds__(256) void k_rank1(const GpDev* gps, int G,
 
   bool safe = true;
   double l0 = 0.0;
+  // GPs that share the factor of the GP in front of them (GpDev::share: same inputs,
+  // kernel, noise and fitting history -- the outputs of a multi-output GP, with their one
+  // new observation at the same x*) have the same w and the same k(X, x), hence the same
+  // c(x): it is computed for the first of them and kept; only (y* - mu) / s^2 differs.
+  bool have_cx = false;
+  double cx_keep = 0.0;
   for (int g = 0; g < G; ++g) {
     double mean = ra.mean[int64_t(g) * pts.N + rrow];
     double var = ra.var[int64_t(g) * pts.N + rrow];
-    if (ra.which[g]) {
+    if (ra.which[g] && gps[g].share >= 0 && have_cx) {
+      const GpDev& gp = gps[g];
+      mean = fma(cx_keep, gp.upd[0], mean);
+      var = fmax(var - cx_keep * cx_keep * gp.upd[1], 1e-15);
+      if (writer) {
+        ra.mean[int64_t(g) * pts.N + row] = mean;
+        ra.var[int64_t(g) * pts.N + row] = var;
+      }
+    } else if (ra.which[g]) {
       const GpDev& gp = gps[g];
       const KernFast<D> kf(gp.kern);
       double xs[D];
@@ -1137,12 +1151,16 @@ __global__ __launch_bounds__(256) void k_rank1(const GpDev* gps, int G,
       }
       dot = sum_lane_groups(dot);
       const double cx = kf.raw(x, gp.upd + 2, tab) - dot;
+      cx_keep = cx;
+      have_cx = true;
       mean = fma(cx, gp.upd[0], mean);
       var = fmax(var - cx * cx * gp.upd[1], 1e-15);
       if (writer) {
         ra.mean[int64_t(g) * pts.N + row] = mean;
         ra.var[int64_t(g) * pts.N + row] = var;
       }
+    } else {
+      have_cx = false;
     }
     const double sd = sqrt(var);
     const double lo = mean - ra.beta * sd;

@@ -687,6 +687,51 @@ def test_shared_factor_same_bits(mods, n, N, layout):
             ctx.set_sweep(forced)
 
 
+@pytest.mark.parametrize("n,layout", [(60, "aaa"), (300, "aab"), (200, "abba"), (25, "aa")])
+def test_rank1_refresh_reuses_the_shared_factor_same_bits(mods, n, layout):
+    """The outputs of a multi-output GP get their new observation at the same x*: c(x) of
+    the closed-form rank-1 refresh (k_rank1) is the same for all of them and computed once
+    when the factor is shared -- mean, var, Q and S must be the same bits as with every GP
+    refreshed on its own, and agree with a sweep of the refitted GPs."""
+    _, gpy, gpn, son = mods
+    from safeopt_amd import _hip
+    rng = np.random.default_rng(n + len(layout))
+    d = 2
+    Xa = rng.uniform(-2, 2, size=(n, d)); Xb = rng.uniform(-2, 2, size=(n, d))
+    pts = rng.uniform(-3, 3, size=(3000, d))
+    xn = rng.uniform(-1, 1, size=d)
+    G = len(layout)
+    fmin = np.full(G, 0.1)
+    out = {}
+    for on in (True, False):
+        gps = []
+        for i, c in enumerate(layout):
+            X = Xa if c == "a" else Xb
+            gps.append(gpy.models.GPRegression(X, smooth(X, 7 + i) + 0.3, kernels(gpy.kern, "Matern52", d),
+                                               noise_var=0.05 ** 2))
+        devs = [g._fitted() for g in gps]
+        ctx = devs[0].ctx
+        old = ctx.set_share(on)
+        try:
+            grid = _hip.DeviceGrid(ctx, pts, G)
+            grid.confidence(devs, 2.0, fmin)
+            for i, dv in enumerate(devs):
+                assert dv.append(xn, 0.4 + 0.1 * i)
+            ml = grid.rank1_update(devs, [1] * G, 2.0, fmin)
+            out[on] = (ml, grid.download(_hip.Q), grid.download(_hip.S), grid.download(_hip.MEAN),
+                       grid.download(_hip.VAR))
+            if on:      # ... and against the sweep of the grown GPs
+                ref = _hip.DeviceGrid(ctx, pts, G)
+                ref.confidence(devs, 2.0, fmin)
+                assert_allclose(out[on][3], ref.download(_hip.MEAN), rtol=0, atol=1e-9)
+                assert_allclose(out[on][4], ref.download(_hip.VAR), rtol=0, atol=1e-9 * 1.7)
+        finally:
+            ctx.set_share(old)
+    assert out[True][0] == out[False][0]
+    for x, y in zip(out[True][1:], out[False][1:]):
+        assert_array_equal(x, y)
+
+
 @pytest.mark.parametrize("which", ["classic", "pair"])
 def test_swarm_fitness_both_kernels(mods, which):
     """_compute_particle_fitness (gp_opt.py:901-1013) on more particles than the
