@@ -135,6 +135,39 @@ def test_fewer_rows_than_ranks_is_refused_on_every_rank(gps):
         safeopt_amd.SafeOpt(gps[0], np.array([[0.], [1.], [2.]]), 0., comm=Comm())
 
 
+def test_tensor_grid_detection_on_the_host():
+    """What SafeOpt hands to sgp_grid_set_axes: counts, strides and axis values of a
+    parameter set built like linearly_spaced_combinations builds it (utilities.py:21-54),
+    with constant context columns; anything else is None (the device then evaluates)."""
+    from safeopt_amd._hip import tensor_grid_axes
+    grid = safeopt_amd.linearly_spaced_combinations([(-1., 1.), (0., 3.), (2., 5.)], [4, 3, 5])
+    counts, strides, values = tensor_grid_axes(grid)
+    assert sorted(counts) == [3, 4, 5] and int(np.prod(counts)) == grid.shape[0]
+    for k in range(3):
+        idx = (np.arange(grid.shape[0]) // strides[k]) % counts[k]
+        assert_array_equal(values[k][idx], grid[:, k])
+    # a context column: one point, stride 1
+    with_ctx = np.hstack([grid, np.full((grid.shape[0], 1), 0.7)])
+    c, st, v = tensor_grid_axes(with_ctx)
+    assert c[3] == 1 and v[3][0] == 0.7 and c[:3] == counts
+    # one column: a 1-D grid; a single row
+    c, st, v = tensor_grid_axes(np.linspace(0, 1, 7)[:, None])
+    assert c == [7] and st == [1]
+    assert tensor_grid_axes(grid[:1])[0] == [1, 1, 1]
+    # two rows swapped: the host looks at run lengths and periods only (necessary
+    # conditions) -- its candidate does not reproduce the rows, which is what the device
+    # check (DeviceGrid.set_axes, every row, bit for bit) finds and refuses
+    perm = grid.copy(); perm[[1, 2]] = perm[[2, 1]]
+    cand = tensor_grid_axes(perm)
+    if cand is not None:
+        idx = (np.arange(perm.shape[0]) // cand[1][2]) % cand[0][2]
+        assert not np.array_equal(cand[2][2][idx], perm[:, 2])
+    # not tensor grids at all: a ragged tail, random points, no rows
+    assert tensor_grid_axes(grid[:-1]) is None
+    assert tensor_grid_axes(np.random.default_rng(0).uniform(size=(50, 2))) is None
+    assert tensor_grid_axes(np.zeros((0, 2))) is None
+
+
 def test_merge_topk_and_argmax():
     w, i = dist.merge_topk([[3., 1., -np.inf], [3., 2., 2.]], [[5, 9, -1], [7, 4, 8]], 4)
     assert_array_equal(i, [7, 5, 8, 4]); assert_allclose(w, [3., 3., 2., 2.])
