@@ -172,6 +172,54 @@ def test_three_way_shard_single_process():
         assert np.array_equal(M, z["M"]) and np.array_equal(G, z["G"])
 
 
+def test_socket_comm_three_ranks_collectives_and_driver():
+    """dist.SocketComm (the interface of RcclComm over a TCP star through rank 0 -- what the
+    N-rank product runs on when several ranks share one GPU, tests/test_gpu_nrank.py):
+    the collectives themselves on three ranks, then the host phase driver on uneven
+    shards against the unsharded golden vectors.  (Ranks as threads of this process.)"""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import threading
+    import safeopt_amd
+    from safeopt_amd import dist
+    from oracle import gp_numpy as gpn
+    from _golden import load, make_kernel
+    from _oracle_backend import use_oracle_backend
+    use_oracle_backend()
+    z, meta = load("sets_1d_seed7")
+    world, port = 3, _free_port()
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            comm = dist.SocketComm(rank, world, "127.0.0.1", port, timeout=60.0)
+            assert not comm.in_stream
+            m = comm.allreduce_max(np.array([float(rank), -float(rank), 7.0]))
+            assert np.array_equal(m, [2.0, 0.0, 7.0])
+            g = comm.allgather(np.array([[rank, 10 * rank]], dtype=np.int64))
+            assert g.shape == (3, 1, 2) and np.array_equal(g[:, 0, 1], [0, 10, 20])
+            assert comm.allgather(np.zeros(0)).shape == (3, 0)
+            comm.barrier()
+            gp = gpn.GPRegression(z["X0"], z["Y0"], make_kernel(gpn, meta["kernels"][0]),
+                                  noise_var=meta["noise_vars"][0])
+            opt = safeopt_amd.SafeOpt(gp, z["parameter_set"], 0., threshold=meta["threshold"],
+                                      comm=comm)
+            x = opt.optimize()
+            out[rank] = (x, opt.S.copy(), opt.M.copy(), opt.G.copy(), opt._shard)
+            comm.barrier()
+            comm.close()
+        except Exception:
+            import traceback
+            errs.append(traceback.format_exc())
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ths]; [t.join(120) for t in ths]
+    assert not errs, errs[0]
+    assert len({o[4] for o in out}) == world          # three different shards
+    for x, S, M, G, _ in out:
+        assert np.array_equal(x, z["x_next"]) and np.array_equal(S, z["S"])
+        assert np.array_equal(M, z["M"]) and np.array_equal(G, z["G"])
+
+
 def test_q_written_in_place_on_three_ranks():
     """SPMD: every rank makes the same element-wise writes into ``opt.Q`` (the
     reference mutates Q in place); the write-back uploads each rank's shard before the
