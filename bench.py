@@ -593,8 +593,15 @@ def main():
     # (the clocks ramp up over the first ~30 ms of load -- profiles/r04/clock_ramp.txt:
     # a kernel is ~10 % slower in the first launches of a process -- so a short run of
     # untimed steps comes in front of the W warm-up steps)
+    # (N ranks: every step is a sequence of collectives, so the ranks must take the SAME
+    # number of ramp steps -- the slowest clock decides for all)
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.1:
+    while True:
+        go = 1.0 if time.perf_counter() - t_ramp < 0.1 else 0.0
+        if world > 1:
+            go = float(comm.allreduce_max(np.array([go]))[0])
+        if go <= 0.0:
+            break
         step()
     for _ in range(args.warmup):
         step()
