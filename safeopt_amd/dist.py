@@ -62,6 +62,11 @@ class RcclComm(object):
     def __init__(self, ctx):
         self.ctx = ctx
         self.rank, self.world = ctx.rank, ctx.world
+        # SAFEOPT_RCCL_IN_STREAM=0: keep the collectives on the host side of the step (the
+        # variant of the N-rank step that SocketComm takes: three round trips instead of
+        # one) -- a switch for the operator, the default is the in-stream step
+        if os.environ.get("SAFEOPT_RCCL_IN_STREAM", "1") == "0":
+            self.in_stream = False
 
     def allreduce_max(self, a):
         a = np.ascontiguousarray(a, dtype=np.float64)
