@@ -22,10 +22,12 @@
 // registers leave two waves per SIMD and the kernels meet (0.157-0.200 / 0.175-0.231):
 // the VALU kernel runs up to 48 observations.
 //
-// Padding: k_j = 0 for j >= n (the padding block of the dense L^-1 is the identity,
-// factor.hip), alpha is zero padded.  Results differ from the matrix-core kernels in the
-// last bits (another summation order); which kernel runs depends on the sizes of the GPs
-// only, so every rank and every shard of a launch takes the same one.
+// Padding: k_j = 0 for j >= n and alpha is zero padded; rows >= n of the dense L^-1 are
+// never SUMMED (they hold whatever the factor left there: the identity of the padding,
+// the row of a popped observation).  Results differ from the matrix-core kernels in the
+// last bits (another summation order); for a grid the choice of the kernel depends on the
+// sizes of the GPs only, so every rank and every shard takes the same one
+// (tiny_sweep_wanted below).
 #include "kern_eval.h"
 #include "sweep_shared.h"
 
