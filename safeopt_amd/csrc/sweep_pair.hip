@@ -172,7 +172,14 @@ struct PairParams {
 #define PGP_STAMP(i) do {} while (0)
 #endif
 
-#ifdef SGP_INSTRUMENT
+// Timing experiments (results are wrong with any bit set).  -DPGP_CT_ABL=mask removes the
+// parts at COMPILE time -- no run-time test next to what is being measured (the run-time
+// mask of -DSGP_INSTRUMENT costs the paired kernel 15 %: profiles/r05/experiments.txt) --
+// bits: 1 stage barrier, 2 LDS-DMA, 4 covariance evaluation, 8 MFMAs, 16 stores,
+// 32 row epilogue, 64 A-operand reads of the slots, 128 B-operand reads.
+#if defined(PGP_CT_ABL)
+#define PGP_ABL(mask) (((PGP_CT_ABL) & (mask)) != 0)
+#elif defined(SGP_INSTRUMENT)
 #define PGP_ABL(mask) (p.ablate & (mask))
 #else
 #define PGP_ABL(mask) false
@@ -231,6 +238,7 @@ struct DmaPlan {
   uint32_t voff;
   int left;          // active slots - first slot of the wave
   bool on;
+  bool no_a;         // (timing experiments: the slots skip their A-operand reads)
 };
 template <int kGroups>
 __device__ __forceinline__ void dma_group(const DmaPlan& d, int i) {
@@ -265,8 +273,16 @@ __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
   if constexpr (S < kWaveSlots) {
     if (S < nw) {
       if (S + 1 < kWaveSlots) {
+#if defined(SGP_INSTRUMENT) || defined(PGP_CT_ABL)
+        if (dma.no_a) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) nxt[q] = aT[((S + 1) * 2 * kSteps + q) * 64];
+          for (int q = 0; q < 4; ++q) nxt[q] = cur[q];
+        } else
+#endif
+        {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) nxt[q] = aT[((S + 1) * 2 * kSteps + q) * 64];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       // The matrix instructions are inline asm: the compiler's hazard recogniser
@@ -654,7 +670,12 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   };
   auto fetch_ops = [&](const double* abuf, const double* kbr, Ops& o, int part) {
     // part 1: B operands, part 2: the rest, 3: both
-    if (part & 1) {
+    if ((part & 1) && PGP_ABL(128)) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o.kb[m][q] = 1.0 + m;
+    } else if (part & 1) {
       const double2_t* r = reinterpret_cast<const double2_t*>(
           kbr + k4 * kKbRow + (lane & 3) * 2);
 #pragma unroll
@@ -859,6 +880,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       plan.left = int(wnext & PW_NACT_MASK) - w0;
       plan.on = more && !PGP_ABL(2);
     }
+    plan.no_a = PGP_ABL(64);
     PGP_STAMP(1);   // LDS-DMA issue
     int si2 = si1 + 1;
     if (si2 == nstages) si2 = 0;    // (a run of chunks ends before it would wrap)

@@ -66,8 +66,11 @@ def run(k, reps):
     ctx.set_sweep("auto")
     if ONLY:
         b = out[ONLY]
-        print("cfg %d %s: %.3f ms (%.1f TF, %.3f of 78.6)%s" % (
-            k, ONLY, b[0], b[1], b[1] / 78.6, TAG), flush=True)
+        import hashlib
+        h = hashlib.sha1(np.ascontiguousarray(b[2]).tobytes()).hexdigest()[:10]
+        kc = " kc" if hasattr(ctx, "cov_cache_used") and ctx.cov_cache_used() else ""
+        print("cfg %d %s: %.3f ms (%.1f TF, %.3f of 78.6) bits %s%s%s" % (
+            k, ONLY, b[0], b[1], b[1] / 78.6, h, kc, TAG), flush=True)
         return
     a, b = out["classic"], out["pair"]
     diff = float(np.max(np.abs(a[2] - b[2])))
