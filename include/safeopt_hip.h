@@ -310,6 +310,21 @@ int sgp_comm_init(sgp_ctx* ctx, const void* id128, int rank, int world);
 int sgp_comm_count(sgp_ctx* ctx, int* n);           /* ncclCommCount: ranks that
                                                      * really joined (1 without a
                                                      * communicator)              */
+/* The same role for a caller that brings its own transport (TCP, MPI, shared memory;
+ * ranks that share a GPU or have no xGMI between them): three collectives on HOST
+ * buffers -- in-place all-reduce(max) of n f64 / n i32, all-gather of nbytes per rank
+ * into rank order -- returning 0 on success.  The N-rank entry points
+ * (sgp_grid_sets_front_comm, sgp_grid_sets_fused_comm) then stage their device operands
+ * through the host around these calls (stream sync, D2H, callback, H2D) at exactly the
+ * points where they enqueue RCCL collectives otherwise; sgp_comm_allreduce_max /
+ * _allgather / _barrier call them directly.  A context has one transport.           */
+typedef int (*sgp_host_allreduce_max_f64)(void* user, double* buf, int n);
+typedef int (*sgp_host_allreduce_max_i32)(void* user, int32_t* buf, int n);
+typedef int (*sgp_host_allgather)(void* user, const void* send, void* recv, int64_t nbytes);
+int sgp_comm_init_host(sgp_ctx* ctx, int rank, int world,
+                       sgp_host_allreduce_max_f64 allreduce_f64,
+                       sgp_host_allreduce_max_i32 allreduce_i32,
+                       sgp_host_allgather allgather, void* user);
 int sgp_comm_allreduce_max(sgp_ctx* ctx, double* buf, int n);   /* in place   */
 int sgp_comm_allgather(sgp_ctx* ctx, const void* send, void* recv,
                        int64_t nbytes);           /* recv = world*nbytes      */

@@ -22,6 +22,10 @@ c_i64_p = C.POINTER(C.c_int64)
 c_u8_p = C.POINTER(C.c_uint8)
 vp = C.c_void_p
 vpp = C.POINTER(C.c_void_p)
+# host-side collectives a caller may plug in (sgp_comm_init_host)
+HOST_ALLREDUCE_F64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+HOST_ALLREDUCE_I32 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_int)
+HOST_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
 
 RBF, MATERN32, MATERN52 = 0, 1, 2
 Q, S, M, G, MEAN, VAR, CAND, WIDTH = 0, 1, 2, 3, 4, 5, 6, 7
@@ -116,6 +120,8 @@ PROTOTYPES = {
                                 C.c_uint64]),
     "sgp_comm_unique_id": (C.c_int, [vp]),
     "sgp_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "sgp_comm_init_host": (C.c_int, [vp, C.c_int, C.c_int, HOST_ALLREDUCE_F64,
+                                     HOST_ALLREDUCE_I32, HOST_ALLGATHER, vp]),
     "sgp_comm_allreduce_max": (C.c_int, [vp, c_double_p, C.c_int]),
     "sgp_comm_allgather": (C.c_int, [vp, vp, vp, C.c_int64]),
     "sgp_comm_barrier": (C.c_int, [vp]),
@@ -316,6 +322,43 @@ class Context(object):
             rc = lib().sgp_comm_init(self.h, buf, rank, world)
         self.check(rc)
         self.rank, self.world = rank, world
+
+    def comm_init_host(self, comm):
+        """The caller's collectives as this context's transport (``sgp_comm_init_host``):
+        ``comm`` has ``rank``, ``world``, ``allreduce_max(array)`` and ``allgather(array)``
+        on host arrays (``dist.SocketComm``).  The N-rank entry points then stage their
+        device operands through the host around these calls."""
+        def _guard(fn):
+            def run(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception:           # noqa -- nothing may unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return run
+
+        def ar_f64(_user, buf, n):
+            a = np.ctypeslib.as_array(buf, shape=(n,))
+            a[:] = comm.allreduce_max(a.copy())
+
+        def ar_i32(_user, buf, n):
+            a = np.ctypeslib.as_array(buf, shape=(n,))
+            # (flags / small counts: exact in float64)
+            a[:] = comm.allreduce_max(a.astype(np.float64)).astype(np.int32)
+
+        def ag(_user, send, recv, nbytes):
+            raw = C.string_at(send, nbytes)
+            parts = comm.allgather(np.frombuffer(raw, dtype=np.uint8))
+            C.memmove(recv, np.ascontiguousarray(parts).ctypes.data, nbytes * comm.world)
+
+        # (the ctypes thunks must outlive the context's use of them)
+        self._host_cbs = (HOST_ALLREDUCE_F64(_guard(ar_f64)), HOST_ALLREDUCE_I32(_guard(ar_i32)),
+                          HOST_ALLGATHER(_guard(ag)))
+        self.check(lib().sgp_comm_init_host(self.h, int(comm.rank), int(comm.world),
+                                            *self._host_cbs, None))
+        self.rank, self.world = int(comm.rank), int(comm.world)
 
     def allreduce_max(self, a):
         a = f64(a).copy()

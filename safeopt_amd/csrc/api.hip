@@ -1192,6 +1192,62 @@ int sgp_grid_sets_front(sgp_grid* g, double max_l, int have_max_var,
   return 0;
 }
 
+// ---- the collectives of the N-rank step on DEVICE operands -------------------------
+// Two transports behind one table: RCCL on the context's stream (sgp_comm_init: the
+// collective is one more operation in the stream, no host round trip), or the caller's
+// own collectives on host buffers (sgp_comm_init_host: stream sync + D2H, the callback,
+// H2D behind it -- ranks without a GPU each / without xGMI between them, and the way the
+// in-stream step is exercised with real foreign data on a one-GPU box).
+static bool have_comm(const sgp_ctx* ctx) {
+  return ctx->comm != nullptr || ctx->hostcomm.allgather != nullptr;
+}
+static int coll_allreduce_max_f64(sgp_ctx* ctx, double* dev, size_t n) {
+  if (ctx->comm) {
+    SGP_NCCL(ctx, g_rccl.AllReduce(dev, dev, n, ncclFloat64, ncclMax,
+                                   static_cast<ncclComm_t>(ctx->comm), ctx->stream));
+    return 0;
+  }
+  if (!ctx->hostcomm.allreduce_max_f64) return 0;
+  std::vector<double> h(n);
+  SGP_TRY(sgp_d2h(ctx, h.data(), dev, n * 8));
+  SGP_CHECK(ctx, ctx->hostcomm.allreduce_max_f64(ctx->hostcomm.user, h.data(), int(n)) == 0,
+            "host collective (all-reduce max, %zu f64) failed", n);
+  return sgp_h2d(ctx, dev, h.data(), n * 8);
+}
+
+static int coll_allreduce_max_i32(sgp_ctx* ctx, int32_t* dev, size_t n) {
+  if (ctx->comm) {
+    SGP_NCCL(ctx, g_rccl.AllReduce(dev, dev, n, ncclInt32, ncclMax,
+                                   static_cast<ncclComm_t>(ctx->comm), ctx->stream));
+    return 0;
+  }
+  if (!ctx->hostcomm.allreduce_max_i32) return 0;
+  std::vector<int32_t> h(n);
+  SGP_TRY(sgp_d2h(ctx, h.data(), dev, n * 4));
+  SGP_CHECK(ctx, ctx->hostcomm.allreduce_max_i32(ctx->hostcomm.user, h.data(), int(n)) == 0,
+            "host collective (all-reduce max, %zu i32) failed", n);
+  return sgp_h2d(ctx, dev, h.data(), n * 4);
+}
+
+// recv (device) = the nbytes of every rank, in rank order
+static int coll_allgather(sgp_ctx* ctx, const void* send, void* recv, size_t nbytes) {
+  if (ctx->comm) {
+    SGP_NCCL(ctx, g_rccl.AllGather(send, recv, nbytes, ncclInt8,
+                                   static_cast<ncclComm_t>(ctx->comm), ctx->stream));
+    return 0;
+  }
+  if (!ctx->hostcomm.allgather) {
+    SGP_HIP(ctx, hipMemcpyAsync(recv, send, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+  }
+  std::vector<char> hs(nbytes), hr(nbytes * size_t(ctx->world));
+  SGP_TRY(sgp_d2h(ctx, hs.data(), send, nbytes));
+  SGP_CHECK(ctx, ctx->hostcomm.allgather(ctx->hostcomm.user, hs.data(), hr.data(),
+                                         int64_t(nbytes)) == 0,
+            "host collective (all-gather, %zu bytes per rank) failed", nbytes);
+  return sgp_h2d(ctx, recv, hr.data(), hr.size());
+}
+
 // Front half of compute_sets on this rank's shard with the cross-rank scalars kept
 // on the device: max l0[S] (left in g->scal[0] by a confidence pass without
 // read-back) and the maximiser width are all-reduced IN STREAM, the kernels read
@@ -1202,19 +1258,15 @@ static int front_half_in_stream(sgp_grid* g, const double* scaling, const double
   sgp_ctx* ctx = g->ctx;
   const int d = g->d, G = g->G;
   SGP_TRY(settle_max_l(g));
-  ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+  const bool comm = have_comm(ctx);
   SGP_CHECK(ctx, comm || ctx->world <= 1,
             "rank %d of %d has no communicator in the grid's context: the "
             "in-stream collectives cannot run (sgp_comm_init on THIS context)",
             ctx->rank, ctx->world);
-  if (comm)
-    SGP_NCCL(ctx, g_rccl.AllReduce(g->scal, g->scal, 1, ncclFloat64, ncclMax,
-                                   comm, ctx->stream));
+  if (comm) SGP_TRY(coll_allreduce_max_f64(ctx, g->scal, 1));
   SGP_TRY(launch_maximizers(g, 0.0, g->scal));
   SGP_TRY(launch_reduce_max(ctx, g->partial, (g->N + 255) / 256, res));
-  if (comm)
-    SGP_NCCL(ctx, g_rccl.AllReduce(res, res, 1, ncclFloat64, ncclMax, comm,
-                                   ctx->stream));
+  if (comm) SGP_TRY(coll_allreduce_max_f64(ctx, res, 1));
   SGP_TRY(launch_candidates(g, 0.0, res, scaling, thr_beta, 0,
                             reinterpret_cast<unsigned long long*>(res + 1)));
   SGP_TRY(launch_topk(g, 0, INFINITY, INT64_MAX, 1, res + 3,
@@ -1366,7 +1418,7 @@ int sgp_grid_sets_fused_comm(sgp_grid* g, sgp_gp* const* gps, int G, double beta
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   const int d = g->d;
   SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
-  ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+  const bool comm = have_comm(ctx);
   SGP_CHECK(ctx, comm || ctx->world <= 1,
             "rank %d of %d has no communicator in the grid's context: the "
             "in-stream collectives cannot run (sgp_comm_init on THIS context)",
@@ -1395,7 +1447,7 @@ int sgp_grid_sets_fused_comm(sgp_grid* g, sgp_gp* const* gps, int G, double beta
   // ---- first candidate of the whole grid
   const double* blocks = mine;
   if (comm) {
-    SGP_NCCL(ctx, g_rccl.AllGather(mine, all, nfront, ncclFloat64, comm, ctx->stream));
+    SGP_TRY(coll_allgather(ctx, mine, all, nfront * 8));
     blocks = all;
   }
   SGP_TRY(launch_merge_front(g, blocks, world, int(nfront), res, eb.xc,
@@ -1404,9 +1456,7 @@ int sgp_grid_sets_fused_comm(sgp_grid* g, sgp_gp* const* gps, int G, double beta
   int32_t* dfl = nullptr;
   SGP_TRY(enqueue_expander(g, gps, G, beta, fmin, 1, nullptr, nullptr, nullptr,
                            near_frac, &dfl, nullptr, true));
-  if (comm)
-    SGP_NCCL(ctx, g_rccl.AllReduce(dfl, dfl, size_t(G), ncclInt32, ncclMax, comm,
-                                   ctx->stream));
+  if (comm) SGP_TRY(coll_allreduce_max_i32(ctx, dfl, size_t(G)));
   // ---- conditional G mark (owner of the candidate) + arg-max over the whole grid
   SGP_TRY(launch_argmax_marked(
       g, scaling, fmin, dfl, reinterpret_cast<int64_t*>(res + 4),
@@ -1414,7 +1464,7 @@ int sgp_grid_sets_fused_comm(sgp_grid* g, sgp_gp* const* gps, int G, double beta
       pair, reinterpret_cast<int64_t*>(pair + 1)));
   const double* prs = pair;
   if (comm) {
-    SGP_NCCL(ctx, g_rccl.AllGather(pair, pairs, 2, ncclFloat64, comm, ctx->stream));
+    SGP_TRY(coll_allgather(ctx, pair, pairs, 16));
     prs = pairs;
   }
   SGP_TRY(launch_merge_argmax(ctx, prs, world, res + nfront + nfl,
@@ -1764,8 +1814,30 @@ int sgp_comm_init(sgp_ctx* ctx, const void* id128, int rank, int world) {
   return 0;
 }
 
+int sgp_comm_init_host(sgp_ctx* ctx, int rank, int world,
+                       sgp_host_allreduce_max_f64 allreduce_f64,
+                       sgp_host_allreduce_max_i32 allreduce_i32,
+                       sgp_host_allgather allgather, void* user) {
+  SGP_CHECK(ctx, world >= 1 && rank >= 0 && rank < world,
+            "bad rank %d / world %d", rank, world);
+  SGP_CHECK(ctx, !ctx->comm, "the context already has an RCCL communicator");
+  SGP_CHECK(ctx, allreduce_f64 && allreduce_i32 && allgather,
+            "sgp_comm_init_host: all three collectives are required");
+  ctx->hostcomm.allreduce_max_f64 = allreduce_f64;
+  ctx->hostcomm.allreduce_max_i32 = allreduce_i32;
+  ctx->hostcomm.allgather = allgather;
+  ctx->hostcomm.user = user;
+  ctx->rank = rank;
+  ctx->world = world;
+  return 0;
+}
+
 int sgp_comm_count(sgp_ctx* ctx, int* n) {
   *n = 1;
+  if (ctx->hostcomm.allgather) {  // (the caller's transport: its word for it)
+    *n = ctx->world;
+    return 0;
+  }
   if (!ctx->comm) return 0;       // no communicator: a single rank
   SGP_NCCL(ctx, g_rccl.CommCount(static_cast<ncclComm_t>(ctx->comm), n));
   return 0;
@@ -1786,6 +1858,11 @@ static int stage_h2d(sgp_ctx* ctx, void* dst, const void* src, size_t bytes) {
 
 int sgp_comm_allreduce_max(sgp_ctx* ctx, double* buf, int n) {
   if ((ctx->world <= 1 && !ctx->comm) || n <= 0) return 0;
+  if (!ctx->comm && ctx->hostcomm.allreduce_max_f64) {
+    SGP_CHECK(ctx, ctx->hostcomm.allreduce_max_f64(ctx->hostcomm.user, buf, n) == 0,
+              "host collective (all-reduce max) failed");
+    return 0;
+  }
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   SGP_CHECK(ctx, ctx->comm, "sgp_comm_init was not called");
   double* d = static_cast<double*>(sgp_scratch(ctx, 6, size_t(n) * 8));
@@ -1802,6 +1879,11 @@ int sgp_comm_allgather(sgp_ctx* ctx, const void* send, void* recv,
   if (nbytes <= 0) return 0;
   if (ctx->world <= 1 && !ctx->comm) {
     memcpy(recv, send, size_t(nbytes));
+    return 0;
+  }
+  if (!ctx->comm && ctx->hostcomm.allgather) {
+    SGP_CHECK(ctx, ctx->hostcomm.allgather(ctx->hostcomm.user, send, recv, nbytes) == 0,
+              "host collective (all-gather) failed");
     return 0;
   }
   SGP_HIP(ctx, hipSetDevice(ctx->device));

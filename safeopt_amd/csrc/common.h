@@ -163,6 +163,14 @@ struct sgp_ctx {
   // RCCL
   void* comm = nullptr;  // ncclComm_t
   int rank = 0, world = 1;
+  // ... or the caller's collectives on host buffers (sgp_comm_init_host): the library
+  // stages the device operands of an N-rank step through the host around them
+  struct HostComm {
+    int (*allreduce_max_f64)(void*, double*, int) = nullptr;
+    int (*allreduce_max_i32)(void*, int32_t*, int) = nullptr;
+    int (*allgather)(void*, const void*, void*, int64_t) = nullptr;
+    void* user = nullptr;
+  } hostcomm;
   int num_cu = 256;
 };
 

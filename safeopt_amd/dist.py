@@ -89,9 +89,15 @@ class SocketComm(object):
     of the grid -- can share one GPU (``SAFEOPT_COMM=socket``; how the N-rank product
     is tested on a one-GPU box, tests/test_gpu_parity.py), or sit on machines without
     xGMI.  The payloads of the path are a few dozen bytes per collective
-    (SURVEY.md section 8e), latency is all that matters.  Not in stream: the library's
-    fused N-rank step (``sgp_grid_sets_fused_comm``) needs device-side collectives, the
-    host driver then takes the packed host collectives (``sets_front`` / ``sets_back``).
+    (SURVEY.md section 8e), latency is all that matters.
+
+    With a device context the communicator registers itself as that context's transport
+    (``sgp_comm_init_host``): the library's one-round-trip N-rank step
+    (``sgp_grid_sets_fused_comm``: first-candidate merge, flag all-reduce and arg-max
+    merge on the device) then runs over it as it does over RCCL, the collectives staged
+    through the host at the points where RCCL's are enqueued in stream (``in_stream``
+    True).  ``SAFEOPT_SOCKET_IN_STREAM=0`` keeps the collectives on the host side of the
+    step instead (``sets_front`` / ``sets_back``: three round trips).
     """
     in_stream = False
 
@@ -99,6 +105,10 @@ class SocketComm(object):
         self.rank, self.world, self.ctx = int(rank), int(world), ctx
         self._peers = []          # rank 0: sockets of ranks 1 .. world - 1
         self._up = None           # other ranks: socket to rank 0
+        if (ctx is not None and hasattr(ctx, "comm_init_host")
+                and os.environ.get("SAFEOPT_SOCKET_IN_STREAM", "1") != "0"):
+            ctx.comm_init_host(self)
+            self.in_stream = True
         if self.world <= 1:
             return
         if self.rank == 0:

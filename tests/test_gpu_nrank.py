@@ -148,21 +148,41 @@ def _loop_cases(sa, gpy, comm, report):
         report.append((name, bool(ok)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, variant):
     try:
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                           MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                          SAFEOPT_COMM="socket", SAFEOPT_HIP_DEVICE="0")
+                          SAFEOPT_COMM="socket", SAFEOPT_HIP_DEVICE="0",
+                          SAFEOPT_SOCKET_IN_STREAM="1" if variant == "fused_comm" else "0")
         sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
         import safeopt_amd as sa
         import safeopt_amd.gpy as gpy
-        from safeopt_amd import dist
+        from safeopt_amd import dist, gp_opt
         ctx, comm = dist.init_from_env()
         assert isinstance(comm, dist.SocketComm) and comm.world == world
+        assert comm.in_stream == (variant == "fused_comm")
+        # which variant of the N-rank step runs: count the entry points
+        calls = {"sets_fused_comm": 0, "sets_front_comm": 0, "sets_back": 0}
+        for name in calls:
+            def counted(self, *a, _f=getattr(gp_opt._HipGridBackend, name), _n=name, **k):
+                calls[_n] += 1
+                return _f(self, *a, **k)
+            setattr(gp_opt._HipGridBackend, name, counted)
         report = []
         _golden_cases(sa, gpy, comm, report)
         _tie_cases(sa, gpy, comm, report)
         _loop_cases(sa, gpy, comm, report)
+        if variant == "fused_comm":
+            # the one-round-trip step (k_merge_front, flag all-reduce, k_merge_argmax behind
+            # the staged collectives) is what ran, on every certified step
+            # (sets_back remains for steps on hand-assigned intervals: the tie fixtures)
+            report.append(("in-stream step taken (%d x sgp_grid_sets_fused_comm, %d x "
+                           "sets_back)" % (calls["sets_fused_comm"], calls["sets_back"]),
+                           calls["sets_fused_comm"] >= 20 and calls["sets_back"] <= 6))
+        else:
+            report.append(("host-side step taken (%d x sets_back, %d x fused_comm)"
+                           % (calls["sets_back"], calls["sets_fused_comm"]),
+                           calls["sets_fused_comm"] == 0 and calls["sets_back"] > 0))
         comm.barrier()
         comm.close()
         q.put((rank, report, None))
@@ -172,13 +192,20 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("variant", ["host", "fused_comm"])
 @pytest.mark.parametrize("world", [2, 4])
-def test_real_processes_true_shards_one_gpu(hip_device, world):
+def test_real_processes_true_shards_one_gpu(hip_device, world, variant):
+    """``variant``: which N-rank step the ranks take -- ``host``: three round trips with
+    the packed collectives on the host side (``sets_front`` / ``sets_back``);
+    ``fused_comm``: the product default on RCCL, ``sgp_grid_sets_fused_comm`` -- one round
+    trip, the merges on the device (``k_merge_front``, the int32 flag all-reduce,
+    ``k_merge_argmax``) behind the collectives, here staged through the host over TCP
+    (``sgp_comm_init_host``) because RCCL wants one GPU per rank."""
     import multiprocessing as mp
     mpc = mp.get_context("spawn")
     port = _free_port()
     q = mpc.Queue()
-    procs = [mpc.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port, q, variant)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=850) for _ in procs]
@@ -192,4 +219,5 @@ def test_real_processes_true_shards_one_gpu(hip_device, world):
         assert report and all(ok for _, ok in report), [w for w, ok in report if not ok]
     # every rank ran the same cases
     assert len({tuple(w for w, _ in rep) for _, rep, _ in
-                [(r, [(w.split(" (no safe")[0], o) for w, o in rep], e) for r, rep, e in results]}) == 1
+                [(r, [(w.split(" (no safe")[0].split(" (")[0], o) for w, o in rep], e)
+                 for r, rep, e in results]}) == 1
