@@ -434,11 +434,13 @@ def reference_regime(gpy, safeopt_amd, ctx, n=20, steps=200):
                          "unit": "T lane-ops/s", "frac": ops / (t * 1e-3) / 1e12 / 39.3}}
 
 
-def config4_strong(gpy, safeopt_amd, dist, ctx, comm, rank, world, steps=4, warmup=2):
+def config4_strong(gpy, safeopt_amd, dist, ctx, comm, rank, world, steps=None, warmup=2):
     """BASELINE.json's 8-GPU config (3-D RBF, n = 1000, the fixed 200^3 grid,
     row-sharded in contiguous blocks of the flat index): ms per SafeOpt.optimize() and
     candidates/s at THIS number of ranks -- strong scaling, whatever --config the line
     itself is for."""
+    if steps is None:
+        steps = 4 if world == 1 else 8 * min(world, 4)     # (137 ms / ranks per step)
     cfg = make_config(4)
     gps = build_gps(cfg, gpy)
     opt = safeopt_amd.SafeOpt(gps[0], cfg["grid"], 0.0, threshold=cfg["threshold"], comm=comm)
@@ -457,6 +459,116 @@ def config4_strong(gpy, safeopt_amd, dist, ctx, comm, rank, world, steps=4, warm
             "scaling": "strong", "n_gpus": world, "steps": steps,
             "ms_per_step": dt * 1e3 / steps, "value": rows / (dt / steps),
             "unit": "candidates/s", "chosen_x": [float(v) for v in np.atleast_1d(x)]}
+
+
+def _probe_transport(kind):
+    """``bench.py --probe-transport KIND`` (a child of every rank, under a watchdog): bring
+    the transport up and take ONE certified N-rank step on a small problem.  Exit code 0 =
+    this rank got through."""
+    import safeopt_amd
+    import safeopt_amd.gpy as gpy
+    from safeopt_amd import dist
+    if kind == "rccl-host":
+        os.environ["SAFEOPT_RCCL_IN_STREAM"] = "0"
+    ctx, comm = dist.init_from_env(timeout=60.0)
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-1.5, 1.5, size=(40, 2))
+    Y = _bumps(X, 7)[:, None]
+    Y = Y - Y.min() + 0.5
+    gp = gpy.models.GPRegression(X, Y, gpy.kern.RBF(2, 2.0, [1.0, 1.0], ARD=True),
+                                 noise_var=0.05 ** 2)
+    grid = safeopt_amd.linearly_spaced_combinations([(-4., 4.)] * 2, [96, 64])
+    opt = safeopt_amd.SafeOpt(gp, grid, 0.0, threshold=0.2, comm=comm)
+    x = opt.optimize()
+    ctx.sync()
+    comm.barrier()
+    assert np.all(np.isfinite(x))
+
+
+def choose_transport(rank, world, timeout=None):
+    """Which transport the N ranks use, decided under a watchdog so that a hang in
+    ncclCommInitRank or in an in-stream collective yields a JSON line, not a timeout.
+
+    Chain: RCCL with the certified step in stream (the product default) -> RCCL with the
+    collectives on the host side of the step (SAFEOPT_RCCL_IN_STREAM=0) -> TCP
+    (SAFEOPT_COMM=socket, the collectives staged through the host).  Every rank starts the
+    same probe in a child process (its own rendezvous tag), the ranks agree on the outcome
+    over a TCP control channel, the first variant that every rank got through is taken.
+    ``SAFEOPT_COMM`` / ``SAFEOPT_RCCL_IN_STREAM`` set by the operator skip the probes."""
+    from safeopt_amd import dist
+    if timeout is None:
+        timeout = float(os.environ.get("SAFEOPT_BENCH_PROBE_TIMEOUT", "150"))
+    report = {"chain": [], "chosen": None}
+    if os.environ.get("SAFEOPT_COMM") == "socket":
+        report["chosen"] = "socket (SAFEOPT_COMM)"
+        return report
+    if os.environ.get("SAFEOPT_BENCH_PROBE", "1") == "0":
+        report["chosen"] = "rccl (not probed: SAFEOPT_BENCH_PROBE=0)"
+        return report
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    mport = int(os.environ.get("MASTER_PORT", "29500"))
+    ctl = dist.SocketComm(rank, world, addr, mport + 23, timeout=120.0)
+    kinds = ["rccl-in-stream", "rccl-host"]
+    if os.environ.get("SAFEOPT_RCCL_IN_STREAM", "1") == "0":
+        kinds = ["rccl-host"]
+    for k, kind in enumerate(kinds):
+        env = dict(os.environ, MASTER_PORT=str(mport + 40 + 3 * k),
+                   SAFEOPT_RDZV_NONCE="probe%d-%s" % (k, os.environ.get("SAFEOPT_RDZV_NONCE", "")))
+        env.pop("SAFEOPT_RDZV_PORT", None)
+        env["SAFEOPT_RDZV"] = "tcp"      # (the file rendezvous names a launch by its parent pid)
+        t0 = time.perf_counter()
+        cmd = [sys.executable, os.path.abspath(__file__), "--probe-transport", kind]
+        if os.environ.get("SAFEOPT_BENCH_PROBE_CMD"):      # (tests: a probe that hangs / fails)
+            cmd = os.environ["SAFEOPT_BENCH_PROBE_CMD"].split("\x1f")
+        child = subprocess.Popen(cmd, env=env,
+                                 stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        try:
+            _, err = child.communicate(timeout=timeout)
+            rc = child.returncode
+        except subprocess.TimeoutExpired:
+            child.kill()                      # (this very process, nothing by pattern)
+            _, err = child.communicate()
+            rc = -9
+        bad = float(ctl.allreduce_max(np.array([0.0 if rc == 0 else 1.0]))[0])
+        report["chain"].append({"transport": kind, "ok": bad == 0.0, "rc_this_rank": rc,
+                                "s": round(time.perf_counter() - t0, 1),
+                                "stderr_tail": None if rc == 0 else (err or "")[-300:]})
+        if bad == 0.0:
+            report["chosen"] = kind
+            break
+    ctl.close()
+    if report["chosen"] is None:
+        report["chosen"] = "socket (fallback)"
+    if report["chosen"] == "rccl-host":
+        os.environ["SAFEOPT_RCCL_IN_STREAM"] = "0"
+    if report["chosen"].startswith("socket"):
+        os.environ["SAFEOPT_COMM"] = "socket"
+    return report
+
+
+def nrank_selfcheck(opt, comm):
+    """One step through BOTH variants of the N-rank step on the same intervals -- the
+    one-round-trip step with the merges on the device behind the collectives
+    (sgp_grid_sets_fused_comm) and the host-side variant (sets_front / sets_back, the
+    merges in NumPy) -- must give the same chosen row and the same set sizes."""
+    from safeopt_amd import _hip
+
+    def once():
+        x = opt.optimize()
+        be = opt._backend
+        cnt = np.array([float(be.download(w).sum()) for w in (_hip.S, _hip.M, _hip.G)])
+        return x, comm.allgather(cnt).sum(axis=0)
+    had = getattr(comm, "in_stream", False)
+    xa, ca = once()
+    try:
+        comm.in_stream = False
+        xb, cb = once()
+    finally:
+        comm.in_stream = had
+    return {"in_stream_variant_ran": bool(had),
+            "same_chosen_x": bool(np.array_equal(xa, xb)),
+            "S_M_G_counts": [int(v) for v in ca], "S_M_G_counts_host_variant": [int(v) for v in cb],
+            "ok": bool(np.array_equal(xa, xb) and np.array_equal(ca, cb))}
 
 
 def spawn_ranks(n, argv):
@@ -513,7 +625,10 @@ def main():
                     help="steps of the separate (untimed) per-launch hipEvent pass")
     ap.add_argument("--launch-check", action="store_true",
                     help="only rendezvous the ranks (no device): launcher self-test")
+    ap.add_argument("--probe-transport", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.probe_transport:
+        return _probe_transport(args.probe_transport)
     default_run = args.config is None
     if default_run:
         args.config = 3
@@ -540,6 +655,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    transport = choose_transport(rank, world) if world > 1 else None
     ctx, comm = dist.init_from_env()
 
     # configs 2/3: weak scaling (1e6 rows per rank); config 4: the fixed 200^3
@@ -589,6 +705,13 @@ def main():
                     (args.config, cfg["d"], cfg["kernels"][0][0]["kind"],
                      cfg["G"], cfg["n"], "x".join(map(str, cfg["sides"])),
                      units, rows_rank))
+
+    selfcheck = None
+    if world > 1 and args.config != 5:
+        try:
+            selfcheck = nrank_selfcheck(opt, comm)
+        except Exception as e:      # noqa -- reported, never fatal
+            selfcheck = {"ok": False, "error": repr(e)}
 
     # (the clocks ramp up over the first ~30 ms of load -- profiles/r04/clock_ramp.txt:
     # a kernel is ~10 % slower in the first launches of a process -- so a short run of
@@ -716,6 +839,11 @@ def main():
                                    "strong: BASELINE.json's fixed 200^3 grid, 8e6 / ranks rows each",
                    "share_factors": False},
         "rccl_ranks": int(rccl_ranks),
+        "transport": transport, "nrank_selfcheck": selfcheck,
+        "nrank_step": (None if world == 1 else
+                       "in stream (sgp_grid_sets_fused_comm: one round trip, merges on the device)"
+                       if getattr(comm, "in_stream", False) else
+                       "host side (sets_front / sets_back: three round trips)"),
         "per_rank_sweep_ms": [float(v) for v in per_rank_ms],
         "scalar_allreduce_us": coll_us if world > 1 else None,
         "roofline": {

@@ -378,3 +378,53 @@ def test_two_ranks_on_one_gpu_fail_loudly(monkeypatch):
     monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
     with pytest.raises(_hip.HipError, match="one process per GPU"):
         _hip.Context.default()
+
+
+def _transport_worker(rank, world, port, cmd, q):
+    try:
+        sys.path.insert(0, REPO)
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port), SAFEOPT_BENCH_PROBE_TIMEOUT="2",
+                          SAFEOPT_BENCH_PROBE_CMD="\x1f".join(cmd))
+        for k in ("SAFEOPT_COMM", "SAFEOPT_RCCL_IN_STREAM"):
+            os.environ.pop(k, None)
+        import bench
+        rep = bench.choose_transport(rank, world)
+        q.put((rank, rep, os.environ.get("SAFEOPT_COMM"), None))
+    except Exception:
+        import traceback
+        q.put((rank, None, None, traceback.format_exc()))
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("probe", ["hangs", "fails on one rank", "passes"])
+def test_bench_transport_chain_under_the_watchdog(probe):
+    """bench.py --gpus N decides its transport under a watchdog (RCCL in stream -> RCCL with
+    host-side collectives -> TCP): a probe that HANGS (ncclCommInitRank, an in-stream
+    collective) or fails on any rank must take every rank to the next variant, and the line
+    says which one ran."""
+    import multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    port = _free_port()
+    q = mpc.Queue()
+    cmd = {"hangs": [sys.executable, "-c", "import time; time.sleep(600)"],
+           "fails on one rank": [sys.executable, "-c",
+                                 "import os, sys; sys.exit(int(os.environ['RANK'] == '1'))"],
+           "passes": [sys.executable, "-c", "pass"]}[probe]
+    procs = [mpc.Process(target=_transport_worker, args=(r, 2, port, cmd, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=100) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    for rank, rep, comm_env, err in res:
+        assert err is None, err
+        if probe == "passes":
+            assert rep["chosen"] == "rccl-in-stream" and comm_env is None
+            assert [c["ok"] for c in rep["chain"]] == [True]
+        else:
+            assert rep["chosen"] == "socket (fallback)" and comm_env == "socket"
+            assert [c["transport"] for c in rep["chain"]] == ["rccl-in-stream", "rccl-host"]
+            assert not any(c["ok"] for c in rep["chain"])
+            if probe == "hangs":
+                assert all(c["rc_this_rank"] == -9 for c in rep["chain"])
