@@ -231,6 +231,22 @@ int sgp_grid_sets_fused(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                         double* x_top, double* mean_top, double* q_top,
                         int32_t* flags, double* value, int64_t* gidx,
                         double* max_l_out);
+/* SMALL grids -- the reference's own regime (safeopt/gp_opt.py:651-675 on the 1000-point
+ * grid of examples/1d_example.ipynb with n <= 20 observations; BASELINE.json config 1):
+ * one whole SafeOpt.optimize() = update_confidence_intervals (gp_opt.py:453-476) +
+ * compute_sets (:483-615) + the arg-max of get_new_query_point (:635-649) in ONE launch
+ * of one workgroup and one read-back, for grids of at most 16384 rows and GPs with at most
+ * 48 observations.  The expander test of the first candidate is the exact scan over all
+ * unsafe rows.  Outputs as sgp_grid_sets_fused; Q / S / M / G / mean / var / candidate
+ * mask and widths stay resident as the large-grid path leaves them.
+ * sgp_grid_step_small_ok: 1 when the grid and the GPs qualify.                        */
+int sgp_grid_step_small(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
+                        const double* fmin, const double* scaling,
+                        const double* thr_beta, double* out5, double* x_top,
+                        double* mean_top, double* q_top, int32_t* flags, double* value,
+                        int64_t* gidx, double* max_l_out);
+int sgp_grid_step_small_ok(sgp_grid* grid, sgp_gp* const* gps, int G);
+
 /* The same on N ranks (row shards, sgp_comm_init on the grid's context) after a
  * confidence pass without read-back: max l0[S] and the maximiser width are
  * all-reduced in stream; every rank's first candidate (with its row, counts and

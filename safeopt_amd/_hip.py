@@ -91,6 +91,10 @@ PROTOTYPES = {
                                       C.c_double, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_i32_p,
                                       c_double_p, c_i64_p, c_double_p]),
+    "sgp_grid_step_small": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p, c_double_p,
+                                      c_double_p, c_double_p, c_double_p, c_double_p,
+                                      c_double_p, c_i32_p, c_double_p, c_i64_p, c_double_p]),
+    "sgp_grid_step_small_ok": (C.c_int, [vp, vpp, C.c_int]),
     "sgp_grid_sets_fused_comm": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p,
                                            c_double_p, c_double_p, C.c_double,
                                            c_double_p, c_double_p, c_double_p,
@@ -304,7 +308,8 @@ class Context(object):
 
     def last_sweep(self):
         """Kernel of the last posterior sweep: 'classic' | 'pair' | 'tiny' | 'few-points'."""
-        return (None, "classic", "pair", "tiny", "few-points")[int(lib().sgp_ctx_last_sweep(self.h))]
+        return (None, "classic", "pair", "tiny", "few-points",
+                "step-small")[int(lib().sgp_ctx_last_sweep(self.h))]
 
     # -- RCCL
     @staticmethod
@@ -712,6 +717,34 @@ class DeviceGrid(object):
             dptr(thr_beta), float(near_frac), dptr(out5), dptr(x), dptr(mean),
             dptr(q), flags.ctypes.data_as(c_i32_p), C.byref(v), C.byref(i),
             C.byref(ml)))
+        return out5, x, mean, q, flags, v.value, i.value, ml.value
+
+    def step_small_ok(self, gps):
+        """Does ``step_small`` serve this grid with these (fitted) GPs?"""
+        return bool(lib().sgp_grid_step_small_ok(self.h, _gp_array(gps), len(gps)))
+
+    def step_small(self, gps, beta, fmin, scaling, thr_beta):
+        """A whole ``SafeOpt.optimize()`` of a small grid in one launch and one read-back
+        (``sgp_grid_step_small``); returns what ``sets_fused`` returns.  The output
+        buffers and their pointers are built once (this is the 30-microsecond path)."""
+        ss = self.__dict__.get("_ss")
+        if ss is None:
+            out5, x, mean, q = np.empty(6), np.empty(self.d), np.empty(self.G), np.empty(2 * self.G)
+            flags = np.zeros(self.G, dtype=np.int32)
+            v, i, ml = C.c_double(0), C.c_int64(0), C.c_double(0)
+            ss = self._ss = dict(
+                out=(out5, x, mean, q, flags, v, i, ml),
+                ptr=(dptr(out5), dptr(x), dptr(mean), dptr(q), flags.ctypes.data_as(c_i32_p),
+                     C.byref(v), C.byref(i), C.byref(ml)),
+                fn=lib().sgp_grid_step_small, gps=None, gp_arr=None)
+        key = tuple(g.h.value for g in gps)
+        if ss["gps"] != key:
+            ss["gps"], ss["gp_arr"] = key, _gp_array(gps)
+        rc = ss["fn"](self.h, ss["gp_arr"], len(gps), beta, dptr(fmin), dptr(scaling),
+                      dptr(thr_beta), *ss["ptr"])
+        if rc != 0:
+            self.ctx.check(rc)
+        out5, x, mean, q, flags, v, i, ml = ss["out"]
         return out5, x, mean, q, flags, v.value, i.value, ml.value
 
     def sets_fused_comm(self, gps, beta, fmin, scaling, thr_beta, near_frac):

@@ -17,11 +17,12 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libsafeopt_hip.so")
-SOURCES = ["api.hip", "sweep.hip", "sweep_pair.hip", "sweep_tiny.hip", "factor.hip", "sets.hip",
-           "swarm.hip"]
+SOURCES = ["api.hip", "sweep.hip", "sweep_pair.hip", "sweep_tiny.hip", "step_small.hip",
+           "factor.hip", "sets.hip", "swarm.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "kern_eval.h", "fitness.h",
                                             "small_path.h", "sweep_shared.h",
-                                            "sweep_slots.h")] + \
+                                            "sweep_slots.h", "set_order.h",
+                                            "tiny_row.h")] + \
           [os.path.join(REPO, "include", "safeopt_hip.h")]
 BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
         "-I", os.path.join(REPO, "include"), "-I", CSRC, "-Wall",

@@ -1396,6 +1396,53 @@ int sgp_grid_sets_fused(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   return 0;
 }
 
+// A whole SafeOpt.optimize() of a SMALL grid -- intervals, S, M, candidates, the exact
+// expander test of the first candidate, the G mark and the arg-max -- in ONE launch of one
+// workgroup and one read-back (step_small.hip).  Same result block as sgp_grid_sets_fused.
+int sgp_grid_step_small(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
+                        const double* fmin, const double* scaling, const double* thr_beta,
+                        double* out5, double* x_top, double* mean_top, double* q_top,
+                        int32_t* flags, double* value, int64_t* gidx, double* max_l_out) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  const int d = g->d;
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  GpDev host[SGP_MAX_GPS];
+  SGP_TRY(collect_gps(ctx, gps, G, d, host));
+  SGP_CHECK(ctx, step_small_eligible(ctx, host, G, g->N),
+            "sgp_grid_step_small: %lld rows / a GP with more than 48 observations "
+            "(sgp_grid_step_small_ok)", (long long)g->N);
+  SGP_TRY(stage_gpdev(g, host, G));
+  const size_t nfront = 6 + size_t(d) + 3 * size_t(G);
+  const size_t nfl = (size_t(G) + 1) / 2;
+  const size_t nres = nfront + nfl + 3;
+  double* res = static_cast<double*>(sgp_scratch(ctx, 1, (nres + 8) * 8));
+  SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
+  g->l0_pending = 0;
+  SGP_TRY(launch_step_small(g, g->gpdev, host, G, beta, fmin, scaling, thr_beta, res,
+                            int(nfront), int(nfl)));
+  std::vector<double> hostres(nres);
+  SGP_TRY(sgp_d2h(ctx, hostres.data(), res, nres * 8));
+  unpack_front(hostres.data(), d, G, out5, x_top, mean_top, q_top);
+  memcpy(flags, &hostres[nfront], size_t(G) * 4);
+  *value = hostres[nfront + nfl];
+  memcpy(gidx, &hostres[nfront + nfl + 1], 8);
+  *max_l_out = hostres[nfront + nfl + 2];
+  return 0;
+}
+
+// 1 when sgp_grid_step_small serves this grid with these GPs (at most 16384 rows, every GP
+// with at most 48 observations, sweep kernel not forced), else 0
+int sgp_grid_step_small_ok(sgp_grid* g, sgp_gp* const* gps, int G) {
+  if (!g || G != g->G || G < 1 || G > SGP_MAX_GPS) return 0;
+  GpDev host[SGP_MAX_GPS];
+  for (int i = 0; i < G; ++i) {
+    if (!gps[i] || gps[i]->n <= 0 || gps[i]->ctx != g->ctx) return 0;
+    host[i] = gps[i]->dev;
+  }
+  return step_small_eligible(g->ctx, host, G, g->N) ? 1 : 0;
+}
+
 // N-rank certified step with ONE stream sync (the N-rank counterpart of
 // sgp_grid_sets_fused; gp_opt.py:511-557, 611-612, 635, 642-644): the front half of
 // sgp_grid_sets_front_comm on this rank's shard, then IN STREAM

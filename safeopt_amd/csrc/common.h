@@ -344,6 +344,13 @@ int rank1_num_blocks(int64_t N);
 int launch_rank1(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d,
                  SweepPoints pts, Rank1Args ra);
 
+// step_small.hip: a whole SafeOpt.optimize() of a small grid in one launch
+constexpr int64_t kStepSmallRows = 16384;
+bool step_small_eligible(const sgp_ctx* ctx, const GpDev* gh, int G, int64_t N);
+int launch_step_small(sgp_grid* g, const GpDev* gps_dev, const GpDev* gh, int G, double beta,
+                      const double* fmin, const double* scaling, const double* thr_beta,
+                      double* res, int nfront, int nfl);
+
 // sets.hip
 int launch_reduce_max(sgp_ctx* ctx, const double* in, int64_t n, double* out);
 int launch_safe_set(sgp_grid* g, const double* fmin);  // from Q -> S, partial

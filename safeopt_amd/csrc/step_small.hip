@@ -1,0 +1,399 @@
+// One SafeOpt.optimize() of a SMALL grid in ONE launch of ONE workgroup: the regime of
+// the reference's own examples and tests (safeopt/gp_opt.py:651-675 on a 1000-point or
+// 100 x 100 grid with n <= 20 observations: examples/1d_example.ipynb cells 2 / 6,
+// safeopt/tests/test_gps.py:21-24 -- BASELINE.json config 1).
+//
+// There the step of the large-grid path -- the posterior sweep plus nine set-pass
+// launches, each a chip-wide reduction the next one depends on -- costs 90-120 us
+// whatever the grid (profiles/r04/experiments.txt section 15): ~7 us per dependent
+// launch, and the kernels themselves are 2-4 us each.  For up to kStepRows rows and GPs
+// with at most 48 observations the whole chain fits one workgroup of 512 threads, with
+// a workgroup barrier where the large-grid path has a kernel boundary:
+//   A  posterior of every row and GP, Q, S          (tiny_row.h: the arithmetic of
+//                                                     k_sweep_tiny, the same bits)
+//   B  max l0[S]                                     gp_opt.py:511
+//   C  M = S & (u0 >= max l0[S]), max width over M   gp_opt.py:511-513
+//   D  candidate mask, widths, counts, the first candidate in visiting order and the
+//      number of candidates tied with it             gp_opt.py:519-552
+//   E  rank-1 expander test of that candidate over ALL unsafe rows (exact, no probe):
+//      t = L^-1 k_c, w = L^-T t, s^2, c(x) = k(x, x_c) - w . k(X, x), l_2(x) >= fmin
+//      (sweep.hip:k_expander_list, factor.hip:k_expkt / k_expw1 -- the same summation
+//      orders, so the flags are those of the large-grid path)      gp_opt.py:579-606
+//   F  G mark when every active GP certified it, arg-max over M | G   gp_opt.py:611-649
+// and one result block in the layout of sgp_grid_sets_fused comes back.  Everything the
+// uncommon branches of the host driver read afterwards (Q, mean, var, S, M, G, the
+// candidate mask and widths, max l0[S]) is resident exactly as the large-grid path
+// leaves it.
+#include <algorithm>
+
+#include "set_order.h"
+#include "tiny_row.h"
+
+namespace {
+
+// (512 threads: two waves per SIMD, 256 registers each -- a row's 48 covariances and four
+// FMA chains of tiny_row need up to ~190)
+constexpr int kStepThreads = 512;
+constexpr int kStepWaves = kStepThreads / 64;
+constexpr int kExpwWaves = 16;    // row groups of k_expw1 (factor.hip), whose order is kept
+constexpr int kStepNP = 48;       // observations per GP, at most (tiny_row)
+
+struct StepParams {
+  const GpDev* gps;
+  int G;
+  SweepPoints pts;
+  ConfOut conf;            // Q, mean, var, S; beta, fmin
+  uint8_t* M;
+  uint8_t* Gm;
+  uint8_t* cand;
+  double* w;
+  int64_t goff;
+  Vec8 scaling, thr_beta;
+  double* res;             // result block (layout of sgp_grid_sets_fused)
+  double* scal;            // [0] = max l0[S]
+  int nfront, nfl;
+};
+
+template <int D, int NP, bool SINGLE>
+__global__ __launch_bounds__(kStepThreads) void k_step_small(StepParams p) {
+  __shared__ double tab[kExpTabSize];
+  __shared__ double shd[kStepWaves];
+  __shared__ Pair shp[kStepWaves];
+  __shared__ unsigned shc[3][kStepWaves];
+  __shared__ double sh_w[kExpwWaves][64];
+  __shared__ double kc[64], tt[64], wv[64], xcs[SGP_MAX_D];
+  __shared__ double s_ops[3];       // delta, 1 / s^2 of the GP being scanned
+  __shared__ int s_flags[SGP_MAX_GPS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t N = p.pts.N;
+  const int G = p.G;
+  exp_tab_init(tab);
+  if (tid < SGP_MAX_GPS) s_flags[tid] = 0;
+  __syncthreads();
+
+  // ---- A: posterior, intervals, S; B: max l0 over the safe rows
+  double lmax = -INFINITY;
+  for (int64_t row = tid; row < ((N + kStepThreads - 1) / kStepThreads) * kStepThreads;
+       row += kStepThreads) {
+    const bool valid = row < N;
+    const int64_t r = valid ? row : N - 1;
+    double x[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      x[k] = p.pts.base[r * p.pts.stride_row + k * p.pts.stride_col];
+    bool safe = true;
+    double l0 = 0.0;
+    tiny_row<D, NP, SINGLE>(p.gps, G, p.conf, N, x, row, valid, tab, safe, l0);
+    if (valid) {
+      p.conf.S[row] = safe ? 1 : 0;
+      if (safe) lmax = fmax(lmax, l0);
+    }
+  }
+  const double max_l = block_max(lmax, shd);        // (syncs: the rows are visible)
+  __syncthreads();
+
+  // ---- C: maximisers
+  double v = -INFINITY;
+  for (int64_t i = tid; i < N; i += kStepThreads) {
+    const double2_t q = *reinterpret_cast<const double2_t*>(p.conf.Q + i * G * 2);
+    const bool m = p.conf.S[i] && (q.y >= max_l);
+    p.M[i] = m ? 1 : 0;
+    if (m) v = fmax(v, q.y - q.x);
+  }
+  const double mw = block_max(v, shd);
+  const double max_var = mw / p.scaling.v[0];
+
+  // ---- D: candidates, their widths, counts, the first one in visiting order
+  unsigned nc = 0, nu = 0;
+  Pair best{-INFINITY, -1};
+  for (int64_t i = tid; i < N; i += kStepThreads) {
+    const bool sf = p.conf.S[i] != 0;
+    const bool mv = p.M[i] != 0;
+    double wmax = -INFINITY, smax = -INFINITY;
+    bool above = false;
+    for (int g = 0; g < G; ++g) {
+      const double2_t q = *reinterpret_cast<const double2_t*>(p.conf.Q + (i * G + g) * 2);
+      const double width = q.y - q.x;
+      wmax = fmax(wmax, width);
+      smax = fmax(smax, width / p.scaling.v[g]);
+      above = above || (width > p.thr_beta.v[g]);
+    }
+    const bool c = sf && !mv && (smax > max_var) && above;
+    if (!sf) ++nu;
+    p.cand[i] = c ? 1 : 0;
+    p.w[i] = sf ? wmax : -INFINITY;
+    p.Gm[i] = 0;
+    if (c) {
+      ++nc;
+      const Pair pr{wmax, p.goff + i};
+      if (best.i < 0 || before_desc(pr, best)) best = pr;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    nc += __shfl_xor(nc, o, 64);
+    nu += __shfl_xor(nu, o, 64);
+  }
+  if (lane == 0) {
+    shc[0][wave] = nc;
+    shc[1][wave] = nu;
+  }
+  const Pair win = block_best<false>(best, shp);     // (syncs)
+  unsigned ncand = 0, nunsafe = 0;
+  for (int wv_ = 0; wv_ < kStepWaves; ++wv_) {
+    ncand += shc[0][wv_];
+    nunsafe += shc[1][wv_];
+  }
+  // candidates that share the first one's width, bit for bit (gp_opt.py:542-552: NumPy's
+  // sort decides among them -- the host settles the order when there is more than one)
+  unsigned nt = 0;
+  if (win.i >= 0)
+    for (int64_t i = tid; i < N; i += kStepThreads)
+      if (p.cand[i] && p.w[i] == win.v) ++nt;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) nt += __shfl_xor(nt, o, 64);
+  __syncthreads();
+  if (lane == 0) shc[2][wave] = nt;
+  __syncthreads();
+  unsigned ntied = 0;
+  for (int wv_ = 0; wv_ < kStepWaves; ++wv_) ntied += shc[2][wv_];
+
+  const int d = D;
+  const int64_t li = win.i - p.goff;
+  if (tid == 0) {
+    p.scal[0] = max_l;
+    p.res[0] = mw;
+    reinterpret_cast<unsigned long long*>(p.res)[1] = ncand;
+    reinterpret_cast<unsigned long long*>(p.res)[2] = nunsafe;
+    p.res[3] = win.v;
+    reinterpret_cast<int64_t*>(p.res)[4] = win.i;
+    reinterpret_cast<int*>(p.res + 5)[0] = win.i >= 0 ? 1 : 0;
+    reinterpret_cast<int*>(p.res + 5)[1] = win.i >= 0 ? int(ntied) : 0;
+    p.res[p.nfront + p.nfl + 2] = max_l;
+  }
+  if (win.i >= 0) {
+    if (tid < d) {
+      const double xv = p.pts.base[li * p.pts.stride_row + tid * p.pts.stride_col];
+      p.res[6 + tid] = xv;
+      xcs[tid] = xv;
+    }
+    if (tid >= 64 && tid < 64 + G) p.res[6 + d + (tid - 64)] = p.conf.mean[int64_t(tid - 64) * N + li];
+    if (tid >= 128 && tid < 128 + 2 * G)
+      p.res[6 + d + G + (tid - 128)] = p.conf.Q[li * 2 * G + (tid - 128)];
+  }
+  __syncthreads();
+
+  // ---- E: is the first candidate an expander?  (gp_opt.py:579-606 with the rank-1
+  // update of the posterior instead of two refits per GP)
+  const gpdev_c_t gpc = (gpdev_c_t)(p.gps);
+  if (win.i >= 0 && nunsafe > 0) {
+    for (int g = 0; g < G; ++g) {          // (workgroup-uniform)
+      if (p.conf.fmin[g] == -INFINITY) continue;
+      const GpDev& gp = p.gps[g];
+      const int n = gpc[g].n, np = gpc[g].n_pad;
+      const int64_t ld = gpc[g].ld;
+      // k_c = k(X, x_c) (the generic evaluation of k_expkt), t = L^-1 k_c
+      if (tid < 64) {
+        double kcv = 0.0;
+        if (tid < n) {
+          double xj[D], xc[D];
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            xj[k] = gp.Xpad[int64_t(tid) * D + k];
+            xc[k] = xcs[k];
+          }
+          kcv = kern_eval<D>(gp.kern, xc, xj);
+        }
+        kc[tid] = kcv;
+        tt[tid] = 0.0;
+      }
+      __syncthreads();
+      for (int i = wave; i < n; i += kStepWaves) {
+        double acc = 0.0;
+        if (lane <= i) acc = fma(gp.Linv[int64_t(i) * ld + lane], kc[lane], acc);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) tt[i] = acc;
+      }
+      __syncthreads();
+      // w = L^-T t (k_expw1: 16 row groups i = q, q + 16, ..., summed over the groups in
+      // order), |t|^2, s^2 = k(x_c, x_c) + noise - |t|^2
+      for (int wq = wave; wq < kExpwWaves; wq += kStepWaves) {
+        double a0 = 0.0;
+        if (lane < n)
+          for (int i = wq; i < n; i += kExpwWaves)
+            if (i >= lane) a0 = fma(gp.Linv[int64_t(i) * ld + lane], tt[i], a0);
+        sh_w[wq][lane] = a0;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int wq = 0; wq < kExpwWaves; ++wq) tot += sh_w[wq][lane];
+        wv[lane] = (lane < n) ? tot : 0.0;
+      }
+      if (wave == 1) {
+        double s = 0.0;
+        if (lane < n) s = fma(tt[lane], tt[lane], s);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) {
+          const double s2 = gp.prior - s;
+          const double resid = p.conf.Q[li * 2 * G + 2 * g + 1] - p.conf.mean[int64_t(g) * N + li];
+          s_ops[0] = resid / s2;      // delta
+          s_ops[1] = 1.0 / s2;
+        }
+      }
+      __syncthreads();
+      const double delta = s_ops[0], inv_s2 = s_ops[1];
+      // scan: 16 rows per wave (lane & 15), the four 16-lane groups split the training
+      // points (k_expander_list); a row counts when it is unsafe
+      const KernFast<D> kf(gp.kern);
+      const double kdiag = gp.kern.kdiag;
+      const int ph = lane >> 4;
+      bool hit = false;
+      for (int64_t i0 = int64_t(wave) * 16; i0 < N; i0 += kStepWaves * 16) {
+        const int64_t row = i0 + (lane & 15);
+        const bool valid = row < N;
+        const int64_t rrow = valid ? row : N - 1;
+        const bool unsafe = valid && p.conf.S[rrow] == 0;
+        if (__ballot(unsafe) == 0ull) continue;
+        double x[D], xs[D], xc[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          x[k] = p.pts.base[rrow * p.pts.stride_row + k * p.pts.stride_col];
+          xc[k] = xcs[k];
+        }
+        kf.prep(x, xs);
+        const double mu = p.conf.mean[int64_t(g) * N + rrow];
+        const double var = p.conf.var[int64_t(g) * N + rrow];
+        double dot = 0.0;
+#pragma unroll 1
+        for (int s0 = 0; s0 < (np >> 2); s0 += 4) {   // 16 training points / step
+          double kq[4], wq[4];
+          kf.template many<4>(xs, gp.Xs + (s0 * 4 + ph) * D, 4 * D, tab, kq);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) wq[q] = wv[(s0 + q) * 4 + ph];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dot = fma(wq[q], kq[q], dot);
+        }
+        dot = sum_lane_groups(dot);
+        const double kxc = kf.raw(x, xc, tab);
+        if (unsafe && kxc >= 0.0 * kdiag) {
+          const double cx = kxc - dot;
+          const double mu2 = mu + cx * delta;
+          const double var2 = fmax(var - cx * cx * inv_s2, 1e-15);
+          hit = hit || (mu2 - p.conf.beta * sqrt(var2) >= p.conf.fmin[g]);
+        }
+      }
+      if (__ballot(hit) != 0ull && lane == 0) atomicOr(&s_flags[g], 1);
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+
+  // ---- F: G mark, arg-max over M | G of max_i (u_i - l_i) / scaling_i (first index)
+  int64_t lmark = -1;
+  if (win.i >= 0) {
+    bool ok = true, any = false;
+    for (int g = 0; g < G; ++g) {
+      if (p.conf.fmin[g] == -INFINITY) continue;
+      any = true;
+      ok = ok && (s_flags[g] != 0);
+    }
+    if (ok && any) lmark = li;
+  }
+  Pair bm{-INFINITY, -1};
+  for (int64_t i = tid; i < N; i += kStepThreads) {
+    const bool marked = i == lmark;
+    if (marked) p.Gm[i] = 1;
+    if (!(p.M[i] || marked)) continue;
+    double vv = -INFINITY;
+    for (int g = 0; g < G; ++g)
+      vv = fmax(vv, (p.conf.Q[(i * G + g) * 2 + 1] - p.conf.Q[(i * G + g) * 2]) / p.scaling.v[g]);
+    const Pair pr{vv, p.goff + i};
+    if (before_first(pr, bm)) bm = pr;
+  }
+  const Pair top = block_best<true>(bm, shp);
+  if (tid == 0) {
+    p.res[p.nfront + p.nfl] = top.v;
+    reinterpret_cast<int64_t*>(p.res)[p.nfront + p.nfl + 1] = top.i;
+  }
+  if (tid < G) reinterpret_cast<int32_t*>(p.res + p.nfront)[tid] = s_flags[tid];
+}
+
+template <int D, int NP>
+void launch_step_np(sgp_ctx* ctx, const StepParams& p, bool single) {
+  if (single)
+    hipLaunchKernelGGL((k_step_small<D, NP, true>), dim3(1), dim3(kStepThreads), 0, ctx->stream, p);
+  else
+    hipLaunchKernelGGL((k_step_small<D, NP, false>), dim3(1), dim3(kStepThreads), 0, ctx->stream, p);
+}
+
+template <int D>
+void launch_step_d(sgp_ctx* ctx, const StepParams& p, int np, bool single) {
+  if (np <= 32) return launch_step_np<D, 32>(ctx, p, single);
+  return launch_step_np<D, 48>(ctx, p, single);
+}
+
+}  // namespace
+
+bool step_small_eligible(const sgp_ctx* ctx, const GpDev* gh, int G, int64_t N) {
+  static const bool off = getenv("SGP_NO_STEP_SMALL") != nullptr;
+  if (off || N > kStepSmallRows || (ctx->sweep_choice & 3) != 0) return false;
+  for (int g = 0; g < G; ++g)
+    if (gh[g].n > kStepNP || gh[g].n_pad > 64) return false;
+  return true;
+}
+
+int launch_step_small(sgp_grid* g, const GpDev* gps_dev, const GpDev* gh, int G, double beta,
+                      const double* fmin, const double* scaling, const double* thr_beta,
+                      double* res, int nfront, int nfl) {
+  sgp_ctx* ctx = g->ctx;
+  StepParams p{};
+  p.gps = gps_dev;
+  p.G = G;
+  p.pts = SweepPoints{g->pts, g->N, 1, g->N};
+  p.conf.Q = g->Q;
+  p.conf.mean = g->mean;
+  p.conf.var = g->var;
+  p.conf.S = g->S;
+  p.conf.partial = g->partial;
+  p.conf.beta = beta;
+  for (int i = 0; i < SGP_MAX_GPS; ++i) {
+    p.conf.fmin[i] = i < G ? fmin[i] : -INFINITY;
+    p.scaling.v[i] = i < G ? scaling[i] : 1.0;
+    p.thr_beta.v[i] = i < G ? thr_beta[i] : 0.0;
+  }
+  p.M = g->M;
+  p.Gm = g->Gm;
+  p.cand = g->cand;
+  p.w = g->w;
+  p.goff = g->goff;
+  p.res = res;
+  p.scal = g->scal;
+  p.nfront = nfront;
+  p.nfl = nfl;
+  int np = 1;
+  bool single = true;
+  for (int i = 0; i < G; ++i) {
+    np = std::max(np, gh[i].n);
+    single = single && gh[i].kern.n_parts == 1;
+  }
+  switch (g->d) {
+    case 1: launch_step_d<1>(ctx, p, np, single); break;
+    case 2: launch_step_d<2>(ctx, p, np, single); break;
+    case 3: launch_step_d<3>(ctx, p, np, single); break;
+    case 4: launch_step_d<4>(ctx, p, np, single); break;
+    case 5: launch_step_d<5>(ctx, p, np, single); break;
+    case 6: launch_step_d<6>(ctx, p, np, single); break;
+    case 7: launch_step_d<7>(ctx, p, np, single); break;
+    case 8: launch_step_d<8>(ctx, p, np, single); break;
+    default:
+      sgp_set_error(ctx, "input dimension %d not in 1..%d", g->d, SGP_MAX_D);
+      return -2;
+  }
+  SGP_HIP(ctx, hipGetLastError());
+  ctx->last_sweep = 5;
+  return 0;
+}

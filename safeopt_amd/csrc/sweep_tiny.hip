@@ -28,13 +28,9 @@
 // last bits (another summation order); for a grid the choice of the kernel depends on the
 // sizes of the GPs only, so every rank and every shard takes the same one
 // (tiny_sweep_wanted below).
-#include "kern_eval.h"
-#include "sweep_shared.h"
+#include "tiny_row.h"
 
 namespace {
-
-typedef const __attribute__((address_space(4))) double* cdbl_t;
-typedef const __attribute__((address_space(4))) GpDev* gpdev_c_t;
 
 struct TinyParams {
   const GpDev* gps;
@@ -56,83 +52,9 @@ __global__ __launch_bounds__(256) void k_sweep_tiny(TinyParams p) {
 #pragma unroll
   for (int k = 0; k < D; ++k)
     x[k] = __builtin_nontemporal_load(p.pts.base + r * p.pts.stride_row + k * p.pts.stride_col);
-  const gpdev_c_t gpc = (gpdev_c_t)(p.gps);
   bool safe = true;
   double l0 = 0.0;
-  for (int g = 0; g < p.G; ++g) {        // (wave-uniform)
-    KernFast<D> kf;
-    kf.load_const(&p.gps[g].kern);
-    const int n = gpc[g].n;
-    const cdbl_t X = (cdbl_t)(gpc[g].Xs);
-    const cdbl_t al = (cdbl_t)(gpc[g].alpha);
-    const cdbl_t Li = (cdbl_t)(gpc[g].Linv);
-    const int64_t ld = gpc[g].ld;
-    double xs[D];
-    kf.template prep_t<SINGLE>(x, xs);
-    // the n covariances of this row, four at a time (training rows: scalar loads)
-    double k[NP];
-    double mean = 0.0;
-#pragma unroll
-    for (int j0 = 0; j0 < NP; j0 += 4) {
-      if (j0 < n) {                      // (uniform)
-        double y[4][D];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int i = 0; i < D; ++i) y[q][i] = (j0 + q < n) ? X[(j0 + q) * D + i] : 0.0;
-        double kv[4];
-        kf.template manyn_t<4, SINGLE>(xs, &y[0][0], D, tab, kv);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          k[j0 + q] = (j0 + q < n) ? kv[q] : 0.0;
-          mean = fma(al[j0 + q], k[j0 + q], mean);      // (alpha: zero padded to 16)
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) k[j0 + q] = 0.0;
-      }
-    }
-    // |L^-1 k|^2 (the entries of L^-1 are scalar operands), four rows at a time: four
-    // independent chains, so that a launch with few rows (a swarm of 20 particles: one
-    // wave, nothing else to hide the FMA latency behind) is not a single dependent chain
-    // of n^2 / 2 instructions.  Every row is summed in the order j = 0 .. i.
-    double ssq = 0.0;
-#pragma unroll
-    for (int i0 = 0; i0 < NP; i0 += 4) {
-      if (i0 < n) {                      // (uniform)
-        double v[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int j = 0; j <= i0 + 3; ++j) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (j <= i0 + q) v[q] = fma(Li[int64_t(i0 + q) * ld + j], k[j], v[q]);
-        }
-        // (rows n .. of the last group are NOT summed: after a pop / in a buffer with room
-        // for appends they hold whatever the factor left there -- only their reads are
-        // harmless)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (i0 + q < n) ssq = fma(v[q], v[q], ssq);
-      }
-    }
-    {
-      // (no contraction: mu -+ beta sd is rounded as the reference rounds it -- multiply,
-      // then add)
-#pragma clang fp contract(off)
-      const double var = fmax(gpc[g].kern.kdiag - ssq, 1e-15);   // GPy clip
-      const double sd = sqrt(var);
-      const double lo = mean - p.conf.beta * sd;
-      const double up = mean + p.conf.beta * sd;
-      if (g == 0) l0 = lo;
-      safe = safe && (lo > p.conf.fmin[g]);
-      if (valid) {
-        __builtin_nontemporal_store(mean, p.conf.mean + int64_t(g) * p.pts.N + row);
-        __builtin_nontemporal_store(var, p.conf.var + int64_t(g) * p.pts.N + row);
-        if (p.conf.Q)
-          *reinterpret_cast<double2_t*>(p.conf.Q + (row * p.G + g) * 2) = double2_t{lo, up};
-      }
-    }
-  }
+  tiny_row<D, NP, SINGLE>(p.gps, p.G, p.conf, p.pts.N, x, row, valid, tab, safe, l0);
   if (p.conf.S) {
     if (valid) p.conf.S[row] = safe ? 1 : 0;
     // max l0 over the safe rows of the workgroup (folded by the consumer, sets.hip)

@@ -22,6 +22,7 @@ array unless the user reads one of the mirrors.
 """
 from __future__ import annotations
 
+import collections
 import logging
 from functools import partial
 
@@ -194,6 +195,14 @@ class _WriteBackView(np.ndarray):
             np.ndarray.__setitem__(self, key, value)
 
 
+#: what the front half of ``compute_sets`` found (``SafeOpt._front_*``): counts of
+#: candidates / unsafe rows over the whole grid, the first candidate in visiting order
+#: (width, global index, its row, means, intervals), the probe flags + arg-max when they
+#: came with it (``fused``), and the number of candidates tied with it (None: unknown)
+_Front = collections.namedtuple(
+    '_Front', 'n_cand n_unsafe w_c idx_c x_c mu_c q_c fused n_tied')
+
+
 class _HipGridBackend(object):
     """Rank-local device state of a ``SafeOpt``: the shard of ``inputs`` in
     HBM plus the GP handles.  (Tests drive the same phase interface with a
@@ -324,6 +333,19 @@ class _HipGridBackend(object):
         return self.grid.sets_fused_comm(self._dev(), beta, fmin, scaling,
                                          thr_beta, near_frac)
 
+    def step_small_ok(self):
+        """Small grid and few observations: a whole step is one launch
+        (``sgp_grid_step_small``)."""
+        return self.grid.N <= 16384 and self.grid.step_small_ok(self._dev())
+
+    def step_small(self, beta, fmin, scaling, thr_beta):
+        devs = self._dev()
+        self._seen = [None] * len(devs)          # unknown until the call is through
+        out = self.grid.step_small(devs, beta, fmin, scaling, thr_beta)
+        self._seen = self._tags(devs)            # (a full sweep: the posterior is current)
+        self._rank1_streak = 0
+        return out
+
     def sets_back(self, beta, fmin, xc, mu_c, u_c, near_frac, gidx_c, scaling,
                   mark):
         return self.grid.sets_back(self._dev(), beta, fmin, xc, mu_c, u_c,
@@ -416,6 +438,9 @@ class SafeOpt(GaussianProcessOptimization):
         self._max_l = -np.inf
         self._ci_fresh = False
         self._argmax_cache = None
+        #: small grids with few observations take the whole step in one launch
+        #: (``sgp_grid_step_small``); False keeps them on the large-grid path
+        self.small_step = True
 
     # -- host mirrors ---------------------------------------------------------
     def _mirror(self, name, what):
@@ -580,6 +605,20 @@ class SafeOpt(GaussianProcessOptimization):
 
         ``full_sets=True`` evaluates every safe point as an expander candidate
         (plotting mode of the reference).
+
+        The common case -- GP certificates, not ``full_sets`` -- runs as a FRONT half
+        (maximisers, candidate mask, the first candidate in visiting order) and the
+        certification of that candidate; which entry points carry the front half depends
+        on where the step runs (one method each):
+
+        ==========================  =====================================================
+        one rank                    ``_front_one_rank_fused``: both halves in one device
+                                    round trip (``sgp_grid_sets_fused``)
+        one rank, no GP active      ``_front_one_rank``
+        N ranks, in-stream comm     ``_front_n_ranks_in_stream``: one round trip, merges on
+                                    the device behind the collectives
+        N ranks otherwise           ``_front_n_ranks_host``: packed host collectives
+        ==========================  =====================================================
         """
         beta = self.beta(self.t)
         self.compute_safe_set()
@@ -604,124 +643,139 @@ class SafeOpt(GaussianProcessOptimization):
 
         active = self.fmin != -np.inf
         world = self._comm.world
-        if not full_sets and not self.use_lipschitz and hasattr(be, 'sets_front'):
-            # Fused passes.  One GPU, or N GPUs with an in-stream communicator
-            # behind a deferred confidence pass: ONE device round trip.  Otherwise
-            # 2 (one GPU) / 3 round trips + 3 scalar collectives (max_var; every
-            # rank's first candidate with its rows; probe flags + local arg-max).
-            d = self.inputs.shape[1]
-            fused = None
-            n_tied = None           # candidates tied with the first one (None: unknown)
-            if world == 1 and np.any(active) and hasattr(be, 'sets_fused'):
-                # both halves in one device round trip
-                (out5, x_c, mu_c, q_c, f_flags, f_val, f_idx,
-                 max_l) = be.sets_fused(beta, self.fmin, self._max_l,
-                                        self.scaling, thr_beta, 0.5)
-                if self._max_l is None:         # deferred confidence pass
-                    self._max_l, self._any_safe = max_l, bool(max_l > -np.inf)
-                    if not self._any_safe:
-                        # the passes ran with max_l = -inf: M = G = False
-                        self._stale.update(M=True, G=True)
-                        return
-                n_cand, n_unsafe, w_c, idx_c = (out5[1], out5[2],
-                                                float(out5[3]), int(out5[4]))
-                fused = (f_flags, f_val, f_idx)
-                n_tied = int(out5[5]) if len(out5) > 5 else None
-            elif world == 1:
-                out5, x_c, mu_c, q_c = be.sets_front(self._max_l, None,
-                                                     self.scaling, thr_beta)
-                n_cand, n_unsafe, w_c, idx_c = (out5[1], out5[2],
-                                                float(out5[3]), int(out5[4]))
-                n_tied = int(out5[5]) if len(out5) > 5 else None
-            elif (self._max_l is None and np.any(active)
-                  and hasattr(be, 'sets_fused_comm')):
-                # N ranks, deferred confidence pass: the whole certified step in one
-                # device round trip -- the first-candidate merge, the probe flags and
-                # the arg-max merge run on the device behind in-stream collectives,
-                # every rank reads back the same (global) numbers
-                (out5, x_c, mu_c, q_c, f_flags, f_val, f_idx,
-                 max_l) = be.sets_fused_comm(beta, self.fmin, self.scaling,
-                                             thr_beta, 0.5)
-                self._max_l, self._any_safe = max_l, bool(max_l > -np.inf)
-                if not self._any_safe:
-                    self._stale.update(M=True, G=True)
-                    return
-                n_cand, n_unsafe, w_c, idx_c = (out5[1], out5[2],
-                                                float(out5[3]), int(out5[4]))
-                fused = (f_flags, f_val, f_idx)
-                n_tied = int(out5[5])
-            else:
-                if self._max_l is None:
-                    # deferred confidence pass: max l0 and the maximiser width
-                    # are all-reduced in stream, one round trip for this half
-                    out5, x_l, mu_l, q_l, max_l = be.sets_front_comm(
-                        self.scaling, thr_beta)
-                    self._max_l, self._any_safe = max_l, bool(max_l > -np.inf)
-                    if not self._any_safe:
-                        self._stale.update(M=True, G=True)
-                        return
-                else:
-                    width = self._comm.allreduce_max(
-                        np.array([be.maximizers(self._max_l)]))[0]
-                    out5, x_l, mu_l, q_l = be.sets_front(
-                        self._max_l, width / self.scaling[0], self.scaling,
-                        thr_beta)
-                tied_l = out5[5] if len(out5) > 5 else np.nan
-                pk = self._comm.allgather(
-                    np.concatenate([out5[1:5], [tied_l], x_l, mu_l, q_l]))
-                n_cand, n_unsafe = pk[:, 0].sum(), pk[:, 1].sum()
-                w_b, i_b = merge_topk(pk[:, 2], pk[:, 3].astype(np.int64), 1)
-                idx_c = int(i_b[0]) if i_b.size else -1
-                w_c = float(w_b[0]) if i_b.size else -np.inf
-                r = int(np.flatnonzero(pk[:, 3].astype(np.int64) == idx_c)[0]) \
-                    if idx_c >= 0 else 0
-                x_c, mu_c, q_c = (pk[r, 5:5 + d], pk[r, 5 + d:5 + d + G],
-                                  pk[r, 5 + d + G:])
-                # candidates of ALL shards tied with the first one: a shard whose
-                # own first candidate is narrower holds none of that width
-                holds = (pk[:, 3] >= 0) & (pk[:, 2] == w_c)
-                tied = pk[holds, 4].sum()
-                n_tied = None if np.isnan(tied) else int(tied)
+        if full_sets or self.use_lipschitz or not hasattr(be, 'sets_front'):
+            return self._general_sets(beta, active, thr_beta, full_sets)
+        if world == 1 and np.any(active) and hasattr(be, 'sets_fused'):
+            front = self._front_one_rank_fused(beta, thr_beta)
+        elif world == 1:
+            front = self._front_one_rank(thr_beta)
+        elif (self._max_l is None and np.any(active) and hasattr(be, 'sets_fused_comm')):
+            front = self._front_n_ranks_in_stream(beta, thr_beta)
+        else:
+            front = self._front_n_ranks_host(thr_beta)
+        if front is not None:                 # (None: no safe row, M = G = False)
+            self._certify_first_candidate(beta, active, front)
+
+    # -- the front half of compute_sets, one method per place the step runs ----------
+    @staticmethod
+    def _front_of(out5, x_c, mu_c, q_c, fused):
+        return _Front(out5[1], out5[2], float(out5[3]), int(out5[4]), x_c, mu_c, q_c,
+                      fused, int(out5[5]) if len(out5) > 5 else None)
+
+    def _deferred_max_l(self, max_l):
+        """``max l0[S]`` arrives with the front half after a deferred confidence pass;
+        False when no row is safe (the passes ran with ``-inf``: ``M = G = False``)."""
+        self._max_l, self._any_safe = max_l, bool(max_l > -np.inf)
+        if not self._any_safe:
             self._stale.update(M=True, G=True)
-            if n_cand == 0 or n_unsafe == 0 or not np.any(active) or idx_c < 0:
-                if fused is not None:       # G untouched: the arg-max over M holds
-                    self._argmax_cache = (fused[1], int(fused[2]))
-                return
-            if fused is not None:
-                flags, val, idx = fused
-            else:
-                flags, val, idx = be.sets_back(beta, self.fmin, x_c, mu_c,
-                                               q_c[1::2], 0.5, idx_c,
-                                               self.scaling, world == 1)
-            merged = fused is not None       # (flags and arg-max already global)
+        return self._any_safe
+
+    def _front_one_rank_fused(self, beta, thr_beta):
+        """One rank: both halves in one device round trip."""
+        (out5, x_c, mu_c, q_c, f_flags, f_val, f_idx,
+         max_l) = self._backend.sets_fused(beta, self.fmin, self._max_l, self.scaling,
+                                           thr_beta, 0.5)
+        if self._max_l is None and not self._deferred_max_l(max_l):
+            return None
+        return self._front_of(out5, x_c, mu_c, q_c, (f_flags, f_val, f_idx))
+
+    def _front_one_rank(self, thr_beta):
+        """One rank without an active GP certificate: the front half alone."""
+        out5, x_c, mu_c, q_c = self._backend.sets_front(self._max_l, None, self.scaling,
+                                                        thr_beta)
+        return self._front_of(out5, x_c, mu_c, q_c, None)
+
+    def _front_n_ranks_in_stream(self, beta, thr_beta):
+        """N ranks behind a deferred confidence pass, communicator in stream: the whole
+        certified step in one device round trip -- the first-candidate merge, the probe
+        flags and the arg-max merge run on the device behind the collectives, every rank
+        reads back the same (global) numbers (gp_opt.py:511-513, 542-557, 611-612, 642-644)."""
+        (out5, x_c, mu_c, q_c, f_flags, f_val, f_idx,
+         max_l) = self._backend.sets_fused_comm(beta, self.fmin, self.scaling, thr_beta, 0.5)
+        if not self._deferred_max_l(max_l):
+            return None
+        return self._front_of(out5, x_c, mu_c, q_c, (f_flags, f_val, f_idx))
+
+    def _front_n_ranks_host(self, thr_beta):
+        """N ranks, collectives on the host side of the step: every rank's first candidate
+        with its rows goes through one packed all-gather and is merged in NumPy."""
+        be = self._backend
+        d, G = self.inputs.shape[1], len(self.gps)
+        if self._max_l is None:
+            # deferred confidence pass: max l0 and the maximiser width
+            # are all-reduced in stream, one round trip for this half
+            out5, x_l, mu_l, q_l, max_l = be.sets_front_comm(self.scaling, thr_beta)
+            if not self._deferred_max_l(max_l):
+                return None
+        else:
+            width = self._comm.allreduce_max(np.array([be.maximizers(self._max_l)]))[0]
+            out5, x_l, mu_l, q_l = be.sets_front(self._max_l, width / self.scaling[0],
+                                                 self.scaling, thr_beta)
+        tied_l = out5[5] if len(out5) > 5 else np.nan
+        pk = self._comm.allgather(np.concatenate([out5[1:5], [tied_l], x_l, mu_l, q_l]))
+        n_cand, n_unsafe = pk[:, 0].sum(), pk[:, 1].sum()
+        w_b, i_b = merge_topk(pk[:, 2], pk[:, 3].astype(np.int64), 1)
+        idx_c = int(i_b[0]) if i_b.size else -1
+        w_c = float(w_b[0]) if i_b.size else -np.inf
+        r = int(np.flatnonzero(pk[:, 3].astype(np.int64) == idx_c)[0]) if idx_c >= 0 else 0
+        x_c, mu_c, q_c = pk[r, 5:5 + d], pk[r, 5 + d:5 + d + G], pk[r, 5 + d + G:]
+        # candidates of ALL shards tied with the first one: a shard whose
+        # own first candidate is narrower holds none of that width
+        holds = (pk[:, 3] >= 0) & (pk[:, 2] == w_c)
+        tied = pk[holds, 4].sum()
+        return _Front(n_cand, n_unsafe, w_c, idx_c, x_c, mu_c, q_c, None,
+                      None if np.isnan(tied) else int(tied))
+
+    def _certify_first_candidate(self, beta, active, front):
+        """Second half, shared by every variant: is the first candidate an expander
+        (gp_opt.py:579-612)?  ``front.fused``: the probe flags and the arg-max came with the
+        front half (already global); otherwise ``sets_back`` runs them now."""
+        be = self._backend
+        G = len(self.gps)
+        world = self._comm.world
+        n_cand, n_unsafe, w_c, idx_c, x_c, mu_c, q_c, fused, n_tied = front
+        self._stale.update(M=True, G=True)
+        if n_cand == 0 or n_unsafe == 0 or not np.any(active) or idx_c < 0:
+            if fused is not None:       # G untouched: the arg-max over M holds
+                self._argmax_cache = (fused[1], int(fused[2]))
+            return
+        if fused is not None:
+            flags, val, idx = fused
+        else:
+            flags, val, idx = be.sets_back(beta, self.fmin, x_c, mu_c, q_c[1::2], 0.5,
+                                           idx_c, self.scaling, world == 1)
+        merged = fused is not None       # (flags and arg-max already global)
+        if world > 1 and not merged:
+            pk = self._comm.allgather(np.concatenate(
+                [flags.astype(np.float64), [val, float(idx)]]))
+            flags = pk[:, :G].max(axis=0)
+        if np.all(flags[active] != 0):
             if world > 1 and not merged:
-                pk = self._comm.allgather(np.concatenate(
-                    [flags.astype(np.float64), [val, float(idx)]]))
-                flags = pk[:, :G].max(axis=0)
-            if np.all(flags[active] != 0):
-                if world > 1 and not merged:
-                    if be.owns(idx_c):
-                        be.mark_expanders(np.array([idx_c], dtype=np.int64))
-                    # arg-max over M on every rank + the certified expander
-                    v_c = np.max((q_c[1::2] - q_c[::2]) / self.scaling)
-                    val, idx = merge_argmax(
-                        np.append(pk[:, G], v_c),
-                        np.append(pk[:, G + 1].astype(np.int64), idx_c))
-                self._argmax_cache = (val, int(idx))
-                if self._settle_ties(beta, active, w_c, idx_c, n_tied) != idx_c:
-                    self._argmax_cache = None
-                return
-            # not certified by the probe: exact scan, then the general loop
-            hit = self._expander_flags(beta, x_c[None, :], mu_c[None, :],
-                                       q_c[None, 1::2], active, probe=False)
-            if hit[0]:
                 if be.owns(idx_c):
                     be.mark_expanders(np.array([idx_c], dtype=np.int64))
-                self._settle_ties(beta, active, w_c, idx_c, n_tied)
-                return
-            self._visit_candidates(beta, active, False, w_c, idx_c)
+                # arg-max over M on every rank + the certified expander
+                v_c = np.max((q_c[1::2] - q_c[::2]) / self.scaling)
+                val, idx = merge_argmax(
+                    np.append(pk[:, G], v_c),
+                    np.append(pk[:, G + 1].astype(np.int64), idx_c))
+            self._argmax_cache = (val, int(idx))
+            if self._settle_ties(beta, active, w_c, idx_c, n_tied) != idx_c:
+                self._argmax_cache = None
             return
+        # not certified by the probe: exact scan, then the general loop
+        hit = self._expander_flags(beta, x_c[None, :], mu_c[None, :],
+                                   q_c[None, 1::2], active, probe=False)
+        if hit[0]:
+            if be.owns(idx_c):
+                be.mark_expanders(np.array([idx_c], dtype=np.int64))
+            self._settle_ties(beta, active, w_c, idx_c, n_tied)
+            return
+        self._visit_candidates(beta, active, False, w_c, idx_c)
 
+    def _general_sets(self, beta, active, thr_beta, full_sets):
+        """Step by step (``full_sets``, Lipschitz certificates, backends without the fused
+        passes): maximisers, candidate mask, then the expander loop from its start."""
+        be = self._backend
         width = self._comm.allreduce_max(
             np.array([be.maximizers(self._max_l)]))[0]
         max_var = width / self.scaling[0]
@@ -925,12 +979,37 @@ class SafeOpt(GaussianProcessOptimization):
                     and bool(np.any(self.fmin != -np.inf))
                     and (self._comm.world == 1
                          or getattr(self._comm, 'in_stream', False)))
+        if (one_trip and self._comm.world == 1 and self.small_step
+                and hasattr(self._backend, 'step_small') and self._backend.step_small_ok()):
+            # a small grid (the reference's own regime): the whole step is one launch
+            self._small_step(context)
+            return self.get_new_query_point()
         self.update_confidence_intervals(context=context, _defer=one_trip)
         if ucb:
             self.compute_safe_set()
         else:
             self.compute_sets()
         return self.get_new_query_point(ucb=ucb)
+
+    def _small_step(self, context):
+        """``update_confidence_intervals`` + ``compute_sets`` of a small grid in one launch
+        and one read-back (``sgp_grid_step_small``: grids of at most 16384 rows, GPs with at
+        most 48 observations -- gp_opt.py:651-675 as the reference's examples run it)."""
+        beta = self.beta(self.t)
+        self.context = context
+        G = len(self.gps)
+        thr_beta = np.broadcast_to(
+            np.asarray(self.threshold, dtype=float) * beta, (G,)).copy()
+        (out5, x_c, mu_c, q_c, flags, val, idx,
+         max_l) = self._backend.step_small(beta, self.fmin, self.scaling, thr_beta)
+        self._stale.update(Q=True, S=True)
+        self._q_written = False          # (the sweep overwrites the intervals)
+        self._ci_fresh = True
+        self._argmax_cache = None
+        if self._deferred_max_l(max_l):
+            self._certify_first_candidate(beta, self.fmin != -np.inf,
+                                          self._front_of(out5, x_c, mu_c, q_c,
+                                                         (flags, val, idx)))
 
     def get_maximum(self, context=None):
         """Best lower bound inside the safe set: ``(x, l)`` or ``None``."""

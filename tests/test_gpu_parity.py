@@ -1910,3 +1910,74 @@ def test_warm_path_makes_no_device_allocations(mods):
         opt.optimize()
         grown += ctx.alloc_count() - before
     assert grown <= 6, grown
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_one_launch_step_of_small_grids(mods, seed):
+    """The reference's own regime -- grids of 1e3-1e4 rows, a few observations
+    (gp_opt.py:651-675 as examples/1d_example.ipynb runs it; BASELINE.json config 1) --
+    takes a whole ``optimize()`` in ONE launch (``sgp_grid_step_small``): against the
+    large-grid path on the same data (``small_step = False``: sweep + nine set passes) the
+    chosen parameter and ``S / M / G`` must be identical and ``Q`` the same bits (one copy
+    of the posterior arithmetic, tiny_row.h), over several BO iterations, and against the
+    oracle."""
+    safeopt_amd, gpy, gpn, son = mods
+    rng = np.random.default_rng(9100 + seed)
+    d = int(rng.integers(1, 4))
+    G = int(rng.integers(1, 4))
+    n = int(rng.integers(1, 49))
+    sides = {1: [int(rng.integers(50, 4000))], 2: [int(rng.integers(8, 120)), int(rng.integers(8, 120))],
+             3: [int(rng.integers(5, 26)) for _ in range(3)]}[d]
+    kind = ["RBF", "Matern32", "Matern52"][int(rng.integers(0, 3))]
+    grid = safeopt_amd.linearly_spaced_combinations([(-4., 4.)] * d, sides)
+    X = rng.uniform(-1.5, 1.5, size=(n, d))
+    Ys = [smooth(X, 70 + g) - smooth(X, 70 + g).min() + 0.3 for g in range(G)]
+    ls = list(rng.uniform(0.6, 1.6, size=d))
+    fmin = [0.0 if (g == 0 or rng.random() < 0.7) else -np.inf for g in range(G)]
+
+    def build(ns):
+        reg = ns.models.GPRegression if hasattr(ns, "models") else ns.GPRegression
+        kns = ns.kern if hasattr(ns, "kern") else ns
+        return [reg(X, Ys[g], getattr(kns, kind)(d, 2.0, ls, ARD=True), noise_var=0.05 ** 2)
+                for g in range(G)]
+    a = safeopt_amd.SafeOpt(build(gpy) if G > 1 else build(gpy)[0], grid,
+                            fmin if G > 1 else fmin[0], threshold=0.2)
+    b = safeopt_amd.SafeOpt(build(gpy) if G > 1 else build(gpy)[0], grid,
+                            fmin if G > 1 else fmin[0], threshold=0.2)
+    b.small_step = False
+    b._backend.incremental = False     # (a full sweep every step, like the one-launch step)
+    ctx = a._backend.ctx
+    for it in range(4):
+        try:
+            xa = a.optimize()
+        except EnvironmentError:
+            # no safe row (gp_opt.py:632): the large-grid path must say the same
+            assert ctx.last_sweep() == "step-small"
+            with pytest.raises(EnvironmentError):
+                b.optimize()
+            assert not a.S.any() and not a.M.any() and not a.G.any()
+            assert_array_equal(a.Q, b.Q)
+            break
+        assert ctx.last_sweep() == "step-small"
+        xb = b.optimize()
+        assert ctx.last_sweep() != "step-small"
+        assert_array_equal(xa, xb)
+        assert_array_equal(a.S, b.S)
+        assert_array_equal(a.M, b.M)
+        assert_array_equal(a.G, b.G)
+        assert_array_equal(a.Q, b.Q)           # the same bits
+        if it == 0:
+            go = build(gpn)
+            scaling = np.array([np.sqrt(g.kern.Kdiag(np.zeros((1, d)))[0]) for g in go])
+            idx, Qo, So, Mo, Go = son.optimize_grid(go, grid, np.asarray(fmin, dtype=float),
+                                                    scaling, 0.2, 2.0)
+            assert_array_equal(a.S, So)
+            assert_array_equal(a.M, Mo)
+            assert_array_equal(a.G, Go)
+            assert_array_equal(xa, grid[idx])
+            assert np.max(np.abs(a.Q - Qo)) < 1e-8
+        if a.gps[0].X.shape[0] >= 48:
+            break
+        y = np.array([float(smooth(xa[None, :], 70 + g)[0, 0]) + 0.3 for g in range(G)])
+        a.add_new_data_point(xa, y)
+        b.add_new_data_point(xb, y)
