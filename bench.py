@@ -250,11 +250,22 @@ def cpu_baseline(cfg, sample_rows, dev_Q=None, row_offset=0):
                       "threads; single thread: %d rows, %.2f s each"
                       % (start, start + rows_all, CPU_BASELINE_REPEATS, t_all,
                          cores, rows_one, t_one))
-    # every core at work: nproc independent row blocks
+    # every core at work: nproc independent row blocks.  THIS is the
+    # baseline's value -- `cores` = the processes that really ran; the BLAS-threaded run
+    # above is elementwise-bound NumPy (faithful to GPy), in effect ONE core whatever the
+    # thread count, and is kept as `blas_threads` next to `single_thread`.
+    out["blas_threads"] = dict(value=out["value"], threads=int(cores), spread=out.pop("spread"),
+                               note="OpenBLAS threads of ONE process: the NumPy restatement "
+                                    "is elementwise-bound, in effect a single core")
     try:
-        out["parallel"] = cpu_baseline_parallel(cfg, rows_one / t_one)
+        par = cpu_baseline_parallel(cfg, rows_one / t_one)
+        out["parallel"] = par
+        out["value"], out["cores"] = par["value"], par["processes"]
+        out["sample"] = par["sample"] + " | one process: " + out["sample"]
     except Exception as e:        # noqa -- the baseline must never break the bench line
         out["parallel"] = {"error": repr(e)}
+        out["cores"] = 1
+        out["sample"] = "(parallel run failed: one process, in effect one core) " + out["sample"]
     parity = None
     if dev_Q is not None:
         dq = dev_Q[start - row_offset:start - row_offset + rows_all]
@@ -432,6 +443,64 @@ def reference_regime(gpy, safeopt_amd, ctx, n=20, steps=200):
             "sweep_kernel": ctx.last_sweep(), "sweep_ms": t,
             "roofline": {"bound": "fp64 valu", "achieved": ops / (t * 1e-3) / 1e12, "peak": 39.3,
                          "unit": "T lane-ops/s", "frac": ops / (t * 1e-3) / 1e12 / 39.3}}
+
+
+def config1(gpy, safeopt_amd, ctx, steps=2000):
+    """BASELINE.json configs[0] -- the reference's own problem size, examples/1d_example.ipynb
+    plumbing: 1-D RBF (variance 2, lengthscale 1, noise 0.05^2), 1 GP that is objective and
+    constraint, the 1000-point grid on [-10, 10], 20 observations gathered by running
+    SafeOpt from x0 = 0 on a sampled GP function (utilities.sample_gp_function), threshold
+    0.2 -- microseconds per SafeOpt.optimize().  Here the whole step is ONE launch of one
+    workgroup (sgp_grid_step_small); the large-grid path on the same object (sweep + nine
+    set passes) is timed next to it, and the oracle once on the same intervals."""
+    from oracle import gp_numpy as gpn
+    from oracle import safeopt_numpy as son
+    rng_state = np.random.get_state()
+    np.random.seed(0)
+    try:
+        bounds = [(-10., 10.)]
+        kern = gpy.kern.RBF(1, variance=2.0, lengthscale=1.0)
+        grid = safeopt_amd.linearly_spaced_combinations(bounds, 1000)
+        fun = safeopt_amd.sample_gp_function(kern, bounds, 0.05 ** 2, 100)
+        x0 = np.zeros((1, 1))
+        gp = gpy.models.GPRegression(x0, fun(x0), kern, noise_var=0.05 ** 2)
+        # (fmin one unit below the start value: the start is safe, the set can grow)
+        opt = safeopt_amd.SafeOpt(gp, grid, float(fun(x0, noise=False)[0, 0]) - 1.0, threshold=0.2)
+        for _ in range(19):                    # 20 observations, as 1d_example gathers them
+            x = opt.optimize()
+            opt.add_new_data_point(x, fun(x))
+    finally:
+        np.random.set_state(rng_state)
+    n = opt.gp.X.shape[0]
+    out = {"workload": "config1: 1-D RBF, G=1, n=%d (19 SafeOpt iterations from x0 = 0 on a "
+                       "sampled GP function), grid 1000 points on [-10, 10], one "
+                       "SafeOpt.optimize()" % n}
+    for name, small in (("one_launch", True), ("large_grid_path", False)):
+        opt.small_step = small
+        opt._backend.incremental = False
+        for _ in range(100):
+            x = opt.optimize()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            x = opt.optimize()
+        ctx.sync()
+        us = (time.perf_counter() - t0) / steps * 1e6
+        out[name] = {"us_per_optimize": us, "candidates_per_s": 1000 / (us * 1e-6),
+                     "sweep_kernel": ctx.last_sweep(), "chosen_x": float(x[0])}
+    opt.small_step = True
+    x = opt.optimize()
+    go = gpn.GPRegression(opt.gp.X, opt.gp.Y, gpn.RBF(1, variance=2.0, lengthscale=1.0),
+                          noise_var=0.05 ** 2)
+    t0 = time.perf_counter()
+    idx, Qo, So, Mo, Go = son.optimize_grid([go], grid, opt.fmin, opt.scaling, 0.2, 2.0)
+    out["oracle"] = {"us_per_optimize": (time.perf_counter() - t0) * 1e6,
+                     "same_chosen_x": bool(np.array_equal(x, grid[idx])),
+                     "S_M_G_identical": bool(np.array_equal(opt.S, So) and np.array_equal(opt.M, Mo)
+                                             and np.array_equal(opt.G, Go)),
+                     "q_linf": float(np.max(np.abs(opt.Q - Qo)))}
+    out["us_per_optimize"] = out["one_launch"]["us_per_optimize"]
+    return out
 
 
 def config4_strong(gpy, safeopt_amd, dist, ctx, comm, rank, world, steps=None, warmup=2):
@@ -803,6 +872,10 @@ def main():
                 extras["reference_regime"] = reference_regime(gpy, safeopt_amd, ctx)
             except Exception as e:      # noqa
                 extras["reference_regime"] = {"error": repr(e)}
+            try:
+                extras["config1"] = config1(gpy, safeopt_amd, ctx)
+            except Exception as e:      # noqa
+                extras["config1"] = {"error": repr(e)}
         if default_run:
             try:
                 extras["config4_strong"] = config4_strong(gpy, safeopt_amd, dist, ctx, comm,
@@ -908,9 +981,8 @@ def main():
         base, parity = cpu_baseline(cfg, rows, dev_Q=opt.Q)
         res["cpu_baseline"] = base
         res["parity"] = parity
-        res["speedup_vs_cpu"] = res["value"] / base["value"]
-        if "value" in base.get("parallel", {}):
-            res["speedup_vs_cpu_parallel"] = res["value"] / base["parallel"]["value"]
+        res["speedup_vs_cpu"] = res["value"] / base["value"]      # (all host cores at work)
+        res["speedup_vs_cpu_one_process"] = res["value"] / base["blas_threads"]["value"]
         if args.check_chosen:
             res["parity"].update(full_grid_check(cfg, opt, res.get("chosen_index")))
     print(json.dumps(res))

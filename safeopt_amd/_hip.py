@@ -225,6 +225,8 @@ class Context(object):
         self.h = h
         self.device = device
         self.rank, self.world = 0, 1
+        self.sweep_forced = any(os.environ.get(k) for k in
+                                ("SGP_SWEEP", "SGP_NO_TINY", "SGP_NO_STEP_SMALL"))
 
     @classmethod
     def default(cls, device=None):
@@ -304,7 +306,10 @@ class Context(object):
         def code(w):          # a name, or the integer of sgp_ctx_set_sweep
             return int(w) if isinstance(w, (int, np.integer)) else names.index(w)
 
-        return names[int(lib().sgp_ctx_set_sweep(self.h, code(which)))]
+        old = names[int(lib().sgp_ctx_set_sweep(self.h, code(which)))]
+        #: a sweep kernel is forced (A/B runs, tests): no one-launch step of small grids
+        self.sweep_forced = (code(which) & 3) != 0
+        return old
 
     def last_sweep(self):
         """Kernel of the last posterior sweep: 'classic' | 'pair' | 'tiny' | 'few-points'."""
@@ -567,6 +572,15 @@ class DeviceGrid(object):
             self.h, int(cnt.size), cnt.ctypes.data_as(C.POINTER(C.c_int64)),
             stv.ctypes.data_as(C.POINTER(C.c_int64)), dptr(vals), C.byref(ok)))
         return bool(ok.value)
+
+    def clear_axes(self):
+        """Forget the tensor-grid declaration (the sweeps evaluate covariances again)."""
+        one = np.ones(self.d, dtype=np.int64)
+        ok = C.c_int(0)
+        self.ctx.check(lib().sgp_grid_set_axes(
+            self.h, self.d, one.ctypes.data_as(C.POINTER(C.c_int64)),
+            one.ctypes.data_as(C.POINTER(C.c_int64)), dptr(np.zeros(self.d)), C.byref(ok)))
+        assert not ok.value
 
     def confidence(self, gps, beta, fmin, defer=False):
         """``defer``: enqueue only; ``max l0[S]`` stays on the device and comes

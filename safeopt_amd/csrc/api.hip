@@ -10,6 +10,9 @@
 #include <limits>
 #include <new>
 
+#include <atomic>
+#include <chrono>
+
 #include "common.h"
 #include "small_path.h"
 
@@ -259,6 +262,7 @@ void sgp_destroy(sgp_ctx* ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->step_host) (void)hipHostFree(ctx->step_host);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -673,6 +677,32 @@ static const SepLaunch* sep_launch(sgp_grid* g, sgp_gp* const* gps, const GpDev*
   for (int k = 0; k < g->d; ++k)
     if (g->ax_count[k] > 1) cols[na++] = k;
   if (na < 1 || na > 3) return nullptr;      // (4 axes: evaluated, launch_posterior)
+  // (GPs with few observations are swept by the VALU kernel, which evaluates: no tables to
+  // build or refresh at every append)
+  if (tiny_sweep_wanted(ctx, host, G, g->N, /*rows_sharded=*/true)) return nullptr;
+  // A table is nblk x count x 128 bytes per axis -- with ONE long axis that is the whole
+  // n_pad x N covariance matrix (a 1-D grid of 1e6 points, n = 544: 4.3 GB) -- and the sweeps
+  // address it with 32-bit offsets.  Beyond a budget that keeps tables an L2 / Infinity-Cache
+  // affair (and far below the 4 GB where the offsets would wrap) the covariances are
+  // evaluated instead.
+  constexpr size_t kSepBudgetBytes = size_t(256) << 20;       // per GP, all axes
+  // The paired kernel (factors of more than 256 rows) streams 2-33 MB of packed factor per
+  // GP through the 4-MB L2 of an XCD once per tile: tables that do not fit NEXT to that
+  // stream are evicted between two uses of a line and every read becomes a fabric request
+  // (config 4: 3 x 1.6 MB of tables, 43 GB per 8e6-row launch against 3.6 GB evaluated --
+  // 126 x the algorithmic bytes for 2-3 % of time; profiles/r05/ab_tables.txt).  There the
+  // tables are used only while all of them fit half an L2 (SGP_SEP_PAIR=1: always).
+  static const bool pair_always = getenv("SGP_SEP_PAIR") && atoi(getenv("SGP_SEP_PAIR")) == 1;
+  const bool paired = pair_sweep_wanted(ctx, host, G);
+  size_t all_bytes = 0;
+  for (int i = 0; i < G; ++i) {
+    size_t bytes = 0;
+    for (int a = 0; a < na; ++a)
+      bytes += sep_table_doubles(host[i], g->ax_count[cols[a]]) * sizeof(double);
+    if (bytes > kSepBudgetBytes) return nullptr;
+    if (host[i].share < 0) all_bytes += bytes;
+  }
+  if (paired && !pair_always && all_bytes > (size_t(2) << 20)) return nullptr;
   std::sort(cols, cols + na, [&](int a, int b) { return g->ax_stride[a] < g->ax_stride[b]; });
   sl->naxes = na;
   sl->goff = g->goff;
@@ -1416,14 +1446,50 @@ int sgp_grid_step_small(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   const size_t nfront = 6 + size_t(d) + 3 * size_t(G);
   const size_t nfl = (size_t(G) + 1) / 2;
   const size_t nres = nfront + nfl + 3;
-  double* res = static_cast<double*>(sgp_scratch(ctx, 1, (nres + 8) * 8));
-  SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
+  SGP_CHECK(ctx, nres < size_t(kStepResWords), "result block of %zu words", nres);
+  if (!ctx->step_host) {
+    void* h = nullptr;
+    SGP_HIP(ctx, hipHostMalloc(&h, kStepResWords * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h, 0, kStepResWords * 8);
+    void* dv = nullptr;
+    SGP_HIP(ctx, hipHostGetDevicePointer(&dv, h, 0));
+    ctx->step_host = static_cast<double*>(h);
+    ctx->step_dev = static_cast<double*>(dv);
+  }
   g->l0_pending = 0;
-  SGP_TRY(launch_step_small(g, g->gpdev, host, G, beta, fmin, scaling, thr_beta, res,
-                            int(nfront), int(nfl)));
-  std::vector<double> hostres(nres);
-  SGP_TRY(sgp_d2h(ctx, hostres.data(), res, nres * 8));
-  unpack_front(hostres.data(), d, G, out5, x_top, mean_top, q_top);
+  const uint64_t seq = ++ctx->step_seq;
+  SGP_TRY(launch_step_small(g, g->gpdev, host, G, beta, fmin, scaling, thr_beta, ctx->step_dev,
+                            int(nfront), int(nfl), seq));
+  // No read-back copy, no stream synchronisation: the kernel writes its result block into
+  // host memory and a completion word behind it; spin on that word (a launch of 20-40 us),
+  // fall back to the stream when it does not turn up.
+  {
+    volatile uint64_t* done = reinterpret_cast<volatile uint64_t*>(ctx->step_host) +
+                              (kStepResWords - 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    while (*done != seq) {
+      if ((++spins & 1023u) == 0 &&
+          std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+        SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SGP_CHECK(ctx, *done == seq, "sgp_grid_step_small: the kernel left no result");
+        break;
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  double hostres[kStepResWords];
+  memcpy(hostres, ctx->step_host, nres * 8);
+  if (getenv("SGP_STEP_STAMPS")) {      // (-DSTEP_STAMPS builds of step_small.hip)
+    const uint64_t* st = reinterpret_cast<const uint64_t*>(ctx->step_host) + 40;
+    static int shown = 0;
+    if (++shown % 500 == 0) {
+      fprintf(stderr, "step stamps (ticks):");
+      for (int i = 1; i < 8; ++i) fprintf(stderr, " %d:%lld", i, (long long)(st[i] - st[i - 1]));
+      fprintf(stderr, "\n");
+    }
+  }
+  unpack_front(hostres, d, G, out5, x_top, mean_top, q_top);
   memcpy(flags, &hostres[nfront], size_t(G) * 4);
   *value = hostres[nfront + nfl];
   memcpy(gidx, &hostres[nfront + nfl + 1], 8);

@@ -160,6 +160,11 @@ struct sgp_ctx {
   int last_sweep = 0;         // kernel of the last posterior sweep (sgp_ctx_last_sweep)
   int share_factors = 1;      // sgp_ctx_set_share: GPs with identical (X, kernel, noise)
                               // share the variance contraction (paired sweep)
+  // sgp_grid_step_small: its result block lives in host memory the device writes directly
+  // (pinned, mapped, coherent), the last word is a completion counter the host spins on
+  double* step_host = nullptr;
+  double* step_dev = nullptr;      // the same memory as the device sees it
+  uint64_t step_seq = 0;
   // RCCL
   void* comm = nullptr;  // ncclComm_t
   int rank = 0, world = 1;
@@ -344,12 +349,21 @@ int rank1_num_blocks(int64_t N);
 int launch_rank1(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d,
                  SweepPoints pts, Rank1Args ra);
 
+// sweep_tiny.hip: do the GPs of a launch go through the VALU kernel (every one with at most
+// 48 observations)?
+bool tiny_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff, int64_t rows,
+                       bool rows_sharded);
+
+// sweep_pair.hip: does the launch take the paired-wave kernel (a GP with more than 256 rows)?
+bool pair_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff);
+
 // step_small.hip: a whole SafeOpt.optimize() of a small grid in one launch
 constexpr int64_t kStepSmallRows = 16384;
 bool step_small_eligible(const sgp_ctx* ctx, const GpDev* gh, int G, int64_t N);
 int launch_step_small(sgp_grid* g, const GpDev* gps_dev, const GpDev* gh, int G, double beta,
                       const double* fmin, const double* scaling, const double* thr_beta,
-                      double* res, int nfront, int nfl);
+                      double* res, int nfront, int nfl, uint64_t seq);
+constexpr int kStepResWords = 64;     // doubles of the result block (6 + d + 3 G + ... <= 50)
 
 // sets.hip
 int launch_reduce_max(sgp_ctx* ctx, const double* in, int64_t n, double* out);

@@ -31,10 +31,10 @@
 
 namespace {
 
-// (512 threads: two waves per SIMD, 256 registers each -- a row's 48 covariances and four
-// FMA chains of tiny_row need up to ~190)
-constexpr int kStepThreads = 512;
-constexpr int kStepWaves = kStepThreads / 64;
+// Workgroup size (template parameter TH): 512 threads -- two waves per SIMD, 256 registers
+// each: a row's 48 covariances and the four FMA chains of tiny_row_gp need up to ~190.
+// (1024 threads with 128 registers for n <= 24 spill 64-320 B and were no faster: the step
+// is a chain of latencies, not of issue slots -- profiles/r05/experiments.txt.)
 constexpr int kExpwWaves = 16;    // row groups of k_expw1 (factor.hip), whose order is kept
 constexpr int kStepNP = 48;       // observations per GP, at most (tiny_row)
 
@@ -52,18 +52,41 @@ struct StepParams {
   double* res;             // result block (layout of sgp_grid_sets_fused)
   double* scal;            // [0] = max l0[S]
   int nfront, nfl;
+  unsigned long long seq;  // written behind the results (system scope): the host spins on it
 };
 
-template <int D, int NP, bool SINGLE>
-__global__ __launch_bounds__(kStepThreads) void k_step_small(StepParams p) {
+// -DSTEP_STAMPS: s_memtime at the phase boundaries into words 40.. of the result block
+// (timing experiments: scripts/dev/small_step_time.py prints them)
+#ifdef STEP_STAMPS
+#define STEP_STAMP(i)                                                                   \
+  do {                                                                                  \
+    if (threadIdx.x == 0)                                                               \
+      reinterpret_cast<unsigned long long*>(p.res)[40 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define STEP_STAMP(i) do {} while (0)
+#endif
+
+template <int D, int NP, bool SINGLE, int TH>
+__global__ __launch_bounds__(TH) void k_step_small(StepParams p) {
+  constexpr int kStepThreads = TH;
+  constexpr int kStepWaves = TH / 64;
   __shared__ double tab[kExpTabSize];
   __shared__ double shd[kStepWaves];
   __shared__ Pair shp[kStepWaves];
   __shared__ unsigned shc[3][kStepWaves];
   __shared__ double sh_w[kExpwWaves][64];
   __shared__ double kc[64], tt[64], wv[64], xcs[SGP_MAX_D];
+  // the GP being worked on, staged: dense L^-1 (rows < n, pitch NP), its scaled and raw
+  // training rows (n_pad <= 64 of them), alpha.  One pass of ONE workgroup has nothing to
+  // hide a chain of scalar- or vector-load round trips behind, so the wave-uniform operands
+  // of tiny_row_gp and of the expander test come from LDS here (same values, same order).
+  __shared__ double gLi[NP * NP], gX[64 * D], gXp[64 * D], gAl[NP];
   __shared__ double s_ops[3];       // delta, 1 / s^2 of the GP being scanned
   __shared__ int s_flags[SGP_MAX_GPS];
+  constexpr int kListCap = 2048;    // rows the pre-filter of the expander test may pass on
+  __shared__ int s_list[kListCap];
+  __shared__ int s_cnt;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t N = p.pts.N;
   const int G = p.G;
@@ -71,30 +94,99 @@ __global__ __launch_bounds__(kStepThreads) void k_step_small(StepParams p) {
   if (tid < SGP_MAX_GPS) s_flags[tid] = 0;
   __syncthreads();
 
-  // ---- A: posterior, intervals, S; B: max l0 over the safe rows
+  const gpdev_c_t gpc = (gpdev_c_t)(p.gps);
+  int staged = -1;
+  auto stage_gp = [&](int g) {            // (workgroup-uniform; syncs)
+    if (staged == g) return;
+    __syncthreads();                      // the readers of the GP staged before
+    const GpDev& gp = p.gps[g];
+    const int n = gpc[g].n, np = gpc[g].n_pad;
+    const int64_t ld = gpc[g].ld;
+    for (int e = tid; e < NP * NP; e += kStepThreads) {
+      const int i = e / NP, j = e - i * NP;
+      gLi[e] = (i < n && j <= i) ? gp.Linv[int64_t(i) * ld + j] : 0.0;
+    }
+    for (int e = tid; e < 64 * D; e += kStepThreads) {
+      gX[e] = e < np * D ? gp.Xs[e] : 0.0;
+      gXp[e] = e < np * D ? gp.Xpad[e] : 0.0;
+    }
+    for (int e = tid; e < NP; e += kStepThreads) gAl[e] = e < np ? gp.alpha[e] : 0.0;
+    __syncthreads();
+    staged = g;
+  };
+
+  STEP_STAMP(0);
+  // ---- A: posterior, intervals, S; B: max l0 over the safe rows.  GP by GP (its operands
+  // staged), GP 0 last: its lower bound then meets the row's final `safe`.
   double lmax = -INFINITY;
-  for (int64_t row = tid; row < ((N + kStepThreads - 1) / kStepThreads) * kStepThreads;
-       row += kStepThreads) {
-    const bool valid = row < N;
-    const int64_t r = valid ? row : N - 1;
-    double x[D];
+  uint32_t safe_bits = 0xffffffffu;       // bit r: this thread's r-th row (<= 32 of them)
+  const int rounds = int((N + kStepThreads - 1) / kStepThreads);
+  for (int gi = 0; gi < G; ++gi) {
+    const int g = (gi + 1 < G) ? gi + 1 : 0;
+    stage_gp(g);
+    const int n = gpc[g].n;
+    for (int r = 0; r < rounds; ++r) {
+      const int64_t row = int64_t(r) * kStepThreads + tid;
+      const bool valid = row < N;
+      const int64_t rr = valid ? row : N - 1;
+      double x[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k)
-      x[k] = p.pts.base[r * p.pts.stride_row + k * p.pts.stride_col];
-    bool safe = true;
-    double l0 = 0.0;
-    tiny_row<D, NP, SINGLE>(p.gps, G, p.conf, N, x, row, valid, tab, safe, l0);
-    if (valid) {
-      p.conf.S[row] = safe ? 1 : 0;
-      if (safe) lmax = fmax(lmax, l0);
+      for (int k = 0; k < D; ++k)
+        x[k] = p.pts.base[rr * p.pts.stride_row + k * p.pts.stride_col];
+      bool safe = ((safe_bits >> r) & 1u) != 0;
+      double l0 = 0.0;
+      tiny_row_gp<D, NP, SINGLE>(p.gps, g, G, n, (const double*)gX, (const double*)gAl,
+                                 (const double*)gLi, int64_t(NP), p.conf, N, x, row, valid, tab,
+                                 safe, l0);
+      safe_bits = safe ? (safe_bits | (1u << r)) : (safe_bits & ~(1u << r));
+      if (g == 0 && valid) {
+        p.conf.S[row] = safe ? 1 : 0;
+        if (safe) lmax = fmax(lmax, l0);
+      }
     }
   }
+  STEP_STAMP(1);
   const double max_l = block_max(lmax, shd);        // (syncs: the rows are visible)
   __syncthreads();
+  STEP_STAMP(2);
 
-  // ---- C: maximisers
+  // ---- C: maximisers.  One read of S and of the intervals serves C and D for the first
+  // kKeep rows of a thread (a 1000-point grid: all of them): every further pass over the
+  // rows is another global round trip on the critical path of a single workgroup.
+  constexpr int kKeep = 2;
+  struct RowKeep {
+    bool sf, above;
+    double u0, w0, wmax, smax;
+  };
+  RowKeep keep[kKeep];
+  auto read_row = [&](int64_t i, RowKeep& k) {
+    k.sf = p.conf.S[i] != 0;
+    k.wmax = k.smax = -INFINITY;
+    k.above = false;
+    for (int g = 0; g < G; ++g) {
+      const double2_t q = *reinterpret_cast<const double2_t*>(p.conf.Q + (i * G + g) * 2);
+      const double width = q.y - q.x;
+      if (g == 0) {
+        k.u0 = q.y;
+        k.w0 = width;
+      }
+      k.wmax = fmax(k.wmax, width);
+      k.smax = fmax(k.smax, width / p.scaling.v[g]);
+      k.above = k.above || (width > p.thr_beta.v[g]);
+    }
+  };
   double v = -INFINITY;
-  for (int64_t i = tid; i < N; i += kStepThreads) {
+#pragma unroll
+  for (int r = 0; r < kKeep; ++r) {
+    const int64_t i = int64_t(r) * kStepThreads + tid;
+    if (i < N) {
+      read_row(i, keep[r]);
+      const bool m = keep[r].sf && (keep[r].u0 >= max_l);
+      p.M[i] = m ? 1 : 0;
+      if (m) v = fmax(v, keep[r].w0);
+    }
+  }
+  for (int64_t i = int64_t(kKeep) * kStepThreads + tid; i < N; i += kStepThreads) {
     const double2_t q = *reinterpret_cast<const double2_t*>(p.conf.Q + i * G * 2);
     const bool m = p.conf.S[i] && (q.y >= max_l);
     p.M[i] = m ? 1 : 0;
@@ -103,31 +195,34 @@ __global__ __launch_bounds__(kStepThreads) void k_step_small(StepParams p) {
   const double mw = block_max(v, shd);
   const double max_var = mw / p.scaling.v[0];
 
+  STEP_STAMP(3);
   // ---- D: candidates, their widths, counts, the first one in visiting order
   unsigned nc = 0, nu = 0;
   Pair best{-INFINITY, -1};
-  for (int64_t i = tid; i < N; i += kStepThreads) {
-    const bool sf = p.conf.S[i] != 0;
-    const bool mv = p.M[i] != 0;
-    double wmax = -INFINITY, smax = -INFINITY;
-    bool above = false;
-    for (int g = 0; g < G; ++g) {
-      const double2_t q = *reinterpret_cast<const double2_t*>(p.conf.Q + (i * G + g) * 2);
-      const double width = q.y - q.x;
-      wmax = fmax(wmax, width);
-      smax = fmax(smax, width / p.scaling.v[g]);
-      above = above || (width > p.thr_beta.v[g]);
-    }
-    const bool c = sf && !mv && (smax > max_var) && above;
-    if (!sf) ++nu;
+  bool ckeep[kKeep];
+  auto candidate = [&](int64_t i, const RowKeep& k) {
+    const bool mv = k.sf && (k.u0 >= max_l);          // (= M[i])
+    const bool c = k.sf && !mv && (k.smax > max_var) && k.above;
+    if (!k.sf) ++nu;
     p.cand[i] = c ? 1 : 0;
-    p.w[i] = sf ? wmax : -INFINITY;
+    p.w[i] = k.sf ? k.wmax : -INFINITY;
     p.Gm[i] = 0;
     if (c) {
       ++nc;
-      const Pair pr{wmax, p.goff + i};
+      const Pair pr{k.wmax, p.goff + i};
       if (best.i < 0 || before_desc(pr, best)) best = pr;
     }
+    return c;
+  };
+#pragma unroll
+  for (int r = 0; r < kKeep; ++r) {
+    const int64_t i = int64_t(r) * kStepThreads + tid;
+    ckeep[r] = (i < N) && candidate(i, keep[r]);
+  }
+  for (int64_t i = int64_t(kKeep) * kStepThreads + tid; i < N; i += kStepThreads) {
+    RowKeep k;
+    read_row(i, k);
+    candidate(i, k);
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
@@ -147,9 +242,13 @@ __global__ __launch_bounds__(kStepThreads) void k_step_small(StepParams p) {
   // candidates that share the first one's width, bit for bit (gp_opt.py:542-552: NumPy's
   // sort decides among them -- the host settles the order when there is more than one)
   unsigned nt = 0;
-  if (win.i >= 0)
-    for (int64_t i = tid; i < N; i += kStepThreads)
+  if (win.i >= 0) {
+#pragma unroll
+    for (int r = 0; r < kKeep; ++r)
+      if (ckeep[r] && keep[r].wmax == win.v) ++nt;
+    for (int64_t i = int64_t(kKeep) * kStepThreads + tid; i < N; i += kStepThreads)
       if (p.cand[i] && p.w[i] == win.v) ++nt;
+  }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) nt += __shfl_xor(nt, o, 64);
   __syncthreads();
@@ -183,15 +282,16 @@ __global__ __launch_bounds__(kStepThreads) void k_step_small(StepParams p) {
   }
   __syncthreads();
 
+  STEP_STAMP(4);
   // ---- E: is the first candidate an expander?  (gp_opt.py:579-606 with the rank-1
   // update of the posterior instead of two refits per GP)
-  const gpdev_c_t gpc = (gpdev_c_t)(p.gps);
   if (win.i >= 0 && nunsafe > 0) {
     for (int g = 0; g < G; ++g) {          // (workgroup-uniform)
       if (p.conf.fmin[g] == -INFINITY) continue;
       const GpDev& gp = p.gps[g];
       const int n = gpc[g].n, np = gpc[g].n_pad;
-      const int64_t ld = gpc[g].ld;
+      constexpr int64_t ld = NP;            // (the staged copy)
+      stage_gp(g);
       // k_c = k(X, x_c) (the generic evaluation of k_expkt), t = L^-1 k_c
       if (tid < 64) {
         double kcv = 0.0;
@@ -199,7 +299,7 @@ __global__ __launch_bounds__(kStepThreads) void k_step_small(StepParams p) {
           double xj[D], xc[D];
 #pragma unroll
           for (int k = 0; k < D; ++k) {
-            xj[k] = gp.Xpad[int64_t(tid) * D + k];
+            xj[k] = gXp[tid * D + k];
             xc[k] = xcs[k];
           }
           kcv = kern_eval<D>(gp.kern, xc, xj);
@@ -210,7 +310,7 @@ __global__ __launch_bounds__(kStepThreads) void k_step_small(StepParams p) {
       __syncthreads();
       for (int i = wave; i < n; i += kStepWaves) {
         double acc = 0.0;
-        if (lane <= i) acc = fma(gp.Linv[int64_t(i) * ld + lane], kc[lane], acc);
+        if (lane <= i) acc = fma(gLi[int64_t(i) * ld + lane], kc[lane], acc);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
         if (lane == 0) tt[i] = acc;
@@ -222,7 +322,7 @@ __global__ __launch_bounds__(kStepThreads) void k_step_small(StepParams p) {
         double a0 = 0.0;
         if (lane < n)
           for (int i = wq; i < n; i += kExpwWaves)
-            if (i >= lane) a0 = fma(gp.Linv[int64_t(i) * ld + lane], tt[i], a0);
+            if (i >= lane) a0 = fma(gLi[int64_t(i) * ld + lane], tt[i], a0);
         sh_w[wq][lane] = a0;
       }
       __syncthreads();
@@ -242,22 +342,20 @@ __global__ __launch_bounds__(kStepThreads) void k_step_small(StepParams p) {
           const double resid = p.conf.Q[li * 2 * G + 2 * g + 1] - p.conf.mean[int64_t(g) * N + li];
           s_ops[0] = resid / s2;      // delta
           s_ops[1] = 1.0 / s2;
+          s_ops[2] = s;               // |t|^2
         }
       }
       __syncthreads();
+      STEP_STAMP(5);
       const double delta = s_ops[0], inv_s2 = s_ops[1];
       // scan: 16 rows per wave (lane & 15), the four 16-lane groups split the training
       // points (k_expander_list); a row counts when it is unsafe
       const KernFast<D> kf(gp.kern);
       const double kdiag = gp.kern.kdiag;
       const int ph = lane >> 4;
-      bool hit = false;
-      for (int64_t i0 = int64_t(wave) * 16; i0 < N; i0 += kStepWaves * 16) {
-        const int64_t row = i0 + (lane & 15);
-        const bool valid = row < N;
-        const int64_t rrow = valid ? row : N - 1;
-        const bool unsafe = valid && p.conf.S[rrow] == 0;
-        if (__ballot(unsafe) == 0ull) continue;
+      // exact update of one row (all four 16-lane groups call it with the same row in the
+      // same lane & 15: they split the training points and fold -- k_expander_list)
+      auto scan_row = [&](int64_t rrow) -> bool {
         double x[D], xs[D], xc[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) {
@@ -271,7 +369,7 @@ __global__ __launch_bounds__(kStepThreads) void k_step_small(StepParams p) {
 #pragma unroll 1
         for (int s0 = 0; s0 < (np >> 2); s0 += 4) {   // 16 training points / step
           double kq[4], wq[4];
-          kf.template many<4>(xs, gp.Xs + (s0 * 4 + ph) * D, 4 * D, tab, kq);
+          kf.template many<4>(xs, gX + (s0 * 4 + ph) * D, 4 * D, tab, kq);
 #pragma unroll
           for (int q = 0; q < 4; ++q) wq[q] = wv[(s0 + q) * 4 + ph];
 #pragma unroll
@@ -279,11 +377,61 @@ __global__ __launch_bounds__(kStepThreads) void k_step_small(StepParams p) {
         }
         dot = sum_lane_groups(dot);
         const double kxc = kf.raw(x, xc, tab);
-        if (unsafe && kxc >= 0.0 * kdiag) {
-          const double cx = kxc - dot;
-          const double mu2 = mu + cx * delta;
-          const double var2 = fmax(var - cx * cx * inv_s2, 1e-15);
-          hit = hit || (mu2 - p.conf.beta * sqrt(var2) >= p.conf.fmin[g]);
+        if (!(kxc >= 0.0 * kdiag)) return false;
+        const double cx = kxc - dot;
+        const double mu2 = mu + cx * delta;
+        const double var2 = fmax(var - cx * cx * inv_s2, 1e-15);
+        return mu2 - p.conf.beta * sqrt(var2) >= p.conf.fmin[g];
+      };
+      // Pre-filter (k_expander_filter, sweep.hip): |c(x)| <= |k(x, x_c)| + |L^-1 k_x| |t| with
+      // |L^-1 k_x|^2 = k(x,x) - var(x) resident -- ONE covariance per unsafe row instead of
+      // n decides for the rows that cannot be lifted to fmin whatever c(x) is; the others
+      // (a few per cent) go on a list in LDS and get the exact n-term dot product below.
+      // A conservative bound: the flags are those of the scan over all unsafe rows.  This
+      // is what keeps the test off the critical path of ONE compute unit (1000 rows x 32
+      // covariances were 10 of the step's 37 us).
+      const double tn2 = s_ops[2];
+      if (tid == 0) s_cnt = 0;
+      __syncthreads();
+      for (int64_t row = tid; row < N; row += kStepThreads) {
+        if (p.conf.S[row] != 0) continue;
+        double x[D], xc[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          x[k] = p.pts.base[row * p.pts.stride_row + k * p.pts.stride_col];
+          xc[k] = xcs[k];
+        }
+        const double mu = p.conf.mean[int64_t(g) * N + row];
+        const double var = p.conf.var[int64_t(g) * N + row];
+        const double qx = fmax(kdiag - var, 0.0);
+        const double kxc = kf.raw(x, xc, tab);
+        const double cmax = (fabs(kxc) + sqrt(qx * tn2)) * (1.0 + 1e-9);
+        const double mu2 = mu + fabs(delta) * cmax;
+        const double var2 = fmax(var - cmax * cmax * inv_s2, 1e-15);
+        const double l2max = mu2 - p.conf.beta * sqrt(var2);
+        if (l2max + 1e-9 * (fabs(mu2) + 1.0) >= p.conf.fmin[g]) {
+          const int at = atomicAdd(&s_cnt, 1);
+          if (at < kListCap) s_list[at] = int(row);
+        }
+      }
+      __syncthreads();
+      const int nlist = s_cnt;
+      bool hit = false;
+      if (nlist > kListCap) {
+        // (more rows than the list holds: scan them all -- rare, and still exact)
+        for (int64_t i0 = int64_t(wave) * 16; i0 < N; i0 += kStepWaves * 16) {
+          const int64_t row = i0 + (lane & 15);
+          const bool valid = row < N;
+          const int64_t rrow = valid ? row : N - 1;
+          const bool unsafe = valid && p.conf.S[rrow] == 0;
+          if (__ballot(unsafe) == 0ull) continue;
+          hit = hit || (unsafe && scan_row(rrow));
+        }
+      } else {
+        for (int i0 = wave * 16; i0 < nlist; i0 += kStepWaves * 16) {
+          const bool valid = i0 + (lane & 15) < nlist;
+          const int64_t rrow = s_list[valid ? i0 + (lane & 15) : i0];
+          hit = hit || (scan_row(rrow) && valid);
         }
       }
       if (__ballot(hit) != 0ull && lane == 0) atomicOr(&s_flags[g], 1);
@@ -292,6 +440,7 @@ __global__ __launch_bounds__(kStepThreads) void k_step_small(StepParams p) {
   }
   __syncthreads();
 
+  STEP_STAMP(6);
   // ---- F: G mark, arg-max over M | G of max_i (u_i - l_i) / scaling_i (first index)
   int64_t lmark = -1;
   if (win.i >= 0) {
@@ -320,20 +469,32 @@ __global__ __launch_bounds__(kStepThreads) void k_step_small(StepParams p) {
     reinterpret_cast<int64_t*>(p.res)[p.nfront + p.nfl + 1] = top.i;
   }
   if (tid < G) reinterpret_cast<int32_t*>(p.res + p.nfront)[tid] = s_flags[tid];
+  // the block is host memory: everything above is out before the completion word
+  __syncthreads();
+  STEP_STAMP(7);
+  if (tid == 0) {
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.res) + (kStepResWords - 1), p.seq,
+                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
-template <int D, int NP>
+template <int D, int NP, int TH>
 void launch_step_np(sgp_ctx* ctx, const StepParams& p, bool single) {
   if (single)
-    hipLaunchKernelGGL((k_step_small<D, NP, true>), dim3(1), dim3(kStepThreads), 0, ctx->stream, p);
+    hipLaunchKernelGGL((k_step_small<D, NP, true, TH>), dim3(1), dim3(TH), 0, ctx->stream, p);
   else
-    hipLaunchKernelGGL((k_step_small<D, NP, false>), dim3(1), dim3(kStepThreads), 0, ctx->stream, p);
+    hipLaunchKernelGGL((k_step_small<D, NP, false, TH>), dim3(1), dim3(TH), 0, ctx->stream, p);
 }
 
 template <int D>
 void launch_step_d(sgp_ctx* ctx, const StepParams& p, int np, bool single) {
-  if (np <= 32) return launch_step_np<D, 32>(ctx, p, single);
-  return launch_step_np<D, 48>(ctx, p, single);
+#ifndef STEP_TH24
+#define STEP_TH24 512
+#endif
+  if (np <= 24) return launch_step_np<D, 24, STEP_TH24>(ctx, p, single);
+  if (np <= 32) return launch_step_np<D, 32, 512>(ctx, p, single);
+  return launch_step_np<D, 48, 512>(ctx, p, single);
 }
 
 }  // namespace
@@ -348,7 +509,7 @@ bool step_small_eligible(const sgp_ctx* ctx, const GpDev* gh, int G, int64_t N) 
 
 int launch_step_small(sgp_grid* g, const GpDev* gps_dev, const GpDev* gh, int G, double beta,
                       const double* fmin, const double* scaling, const double* thr_beta,
-                      double* res, int nfront, int nfl) {
+                      double* res, int nfront, int nfl, uint64_t seq) {
   sgp_ctx* ctx = g->ctx;
   StepParams p{};
   p.gps = gps_dev;
@@ -374,6 +535,7 @@ int launch_step_small(sgp_grid* g, const GpDev* gps_dev, const GpDev* gh, int G,
   p.scal = g->scal;
   p.nfront = nfront;
   p.nfl = nfl;
+  p.seq = seq;
   int np = 1;
   bool single = true;
   for (int i = 0; i < G; ++i) {

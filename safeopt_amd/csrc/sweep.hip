@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
     typedef const __attribute__((address_space(1))) double4_t* gvec_t;
 #pragma unroll
     for (int a = 0; a < kAx; ++a) {
-      const char* src = sep_tab[a] + e.jb * sep_pitch[a];      // (tables below 4 GB)
+      const char* src = sep_tab[a] + e.jb * sep_pitch[a];      // (<= 256 MB per GP: sep_launch)
       efn[a] = *(gvec_t)(reinterpret_cast<const double4_t*>(src + soff[a]));
     }
   };

@@ -543,7 +543,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     typedef const __attribute__((address_space(1))) double2_t* gvec_t;
 #pragma unroll
     for (int a = 0; a < kAx; ++a) {
-      const char* src = sep_tab[a] + e.jb * sep_pitch[a];      // (tables below 4 GB)
+      const char* src = sep_tab[a] + e.jb * sep_pitch[a];      // (<= 256 MB per GP: sep_launch)
       efn[a] = *(gvec_t)(reinterpret_cast<const double2_t*>(src + soff[a]));
     }
   };

@@ -333,13 +333,31 @@ class _HipGridBackend(object):
         return self.grid.sets_fused_comm(self._dev(), beta, fmin, scaling,
                                          thr_beta, near_frac)
 
-    def step_small_ok(self):
-        """Small grid and few observations: a whole step is one launch
-        (``sgp_grid_step_small``)."""
-        return self.grid.N <= 16384 and self.grid.step_small_ok(self._dev())
+    #: budget of the one-launch step, in per-thread instructions of its posterior phase
+    #: (~16 cycles each with two waves per SIMD): above it the nine launches of the
+    #: large-grid path (~90 us whatever the grid) are the faster way
+    SMALL_STEP_BUDGET = 5000
 
-    def step_small(self, beta, fmin, scaling, thr_beta):
-        devs = self._dev()
+    def small_step_devs(self):
+        """The fitted device GPs when a whole step of this grid is better taken in ONE
+        launch (``sgp_grid_step_small``: at most 16384 rows, GPs with at most 48
+        observations -- and few enough of both that one workgroup is through in ~30 us:
+        the 1000-point grid with 20 observations of the reference's examples), else None."""
+        N = self.grid.N
+        if N > 16384 or getattr(self.ctx, 'sweep_forced', False):
+            return None
+        devs = [g._fitted() for g in self.gps]
+        cost = 0
+        for dv in devs:
+            n = dv.n
+            if n > 48:
+                return None
+            cost += n * (30 + n // 2)
+        if -(-N // 512) * cost > self.SMALL_STEP_BUDGET:     # (512 threads: step_small.hip)
+            return None
+        return devs
+
+    def step_small(self, devs, beta, fmin, scaling, thr_beta):
         self._seen = [None] * len(devs)          # unknown until the call is through
         out = self.grid.step_small(devs, beta, fmin, scaling, thr_beta)
         self._seen = self._tags(devs)            # (a full sweep: the posterior is current)
@@ -434,6 +452,15 @@ class SafeOpt(GaussianProcessOptimization):
             self._backend = _HipGridBackend(self.gps, self.inputs[lo:hi], lo,
                                             ctx=getattr(self._comm, 'ctx', None),
                                             axes=_hip.tensor_grid_axes(self.inputs))
+        # every rank must sweep with the same arithmetic (the N-rank run equals the one-rank
+        # run bit for bit): a parameter set that is a tensor grid on some shards only -- the
+        # device check is per shard -- is a tensor grid on none
+        if self._comm.world > 1 and hasattr(self._backend, 'tensor_grid'):
+            bad = self._comm.allreduce_max(
+                np.array([0.0 if self._backend.tensor_grid else 1.0]))[0] > 0
+            if bad and self._backend.tensor_grid:
+                self._backend.grid.clear_axes()
+                self._backend.tensor_grid = False
         self._any_safe = False
         self._max_l = -np.inf
         self._ci_fresh = False
@@ -441,6 +468,7 @@ class SafeOpt(GaussianProcessOptimization):
         #: small grids with few observations take the whole step in one launch
         #: (``sgp_grid_step_small``); False keeps them on the large-grid path
         self.small_step = True
+        self._thr_beta_key = self._thr_beta = None
 
     # -- host mirrors ---------------------------------------------------------
     def _mirror(self, name, what):
@@ -980,10 +1008,12 @@ class SafeOpt(GaussianProcessOptimization):
                     and (self._comm.world == 1
                          or getattr(self._comm, 'in_stream', False)))
         if (one_trip and self._comm.world == 1 and self.small_step
-                and hasattr(self._backend, 'step_small') and self._backend.step_small_ok()):
-            # a small grid (the reference's own regime): the whole step is one launch
-            self._small_step(context)
-            return self.get_new_query_point()
+                and hasattr(self._backend, 'step_small')):
+            devs = self._backend.small_step_devs()
+            if devs is not None:
+                # a small grid (the reference's own regime): the whole step is one launch
+                self._small_step(context, devs)
+                return self.get_new_query_point()
         self.update_confidence_intervals(context=context, _defer=one_trip)
         if ucb:
             self.compute_safe_set()
@@ -991,17 +1021,21 @@ class SafeOpt(GaussianProcessOptimization):
             self.compute_sets()
         return self.get_new_query_point(ucb=ucb)
 
-    def _small_step(self, context):
+    def _small_step(self, context, devs):
         """``update_confidence_intervals`` + ``compute_sets`` of a small grid in one launch
         and one read-back (``sgp_grid_step_small``: grids of at most 16384 rows, GPs with at
         most 48 observations -- gp_opt.py:651-675 as the reference's examples run it)."""
         beta = self.beta(self.t)
-        self.context = context
-        G = len(self.gps)
-        thr_beta = np.broadcast_to(
-            np.asarray(self.threshold, dtype=float) * beta, (G,)).copy()
+        if self.num_contexts:
+            self.context = context
+        thr = self.threshold
+        key = (beta, thr if isinstance(thr, (int, float)) else tuple(np.ravel(thr)))
+        if self._thr_beta_key != key:        # (constant for a constant beta: built once)
+            self._thr_beta = np.broadcast_to(
+                np.asarray(self.threshold, dtype=float) * beta, (len(self.gps),)).copy()
+            self._thr_beta_key = key
         (out5, x_c, mu_c, q_c, flags, val, idx,
-         max_l) = self._backend.step_small(beta, self.fmin, self.scaling, thr_beta)
+         max_l) = self._backend.step_small(devs, beta, self.fmin, self.scaling, self._thr_beta)
         self._stale.update(Q=True, S=True)
         self._q_written = False          # (the sweep overwrites the intervals)
         self._ci_fresh = True

@@ -1864,6 +1864,7 @@ def test_bo_loop_with_rank1_updates_matches_reference(mods, name, last):
            for i, spec in enumerate(meta["kernels"])]
     opt = safeopt_amd.SafeOpt(gps if G > 1 else gps[0], z["parameter_set"],
                               meta["fmin"] if G > 1 else meta["fmin"][0], threshold=meta["threshold"])
+    opt.small_step = False      # (grids this small take a full step in one launch otherwise)
     n0 = z["it0_X0"].shape[0]
     Yall = np.hstack([z["it%d_Y%d" % (last, i)] for i in range(G)])
     for t in range(last + 1):
@@ -1944,6 +1945,7 @@ def test_one_launch_step_of_small_grids(mods, seed):
                             fmin if G > 1 else fmin[0], threshold=0.2)
     b = safeopt_amd.SafeOpt(build(gpy) if G > 1 else build(gpy)[0], grid,
                             fmin if G > 1 else fmin[0], threshold=0.2)
+    a._backend.SMALL_STEP_BUDGET = 10 ** 9   # (the one-launch step whatever it costs)
     b.small_step = False
     b._backend.incremental = False     # (a full sweep every step, like the one-launch step)
     ctx = a._backend.ctx
@@ -1981,3 +1983,78 @@ def test_one_launch_step_of_small_grids(mods, seed):
         y = np.array([float(smooth(xa[None, :], 70 + g)[0, 0]) + 0.3 for g in range(G)])
         a.add_new_data_point(xa, y)
         b.add_new_data_point(xb, y)
+
+
+def test_long_axis_tables_are_skipped(mods):
+    """A per-axis factor table is ``n_pad / 16 x count x 128`` bytes: on a grid with ONE long
+    axis that is the whole covariance matrix (a 1-D grid of 1e6 points, n = 544: 4.3 GB, past
+    the 32-bit offsets of the sweeps).  Beyond 256 MB per GP the tables are not built and the
+    covariances are evaluated -- the same bits as with tables switched off -- while a grid
+    below the budget still goes through them (last bits differ).  The paired kernel (more
+    than 256 rows in a factor) takes tables only while they fit half an L2 next to the
+    factor it streams."""
+    sa, gpy, gpn, son = mods
+    from safeopt_amd import _hip
+    rng = np.random.default_rng(77)
+    # (n, rows, tables expected): 13 blocks x 6e5 x 128 B = 998 MB: skipped | 33 MB: tables |
+    # paired kernel, 19 x 2e4 x 128 B = 49 MB > 2 MB: skipped | paired, 19 x 600 x 128 B: tables
+    for n, N, tables in ((200, 600000, False), (200, 20000, True), (300, 20000, False),
+                         (300, 600, True)):
+        X = rng.uniform(-2.5, 2.5, size=(n, 1))
+        Y = smooth(X, 5) - smooth(X, 5).min() + 0.5
+        gp = gpy.models.GPRegression(X, Y, gpy.kern.RBF(1, 2.0, 1.0), noise_var=0.05 ** 2)
+        dev = gp._fitted()
+        ctx = dev.ctx
+        grid = sa.linearly_spaced_combinations([(-3., 3.)], N)
+        out = {}
+        for name in ("auto", "auto-notables"):
+            g = _hip.DeviceGrid(ctx, grid, 1)
+            assert g.set_axes(_hip.tensor_grid_axes(grid))
+            old = ctx.set_sweep(name)
+            try:
+                g.confidence([dev], 2.0, np.zeros(1))
+            finally:
+                ctx.set_sweep(old)
+            out[name] = g.download(_hip.Q)
+        assert np.max(np.abs(out["auto"] - out["auto-notables"])) < 1e-10
+        assert np.array_equal(out["auto"], out["auto-notables"]) == (not tables), (n, N)
+
+
+@pytest.mark.parametrize("n,kind", [(8, "RBF"), (20, "Matern52"), (40, "RBF"), (100, "Matern32"),
+                                    (200, "RBF"), (300, "Matern52")])
+def test_predict_of_a_prefix_of_the_points(mods, n, kind):
+    """``predict(P)[:k]`` against ``predict(P[:k])`` (gp.predict_noiseless, gp_opt.py:469,
+    929, 973).  For a set of points handed over per call the kernel is chosen for latency
+    by (n, number of rows) -- VALU kernel / 4-wave / paired / few-points path -- and the
+    kernels sum in different orders.  The guarantee, pinned here: within ONE kernel a
+    row's posterior does not depend on which other rows it was submitted with (the same
+    bits); across kernels it moves by at most 1e-12 of the prior variance.  (Grids are
+    different: there the kernel depends on the GPs alone -- rank- and shard-invariant.)"""
+    sa, gpy, gpn, son = mods
+    rng = np.random.default_rng(n)
+    d = 2
+    X = rng.uniform(-2, 2, size=(n, d))
+    Y = smooth(X, 3)
+    gp = gpy.models.GPRegression(X, Y, getattr(gpy.kern, kind)(d, 2.0, [0.9, 1.2], ARD=True),
+                                 noise_var=0.05 ** 2)
+    ctx = gp._fitted().ctx
+    P = rng.uniform(-3, 3, size=(70000, d))
+    mf, vf = gp.predict_noiseless(P)
+    kf = ctx.last_sweep()
+    seen = set()
+    for k in (1, 20, 777, 4096, 4097, 30000, 69999):
+        m, v = gp.predict_noiseless(P[:k])
+        kk = ctx.last_sweep()
+        seen.add(kk)
+        if kk == kf:
+            assert_array_equal(m, mf[:k])
+            assert_array_equal(v, vf[:k])
+        else:
+            assert np.max(np.abs(m - mf[:k])) <= 1e-12 * max(1.0, np.max(np.abs(mf)))
+            assert np.max(np.abs(v - vf[:k])) <= 2.0 * 1e-12
+        # ... and a second call with the same rows repeats the bits
+        m2, v2 = gp.predict_noiseless(P[:k])
+        assert ctx.last_sweep() == kk
+        assert_array_equal(m, m2)
+        assert_array_equal(v, v2)
+    print("n = %d: full set by %s, prefixes by %s" % (n, kf, sorted(seen)))
