@@ -231,6 +231,17 @@ int sgp_grid_sets_fused(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                         double* x_top, double* mean_top, double* q_top,
                         int32_t* flags, double* value, int64_t* gidx,
                         double* max_l_out);
+/* One pass of the expander loop (safeopt/gp_opt.py:557-612) over the next k <= 16
+ * candidates behind the cut (cut_w, cut_idx) in visiting order -- sgp_grid_topk,
+ * sgp_grid_gather_rows and the exact sgp_grid_expander_check of those rows -- with one
+ * stream synchronisation instead of three host round trips: w_out / gidx_out / n_out as
+ * sgp_grid_topk, flags[c * G + i] != 0: candidate c lifts an unsafe row above fmin_i.
+ * One rank (the shard is the grid).                                                 */
+int sgp_grid_expander_batch(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
+                            const double* fmin, int mode, double cut_w, int64_t cut_idx,
+                            int k, double* w_out, int64_t* gidx_out, int* n_out,
+                            int32_t* flags);
+
 /* SMALL grids -- the reference's own regime (safeopt/gp_opt.py:651-675 on the 1000-point
  * grid of examples/1d_example.ipynb with n <= 20 observations; BASELINE.json config 1):
  * one whole SafeOpt.optimize() = update_confidence_intervals (gp_opt.py:453-476) +
@@ -279,6 +290,10 @@ int sgp_grid_argmax(sgp_grid* grid, int mode, const double* scaling,
                     double* value, int64_t* gidx);
 /* copy a resident array to the host: Q (N,2G) f64 | S/M/G (N) u8 |
  * mean/var (G,N) f64                                                         */
+/* S / M / G of the shard from the host: the reference's arrays are mutated in place
+ * (safeopt/gp_opt.py:481, 505-506, 511, 615) and user code may write into them; the next
+ * arg-max (get_new_query_point, gp_opt.py:635-649) reads what was uploaded.            */
+int sgp_grid_upload_mask(sgp_grid* grid, int what, const uint8_t* mask);
 int sgp_grid_download(sgp_grid* grid, int what, void* out);
 
 /* ---- SafeOptSwarm._compute_particle_fitness (gp_opt.py:901-1013) -----------

@@ -91,6 +91,9 @@ PROTOTYPES = {
                                       C.c_double, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_i32_p,
                                       c_double_p, c_i64_p, c_double_p]),
+    "sgp_grid_expander_batch": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p, C.c_int,
+                                          C.c_double, C.c_int64, C.c_int, c_double_p, c_i64_p,
+                                          c_int_p, c_i32_p]),
     "sgp_grid_step_small": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_double_p, c_double_p,
                                       c_double_p, c_i32_p, c_double_p, c_i64_p, c_double_p]),
@@ -110,6 +113,7 @@ PROTOTYPES = {
     "sgp_grid_argmax": (C.c_int, [vp, C.c_int, c_double_p, c_double_p,
                                   c_i64_p]),
     "sgp_grid_download": (C.c_int, [vp, C.c_int, vp]),
+    "sgp_grid_upload_mask": (C.c_int, [vp, C.c_int, c_u8_p]),
     "sgp_swarm_fitness": (C.c_int, [vp, vpp, C.c_int, C.c_int, c_double_p,
                                     C.c_int64, C.c_double, c_double_p,
                                     c_double_p, C.c_double, c_double_p,
@@ -573,6 +577,12 @@ class DeviceGrid(object):
             stv.ctypes.data_as(C.POINTER(C.c_int64)), dptr(vals), C.byref(ok)))
         return bool(ok.value)
 
+    def upload_mask(self, what, mask):
+        """``S`` / ``M`` / ``G`` of this shard from the host (user code wrote into the mirror)."""
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert m.shape == (self.N,)
+        self.ctx.check(lib().sgp_grid_upload_mask(self.h, int(what), m.ctypes.data_as(c_u8_p)))
+
     def clear_axes(self):
         """Forget the tensor-grid declaration (the sweeps evaluate covariances again)."""
         one = np.ones(self.d, dtype=np.int64)
@@ -662,6 +672,20 @@ class DeviceGrid(object):
             dptr(xc), dptr(mu_c), dptr(u_c), float(near_frac),
             flags.ctypes.data_as(c_i32_p)))
         return flags
+
+    def expander_batch(self, gps, beta, fmin, mode, cut_w, cut_idx, k):
+        """The next ``k`` candidates behind the cut and whether they are expanders (exact
+        scan), one device round trip: ``(widths, global indices, flags (m, G))``."""
+        fmin = f64(fmin)
+        w = np.empty(k)
+        idx = np.empty(k, dtype=np.int64)
+        n = C.c_int(0)
+        flags = np.zeros((k, self.G), dtype=np.int32)
+        self.ctx.check(lib().sgp_grid_expander_batch(
+            self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin), int(mode),
+            float(cut_w), int(cut_idx), int(k), dptr(w), idx.ctypes.data_as(c_i64_p),
+            C.byref(n), flags.ctypes.data_as(c_i32_p)))
+        return w[:n.value], idx[:n.value], flags[:n.value]
 
     def lipschitz_check(self, fmin, lipschitz, xc, u_c):
         fmin = f64(fmin)

@@ -1007,6 +1007,14 @@ int sgp_grid_argmax(sgp_grid* g, int mode, const double* scaling, double* value,
   return 0;
 }
 
+int sgp_grid_upload_mask(sgp_grid* g, int what, const uint8_t* mask) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  uint8_t* dst = what == SGP_S ? g->S : what == SGP_M ? g->M : what == SGP_G ? g->Gm : nullptr;
+  SGP_CHECK(ctx, dst, "sgp_grid_upload_mask: selector %d is not SGP_S / SGP_M / SGP_G", what);
+  return sgp_h2d(ctx, dst, mask, size_t(g->N));
+}
+
 int sgp_grid_download(sgp_grid* g, int what, void* out) {
   sgp_ctx* ctx = g->ctx;
   SGP_HIP(ctx, hipSetDevice(ctx->device));
@@ -1153,6 +1161,50 @@ int sgp_grid_expander_check(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   std::vector<int32_t> fl(size_t(SGP_TOPK) * G);
   SGP_TRY(sgp_d2h(ctx, fl.data(), dfl, fl.size() * 4));
   memcpy(flags, fl.data(), size_t(m) * G * 4);
+  return 0;
+}
+
+// One pass of the expander loop (gp_opt.py:557-612) over the next k candidates in visiting
+// order with ONE stream synchronisation: top-k behind the cut -> their rows staged on the
+// device as the operands of the test -> the exact scan over the unsafe rows -> widths,
+// global indices, count and flags in one read-back.  (The step-by-step entry points --
+// sgp_grid_topk, _gather_rows, _expander_check -- need a host round trip each; a grid
+// without expanders, the usual state of a converged run, visits ALL its candidates every
+// iteration.)  One rank: on N ranks the candidates of the shards are merged on the host.
+int sgp_grid_expander_batch(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
+                            const double* fmin, int mode, double cut_w, int64_t cut_idx,
+                            int k, double* w_out, int64_t* gidx_out, int* n_out,
+                            int32_t* flags) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, k >= 1 && k <= SGP_TOPK, "k = %d not in 1..%d", k, SGP_TOPK);
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  char* res = static_cast<char*>(sgp_scratch(ctx, 1, 2048));
+  SGP_CHECK(ctx, res, "device allocation failed: %s", ctx->err.c_str());
+  double* wd = reinterpret_cast<double*>(res);
+  int64_t* id = reinterpret_cast<int64_t*>(res + 512);
+  int* nd = reinterpret_cast<int*>(res + 1024);
+  if (mode == 1) cut_w = (cut_idx < 0) ? INFINITY : -double(cut_idx);
+  SGP_TRY(launch_topk(g, mode, cut_w, cut_idx, k, wd, id, nd));
+  GpDev ghost[SGP_MAX_GPS];
+  SGP_TRY(collect_gps(ctx, gps, G, g->d, ghost));
+  ExpanderBufs eb;
+  SGP_TRY(expander_bufs(g, ghost, G, &eb));
+  SGP_TRY(launch_stage_batch(g, id, nd, k, eb.xc, int((eb.bx + eb.bv) / 8), eb.flags,
+                             int(eb.bf / 4)));
+  int32_t* dfl = nullptr;
+  SGP_TRY(enqueue_expander(g, gps, G, beta, fmin, k, nullptr, nullptr, nullptr, 0.0, &dfl,
+                           nullptr, true));
+  // flags behind the top-k block of the scratch: one read-back for both
+  SGP_HIP(ctx, hipMemcpyAsync(res + 1032, dfl, size_t(SGP_TOPK) * G * 4,
+                              hipMemcpyDeviceToDevice, ctx->stream));
+  char host[2048];
+  const size_t span = 1032 + size_t(SGP_TOPK) * G * 4;
+  SGP_TRY(sgp_d2h(ctx, host, res, span));
+  memcpy(w_out, host, size_t(k) * sizeof(double));
+  memcpy(gidx_out, host + 512, size_t(k) * sizeof(int64_t));
+  memcpy(n_out, host + 1024, sizeof(int));
+  memcpy(flags, host + 1032, size_t(k) * G * 4);
   return 0;
 }
 

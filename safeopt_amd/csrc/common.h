@@ -375,6 +375,8 @@ int launch_candidates(sgp_grid* g, double max_var, const double* max_width_dev,
                       int full_sets, unsigned long long* counts_dev);
 int launch_gather_top(sgp_grid* g, const int64_t* gidx_dev, double* x,
                       double* mean, double* Q);
+int launch_stage_batch(sgp_grid* g, const int64_t* gidx_dev, const int* nfound_dev, int K,
+                       double* xc, int n_xc_resid, int32_t* flags, int n_flag_words);
 int launch_stage_top(sgp_grid* g, const double* x_top, const double* mean_top,
                      const double* q_top, double* xc, double* resid);
 int launch_mark_top_if(sgp_grid* g, const int64_t* gidx_dev, const int* nfound_dev,

@@ -328,6 +328,29 @@ __global__ void k_stage_top(const double* x_top, const double* mean_top,
   if (t < G) resid[t * 16] = q_top[2 * t + 1] - mean_top[t];
 }
 
+// A batch of candidates (the next k in visiting order, k_topk: global indices, -1 / beyond
+// *nfound = none) becomes the operand block of the expander test on the device: xc[c][d] =
+// the rows, resid[g * 16 + c] = u_g - mu_g, everything else of the block and the flags zero.
+__global__ __launch_bounds__(256) void k_stage_batch(
+    const int64_t* gidx, const int* nfound, int K, const double* pts, const double* mean,
+    const double* Q, int64_t N, int d, int G, int64_t goff, double* xc, int n_xc_resid,
+    int32_t* flags, int n_flag_words) {
+  for (int e = threadIdx.x; e < n_xc_resid; e += 256) xc[e] = 0.0;
+  for (int e = threadIdx.x; e < n_flag_words; e += 256) flags[e] = 0;
+  __syncthreads();
+  const int m = *nfound < K ? *nfound : K;
+  double* resid = xc + (n_xc_resid - G * 16);      // the block is xc | resid[G][16]
+  for (int e = threadIdx.x; e < m * d; e += 256) {
+    const int c = e / d, k = e - c * d;
+    xc[e] = pts[int64_t(k) * N + (gidx[c] - goff)];
+  }
+  for (int e = threadIdx.x; e < m * G; e += 256) {
+    const int c = e / G, g = e - c * G;
+    const int64_t li = gidx[c] - goff;
+    resid[g * 16 + c] = Q[li * 2 * G + 2 * g + 1] - mean[int64_t(g) * N + li];
+  }
+}
+
 // ... and G[that row] = 1 when a candidate was found and every active GP
 // certified it.
 __global__ void k_mark_top_if(uint8_t* Gm, const int64_t* gidx, const int* nfound,
@@ -899,6 +922,16 @@ int launch_stage_top(sgp_grid* g, const double* x_top, const double* mean_top,
   sgp_ctx* ctx = g->ctx;
   hipLaunchKernelGGL(k_stage_top, dim3(1), dim3(64), 0, ctx->stream, x_top,
                      mean_top, q_top, g->d, g->G, xc, resid);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_stage_batch(sgp_grid* g, const int64_t* gidx_dev, const int* nfound_dev, int K,
+                       double* xc, int n_xc_resid, int32_t* flags, int n_flag_words) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_stage_batch, dim3(1), dim3(256), 0, ctx->stream, gidx_dev, nfound_dev, K,
+                     g->pts, g->mean, g->Q, g->N, g->d, g->G, g->goff, xc, n_xc_resid, flags,
+                     n_flag_words);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -169,28 +169,34 @@ _BACKEND_FACTORY = None
 
 
 class _WriteBackView(np.ndarray):
-    """View of the host mirror of ``Q`` that remembers element-wise writes: the
-    reference mutates ``opt.Q`` in place (``gp_opt.py:374-390, 475-476``) and user
-    code may do the same (``opt.Q[:, 0] = ...``); the optimiser uploads the mirror
-    before the next device pass that reads the intervals.  (Writes that bypass
-    ``__setitem__`` -- ``np.add(..., out=opt.Q)`` -- are not seen: assign
-    ``opt.Q = array`` for those.)"""
+    """View of the host mirror of ``Q`` (or of ``S`` / ``M`` / ``G``) that remembers
+    element-wise writes: the reference mutates these arrays in place
+    (``gp_opt.py:374-390, 475-476, 481, 505-506, 511, 615``) and user code may do the same
+    (``opt.Q[:, 0] = ...``, ``opt.S[:] = ...``); the optimiser uploads the mirror before
+    the next device pass that reads it.  (Writes that bypass ``__setitem__`` --
+    ``np.add(..., out=opt.Q)`` -- are not seen: assign ``opt.Q = array`` for those.)"""
 
     _owner = None
+    _field = 'Q'
 
     def __array_finalize__(self, obj):
         self._owner = getattr(obj, '_owner', None)
+        self._field = getattr(obj, '_field', 'Q')
 
     def __setitem__(self, key, value):
         owner = self._owner() if self._owner is not None else None
+        field = self._field
         # only writes that land IN the mirror count: a copy of opt.Q, or an array
         # computed from it, inherits this class but not the memory
-        if owner is not None and np.may_share_memory(self, owner._Q):
+        if owner is not None and np.may_share_memory(self, getattr(owner, '_' + field)):
             # the mirror may lag behind the device (a sweep since this view was
             # taken): bring it up to date first -- in the reference the array is live
-            owner._mirror('Q', _hip.Q)
+            owner._mirror(field, getattr(_hip, field))
             np.ndarray.__setitem__(self, key, value)
-            owner._q_written = True
+            if field == 'Q':
+                owner._q_written = True
+            else:
+                owner._masks_written.add(field)
         else:
             np.ndarray.__setitem__(self, key, value)
 
@@ -289,6 +295,9 @@ class _HipGridBackend(object):
         self._seen = [None] * len(self.gps)      # mean/var no longer match Q
         return self.grid.upload_Q(Q, fmin)
 
+    def upload_mask(self, what, mask):
+        self.grid.upload_mask(what, mask)
+
     def maximizers(self, max_l):
         return self.grid.maximizers(max_l)
 
@@ -307,6 +316,9 @@ class _HipGridBackend(object):
 
     def lipschitz_check(self, fmin, lipschitz, xc, u_c):
         return self.grid.lipschitz_check(fmin, lipschitz, xc, u_c)
+
+    def expander_batch(self, beta, fmin, mode, cut_w, cut_idx, k):
+        return self.grid.expander_batch(self._dev(), beta, fmin, mode, cut_w, cut_idx, k)
 
     def mark_expanders(self, gidx):
         self.grid.mark_expanders(gidx)
@@ -436,6 +448,8 @@ class SafeOpt(GaussianProcessOptimization):
         self._Q = np.empty((N, 2 * len(self.gps)), dtype=float)
         self._S, self._M, self._G = (np.zeros(N, dtype=bool) for _ in range(3))
         self._stale = dict(Q=False, S=False, M=False, G=False)
+        self._s_user = False       # the device's S was assigned by user code (opt.S[...] = ...)
+        self._masks_written = set()
         self._q_written = False
 
         # this rank's contiguous block of rows, resident on its GPU
@@ -491,19 +505,19 @@ class SafeOpt(GaussianProcessOptimization):
                     arr[off:off + c] = allp[r][:c]
                     off += c
             self._stale[name] = False
-        # S / M / G are results: read-only views (the device would not see writes);
-        # Q goes out as a write-back view, see the property
-        view = getattr(self, '_' + name).view()
-        view.flags.writeable = False
-        return view
+        # (the properties hand out write-back views of this array)
+        return getattr(self, '_' + name)
 
     @property
     def Q(self):
         """Confidence intervals ``[l_0, u_0, l_1, u_1, ...]`` per row.  Writable:
         element-wise writes are uploaded before the next pass that reads them."""
-        self._mirror('Q', _hip.Q)
-        view = self._Q.view(_WriteBackView)
+        return self._view('Q', _hip.Q)
+
+    def _view(self, name, what):
+        view = self._mirror(name, what).view(_WriteBackView)
         view._owner = weakref.ref(self)
+        view._field = name
         return view
 
     def _flush_Q(self):
@@ -528,18 +542,44 @@ class SafeOpt(GaussianProcessOptimization):
 
     @property
     def S(self):
-        """Safe set mask."""
-        return self._mirror('S', _hip.S)
+        """Safe set mask.  Writable like in the reference (``opt.S[:] = ...``): the next
+        ``get_new_query_point`` reads the edited mask; ``compute_sets`` recomputes it from
+        the intervals, as the reference's ``compute_safe_set`` does (gp_opt.py:478-481)."""
+        return self._view('S', _hip.S)
 
     @property
     def M(self):
-        """Potential maximisers mask."""
-        return self._mirror('M', _hip.M)
+        """Potential maximisers mask (writable; ``compute_sets`` recomputes it)."""
+        return self._view('M', _hip.M)
 
     @property
     def G(self):
-        """Expanders mask."""
-        return self._mirror('G', _hip.G)
+        """Expanders mask (writable; ``compute_sets`` recomputes it)."""
+        return self._view('G', _hip.G)
+
+    def _flush_masks(self, for_sets=False):
+        """Element-wise writes into ``opt.S / M / G`` since the last pass reach the device.
+        ``for_sets``: ``compute_sets`` is about to overwrite M and G and recomputes S from
+        the intervals (gp_opt.py:478-481, 505-615): an edited S is dropped, not uploaded."""
+        written, self._masks_written = self._masks_written, set()
+        if for_sets and (self._s_user or 'S' in written):
+            # (an S that user code assigned -- now or before an earlier arg-max -- is
+            # recomputed from the intervals, like compute_safe_set does in the reference)
+            self._s_user = False
+            self._argmax_cache = None
+            self.Q = self._mirror('Q', _hip.Q).copy()
+            return
+        if not written:
+            return
+        self._argmax_cache = None
+        if for_sets:
+            return
+        lo, hi = self._shard
+        for name in sorted(written):
+            self._backend.upload_mask(getattr(_hip, name), getattr(self, '_' + name)[lo:hi])
+        if 'S' in written:
+            self._any_safe = bool(self._S.any())
+            self._s_user = True
 
     # -- reference properties ---------------------------------------------------
     @property
@@ -615,12 +655,14 @@ class SafeOpt(GaussianProcessOptimization):
             self._max_l, self._any_safe = red[0], bool(red[1] > 0)
         self._stale.update(Q=True, S=True)
         self._q_written = False          # (the sweep overwrites the intervals)
+        self._s_user = False
         self._ci_fresh = True
         self._argmax_cache = None
 
     def compute_safe_set(self):
         """``S = all(l_i > fmin_i)``; fused into the sweep, nothing to redo."""
         self._flush_Q()
+        self._flush_masks(for_sets=True)
         if not self._ci_fresh:
             self.update_confidence_intervals(context=self.context)
 
@@ -754,10 +796,11 @@ class SafeOpt(GaussianProcessOptimization):
         return _Front(n_cand, n_unsafe, w_c, idx_c, x_c, mu_c, q_c, None,
                       None if np.isnan(tied) else int(tied))
 
-    def _certify_first_candidate(self, beta, active, front):
+    def _certify_first_candidate(self, beta, active, front, exact=False):
         """Second half, shared by every variant: is the first candidate an expander
         (gp_opt.py:579-612)?  ``front.fused``: the probe flags and the arg-max came with the
-        front half (already global); otherwise ``sets_back`` runs them now."""
+        front half (already global); otherwise ``sets_back`` runs them now.  ``exact``: the
+        flags are those of the scan over ALL unsafe rows, not of the probe."""
         be = self._backend
         G = len(self.gps)
         world = self._comm.world
@@ -791,8 +834,8 @@ class SafeOpt(GaussianProcessOptimization):
                 self._argmax_cache = None
             return
         # not certified by the probe: exact scan, then the general loop
-        hit = self._expander_flags(beta, x_c[None, :], mu_c[None, :],
-                                   q_c[None, 1::2], active, probe=False)
+        hit = [False] if exact else self._expander_flags(
+            beta, x_c[None, :], mu_c[None, :], q_c[None, 1::2], active, probe=False)
         if hit[0]:
             if be.owns(idx_c):
                 be.mark_expanders(np.array([idx_c], dtype=np.int64))
@@ -827,6 +870,28 @@ class SafeOpt(GaussianProcessOptimization):
         # candidate, so the first pass fetches and tests only that one; later
         # passes take SGP_TOPK candidates at a time.
         K = _hip.TOPK if (full_sets or cut_idx != _I64_MAX) else 1
+        if (self._comm.world == 1 and not self.use_lipschitz
+                and hasattr(be, 'expander_batch')):
+            # one rank: a pass of the loop -- the next K candidates, their rows, the exact
+            # test -- is ONE device round trip
+            while True:
+                w_b, i_b, fl = be.expander_batch(beta, self.fmin, mode, cut_w, cut_idx, K)
+                m = i_b.size
+                if m == 0:
+                    break
+                is_exp = np.all(fl[:, active] != 0, axis=1)
+                if full_sets:
+                    be.mark_expanders(i_b[is_exp])
+                elif is_exp.any():
+                    first = int(np.argmax(is_exp))
+                    be.mark_expanders(i_b[first:first + 1])
+                    self._settle_ties(beta, active, float(w_b[first]), int(i_b[first]))
+                    break
+                if m < K:
+                    break
+                cut_w, cut_idx = float(w_b[-1]), int(i_b[-1])
+                K = _hip.TOPK
+            return
         while True:
             w_loc, i_loc = be.topk(mode, cut_w, cut_idx, K)
             if self._comm.world > 1:
@@ -976,6 +1041,7 @@ class SafeOpt(GaussianProcessOptimization):
     def get_new_query_point(self, ucb=False):
         """Next parameters to evaluate (first index wins among equals)."""
         self._flush_Q()
+        self._flush_masks()
         if not self._any_safe:
             raise EnvironmentError('There are no safe points to evaluate.')
         mode = _hip.ARGMAX_UCB if ucb else _hip.ARGMAX_MG_WIDTH
@@ -1038,12 +1104,13 @@ class SafeOpt(GaussianProcessOptimization):
          max_l) = self._backend.step_small(devs, beta, self.fmin, self.scaling, self._thr_beta)
         self._stale.update(Q=True, S=True)
         self._q_written = False          # (the sweep overwrites the intervals)
+        self._s_user = False
         self._ci_fresh = True
         self._argmax_cache = None
         if self._deferred_max_l(max_l):
             self._certify_first_candidate(beta, self.fmin != -np.inf,
                                           self._front_of(out5, x_c, mu_c, q_c,
-                                                         (flags, val, idx)))
+                                                         (flags, val, idx)), exact=True)
 
     def get_maximum(self, context=None):
         """Best lower bound inside the safe set: ``(x, l)`` or ``None``."""

@@ -51,6 +51,9 @@ class OracleGridBackend(object):
         self.Q[:] = Q
         return self._safe(fmin)
 
+    def upload_mask(self, what, mask):
+        {S_: self.S, M_: self.M, G_: self.G}[what][:] = np.asarray(mask, dtype=bool)
+
     def maximizers(self, max_l):
         l0, u0 = self.Q[:, 0], self.Q[:, 1]
         self.M = self.S & (u0 >= max_l)

@@ -2058,3 +2058,35 @@ def test_predict_of_a_prefix_of_the_points(mods, n, kind):
         assert_array_equal(m, m2)
         assert_array_equal(v, v2)
     print("n = %d: full set by %s, prefixes by %s" % (n, kf, sorted(seen)))
+
+
+def test_mask_writes_reach_the_device(mods):
+    """``opt.S / M / G`` are live arrays in the reference (gp_opt.py:481, 505-506, 511, 615);
+    here an element-wise write into the host mirror is uploaded (``sgp_grid_upload_mask``)
+    before the next ``get_new_query_point``, whose arg-max runs over the EDITED ``M | G``
+    (gp_opt.py:635-649); ``compute_sets`` recomputes all three, ``S`` from the intervals."""
+    safeopt_amd, gpy, gpn, son = mods
+    rng = np.random.default_rng(12)
+    X = rng.uniform(-2, 2, size=(60, 2))
+    Y = smooth(X, 9) - smooth(X, 9).min() + 0.5
+    grid = safeopt_amd.linearly_spaced_combinations([(-4., 4.)] * 2, [150, 140])
+    gp = gpy.models.GPRegression(X, Y, gpy.kern.RBF(2, 2.0, [1.0, 1.2], ARD=True), noise_var=0.05 ** 2)
+    opt = safeopt_amd.SafeOpt(gp, grid, 0.0, threshold=0.2)
+    x0 = opt.optimize()
+    S0, M0, G0 = np.array(opt.S), np.array(opt.M), np.array(opt.G)
+    Q = np.array(opt.Q)
+    rows = np.flatnonzero(M0 | G0)
+    keep = rows[~np.all(grid[rows] == x0, axis=1)][::3]
+    opt.G[:] = False
+    opt.M[:] = False
+    opt.M[keep] = True
+    x1 = opt.get_new_query_point()
+    val = (Q[:, 1] - Q[:, 0]) / opt.scaling[0]
+    assert_array_equal(x1, grid[keep[np.argmax(val[keep])]])
+    assert_array_equal(opt._backend.download(safeopt_amd._hip.M).astype(bool), np.isin(np.arange(len(grid)), keep))
+    opt.S[:] = False
+    with pytest.raises(EnvironmentError):
+        opt.get_new_query_point()
+    opt.compute_sets()
+    assert_array_equal(opt.S, S0); assert_array_equal(opt.M, M0); assert_array_equal(opt.G, G0)
+    assert_array_equal(opt.get_new_query_point(), x0)

@@ -268,8 +268,10 @@ def test_sample_gp_function_matches_reference():
 def test_q_mirror_writes_reach_the_device_and_the_setter_uploads():
     """``opt.Q`` can be mutated in place as in the reference (``gp_opt.py:374-390,
     475-476``): an element-wise write into the mirror is uploaded before the next
-    pass that reads the intervals, and gives what assigning the whole array gives;
-    ``S`` / ``M`` / ``G`` are results and stay read-only."""
+    pass that reads the intervals, and gives what assigning the whole array gives.
+    ``S`` / ``M`` / ``G`` are writable like the reference's arrays (``gp_opt.py:481,
+    505-506, 511, 615``): ``get_new_query_point`` reads an edited mask, ``compute_sets``
+    recomputes all three (``S`` from the intervals, as ``compute_safe_set`` does)."""
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import safeopt_amd
@@ -286,9 +288,29 @@ def test_q_mirror_writes_reach_the_device_and_the_setter_uploads():
         opt.update_confidence_intervals()
         return opt
     opt = make()
-    for mirror in (opt.S, opt.M, opt.G):
-        with pytest.raises(ValueError):
-            mirror[0] = 1
+    # masks edited in place: the arg-max of get_new_query_point is taken over the EDITED
+    # M | G (gp_opt.py:635-649), as in the reference where the arrays are live
+    opt.compute_sets()
+    ref = make(); ref.compute_sets()
+    rows = np.flatnonzero(np.asarray(ref.M | ref.G))
+    first = ref.get_new_query_point()
+    keep = rows[~np.all(z["parameter_set"][rows] == first, axis=1)]
+    opt.M[:] = False
+    opt.G[:] = False
+    opt.M[keep] = True
+    x2 = opt.get_new_query_point()
+    Qh = np.asarray(ref.Q)
+    val = np.max((Qh[:, 1::2] - Qh[:, ::2]) / ref.scaling, axis=1)
+    assert np.array_equal(x2, z["parameter_set"][keep[np.argmax(val[keep])]])
+    assert not np.array_equal(x2, first) or keep.size == rows.size
+    # an edited S: nothing safe -> the reference's error; compute_sets recomputes S from Q
+    opt.S[:] = False
+    with pytest.raises(EnvironmentError):
+        opt.get_new_query_point()
+    opt.compute_sets()
+    for name in ("S", "M", "G"):
+        assert np.array_equal(getattr(opt, name), getattr(ref, name))
+    assert np.array_equal(opt.get_new_query_point(), first)
     new = np.array(opt.Q) + 0.25
     opt.Q = new
     assert np.array_equal(opt.Q, new)
