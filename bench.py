@@ -756,7 +756,9 @@ def main():
             for st in ("greedy", "maximizers", "expanders"):
                 opt._compute_particle_fitness(st, parts)
         workload = ("config5: ONE SafeOptSwarm._compute_particle_fitness call "
-                    "('maximizers': both GPs), 4-D RBF, G=2, n=2000, P=%d particles" % units)
+                    "('maximizers': both GPs), 4-D RBF, G=2, n=2000, P=%d particles "
+                    "[unit since round 4: particles / ONE fitness call (SURVEY 8d); rounds 1-3 "
+                    "timed the greedy + maximizers + expanders step -- see three_call_step]" % units)
     else:
         grid = cfg["grid"]
         opt = safeopt_amd.SafeOpt(gps if cfg["G"] > 1 else gps[0], grid,

@@ -778,8 +778,18 @@ class DeviceGrid(object):
         key = tuple(g.h.value for g in gps)
         if ss["gps"] != key:
             ss["gps"], ss["gp_arr"] = key, _gp_array(gps)
-        rc = ss["fn"](self.h, ss["gp_arr"], len(gps), beta, dptr(fmin), dptr(scaling),
-                      dptr(thr_beta), *ss["ptr"])
+        # (the three input arrays are the optimiser's own attributes: their pointers are
+        # looked up once per array object -- the cache holds the arrays, so an id is not reused)
+        ins = ss.get("ins")
+        if ins is None or ins[0] is not fmin or ins[1] is not scaling or ins[2] is not thr_beta:
+            # (f64: the same object back when it already is a contiguous float64 array)
+            conv = (f64(fmin), f64(scaling), f64(thr_beta))
+            ins = ss["ins"] = (fmin, scaling, thr_beta) + conv + tuple(dptr(a) for a in conv)
+        elif ins[3] is not fmin or ins[4] is not scaling:
+            # converted copies (an integer fmin, say): their VALUES may have been edited
+            ins[3][...], ins[4][...], ins[5][...] = fmin, scaling, thr_beta
+        rc = ss["fn"](self.h, ss["gp_arr"], len(gps), float(beta), ins[6], ins[7], ins[8],
+                      *ss["ptr"])
         if rc != 0:
             self.ctx.check(rc)
         out5, x, mean, q, flags, v, i, ml = ss["out"]
