@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): rocprofv3 evidence for profiles/<tag>/.
-#   scripts/collect_profiles.sh r04 [configs...]      (default configs: 3 2 4 5)
+#   scripts/collect_profiles.sh r04 [configs...]      (default configs: 3 2 4 5; QUICK=1: without the
+#   reconcile / probes / product-kernel / swarm blocks, whose code did not change since r04)
 # Per config: the bench JSON line, kernel stats of the same command, and three
 # separate PMC passes (MFMA busy + clock; FETCH_SIZE; WRITE_SIZE) -- never
 # combined with trace domains other than --kernel-trace, as the MI355X guide
@@ -51,12 +52,15 @@ cd $R
 if [ -n "$ONLY_PMC" ]; then python scripts/profiles_digest.py $OUT > $OUT/SUMMARY.txt 2>&1; cat $OUT/SUMMARY.txt; exit 0; fi
 # the two sweep kernels side by side (same process, same box), un-shared path
 python scripts/dev/ab_sweep.py 3 2 4 5 > $OUT/ab_kernels.txt 2>&1
-# factor tables (tensor grids, RBF) against evaluated covariances: configs 2 and 4
-{ for c in 2 4; do
-    which=pair; [ $c = 2 ] && which=classic
-    AB_ONLY=$which AB_TAG="  [factor tables]" python scripts/dev/ab_sweep.py $c 2>&1 | tail -1
-    AB_ONLY=$which AB_SEP=0 AB_TAG="  [evaluated]" python scripts/dev/ab_sweep.py $c 2>&1 | tail -1
-  done; } > $OUT/ab_tables.txt 2>&1
+# factor tables (tensor grids, RBF) against evaluated covariances: config 2 (4-wave kernel:
+# tables by default) and config 4 (paired kernel: tables only while they fit half an L2 --
+# the default evaluates; SGP_SEP_PAIR=1 forces them)
+{ AB_ONLY=classic AB_TAG="  [config 2, factor tables (default)]" python scripts/dev/ab_sweep.py 2 2>&1 | tail -1
+  AB_ONLY=classic AB_SEP=0 AB_TAG="  [config 2, evaluated]" python scripts/dev/ab_sweep.py 2 2>&1 | tail -1
+  AB_ONLY=pair AB_TAG="  [config 4, default: evaluated (tables 4.8 MB > half an L2)]" python scripts/dev/ab_sweep.py 4 2>&1 | tail -1
+  SGP_SEP_PAIR=1 AB_ONLY=pair AB_TAG="  [config 4, factor tables forced (SGP_SEP_PAIR=1)]" python scripts/dev/ab_sweep.py 4 2>&1 | tail -1
+  AB_ONLY=pair AB_SEP=0 AB_TAG="  [config 4, no axes declared]" python scripts/dev/ab_sweep.py 4 2>&1 | tail -1
+} > $OUT/ab_tables.txt 2>&1
 # ablation ("what does the paired sweep cost without X") and per-phase cycle stamps
 if [ -f scripts/dev/ab/instr.so ]; then
   for c in 3 4; do for m in 0 1 2 4 8 16 32 6 7 15; do
@@ -82,6 +86,12 @@ fi
 python scripts/dev/small_n.py > $OUT/small_n.txt 2>&1
 python scripts/dev/small_n.py 4 8 16 20 32 48 64 > $OUT/small_n_few.txt 2>&1
 python scripts/dev/high_d.py > $OUT/high_d.txt 2>&1
+# the reference's own problem sizes: the one-launch step against the large-grid path
+python scripts/dev/small_step_time.py > $OUT/small_step.txt 2>&1
+if [ -n "$QUICK" ]; then
+  { python scripts/bench_bo_loop.py --config 2; python scripts/bench_bo_loop.py --config 3; } > $OUT/bo_loop.json 2>$OUT/bo_loop.err
+  python scripts/profiles_digest.py $OUT > $OUT/SUMMARY.txt 2>&1; cat $OUT/SUMMARY.txt; exit 0
+fi
 # hipEvent vs rocprof on identical launches, and the clock ramp
 {
   for mult in 1 8; do python scripts/dev/clock_reconcile.py $mult 40; done
