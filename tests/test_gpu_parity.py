@@ -2093,3 +2093,71 @@ def test_mask_writes_reach_the_device(mods):
     opt.compute_sets()
     assert_array_equal(opt.S, S0); assert_array_equal(opt.M, M0); assert_array_equal(opt.G, G0)
     assert_array_equal(opt.get_new_query_point(), x0)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("k", [2, 3])
+def test_whole_grid_of_configs_2_and_3_against_oracle(mods, k):
+    """BASELINE.json configs[1] and configs[2] (the north-star config) at FULL size, EVERY one
+    of the 1e6 rows against the oracle (7 s / 28 s of host work): ``Q`` within 1e-8, ``S / M /
+    G`` identical row for row, the chosen row identical -- what ``bench.py`` checks behind
+    its timed region, inside the test suite (the other full-size tests take spot rows +
+    size-independent properties)."""
+    safeopt_amd, gpy, gpn, son = mods
+    from bench import make_config, build_gps
+    cfg = make_config(k)
+    G = cfg["G"]
+    gps, gos = build_gps(cfg, gpy), build_gps(cfg, gpn)
+    grid = cfg["grid"]
+    assert grid.shape[0] == 1000000
+    opt = safeopt_amd.SafeOpt(gps if G > 1 else gps[0], grid, cfg["fmin"] if G > 1 else 0.,
+                              threshold=cfg["threshold"])
+    x = opt.optimize()
+    idx, Qo, So, Mo, Go = son.optimize_grid(gos, grid, cfg["fmin"], opt.scaling,
+                                            cfg["threshold"], cfg["beta"])
+    assert_allclose(opt.Q, Qo, rtol=0, atol=1e-8)
+    assert_array_equal(opt.S, So)
+    assert_array_equal(opt.M, Mo)
+    assert_array_equal(opt.G, Go)
+    assert_array_equal(x, grid[idx])
+    # the product default (shared factor, k = 3: riders) gives the same masks and point
+    if G > 1:
+        ctx = opt._backend.ctx
+        old = ctx.set_share(True)
+        try:
+            opt2 = safeopt_amd.SafeOpt(build_gps(cfg, gpy), grid, cfg["fmin"], threshold=cfg["threshold"])
+            assert_array_equal(opt2.optimize(), x)
+            assert_array_equal(opt2.S, So); assert_array_equal(opt2.M, Mo); assert_array_equal(opt2.G, Go)
+        finally:
+            ctx.set_share(old)
+
+
+@pytest.mark.timeout(900)
+def test_all_particles_of_config5_against_oracle(mods):
+    """BASELINE.json configs[4] at FULL size: ALL 1e5 particles and all four swarm types
+    against the oracle (gp_opt.py:901-1013), not a sample."""
+    safeopt_amd, gpy, gpn, son = mods
+    from bench import make_config, build_gps
+    cfg = make_config(5)
+    gps, gos = build_gps(cfg, gpy), build_gps(cfg, gpn)
+    P = cfg["particles"]
+    opt = safeopt_amd.SafeOptSwarm(gps, cfg["fmin"], bounds=[(-5., 5.)] * 4,
+                                   threshold=cfg["threshold"])
+    opt.best_lower_bound = 0.4
+    for st in ["greedy", "maximizers", "expanders", "safe_set"]:
+        v, sf = opt._compute_particle_fitness(st, P)
+        vo = np.empty(P.shape[0]); so = np.empty(P.shape[0], dtype=bool)
+        for a in range(0, P.shape[0], 20000):
+            vo[a:a + 20000], so[a:a + 20000] = son.swarm_fitness(gos, P[a:a + 20000], st, 2., cfg["fmin"],
+                                                                 opt.scaling, 0.4)
+        # (a particle whose slack sits within the posterior tolerance of 0 may flip its flag
+        # and, with it, a penalty branch)
+        edge = np.zeros(P.shape[0], dtype=bool)
+        if st != "greedy":
+            m0, v0 = gos[0].predict_noiseless(P[:1])       # (shapes only)
+            lo = [gos[g].predict_noiseless(P) for g in range(len(gos))]
+            for g, (m, vv) in enumerate(lo):
+                edge |= np.abs(m[:, 0] - 2. * np.sqrt(vv[:, 0]) - cfg["fmin"][g]) < 1e-7
+        assert edge.sum() < 50
+        assert_array_equal(sf[~edge], so[~edge])
+        assert_allclose(v[~edge], vo[~edge], rtol=1e-7, atol=1e-8)
