@@ -466,7 +466,33 @@ def config1(gpy, safeopt_amd, ctx, steps=2000):
         gp = gpy.models.GPRegression(x0, fun(x0), kern, noise_var=0.05 ** 2)
         # (fmin one unit below the start value: the start is safe, the set can grow)
         opt = safeopt_amd.SafeOpt(gp, grid, float(fun(x0, noise=False)[0, 0]) - 1.0, threshold=0.2)
-        for _ in range(19):                    # 20 observations, as 1d_example gathers them
+
+        def timed(small, reps):
+            opt.small_step = small
+            opt._backend.incremental = False
+            for _ in range(50):
+                xx = opt.optimize()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                xx = opt.optimize()
+            ctx.sync()
+            return (time.perf_counter() - t0) / reps * 1e6, xx
+
+        # along the run: what a step costs while the safe set still grows (the first
+        # candidate in visiting order is an expander: the whole step is the one launch) and
+        # once no expander is left (the loop then visits every candidate, 16 per round trip)
+        along = []
+        for it in range(19):                   # 20 observations, as 1d_example gathers them
+            if it in (2, 5, 9, 14):
+                us1, _ = timed(True, 300)
+                us2, _ = timed(False, 300)
+                opt.small_step = True
+                opt.optimize()
+                along.append({"n": int(opt.gp.X.shape[0]), "one_launch_us": us1,
+                              "large_grid_path_us": us2, "expander_found": bool(opt.G.any()),
+                              "safe_rows": int(opt.S.sum())})
+            opt.small_step = True
             x = opt.optimize()
             opt.add_new_data_point(x, fun(x))
     finally:
@@ -474,18 +500,10 @@ def config1(gpy, safeopt_amd, ctx, steps=2000):
     n = opt.gp.X.shape[0]
     out = {"workload": "config1: 1-D RBF, G=1, n=%d (19 SafeOpt iterations from x0 = 0 on a "
                        "sampled GP function), grid 1000 points on [-10, 10], one "
-                       "SafeOpt.optimize()" % n}
+                       "SafeOpt.optimize()" % n,
+           "along_the_run": along}
     for name, small in (("one_launch", True), ("large_grid_path", False)):
-        opt.small_step = small
-        opt._backend.incremental = False
-        for _ in range(100):
-            x = opt.optimize()
-        ctx.sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            x = opt.optimize()
-        ctx.sync()
-        us = (time.perf_counter() - t0) / steps * 1e6
+        us, x = timed(small, steps)
         out[name] = {"us_per_optimize": us, "candidates_per_s": 1000 / (us * 1e-6),
                      "sweep_kernel": ctx.last_sweep(), "chosen_x": float(x[0])}
     opt.small_step = True
@@ -499,6 +517,7 @@ def config1(gpy, safeopt_amd, ctx, steps=2000):
                      "S_M_G_identical": bool(np.array_equal(opt.S, So) and np.array_equal(opt.M, Mo)
                                              and np.array_equal(opt.G, Go)),
                      "q_linf": float(np.max(np.abs(opt.Q - Qo)))}
+    out["oracle"]["expander_found"] = bool(Go.any())
     out["us_per_optimize"] = out["one_launch"]["us_per_optimize"]
     return out
 

@@ -257,6 +257,13 @@ int sgp_grid_step_small(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                         double* mean_top, double* q_top, int32_t* flags, double* value,
                         int64_t* gidx, double* max_l_out);
 int sgp_grid_step_small_ok(sgp_grid* grid, sgp_gp* const* gps, int G);
+/* ... and when its first candidate is no expander: the expander test of gp_opt.py:579-606
+ * for EVERY candidate of the list (global row indices, any order) in two launches and one
+ * round trip; flags[c * G + i] != 0: candidate c lifts an unsafe row above fmin_i.  The
+ * caller walks the flags in the reference's visiting order (gp_opt.py:542-557).         */
+int sgp_grid_expanders_small(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
+                             const double* fmin, const int64_t* gidx, int m,
+                             int32_t* flags);
 
 /* The same on N ranks (row shards, sgp_comm_init on the grid's context) after a
  * confidence pass without read-back: max l0[S] and the maximiser width are

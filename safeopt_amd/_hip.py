@@ -98,6 +98,8 @@ PROTOTYPES = {
                                       c_double_p, c_double_p, c_double_p, c_double_p,
                                       c_double_p, c_i32_p, c_double_p, c_i64_p, c_double_p]),
     "sgp_grid_step_small_ok": (C.c_int, [vp, vpp, C.c_int]),
+    "sgp_grid_expanders_small": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p, c_i64_p,
+                                           C.c_int, c_i32_p]),
     "sgp_grid_sets_fused_comm": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p,
                                            c_double_p, c_double_p, C.c_double,
                                            c_double_p, c_double_p, c_double_p,
@@ -756,6 +758,17 @@ class DeviceGrid(object):
             dptr(q), flags.ctypes.data_as(c_i32_p), C.byref(v), C.byref(i),
             C.byref(ml)))
         return out5, x, mean, q, flags, v.value, i.value, ml.value
+
+    def expanders_small(self, gps, beta, fmin, gidx):
+        """Which of the candidate rows ``gidx`` are expanders, per GP: ``(m, G)`` flags in
+        one round trip (small grids: ``sgp_grid_expanders_small``)."""
+        gidx = np.ascontiguousarray(gidx, dtype=np.int64)
+        flags = np.zeros((gidx.size, self.G), dtype=np.int32)
+        if gidx.size:
+            self.ctx.check(lib().sgp_grid_expanders_small(
+                self.h, _gp_array(gps), len(gps), float(beta), dptr(f64(fmin)),
+                gidx.ctypes.data_as(c_i64_p), int(gidx.size), flags.ctypes.data_as(c_i32_p)))
+        return flags
 
     def step_small_ok(self, gps):
         """Does ``step_small`` serve this grid with these (fitted) GPs?"""

@@ -1549,6 +1549,38 @@ int sgp_grid_step_small(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   return 0;
 }
 
+// Every candidate of a small grid at once (step_small.hip: k_cand_ops, k_cand_scan):
+// flags[c * G + i] != 0 when candidate gidx[c] lifts an unsafe row above fmin_i after the
+// rank-1 update by (x_c, u_i(x_c)) -- the test of gp_opt.py:579-606 for m candidates in
+// two launches and one round trip.  Grids of at most 16384 rows, GPs with at most 48
+// observations (sgp_grid_step_small_ok).
+int sgp_grid_expanders_small(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
+                             const double* fmin, const int64_t* gidx, int m, int32_t* flags) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  if (m <= 0) return 0;
+  GpDev host[SGP_MAX_GPS];
+  SGP_TRY(collect_gps(ctx, gps, G, g->d, host));
+  SGP_CHECK(ctx, step_small_eligible(ctx, host, G, g->N),
+            "sgp_grid_expanders_small: %lld rows / a GP with more than 48 observations",
+            (long long)g->N);
+  for (int c = 0; c < m; ++c)
+    SGP_CHECK(ctx, gidx[c] >= g->goff && gidx[c] < g->goff + g->N,
+              "candidate %lld is not a row of this grid", (long long)gidx[c]);
+  SGP_TRY(stage_gpdev(g, host, G));
+  const size_t nops = cand_ops_doubles(m, G);
+  char* buf = static_cast<char*>(sgp_scratch(ctx, 7, nops * 8 + size_t(m) * 8 + size_t(m) * G * 4));
+  SGP_CHECK(ctx, buf, "device allocation failed: %s", ctx->err.c_str());
+  double* ops = reinterpret_cast<double*>(buf);
+  int64_t* cl = reinterpret_cast<int64_t*>(buf + nops * 8);
+  int32_t* dfl = reinterpret_cast<int32_t*>(buf + nops * 8 + size_t(m) * 8);
+  SGP_TRY(sgp_h2d(ctx, cl, gidx, size_t(m) * 8));
+  SGP_HIP(ctx, hipMemsetAsync(dfl, 0, size_t(m) * G * 4, ctx->stream));
+  SGP_TRY(launch_cand_all(g, g->gpdev, host, G, beta, fmin, cl, m, ops, dfl));
+  return sgp_d2h(ctx, flags, dfl, size_t(m) * G * 4);
+}
+
 // 1 when sgp_grid_step_small serves this grid with these GPs (at most 16384 rows, every GP
 // with at most 48 observations, sweep kernel not forced), else 0
 int sgp_grid_step_small_ok(sgp_grid* g, sgp_gp* const* gps, int G) {

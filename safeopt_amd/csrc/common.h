@@ -363,6 +363,10 @@ bool step_small_eligible(const sgp_ctx* ctx, const GpDev* gh, int G, int64_t N);
 int launch_step_small(sgp_grid* g, const GpDev* gps_dev, const GpDev* gh, int G, double beta,
                       const double* fmin, const double* scaling, const double* thr_beta,
                       double* res, int nfront, int nfl, uint64_t seq);
+int launch_cand_all(sgp_grid* g, const GpDev* gps_dev, const GpDev* gh, int G, double beta,
+                    const double* fmin, const int64_t* clist_dev, int m, double* ops,
+                    int32_t* flags);
+size_t cand_ops_doubles(int m, int G);
 constexpr int kStepResWords = 64;     // doubles of the result block (6 + d + 3 G + ... <= 50)
 
 // sets.hip

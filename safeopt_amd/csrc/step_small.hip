@@ -497,7 +497,182 @@ void launch_step_d(sgp_ctx* ctx, const StepParams& p, int np, bool single) {
   return launch_step_np<D, 48, 512>(ctx, p, single);
 }
 
+// ---- every candidate of a small grid at once ------------------------------------------
+// When the first candidate is no expander the reference walks through ALL candidates in
+// visiting order until one is (gp_opt.py:557-612) -- and in a converged run none is, every
+// iteration.  The large-grid path takes them 16 per device round trip (a scan of the unsafe
+// rows per pass is what it can afford at 1e6 rows).  On a small grid the whole product
+// candidates x unsafe rows is tiny: two launches test EVERY candidate of the list --
+//   k_cand_ops:  one wave per candidate: t = L^-1 k_c, w = L^-T t, s^2, delta (rank-1
+//                update of the posterior by the observation (x_c, u_i(x_c)))
+//   k_cand_scan: one thread per unsafe row: its n covariances with the training points
+//                once (registers), then for every candidate of the workgroup's chunk
+//                c(x) = k(x, x_c) - w_c . k(X, x), l_2(x) >= fmin -> flags[c][g]
+// and the host picks the first expander in the reference's own order (argsort()[::-1] of the
+// candidate widths: exact ties included).
+constexpr int kCandChunk = 32;          // candidates per workgroup of the scan
+constexpr int kCandOps = 64 + 2;        // doubles per (candidate, GP): w[64] | delta | 1 / s^2
+
+template <int D>
+__global__ __launch_bounds__(64) void k_cand_ops(const GpDev* gps, int G, SweepPoints pts,
+                                                 const double* Q, const double* mean, Vec8 fmin,
+                                                 const int64_t* clist, int64_t goff, double* ops) {
+  __shared__ double kc[64], tt[64];
+  const int lane = threadIdx.x, c = blockIdx.x;
+  const gpdev_c_t gpc = (gpdev_c_t)(gps);
+  const int64_t li = clist[c] - goff;
+  double xc[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) xc[k] = pts.base[li * pts.stride_row + k * pts.stride_col];
+  for (int g = 0; g < G; ++g) {
+    double* out = ops + (size_t(c) * G + g) * kCandOps;
+    if (fmin.v[g] == -INFINITY) continue;
+    const GpDev& gp = gps[g];
+    const int n = gpc[g].n;
+    const int64_t ld = gpc[g].ld;
+    __syncthreads();
+    double kcv = 0.0;
+    if (lane < n) {
+      double xj[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) xj[k] = gp.Xpad[int64_t(lane) * D + k];
+      kcv = kern_eval<D>(gp.kern, xc, xj);
+    }
+    kc[lane] = kcv;
+    __syncthreads();
+    double t = 0.0;                       // t_i, i = lane
+    if (lane < n)
+      for (int j = 0; j <= lane; ++j) t = fma(gp.Linv[int64_t(lane) * ld + j], kc[j], t);
+    tt[lane] = t;
+    double s = lane < n ? t * t : 0.0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    __syncthreads();
+    double w = 0.0;                       // w_j, j = lane
+    if (lane < n)
+      for (int i = lane; i < n; ++i) w = fma(gp.Linv[int64_t(i) * ld + lane], tt[i], w);
+    out[lane] = w;
+    if (lane == 0) {
+      const double s2 = gp.prior - s;
+      const double resid = Q[li * 2 * G + 2 * g + 1] - mean[int64_t(g) * pts.N + li];
+      out[64] = resid / s2;
+      out[65] = 1.0 / s2;
+    }
+  }
+}
+
+template <int D, int NP>
+__global__ __launch_bounds__(256) void k_cand_scan(const GpDev* gps, int G, SweepPoints pts,
+                                                   const uint8_t* S, const double* mean,
+                                                   const double* var, double beta, Vec8 fmin,
+                                                   const int64_t* clist, int m, int64_t goff,
+                                                   const double* ops, int32_t* flags) {
+  __shared__ double tab[kExpTabSize];
+  __shared__ double sw[kCandChunk][kCandOps];
+  __shared__ double sxc[kCandChunk][D];
+  __shared__ int shit[kCandChunk];
+  exp_tab_init(tab);
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.y * kCandChunk;
+  const int mc = min(kCandChunk, m - c0);
+  const gpdev_c_t gpc = (gpdev_c_t)(gps);
+  const int64_t row = int64_t(blockIdx.x) * 256 + tid;
+  const bool valid = row < pts.N;
+  const int64_t rr = valid ? row : pts.N - 1;
+  const bool unsafe = valid && S[rr] == 0;
+  for (int e = tid; e < mc * D; e += 256) {
+    const int c = e / D, k = e - c * D;
+    sxc[c][k] = pts.base[(clist[c0 + c] - goff) * pts.stride_row + k * pts.stride_col];
+  }
+  double x[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) x[k] = pts.base[rr * pts.stride_row + k * pts.stride_col];
+  const bool any_unsafe = __syncthreads_or(unsafe ? 1 : 0) != 0;      // (also: tab, sxc)
+  if (!any_unsafe) return;
+  for (int g = 0; g < G; ++g) {
+    if (fmin.v[g] == -INFINITY) continue;
+    __syncthreads();
+    for (int e = tid; e < mc * kCandOps; e += 256)
+      sw[e / kCandOps][e % kCandOps] = ops[(size_t(c0 + e / kCandOps) * G + g) * kCandOps + e % kCandOps];
+    if (tid < kCandChunk) shit[tid] = 0;
+    __syncthreads();
+    const GpDev& gp = gps[g];
+    const int n = gpc[g].n;
+    const KernFast<D> kf(gp.kern);
+    double xs[D];
+    kf.prep(x, xs);
+    // this row's covariances with the training points, once for all candidates
+    double kx[NP];
+#pragma unroll
+    for (int j0 = 0; j0 < NP; j0 += 4) {
+      if (j0 < n) {
+        double kv[4];
+        kf.template many<4>(xs, gp.Xs + j0 * D, D, tab, kv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kx[j0 + q] = (j0 + q < n) ? kv[q] : 0.0;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kx[j0 + q] = 0.0;
+      }
+    }
+    const double mu = mean[int64_t(g) * pts.N + rr];
+    const double vr = var[int64_t(g) * pts.N + rr];
+    for (int c = 0; c < mc; ++c) {
+      double dot = 0.0;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) dot = fma(sw[c][j], kx[j], dot);
+      double xc[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) xc[k] = sxc[c][k];
+      const double cx = kf.raw(x, xc, tab) - dot;
+      const double mu2 = mu + cx * sw[c][64];
+      const double var2 = fmax(vr - cx * cx * sw[c][65], 1e-15);
+      const bool hit = unsafe && (mu2 - beta * sqrt(var2) >= fmin.v[g]);
+      if (__ballot(hit) != 0ull && (tid & 63) == 0) shit[c] = 1;
+    }
+    __syncthreads();
+    if (tid < mc && shit[tid]) atomicOr(&flags[(c0 + tid) * G + g], 1);
+  }
+}
+
 }  // namespace
+
+int launch_cand_all(sgp_grid* g, const GpDev* gps_dev, const GpDev* gh, int G, double beta,
+                    const double* fmin, const int64_t* clist_dev, int m, double* ops,
+                    int32_t* flags) {
+  sgp_ctx* ctx = g->ctx;
+  SweepPoints pts{g->pts, g->N, 1, g->N};
+  Vec8 fm;
+  int np = 1;
+  for (int i = 0; i < SGP_MAX_GPS; ++i) fm.v[i] = i < G ? fmin[i] : -INFINITY;
+  for (int i = 0; i < G; ++i) np = std::max(np, gh[i].n);
+  const dim3 sg(unsigned((g->N + 255) / 256), unsigned((m + kCandChunk - 1) / kCandChunk));
+#define CAND_CASE(DD)                                                                          \
+  case DD:                                                                                     \
+    hipLaunchKernelGGL(k_cand_ops<DD>, dim3(m), dim3(64), 0, ctx->stream, gps_dev, G, pts,     \
+                       g->Q, g->mean, fm, clist_dev, g->goff, ops);                            \
+    if (np <= 24)                                                                              \
+      hipLaunchKernelGGL((k_cand_scan<DD, 24>), sg, dim3(256), 0, ctx->stream, gps_dev, G,     \
+                         pts, g->S, g->mean, g->var, beta, fm, clist_dev, m, g->goff, ops,     \
+                         flags);                                                               \
+    else                                                                                       \
+      hipLaunchKernelGGL((k_cand_scan<DD, 48>), sg, dim3(256), 0, ctx->stream, gps_dev, G,     \
+                         pts, g->S, g->mean, g->var, beta, fm, clist_dev, m, g->goff, ops,     \
+                         flags);                                                               \
+    break;
+  switch (g->d) {
+    CAND_CASE(1) CAND_CASE(2) CAND_CASE(3) CAND_CASE(4)
+    CAND_CASE(5) CAND_CASE(6) CAND_CASE(7) CAND_CASE(8)
+    default:
+      sgp_set_error(ctx, "input dimension %d not in 1..%d", g->d, SGP_MAX_D);
+      return -2;
+  }
+#undef CAND_CASE
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+size_t cand_ops_doubles(int m, int G) { return size_t(m) * G * kCandOps; }
 
 bool step_small_eligible(const sgp_ctx* ctx, const GpDev* gh, int G, int64_t N) {
   static const bool off = getenv("SGP_NO_STEP_SMALL") != nullptr;

@@ -320,6 +320,15 @@ class _HipGridBackend(object):
     def expander_batch(self, beta, fmin, mode, cut_w, cut_idx, k):
         return self.grid.expander_batch(self._dev(), beta, fmin, mode, cut_w, cut_idx, k)
 
+    def small_grid(self):
+        """At most 16384 rows and 48 observations per GP: every candidate can be tested at
+        once (``sgp_grid_expanders_small``)."""
+        return (self.grid.N <= 16384 and not getattr(self.ctx, 'sweep_forced', False)
+                and all(g._fitted().n <= 48 for g in self.gps))
+
+    def expanders_small(self, beta, fmin, gidx):
+        return self.grid.expanders_small(self._dev(), beta, fmin, gidx)
+
     def mark_expanders(self, gidx):
         self.grid.mark_expanders(gidx)
 
@@ -870,6 +879,9 @@ class SafeOpt(GaussianProcessOptimization):
         # candidate, so the first pass fetches and tests only that one; later
         # passes take SGP_TOPK candidates at a time.
         K = _hip.TOPK if (full_sets or cut_idx != _I64_MAX) else 1
+        if (self._comm.world == 1 and not self.use_lipschitz and self.small_step
+                and hasattr(be, 'expanders_small') and be.small_grid()):
+            return self._visit_all_candidates(beta, active, full_sets, cut_idx)
         if (self._comm.world == 1 and not self.use_lipschitz
                 and hasattr(be, 'expander_batch')):
             # one rank: a pass of the loop -- the next K candidates, their rows, the exact
@@ -939,6 +951,33 @@ class SafeOpt(GaussianProcessOptimization):
                 break
             cut_w, cut_idx = float(w_b[-1]), int(i_b[-1])
             K = _hip.TOPK
+
+    def _visit_all_candidates(self, beta, active, full_sets, cut_idx, chunk=1024):
+        """The expander loop of a SMALL grid on one rank: every candidate is tested at once
+        (two launches, one round trip per ``chunk`` candidates) and the flags are walked in
+        the reference's own visiting order -- ``argsort()[::-1]`` of the candidate widths
+        (gp_opt.py:542-552), exact ties included, so nothing is left to settle.  ``cut_idx``:
+        the first candidate of the device's order when it is already known to be no expander
+        (it is skipped wherever the reference's order puts it)."""
+        be = self._backend
+        cand, width = be.candidate_widths()
+        rows = np.flatnonzero(np.asarray(cand, dtype=bool))
+        if full_sets:
+            order = rows                                   # natural order, no early exit
+        else:
+            order = rows[np.asarray(width)[rows].argsort()[::-1]]
+            if 0 <= cut_idx < _I64_MAX:
+                order = order[order != cut_idx]
+        for a in range(0, order.size, chunk):
+            part = order[a:a + chunk]
+            flags = be.expanders_small(beta, self.fmin, part)
+            is_exp = np.all(flags[:, active] != 0, axis=1)
+            if full_sets:
+                be.mark_expanders(part[is_exp])
+            elif is_exp.any():
+                be.mark_expanders(part[int(np.argmax(is_exp))][None])
+                self._argmax_cache = None
+                return
 
     def _gather_shards(self, part, N):
         """Concatenate every rank's block of a per-row array."""
