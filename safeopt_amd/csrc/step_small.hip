@@ -377,7 +377,6 @@ __global__ __launch_bounds__(TH) void k_step_small(StepParams p) {
         }
         dot = sum_lane_groups(dot);
         const double kxc = kf.raw(x, xc, tab);
-        if (!(kxc >= 0.0 * kdiag)) return false;
         const double cx = kxc - dot;
         const double mu2 = mu + cx * delta;
         const double var2 = fmax(var - cx * cx * inv_s2, 1e-15);
@@ -489,10 +488,7 @@ void launch_step_np(sgp_ctx* ctx, const StepParams& p, bool single) {
 
 template <int D>
 void launch_step_d(sgp_ctx* ctx, const StepParams& p, int np, bool single) {
-#ifndef STEP_TH24
-#define STEP_TH24 512
-#endif
-  if (np <= 24) return launch_step_np<D, 24, STEP_TH24>(ctx, p, single);
+  if (np <= 24) return launch_step_np<D, 24, 512>(ctx, p, single);
   if (np <= 32) return launch_step_np<D, 32, 512>(ctx, p, single);
   return launch_step_np<D, 48, 512>(ctx, p, single);
 }
