@@ -1016,16 +1016,28 @@ class SafeOpt(GaussianProcessOptimization):
             n_tied = 2 if np.max(self._comm.allgather(wp)) == w_star else 1
         if n_tied <= 1:
             return idx_star
-        N = self.inputs.shape[0]
+        # the candidate rows of the whole grid and their widths, in row order: what the
+        # reference's ``width[rows]`` is.  N ranks exchange the CANDIDATES only (12 bytes
+        # each), not the masks and widths of all rows (9 N bytes per shard)
         cand_loc, w_loc = be.candidate_widths()
-        cand = self._gather_shards(np.asarray(cand_loc, dtype=bool), N)
-        width = self._gather_shards(np.asarray(w_loc, dtype=float), N)
-        rows = np.flatnonzero(cand)
-        order = width[rows].argsort()[::-1]        # the reference's own expression
+        rows_loc = np.flatnonzero(np.asarray(cand_loc, dtype=bool))
+        wc_loc = np.asarray(w_loc, dtype=float)[rows_loc]
+        rows_loc = rows_loc + self._shard[0]
+        if self._comm.world > 1:
+            counts = self._comm.allgather(np.array([rows_loc.size], dtype=np.int64))[:, 0]
+            pad = int(counts.max())
+            buf = np.zeros((pad, 2))
+            buf[:rows_loc.size, 0], buf[:rows_loc.size, 1] = rows_loc, wc_loc   # (idx < 2^53)
+            allp = self._comm.allgather(buf)
+            rows = np.concatenate([allp[r][:c, 0] for r, c in enumerate(counts)]).astype(np.int64)
+            wrows = np.concatenate([allp[r][:c, 1] for r, c in enumerate(counts)])
+        else:
+            rows, wrows = rows_loc, wc_loc
+        order = wrows.argsort()[::-1]              # the reference's own expression
         winner = idx_star
         for k in order:
             idx = int(rows[k])
-            if width[idx] != w_star or idx > idx_star:
+            if wrows[k] != w_star or idx > idx_star:
                 continue                           # other width / rejected before
             if idx == idx_star:
                 break
