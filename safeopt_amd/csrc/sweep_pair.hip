@@ -262,6 +262,82 @@ __device__ __forceinline__ void dma_group(const DmaPlan& d, int i) {
 // instead (a few register copies at the joins of the slot sequence); since no
 // instance has scratch any more (d >= 7 without registers for the raw rows, kLeanX)
 // all of them take the asm path, and the scanner runs over every one of them.
+// One accumulator slot: the A operands of the NEXT slot are requested first, then the 16
+// (narrow: 4) matrix instructions, then -- half 0 -- a group of the chunk copy.
+template <int S, bool NARROW_OK, int kGroups, bool ASM_MFMA>
+__device__ __forceinline__ void pair_slot_body(bool narrow0, double (&acc)[kWaveSlots][4],
+                                               double& accx, const double* aT,
+                                               const double (&kb)[4][4], const double (&kvn)[4],
+                                               double (&cur)[4], double (&nxt)[4],
+                                               const DmaPlan& dma) {
+  if (S + 1 < kWaveSlots) {
+#if defined(SGP_INSTRUMENT) || defined(PGP_CT_ABL)
+    if (dma.no_a) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) nxt[q] = cur[q];
+    } else
+#endif
+    {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) nxt[q] = aT[((S + 1) * 2 * kSteps + q) * 64];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // The matrix instructions are inline asm: the compiler's hazard recogniser does not
+  // see them.  A VALU write of an operand needs two wait states before an MFMA may read
+  // the register: the wave's FIRST slot -- behind the evaluation and the operand fetch --
+  // opens with s_nop 1.  Between two slots there are LDS reads (s_waitcnt), the chunk
+  // copy and a branch, no VALU instruction: the guard in front of every slot (until
+  // round 5) cost 0.9-1.2 % of the kernel (profiles/r05/experiments.txt, section 8);
+  // scripts/dev/check_mfma_hazards.py (tests/test_abi.py) scans every instance's ISA for
+  // a register copy the compiler might place there after all.
+  if (!ASM_MFMA) {
+    if (NARROW_OK && S == 0 && narrow0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        accx = __builtin_amdgcn_mfma_f64_4x4x4f64(cur[q], kvn[q], accx, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[S][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(cur[q], kb[m][q], acc[S][m], 0, 0, 0);
+      }
+    }
+  } else if (NARROW_OK && S == 0 && narrow0) {
+    // four DEPENDENT MFMAs on one accumulator (4 wait states by hand)
+    asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
+                 : "+v"(accx) : "v"(cur[0]), "v"(kvn[0]));
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+      asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
+                   : "+v"(accx) : "v"(cur[q]), "v"(kvn[q]));
+  } else {
+    if (S == 0)
+      asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0"
+                   : "+v"(acc[S][0]) : "v"(cur[0]), "v"(kb[0][0]));
+    else
+      mfma_acc(acc[S][0], cur[0], kb[0][0]);
+#pragma unroll
+    for (int m = 1; m < 4; ++m) mfma_acc(acc[S][m], cur[0], kb[m][0]);
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) mfma_acc(acc[S][m], cur[q], kb[m][q]);
+    }
+  }
+  if (S + 1 < kWaveSlots)
+    asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
+  if constexpr (kGroups > 0) {
+    constexpr int kEvery = kWaveSlots / kGroups;
+    if (S % kEvery == 0 && S / kEvery < kGroups) dma_group<kGroups>(dma, S / kEvery);
+  }
+}
+
+// (One compare-and-branch per slot.  Branching once per TWO slots -- two copies of a slot
+// body on different paths -- makes the register allocator duplicate the tied accumulators:
+// 430-560 B of scratch in every instance, as with every other second control-flow shape
+// around them; profiles/r05/experiments.txt, section 8.)
 template <int S, bool NARROW_OK, int kGroups, bool ASM_MFMA>
 __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
                                            double (&acc)[kWaveSlots][4], double& accx,
@@ -272,64 +348,8 @@ __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
                                            const DmaPlan& dma) {
   if constexpr (S < kWaveSlots) {
     if (S < nw) {
-      if (S + 1 < kWaveSlots) {
-#if defined(SGP_INSTRUMENT) || defined(PGP_CT_ABL)
-        if (dma.no_a) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) nxt[q] = cur[q];
-        } else
-#endif
-        {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) nxt[q] = aT[((S + 1) * 2 * kSteps + q) * 64];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // The matrix instructions are inline asm: the compiler's hazard recogniser
-      // does not see them.  A register copy it places at the join in front of a
-      // slot (VALU write) needs two wait states before an MFMA may read that
-      // register: every slot opens with s_nop 1.
-      if (!ASM_MFMA) {
-        if (NARROW_OK && S == 0 && narrow0) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            accx = __builtin_amdgcn_mfma_f64_4x4x4f64(cur[q], kvn[q], accx, 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-              acc[S][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(cur[q], kb[m][q], acc[S][m],
-                                                             0, 0, 0);
-          }
-        }
-      } else if (NARROW_OK && S == 0 && narrow0) {
-        // four DEPENDENT MFMAs on one accumulator (4 wait states by hand)
-        asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
-                     : "+v"(accx) : "v"(cur[0]), "v"(kvn[0]));
-#pragma unroll
-        for (int q = 1; q < 4; ++q)
-          asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\ts_nop 4"
-                       : "+v"(accx) : "v"(cur[q]), "v"(kvn[q]));
-      } else {
-        asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0"
-                     : "+v"(acc[S][0]) : "v"(cur[0]), "v"(kb[0][0]));
-#pragma unroll
-        for (int m = 1; m < 4; ++m) mfma_acc(acc[S][m], cur[0], kb[m][0]);
-#pragma unroll
-        for (int q = 1; q < 4; ++q) {
-#pragma unroll
-          for (int m = 0; m < 4; ++m) mfma_acc(acc[S][m], cur[q], kb[m][q]);
-        }
-      }
-      if (S + 1 < kWaveSlots)
-        asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
-      if constexpr (kGroups > 0) {
-        constexpr int kEvery = kWaveSlots / kGroups;
-        if (S % kEvery == 0 && S / kEvery < kGroups) dma_group<kGroups>(dma, S / kEvery);
-      }
-      pair_slots<S + 1, false, kGroups, ASM_MFMA>(nw, false, acc, accx, aT, kb, kvn, nxt,
-                                                  cur, dma);
+      pair_slot_body<S, NARROW_OK, kGroups, ASM_MFMA>(narrow0, acc, accx, aT, kb, kvn, cur, nxt, dma);
+      pair_slots<S + 1, false, kGroups, ASM_MFMA>(nw, false, acc, accx, aT, kb, kvn, nxt, cur, dma);
     }
   }
 }
