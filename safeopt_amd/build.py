@@ -22,7 +22,7 @@ SOURCES = ["api.hip", "sweep.hip", "sweep_pair.hip", "sweep_tiny.hip", "step_sma
 HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "kern_eval.h", "fitness.h",
                                             "small_path.h", "sweep_shared.h",
                                             "sweep_slots.h", "set_order.h",
-                                            "tiny_row.h")] + \
+                                            "tiny_row.h", "sets_front.h")] + \
           [os.path.join(REPO, "include", "safeopt_hip.h")]
 BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
         "-I", os.path.join(REPO, "include"), "-I", CSRC, "-Wall",

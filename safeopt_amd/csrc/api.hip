@@ -14,6 +14,7 @@
 #include <chrono>
 
 #include "common.h"
+#include "sets_front.h"
 #include "small_path.h"
 
 namespace {
@@ -263,6 +264,7 @@ void sgp_destroy(sgp_ctx* ctx) {
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->step_host) (void)hipHostFree(ctx->step_host);
+  if (ctx->sets_host) (void)hipHostFree(ctx->sets_host);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1070,7 +1072,8 @@ static int enqueue_expander(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
                             const double* fmin, int m, const double* xc,
                             const double* mu_c, const double* u_c,
                             double near_frac, int32_t** flags_dev,
-                            const double* top = nullptr, bool staged = false) {
+                            const double* top = nullptr, bool staged = false,
+                            const FrontArgs* fold = nullptr) {
   sgp_ctx* ctx = g->ctx;
   SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
   SGP_CHECK(ctx, m >= 1 && m <= SGP_TOPK, "m = %d not in 1..%d", m, SGP_TOPK);
@@ -1122,7 +1125,7 @@ static int enqueue_expander(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   ops.wstride = wstride;
   ops.m = m;
   for (int i = 0; i < SGP_MAX_GPS; ++i) ops.active[i] = ea.active[i];
-  SGP_TRY(expander_operands_all(ctx, g->gpdev, host, G, d, ops));
+  SGP_TRY(expander_operands_all(ctx, g->gpdev, host, G, d, ops, fold));
   ea.Wpack = dW;
   ea.xc = dxc;
   ea.delta = ddel;
@@ -1451,30 +1454,93 @@ int sgp_grid_sets_fused(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   SGP_TRY(collect_gps(ctx, gps, G, d, ghost));
   ExpanderBufs eb;
   SGP_TRY(expander_bufs(g, ghost, G, &eb));
-  // maximisers -> candidates (+ the first one per workgroup) -> first candidate
-  // of the shard, staged as the operand of the expander test: three launches,
-  // the reductions in between are folded into the consumers
+  // Seven launches and one stream synchronisation: maximisers -> candidates (+ the first
+  // one per workgroup) -> [k_expkt: first candidate of the shard, staged as the operand of
+  // the expander test, AND L^-1 k_c] -> k_expw1 -> pre-filter -> listed rows -> conditional
+  // G mark + M|G arg-max per workgroup.  The reductions in between are folded into the
+  // consumers; the result block and the arg-max partials land in mapped host memory, where
+  // the last level of the arg-max is taken (no final launch, no read-back copy).
+  const int nbp = argmax_marked_blocks(g->N);
+  const size_t need = nres + 8 + 2 * size_t(nbp);
+  const bool zero_copy = need * 8 <= (size_t(4) << 20) && !getenv("SGP_SETS_COPY");
+  if (zero_copy && ctx->sets_cap < need) {
+    if (ctx->sets_host) (void)hipHostFree(ctx->sets_host);
+    ctx->sets_host = nullptr;
+    ctx->sets_cap = 0;
+    void* h = nullptr;
+    const size_t cap = std::max<size_t>(need, 4096);
+    SGP_HIP(ctx, hipHostMalloc(&h, cap * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h, 0, cap * 8);
+    void* dv = nullptr;
+    SGP_HIP(ctx, hipHostGetDevicePointer(&dv, h, 0));
+    ctx->sets_host = static_cast<double*>(h);
+    ctx->sets_dev = static_cast<double*>(dv);
+    ctx->sets_cap = cap;
+  }
+  if (!zero_copy) {
+    // (grids beyond ~2.5e8 rows, or SGP_SETS_COPY=1: the round-4 chain -- final launches
+    // and one read-back copy)
+    SGP_TRY(launch_sets_front_fused(
+        g, max_l, pending ? g->partial : nullptr, g->l0_pending,
+        (resident && !pending) ? g->scal : nullptr, scaling, thr_beta, res,
+        res + nfront + nfl + 2, eb.xc, int((eb.bx + eb.bv) / 8), eb.flags,
+        int(eb.bf / 4)));
+    g->l0_pending = 0;
+    int32_t* dfl = nullptr;
+    SGP_TRY(enqueue_expander(g, gps, G, beta, fmin, 1, nullptr, nullptr, nullptr,
+                             near_frac, &dfl, nullptr, true));
+    SGP_TRY(launch_argmax_marked(
+        g, scaling, fmin, dfl, reinterpret_cast<int64_t*>(res + 4),
+        reinterpret_cast<int*>(res + 5), reinterpret_cast<int32_t*>(res + nfront),
+        res + nfront + nfl, reinterpret_cast<int64_t*>(res + nfront + nfl + 1)));
+    std::vector<double> host(nres);
+    SGP_TRY(sgp_d2h(ctx, host.data(), res, nres * 8));
+    unpack_front(host.data(), d, G, out5, x_top, mean_top, q_top);
+    memcpy(flags, &host[nfront], size_t(G) * 4);
+    *value = host[nfront + nfl];
+    memcpy(gidx, &host[nfront + nfl + 1], 8);
+    if (max_l_out) *max_l_out = resident ? host[nfront + nfl + 2] : max_l;
+    return 0;
+  }
+  double* hres = ctx->sets_host;
+  double* dres = ctx->sets_dev;
+  double* hpart = hres + nres + 8 - (nres & 1);      // (16-byte aligned pairs)
+  double* dpart = dres + (hpart - hres);
+  FrontArgs fold{};
   SGP_TRY(launch_sets_front_fused(
       g, max_l, pending ? g->partial : nullptr, g->l0_pending,
       (resident && !pending) ? g->scal : nullptr, scaling, thr_beta, res,
-      res + nfront + nfl + 2, eb.xc, int((eb.bx + eb.bv) / 8), eb.flags,
-      int(eb.bf / 4)));
+      dres + nfront + nfl + 2, eb.xc, int((eb.bx + eb.bv) / 8), eb.flags,
+      int(eb.bf / 4), &fold));
+  fold.res_host = dres;
   g->l0_pending = 0;
   int32_t* dfl = nullptr;
   SGP_TRY(enqueue_expander(g, gps, G, beta, fmin, 1, nullptr, nullptr, nullptr,
-                           near_frac, &dfl, nullptr, true));
-  // conditional G mark + M|G arg-max + the flags into the result block
+                           near_frac, &dfl, nullptr, true, &fold));
   SGP_TRY(launch_argmax_marked(
       g, scaling, fmin, dfl, reinterpret_cast<int64_t*>(res + 4),
-      reinterpret_cast<int*>(res + 5), reinterpret_cast<int32_t*>(res + nfront),
-      res + nfront + nfl, reinterpret_cast<int64_t*>(res + nfront + nfl + 1)));
-  std::vector<double> host(nres);
-  SGP_TRY(sgp_d2h(ctx, host.data(), res, nres * 8));
-  unpack_front(host.data(), d, G, out5, x_top, mean_top, q_top);
-  memcpy(flags, &host[nfront], size_t(G) * 4);
-  *value = host[nfront + nfl];
-  memcpy(gidx, &host[nfront + nfl + 1], 8);
-  if (max_l_out) *max_l_out = resident ? host[nfront + nfl + 2] : max_l;
+      reinterpret_cast<int*>(res + 5), reinterpret_cast<int32_t*>(dres + nfront),
+      nullptr, nullptr, dpart));
+  SGP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  unpack_front(hres, d, G, out5, x_top, mean_top, q_top);
+  memcpy(flags, &hres[nfront], size_t(G) * 4);
+  {   // np.argmax over the workgroups' results: largest value, first index among equals
+    const int64_t* hidx = reinterpret_cast<const int64_t*>(hpart + nbp);
+    double bv = -INFINITY;
+    int64_t bi = -1;
+    for (int e = 0; e < nbp; ++e) {
+      const int64_t i = hidx[e];
+      if (i < 0) continue;
+      const double v = hpart[e];
+      if (bi < 0 || v > bv || (v == bv && i < bi)) {
+        bv = v;
+        bi = i;
+      }
+    }
+    *value = bv;
+    *gidx = bi;
+  }
+  if (max_l_out) *max_l_out = resident ? hres[nfront + nfl + 2] : max_l;
   return 0;
 }
 

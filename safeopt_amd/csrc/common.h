@@ -164,6 +164,11 @@ struct sgp_ctx {
   // (pinned, mapped, coherent), the last word is a completion counter the host spins on
   double* step_host = nullptr;
   double* step_dev = nullptr;      // the same memory as the device sees it
+  // ... and of the one-rank chain of the large-grid path (sgp_grid_sets_fused): result
+  // block + the per-workgroup results of the last arg-max pass
+  double* sets_host = nullptr;
+  double* sets_dev = nullptr;
+  size_t sets_cap = 0;             // doubles
   uint64_t step_seq = 0;
   // RCCL
   void* comm = nullptr;  // ncclComm_t
@@ -263,9 +268,11 @@ struct ExpanderOps {      // all arrays on the device; [g] blocks as noted
   int m;
   int active[SGP_MAX_GPS];
 };
+struct FrontArgs;   // sets_front.h: the fold of the front half's last step into k_expkt
 // operands of every active GP in three launches (all GPs per launch)
 int expander_operands_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
-                          int G, int d, const ExpanderOps& ops);
+                          int G, int d, const ExpanderOps& ops,
+                          const FrontArgs* fold = nullptr);
 
 // sweep.hip
 struct SweepPoints {
@@ -400,7 +407,10 @@ int launch_sets_front_fused(sgp_grid* g, double max_l, const double* l0_part,
                             int n_l0, const double* max_l_dev,
                             const double* scaling, const double* thr_beta,
                             double* res, double* max_l_slot, double* xc,
-                            int n_xc_resid, int32_t* flags, int n_flag_words);
+                            int n_xc_resid, int32_t* flags, int n_flag_words,
+                            FrontArgs* fold = nullptr);
+int launch_front_final(sgp_ctx* ctx, const FrontArgs& fa);
+int argmax_marked_blocks(int64_t N);
 int launch_merge_front(sgp_grid* g, const double* all, int world, int nfront, double* res,
                        double* xc, int n_xc_resid, int32_t* flags, int n_flag_words);
 int launch_merge_argmax(sgp_ctx* ctx, const double* all, int world, double* out_v,
@@ -408,7 +418,7 @@ int launch_merge_argmax(sgp_ctx* ctx, const double* all, int world, double* out_
 int launch_argmax_marked(sgp_grid* g, const double* scaling, const double* fmin,
                          const int32_t* flags_dev, const int64_t* cand_gidx_dev,
                          const int* nfound_dev, int32_t* flags_out,
-                         double* value_dev, int64_t* idx_dev);
+                         double* value_dev, int64_t* idx_dev, double* host_part = nullptr);
 int launch_fill_cols(sgp_grid* g, const double* c, int nc);
 int launch_gather_rows(sgp_grid* g, const int64_t* lidx_dev, int m, double* x,
                        double* mean, double* var, double* Q);

@@ -14,6 +14,7 @@
 #include "small_path.h"
 
 #include "kern_eval.h"
+#include "sets_front.h"
 
 namespace {
 
@@ -768,16 +769,26 @@ __global__ __launch_bounds__(256) void k_expt(const GpDev* gps, ExpGpSel sel,
 template <int D>
 __global__ __launch_bounds__(256) void k_expkt(const GpDev* gps, ExpGpSel sel,
                                                const double* xc, double* Tt,
-                                               int64_t ldk) {
+                                               int64_t ldk, FrontArgs fa, int g_writer) {
   const int g = blockIdx.y;
   if (!sel.active[g]) return;
   const GpDev& gp = gps[g];
   const int lane = threadIdx.x & 63;
+  double x[D];
+  if (fa.nb > 0) {
+    // one-rank chain: the candidate is not staged yet -- the last step of the front half
+    // runs here (sets_front.h); one workgroup leaves the result block and the staged
+    // operand for the kernels behind this one
+    const int64_t top = front_final_fold(fa, blockIdx.x == 0 && g == g_writer);
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      x[k] = top >= 0 ? fa.pts[int64_t(k) * fa.N + (top - fa.goff)] : 0.0;
+  } else {
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = xc[k];
+  }
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= gp.n) return;
-  double x[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) x[k] = xc[k];
   const double* row = gp.Linv + int64_t(i) * gp.ld;
   double acc = 0.0;
   for (int j = lane; j <= i; j += 64) {
@@ -910,16 +921,24 @@ __global__ __launch_bounds__(512) void k_expw(const GpDev* gps, ExpGpSel sel,
 }  // namespace
 
 int expander_operands_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
-                          int G, int d, const ExpanderOps& ops) {
-  int n_max = 0, np_max = 0;
+                          int G, int d, const ExpanderOps& ops, const FrontArgs* fold) {
+  int n_max = 0, np_max = 0, g_writer = -1;
   ExpGpSel sel{};
+  FrontArgs fa{};
+  if (fold) fa = *fold;
   for (int g = 0; g < G; ++g) {
     sel.active[g] = ops.active[g];
     if (!ops.active[g]) continue;
+    if (g_writer < 0) g_writer = g;
     n_max = std::max(n_max, gps_host[g].n);
     np_max = std::max(np_max, gps_host[g].n_pad);
   }
-  if (n_max == 0) return 0;
+  if (n_max == 0) {
+    // no GP with a constraint: nothing evaluates the candidate, the fold has no host
+    if (fold) return launch_front_final(ctx, *fold);
+    return 0;
+  }
+  SGP_CHECK(ctx, !fold || ops.m == 1, "the front fold goes with one candidate");
   const int64_t ldk = (np_max + 31) / 32 * 32;
   double* buf = static_cast<double*>(
       sgp_scratch(ctx, 3, size_t(2) * G * kMaxRhs * ldk * sizeof(double)));
@@ -930,7 +949,8 @@ int expander_operands_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_h
 #define EXPKT_CASE(DD)                                                        \
   case DD:                                                                    \
     hipLaunchKernelGGL(k_expkt<DD>, dim3((n_max + 3) / 4, G), dim3(256), 0,   \
-                       ctx->stream, gps_dev, sel, ops.xc, Tt, ldk);           \
+                       ctx->stream, gps_dev, sel, ops.xc, Tt, ldk, fa,        \
+                       g_writer);                                             \
     break;
     switch (d) {
       EXPKT_CASE(1) EXPKT_CASE(2) EXPKT_CASE(3) EXPKT_CASE(4)

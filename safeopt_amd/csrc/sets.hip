@@ -7,6 +7,7 @@
 // are bit-exact with the NumPy restatement for identical Q.
 #include "kern_eval.h"
 #include "set_order.h"
+#include "sets_front.h"
 
 namespace {
 
@@ -542,84 +543,11 @@ __global__ __launch_bounds__(T) void k_candidates_f(
 
 // One workgroup: total counts, the first candidate of the whole shard, its row
 // (x, mean, Q) into the result block AND as the operand of the expander test
-// (xc, resid[g * 16] = u_g - mu_g), flags / list counter zeroed.
-__global__ __launch_bounds__(T) void k_front_final(
-    const unsigned* block_counts, const double* best_w, const int64_t* best_i,
-    const unsigned* best_ties, int nb, const double* pts, const double* mean,
-    const double* Q, int64_t N,
-    int d, int G, int64_t goff, double* res, double* xc, int n_xc_resid,
-    int32_t* flags, int n_flag_words) {
-  __shared__ Pair shp[T / 64];
-  __shared__ unsigned long long shc[2][T / 64];
-  __shared__ int64_t top;
-  __shared__ double topw;
-  unsigned long long a = 0, b = 0;
-  Pair best{-INFINITY, -1};
-  for (int e = threadIdx.x; e < nb; e += T) {
-    a += block_counts[2 * e];
-    b += block_counts[2 * e + 1];
-    const Pair p{best_w[e], best_i[e]};
-    if (p.i >= 0 && (best.i < 0 || before_desc(p, best))) best = p;
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    a += __shfl_xor(a, o, 64);
-    b += __shfl_xor(b, o, 64);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    shc[0][threadIdx.x >> 6] = a;
-    shc[1][threadIdx.x >> 6] = b;
-  }
-  const Pair win = block_best<false>(best, shp);     // (syncs)
-  for (int e = threadIdx.x; e < n_xc_resid; e += T) xc[e] = 0.0;
-  for (int e = threadIdx.x; e < n_flag_words; e += T) flags[e] = 0;
-  if (threadIdx.x == 0) {
-    unsigned long long ta = 0, tb = 0;
-    for (int wv = 0; wv < T / 64; ++wv) {
-      ta += shc[0][wv];
-      tb += shc[1][wv];
-    }
-    reinterpret_cast<unsigned long long*>(res)[1] = ta;
-    reinterpret_cast<unsigned long long*>(res)[2] = tb;
-    res[3] = win.v;
-    reinterpret_cast<int64_t*>(res)[4] = win.i;
-    reinterpret_cast<int*>(res + 5)[0] = win.i >= 0 ? 1 : 0;
-    top = win.i;
-    topw = win.v;
-  }
-  __syncthreads();
-  if (top < 0) {
-    if (threadIdx.x == 0) reinterpret_cast<int*>(res + 5)[1] = 0;
-    return;
-  }
-  {   // candidates of the whole shard that share the first one's width
-    unsigned nt = 0;
-    for (int e = threadIdx.x; e < nb; e += T)
-      if (best_i[e] >= 0 && best_w[e] == topw) nt += best_ties[e];
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) nt += __shfl_xor(nt, o, 64);
-    if ((threadIdx.x & 63) == 0) shc[0][threadIdx.x >> 6] = nt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned t = 0;
-      for (int wv = 0; wv < T / 64; ++wv) t += unsigned(shc[0][wv]);
-      reinterpret_cast<int*>(res + 5)[1] = int(t);
-    }
-  }
-  const int64_t li = top - goff;
-  double* resid = xc + (n_xc_resid - G * 16);   // the block is xc | resid[G][16]
-  for (int k = threadIdx.x; k < d; k += T) {
-    const double v = pts[int64_t(k) * N + li];
-    res[6 + k] = v;
-    xc[k] = v;
-  }
-  for (int g = threadIdx.x; g < G; g += T) {
-    const double mu = mean[int64_t(g) * N + li];
-    const double up = Q[li * 2 * G + 2 * g + 1];
-    res[6 + d + g] = mu;
-    resid[g * 16] = up - mu;
-  }
-  for (int q = threadIdx.x; q < 2 * G; q += T) res[6 + d + G + q] = Q[li * 2 * G + q];
+// (xc, resid[g * 16] = u_g - mu_g), flags / list counter zeroed: front_final_fold
+// (sets_front.h) as a launch of its own -- N ranks, or no GP with a constraint; the
+// one-rank chain runs it at the top of k_expkt instead.
+__global__ __launch_bounds__(T) void k_front_final(FrontArgs a) {
+  front_final_fold(a, true);
 }
 
 // M | G arg-max of max_i (u_i - l_i) / scaling_i with the conditional G mark of
@@ -628,8 +556,12 @@ __global__ __launch_bounds__(T) void k_front_final(
 __global__ __launch_bounds__(T) void k_argmax_marked(
     const double* Q, const uint8_t* M, uint8_t* Gm, int64_t N, int G,
     int64_t goff, Vec8 scaling, Vec8 fmin, const int32_t* flags,
-    const int64_t* cand_gidx, const int* nfound, double* out_v, int64_t* out_i) {
+    const int64_t* cand_gidx, const int* nfound, double* out_v, int64_t* out_i,
+    int32_t* flags_out) {
   __shared__ Pair sh[T / 64];
+  // (one-rank chain: the partial results go to mapped host memory, where the host takes
+  // the last level -- no final launch, no read-back copy -- and the flags with them)
+  if (flags_out && blockIdx.x == 0 && threadIdx.x < G) flags_out[threadIdx.x] = flags[threadIdx.x];
   int64_t lmark = -1;
   if (*nfound > 0) {
     bool ok = true, any = false;
@@ -973,7 +905,8 @@ int launch_sets_front_fused(sgp_grid* g, double max_l, const double* l0_part,
                             int n_l0, const double* max_l_dev,
                             const double* scaling, const double* thr_beta,
                             double* res, double* max_l_slot, double* xc,
-                            int n_xc_resid, int32_t* flags, int n_flag_words) {
+                            int n_xc_resid, int32_t* flags, int n_flag_words,
+                            FrontArgs* fold) {
   sgp_ctx* ctx = g->ctx;
   const unsigned nb = front_blocks(g->N);
   // scratch: width partials | block counts | block bests
@@ -992,19 +925,59 @@ int launch_sets_front_fused(sgp_grid* g, double max_l, const double* l0_part,
                      g->S, g->M, g->N, g->G, wpart, int(nb),
                      vec8(scaling, g->G, 1.0), vec8(thr_beta, g->G, 0.0), g->goff,
                      g->cand, g->w, g->Gm, bc, bw, bi, bt, res);
-  hipLaunchKernelGGL(k_front_final, dim3(1), dim3(T), 0, ctx->stream, bc, bw, bi,
-                     bt, int(nb), g->pts, g->mean, g->Q, g->N, g->d, g->G, g->goff,
-                     res, xc, n_xc_resid, flags, n_flag_words);
+  FrontArgs fa{};
+  fa.block_counts = bc;
+  fa.best_w = bw;
+  fa.best_i = bi;
+  fa.best_ties = bt;
+  fa.nb = int(nb);
+  fa.pts = g->pts;
+  fa.mean = g->mean;
+  fa.Q = g->Q;
+  fa.N = g->N;
+  fa.goff = g->goff;
+  fa.d = g->d;
+  fa.G = g->G;
+  fa.res = res;
+  fa.res_host = nullptr;
+  fa.xc = xc;
+  fa.n_xc_resid = n_xc_resid;
+  fa.flags = flags;
+  fa.n_flag_words = n_flag_words;
+  if (fold)
+    *fold = fa;      // (the caller's next kernel -- or launch_front_final -- takes it from here)
+  else
+    hipLaunchKernelGGL(k_front_final, dim3(1), dim3(T), 0, ctx->stream, fa);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }
 
+int launch_front_final(sgp_ctx* ctx, const FrontArgs& fa) {
+  hipLaunchKernelGGL(k_front_final, dim3(1), dim3(T), 0, ctx->stream, fa);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int argmax_marked_blocks(int64_t N) { return int(nblk(N, T * 4)); }
+
+// `host_part`: [nb] values | [nb] indices in mapped host memory and `flags_out` next to
+// them -- the last level is the host's (sgp_grid_sets_fused); else a final launch leaves
+// value / index / flags on the device.
 int launch_argmax_marked(sgp_grid* g, const double* scaling, const double* fmin,
                          const int32_t* flags_dev, const int64_t* cand_gidx_dev,
                          const int* nfound_dev, int32_t* flags_out,
-                         double* value_dev, int64_t* idx_dev) {
+                         double* value_dev, int64_t* idx_dev, double* host_part) {
   sgp_ctx* ctx = g->ctx;
   const unsigned nb = nblk(g->N, T * 4);
+  if (host_part) {
+    hipLaunchKernelGGL(k_argmax_marked, dim3(nb), dim3(T), 0, ctx->stream, g->Q,
+                       g->M, g->Gm, g->N, g->G, g->goff, vec8(scaling, g->G, 1.0),
+                       vec8(fmin, g->G, -INFINITY), flags_dev, cand_gidx_dev,
+                       nfound_dev, host_part, reinterpret_cast<int64_t*>(host_part + nb),
+                       flags_out);
+    SGP_HIP(ctx, hipGetLastError());
+    return 0;
+  }
   double* pv = static_cast<double*>(
       sgp_scratch(ctx, 2, size_t(nb) * (sizeof(double) + sizeof(int64_t))));
   if (!pv) return -1;
@@ -1012,7 +985,7 @@ int launch_argmax_marked(sgp_grid* g, const double* scaling, const double* fmin,
   hipLaunchKernelGGL(k_argmax_marked, dim3(nb), dim3(T), 0, ctx->stream, g->Q,
                      g->M, g->Gm, g->N, g->G, g->goff, vec8(scaling, g->G, 1.0),
                      vec8(fmin, g->G, -INFINITY), flags_dev, cand_gidx_dev,
-                     nfound_dev, pv, pi);
+                     nfound_dev, pv, pi, static_cast<int32_t*>(nullptr));
   hipLaunchKernelGGL(k_argmax_final_f, dim3(1), dim3(T), 0, ctx->stream, pv, pi,
                      int64_t(nb), flags_dev, g->G, flags_out, value_dev, idx_dev);
   SGP_HIP(ctx, hipGetLastError());

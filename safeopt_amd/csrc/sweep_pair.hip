@@ -291,6 +291,13 @@ __device__ __forceinline__ void pair_slot_body(bool narrow0, double (&acc)[kWave
   // round 5) cost 0.9-1.2 % of the kernel (profiles/r05/experiments.txt, section 8);
   // scripts/dev/check_mfma_hazards.py (tests/test_abi.py) scans every instance's ISA for
   // a register copy the compiler might place there after all.
+  // One asm statement per MFMA, on purpose: an accumulator is the addend again four
+  // instructions later and needs 4 wait states -- three MFMAs and ONE more instruction.
+  // The compiler supplies it (its hazard recogniser treats every inline asm as a
+  // destination-forwarding producer and does not count asm statements as wait states:
+  // an s_nop 0, or the slot's s_cmp, lands in front of MFMAs 5, 9 and 13), the scanner
+  // checks it.  All 16 in one statement: no nops, two register copies per slot instead,
+  // +5.8 % (profiles/r05/experiments.txt, section 9).
   if (!ASM_MFMA) {
     if (NARROW_OK && S == 0 && narrow0) {
 #pragma unroll

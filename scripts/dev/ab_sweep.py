@@ -22,8 +22,8 @@ def run(k, reps):
     ctx.set_share(os.environ.get("AB_SHARE", "0") == "1")   # headline: every GP on its own
     cfg = bench.make_config(k)
     gps = bench.build_gps(cfg, gpy)
-    devs = [g._fitted() for g in gps]
-    G = cfg["G"]
+    G = int(os.environ.get("AB_G", cfg["G"]))     # AB_G=1: the first GP only
+    devs = [g._fitted() for g in gps[:G]]
     fmin = np.zeros(G)
     out = {}
     if k == 5:
