@@ -1,6 +1,6 @@
 """Build libsafeopt_hip.so (hipcc, gfx950 only) in-tree.
 
-    python -m safeopt_amd.build [--force] [--verbose]
+    python -m safeopt_amd.build [--force] [--verbose] [--scan]
 
 The library is the whole device side of the product: hand-written HIP kernels
 plus the C ABI declared in include/safeopt_hip.h.  hipcc cross-compiles for
@@ -49,7 +49,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, scan=False):
     hipcc = _hipcc()
     objs, jobs = [], []
     for src in SOURCES:
@@ -72,6 +72,20 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     if jobs or force or _stale(OUT, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"])
+    # The sweep kernels keep state in hand-assigned registers across inline-asm matrix
+    # instructions the compiler does not look into: with flags other than the shipped
+    # ones (SGP_HIPCC_FLAGS), or on request (--scan / SGP_BUILD_SCAN=1), the ISA of every
+    # instance is scanned for hazards, stray AccVGPRs and spills before the library is
+    # handed out (tests/test_abi.py runs the same scan over the shipped sources).
+    if scan or USER or os.environ.get("SGP_BUILD_SCAN") == "1":
+        import importlib.util
+        spec = importlib.util.spec_from_file_location(
+            "check_mfma_hazards", os.path.join(REPO, "scripts", "dev", "check_mfma_hazards.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if mod.main(list(USER)):
+            raise RuntimeError("ISA scan of the sweep kernels failed (scripts/dev/"
+                               "check_mfma_hazards.py): the library must not be used")
     # test harness for the device-side merges of the N-rank step (tests/native): its own
     # translation unit around csrc/sets.hip, linked against the library for the rest
     hs = os.path.join(REPO, "tests", "native", "merge_check.hip")
@@ -84,4 +98,5 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv,
+                scan="--scan" in sys.argv))

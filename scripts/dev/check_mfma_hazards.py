@@ -9,6 +9,7 @@ go unpadded (wait states as in LLVM's GCNHazardRecognizer for gfx90a+ DGEMM 4x4)
   R3  MFMA write of a VGPR -> VMEM / LDS / FLAT reads it needs 9  (e.g. a SPILL of
       an accumulator right behind the slot sequence)
   R4  MFMA write -> MFMA reads it as SrcC                needs 4
+  A2  a scratch access (spill) in an instance of either sweep kernel
   A1  (k_sweep only) an AccVGPR named by an instruction outside the inline asm
       blocks: the accumulators live in hand-assigned AccVGPRs (csrc/sweep_slots.h)
 
@@ -24,7 +25,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "safeopt_amd", "csrc")
-NEED = {"R1": 2, "R2": 6, "R3": 9, "R4": 4, "A1": 0}
+NEED = {"R1": 2, "R2": 6, "R3": 9, "R4": 4, "A1": 0, "A2": 0}
 COUNT = {}
 HORIZON = 10
 
@@ -113,6 +114,11 @@ def scan(asm, verbose=True):
         if not in_asm and "k_sweepI" in func and (
                 "accvgpr" in op or any(r[0] == "a" for a in args for r in regs(a))):
             bad.append((func, "A1", 0, "(compiler-generated)", t))
+        # A2: ... and no instance of either sweep may spill: a scratch access between the
+        # asm statements is a register copy the hazard rules below would have to know
+        # about (round 3, finding (b)), and costs 5 x in the stage loop besides
+        if op.startswith("scratch_") and ("k_sweepI" in func or "k_sweep_pairI" in func):
+            bad.append((func, "A2", 0, "(spill)", t))
         is_mfma = op.startswith("v_mfma") and in_asm
         is_valu = op.startswith("v_") and not op.startswith("v_mfma")
         is_mem = op.startswith(("ds_", "global_", "scratch_", "flat_", "buffer_"))
