@@ -299,12 +299,13 @@ class Context(object):
 
     def set_sweep(self, which):
         """Posterior-sweep kernel: 'auto' | 'classic' (4 waves) | 'pair' (paired
-        waves), '-nosplit' appended: remainder tiles are not cut into runs of
+        waves) | 'mid' (= auto: the resident-factor kernel where it applies, which
+        'classic' and 'pair' switch off), '-nosplit' appended: remainder tiles are not cut into runs of
         chunks, '-notables': no factor tables on tensor grids (set_axes), '-streamed':
         small factors go through the 4-wave kernel's double buffer instead of staying
         in LDS for the launch; or the integer of sgp_ctx_set_sweep.  Returns the
         previous setting (a name)."""
-        names = ("auto", "classic", "pair", None, "auto-nosplit", "classic-nosplit",
+        names = ("auto", "classic", "pair", "mid", "auto-nosplit", "classic-nosplit",
                  "pair-nosplit", None)
         names = names + tuple(n + "-notables" if n else None for n in names)
         names = names + tuple(n + "-streamed" if n else None for n in names)
@@ -314,13 +315,14 @@ class Context(object):
 
         old = names[int(lib().sgp_ctx_set_sweep(self.h, code(which)))]
         #: a sweep kernel is forced (A/B runs, tests): no one-launch step of small grids
-        self.sweep_forced = (code(which) & 3) != 0
+        self.sweep_forced = (code(which) & 3) in (1, 2)
         return old
 
     def last_sweep(self):
-        """Kernel of the last posterior sweep: 'classic' | 'pair' | 'tiny' | 'few-points'."""
+        """Kernel of the last posterior sweep: 'classic' | 'pair' | 'tiny' | 'few-points' |
+        'step-small' | 'mid'."""
         return (None, "classic", "pair", "tiny", "few-points",
-                "step-small")[int(lib().sgp_ctx_last_sweep(self.h))]
+                "step-small", "mid")[int(lib().sgp_ctx_last_sweep(self.h))]
 
     # -- RCCL
     @staticmethod

@@ -17,7 +17,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libsafeopt_hip.so")
-SOURCES = ["api.hip", "sweep.hip", "sweep_pair.hip", "sweep_tiny.hip", "step_small.hip",
+SOURCES = ["api.hip", "sweep.hip", "sweep_pair.hip", "sweep_mid.hip", "sweep_tiny.hip",
+           "step_small.hip",
            "factor.hip", "sets.hip", "swarm.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "kern_eval.h", "fitness.h",
                                             "small_path.h", "sweep_shared.h",

@@ -156,7 +156,7 @@ struct sgp_ctx {
   DevBuf pair_split;                     // per-lane partial sums of split remainder tiles
   DevBuf pair_post;                      // [G][P] mean | var of a swarm (sweep_pair.hip)
   int sweep_partials = 0;     // partials of max l0[S] the last confidence sweep left
-  int sweep_choice = 0;       // sgp_ctx_set_sweep: 0 auto, 1 4-wave, 2 paired
+  int sweep_choice = 0;       // sgp_ctx_set_sweep: 0 auto, 1 4-wave, 2 paired, 3 auto (mid kernel asked for)
   int last_sweep = 0;         // kernel of the last posterior sweep (sgp_ctx_last_sweep)
   int share_factors = 1;      // sgp_ctx_set_share: GPs with identical (X, kernel, noise)
                               // share the variance contraction (paired sweep)
@@ -360,6 +360,9 @@ int launch_rank1(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d,
 // 48 observations)?
 bool tiny_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff, int64_t rows,
                        bool rows_sharded);
+
+// sweep_mid.hip: 49 .. 128 observations, single-part kernels, d <= 4, all GPs resident in LDS
+bool mid_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff, int d);
 
 // sweep_pair.hip: does the launch take the paired-wave kernel (a GP with more than 256 rows)?
 bool pair_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff);

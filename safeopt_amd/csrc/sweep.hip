@@ -205,28 +205,7 @@ constexpr int kSweepRide = 2;      // riders per leader (what two workgroups' LD
 // Accumulator component m of a slot holds rows 4((l>>2)&3) + (l>>4), column
 // 4m + (l&3).
 
-// Covariance values of a stage -> B operands.  Lane (k, c) = (l >> 4, l & 15)
-// holds kv[q] = k(X_{4q+k}, x_c); operand (q, m) of lane (k, a, j) is kv[q] of
-// lane (k, m, j).  Through a wave-private LDS buffer laid out [k][c][q]: two
-// 16-byte stores and eight 16-byte loads per lane (LDS instructions of one wave
-// execute in order; no barrier).
-template <int kKbRow>
-__device__ __forceinline__ void broadcast_quads(const double (&kv)[4], double* kbw,
-                                                int lane, double (&kb)[4][4]) {
-  double2_t* w = reinterpret_cast<double2_t*>(kbw + (lane >> 4) * kKbRow +
-                                              (lane & 15) * 4);
-  w[0] = double2_t{kv[0], kv[1]};
-  w[1] = double2_t{kv[2], kv[3]};
-  __builtin_amdgcn_wave_barrier();
-  const double2_t* r = reinterpret_cast<const double2_t*>(
-      kbw + (lane >> 4) * kKbRow + (lane & 3) * 4);
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const double2_t a = r[m * 8], b = r[m * 8 + 1];
-    kb[m][0] = a.x; kb[m][1] = a.y; kb[m][2] = b.x; kb[m][3] = b.y;
-  }
-  __builtin_amdgcn_wave_barrier();
-}
+// (broadcast_quads: sweep_shared.h)
 
 // A operands of one slot: the 4 k-steps of the staged j-block.
 __device__ __forceinline__ void load_slot(double (&ops)[4], const double* aT,
@@ -1402,14 +1381,20 @@ int launch_sweep(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d,
   return launch_fitness_small(ctx, p.G, p.pts.N, q.conf.mean, q.conf.var, p.fit);
 }
 
-// The confidence sweep proper: the paired-wave kernel from 257 rows of L^-1 on,
-// the 4-wave kernel below, the VALU kernel (sweep_tiny.hip) up to 32 observations.
+// The confidence sweep proper: the paired-wave kernel from 257 rows of L^-1 on, the 4-wave
+// kernel below, the resident-factor kernel (sweep_mid.hip) for 49 .. 128 observations of
+// single-part kernels, the VALU kernel (sweep_tiny.hip) up to 48 observations.
 int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d, int Geff,
                      double flops, const SepLaunch* sep, bool rows_sharded) {
   if (tiny_sweep_wanted(ctx, gh, Geff, p.pts.N, rows_sharded)) {
     ctx->last_sweep = 3;
     SweepArgs a{p.gps, p.G, p.mode, p.pts, p.conf, p.fit};
     return launch_sweep_tiny(ctx, a, gh, d, Geff, flops);    // (sets ctx->sweep_partials)
+  }
+  if (mid_sweep_wanted(ctx, gh, Geff, d)) {
+    ctx->last_sweep = 6;
+    SweepArgs a{p.gps, p.G, p.mode, p.pts, p.conf, p.fit};
+    return launch_sweep_mid(ctx, a, gh, d, Geff, flops, sep);   // (sets ctx->sweep_partials)
   }
   if (pair_sweep_wanted(ctx, gh, Geff)) {
     ctx->last_sweep = 2;

@@ -43,6 +43,67 @@ struct SweepTimer {
   }
 };
 
+// (operand maps of v_mfma_f64_4x4x4_4b_f64: sweep.hip, "matrix part")
+// Covariance values of a stage -> B operands.  Lane (k, c) = (l >> 4, l & 15)
+// holds kv[q] = k(X_{4q+k}, x_c); operand (q, m) of lane (k, a, j) is kv[q] of
+// lane (k, m, j).  Through a wave-private LDS buffer laid out [k][c][q]: two
+// 16-byte stores and eight 16-byte loads per lane (LDS instructions of one wave
+// execute in order; no barrier).
+template <int kKbRow>
+__device__ __forceinline__ void broadcast_quads(const double (&kv)[4], double* kbw,
+                                                int lane, double (&kb)[4][4]) {
+  double2_t* w = reinterpret_cast<double2_t*>(kbw + (lane >> 4) * kKbRow +
+                                              (lane & 15) * 4);
+  w[0] = double2_t{kv[0], kv[1]};
+  w[1] = double2_t{kv[2], kv[3]};
+  __builtin_amdgcn_wave_barrier();
+  const double2_t* r = reinterpret_cast<const double2_t*>(
+      kbw + (lane >> 4) * kKbRow + (lane & 3) * 4);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const double2_t a = r[m * 8], b = r[m * 8 + 1];
+    kb[m][0] = a.x; kb[m][1] = a.y; kb[m][2] = b.x; kb[m][3] = b.y;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Lane exchanges without the LDS (gfx950; semantics probed, scripts/dev/probe_dpp... in
+// profiles/r05/experiments.txt, section 14): a row rotation by DPP -- lane i of a 16-lane
+// row receives lane (i - n) mod 16 -- and the row / half swaps of v_permlane16_swap /
+// v_permlane32_swap.  One or two VALU instructions per dword instead of a ds_bpermute
+// round trip (~100 cycles of latency, two LDS instructions per double).
+template <int ROR>
+__device__ __forceinline__ double row_ror(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + ROR, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + ROR, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// what lane l ^ 4 / l ^ 8 holds in `v` (bit2: (l & 4) != 0)
+__device__ __forceinline__ double take_xor4(double v, bool bit2) {
+  const double up = row_ror<4>(v), down = row_ror<12>(v);   // from l - 4, from l + 4
+  return bit2 ? up : down;
+}
+__device__ __forceinline__ double take_xor8(double v) { return row_ror<8>(v); }
+// v + (v of lane l ^ 16), v + (v of lane l ^ 32); together = sum_lane_groups, same order
+__device__ __forceinline__ double add_xor16(double v) {
+  const unsigned lo = unsigned(__double2loint(v)), hi = unsigned(__double2hiint(v));
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double even = __hiloint2double(int(b[0]), int(a[0])), odd = __hiloint2double(int(b[1]), int(a[1]));
+  // (even: rows 0 0 2 2 of v, odd: rows 1 1 3 3; the lane's own value first, as v + shfl(v))
+  const bool own_even = (threadIdx.x & 16) == 0;
+  return own_even ? even + odd : odd + even;
+}
+__device__ __forceinline__ double add_xor32(double v) {
+  const unsigned lo = unsigned(__double2loint(v)), hi = unsigned(__double2hiint(v));
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const double low = __hiloint2double(int(b[0]), int(a[0])), high = __hiloint2double(int(b[1]), int(a[1]));
+  const bool own_low = (threadIdx.x & 32) == 0;
+  return own_low ? low + high : high + low;
+}
+__device__ __forceinline__ double sum_lane_groups_valu(double v) { return add_xor32(add_xor16(v)); }
+
 // MFMA with the accumulator tied to destination AND addend (the builtin lets the
 // register allocator rename the destination, which costs v_mov_b64 copies at every
 // join of a guarded slot sequence).
@@ -128,5 +189,8 @@ int launch_sweep_tiny(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d, 
 // sweep_pair.hip
 bool pair_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff);
 int pair_sweep_partials(const sgp_ctx* ctx, int64_t N);
+// sweep_mid.hip: the resident-factor kernel for 49 .. 128 observations (mid_sweep_wanted)
+int launch_sweep_mid(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d, int Geff,
+                     double flops, const SepLaunch* sep);
 int launch_sweep_pair(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d,
                       int Geff, double flops, const SepLaunch* sep);

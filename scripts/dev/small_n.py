@@ -20,7 +20,7 @@ import bench  # noqa: E402
 import safeopt_amd.gpy as gpy  # noqa: E402
 from safeopt_amd import _hip  # noqa: E402
 
-ns = [int(a) for a in sys.argv[1:]] or [8, 20, 32, 64, 128, 200, 256]
+ns = [int(a) for a in sys.argv[1:]] or [8, 20, 32, 64, 96, 128, 200, 256]
 ctx = _hip.Context.default()
 ctx.set_share(False)
 cfg = bench.make_config(2)
@@ -33,6 +33,8 @@ for n in ns:
     X = rng.uniform(-2, 2, size=(n, 2))
     Y = (bench._bumps(X, 3) - bench._bumps(X, 3).min() + 0.5)[:, None]
     cases = [("RBF", True, "auto"), ("RBF", False, "auto"), ("Matern52", False, "auto")]
+    if 48 < n <= 128:    # auto = the resident-factor kernel (sweep_mid.hip); the 4-wave kernel next to it
+        cases = cases + [("RBF", True, "classic"), ("RBF", False, "classic"), ("Matern52", False, "classic")]
     if n <= 48:      # auto = the VALU kernel (sweep_tiny.hip); the matrix-core kernel next to it
         cases = [("RBF", False, "auto"), ("Matern52", False, "auto"), ("RBF", True, "classic"),
                  ("RBF", False, "classic"), ("Matern52", False, "classic")]

@@ -551,12 +551,111 @@ def test_few_observations_valu_kernel(mods, kind, d, ns, N):
         many = rng.uniform(-3, 3, size=(1536 * ns[0], d))
         gps[0].predict_noiseless(many)
         assert ctx.last_sweep() == "tiny"
-    # from 49 observations on the matrix-core kernels take over
+    # from 49 observations on the matrix-core kernels take over: the resident-factor kernel
+    # (sweep_mid.hip) for single-part kernels up to d = 4, the 4-wave kernel otherwise
     X = rng.uniform(-2, 2, size=(49, d)); Y = smooth(X, 3) + 0.3
     big = gpy.models.GPRegression(X, Y, kern(gpy.kern), noise_var=0.05 ** 2)
     g1 = _hip.DeviceGrid(ctx, pts, 1)
     g1.confidence([big._fitted()], 2.0, np.zeros(1))
-    assert ctx.last_sweep() == "classic"
+    assert ctx.last_sweep() == ("mid" if (d <= 4 and kind != "RBF*RBF") else "classic")
+
+
+@pytest.mark.parametrize("kind,d,ns,N,layout,grid", [
+    ("RBF", 2, [64], 64 * 520 + 3, "a", True), ("Matern52", 2, [49], 5000, "a", False),
+    ("Matern32", 3, [80, 64, 50], 9000, "abc", False), ("RBF", 1, [100], 3000, "a", True),
+    ("RBF", 4, [128], 4000, "a", False), ("Matern52", 2, [96], 20001, "aa", False),
+    ("RBF", 2, [72], 5, "aab", False), ("RBF", 3, [112], 17 * 19 * 23, "a", True),
+    ("Matern52", 1, [128], 777, "a", False), ("RBF", 2, [60], 16 * 12 * 256 + 16, "aaa", True)])
+def test_resident_factor_kernel_49_to_128(mods, kind, d, ns, N, layout, grid):
+    """49 .. 128 observations, single-part kernels, d <= 4: the resident-factor kernel
+    (csrc/sweep_mid.hip; the whole L^-1 of every GP in LDS, straight-line j-block / row-block
+    nest, three waves per SIMD).  Posterior against the oracle and against the 4-wave kernel
+    (another summation order: 1e-12), Q = mean -+ beta sd exactly, S and max l0 from Q; GPs
+    with a shared factor (same bits as swept on their own), factor tables on tensor grids,
+    ragged row counts, and the posterior of a prefix of the rows = the prefix of the
+    posterior (the kernel is chosen by the GPs alone)."""
+    sa, gpy, gpn, son = mods
+    from safeopt_amd import _hip
+    rng = np.random.default_rng(N + 7 * d + sum(ns))
+    groups = {}
+    gps, gos = [], []
+    for i, c in enumerate(layout):
+        if c not in groups:
+            n = ns[len(groups) % len(ns)]
+            groups[c] = rng.uniform(-2, 2, size=(n, d))
+        X = groups[c]
+        Y = smooth(X, 5 + i) + 0.3
+        gps.append(gpy.models.GPRegression(X, Y, kernels(gpy.kern, kind, d), noise_var=0.05 ** 2))
+        gos.append(gpn.GPRegression(X, Y, kernels(gpn, kind, d), noise_var=0.05 ** 2))
+    if grid:
+        side = max(2, int(round(N ** (1.0 / d))))
+        pts = sa.linearly_spaced_combinations([(-3., 3.)] * d, [side + k for k in range(d)])
+    else:
+        pts = rng.uniform(-3, 3, size=(N, d))
+    G = len(layout)
+    fmin = np.where(np.arange(G) % 3 == 2, -np.inf, 0.1)
+    ctx = gps[0]._fitted().ctx
+    out = {}
+    old = ctx.set_sweep("auto")
+    old_share = ctx.set_share(True)
+    try:
+        for which, share, tables in (("auto", True, grid), ("auto", False, False), ("classic", False, False)):
+            ctx.set_sweep(which)
+            ctx.set_share(share)
+            g = _hip.DeviceGrid(ctx, pts, G)
+            if tables:
+                assert g.set_axes(_hip.tensor_grid_axes(pts))
+            ml = g.confidence([gp._fitted() for gp in gps], 2.0, fmin)
+            assert ctx.last_sweep() == ("mid" if which == "auto" else "classic")
+            out[(which, share)] = (ml, g.download(_hip.Q), g.download(_hip.S),
+                                   g.download(_hip.MEAN), g.download(_hip.VAR))
+    finally:
+        ctx.set_sweep(old)
+        ctx.set_share(old_share)
+    (max_l, any_safe), Q, S, mean, var = out[("auto", True)]
+    own = out[("auto", False)]
+    if not (grid and kind == "RBF"):
+        # the shared factor: same bits as every GP swept on its own (factor tables: their
+        # covariances are products of table entries, another rounding -- 1e-12 below)
+        for x, y in zip(out[("auto", True)][1:], own[1:]):
+            assert_array_equal(x, y)
+    sel = rng.choice(pts.shape[0], size=min(400, pts.shape[0]), replace=False)
+    for i, go in enumerate(gos):
+        kd = float(gps[i].kern.Kdiag(np.zeros((1, d)))[0])
+        mo, vo = go.predict_noiseless(pts[sel])
+        check_posterior(mean[i][sel, None], var[i][sel, None], mo, vo, kd)
+        sd = np.sqrt(var[i])
+        assert_array_equal(Q[:, 2 * i], mean[i] - 2.0 * sd)
+        assert_array_equal(Q[:, 2 * i + 1], mean[i] + 2.0 * sd)
+        for other in (own, out[("classic", False)]):
+            assert_allclose(mean[i], other[3][i], rtol=0, atol=1e-11 * max(1.0, np.abs(mo).max()))
+            assert_allclose(var[i], other[4][i], rtol=0, atol=1e-11 * kd)
+    assert_array_equal(S, np.all(Q[:, ::2] > fmin, axis=1))
+    assert any_safe == bool(S.any())
+    if S.any():
+        assert max_l == Q[S, 0].max()
+    # a prefix of the rows, handed over per call: the same kernel, the same bits
+    k = min(pts.shape[0], 37)
+    ctx.set_share(False)
+    try:
+        m_all, v_all = gps[0].predict_noiseless(pts)
+        k_all = ctx.last_sweep()
+        m_few, v_few = gps[0].predict_noiseless(pts[:k])
+        k_few = ctx.last_sweep()
+    finally:
+        ctx.set_share(old_share)
+    # (point sets of a few thousand rows against 100+ observations go chip-wide, factor.hip
+    # "few-points": by the GP and the row count of the CALL -- test_predict_of_a_prefix_of_
+    # the_points pins that path; here the sweep kernel)
+    assert k_few in ("mid", "few-points") and k_all in ("mid", "few-points")
+    if k_all == k_few == "mid":
+        assert_array_equal(m_few, m_all[:k])
+        assert_array_equal(v_few, v_all[:k])
+        assert_array_equal(m_all[:, 0], own[3][0])
+    else:
+        kd = float(gps[0].kern.Kdiag(np.zeros((1, d)))[0])
+        assert_allclose(m_few, m_all[:k], rtol=0, atol=1e-11 * max(1.0, np.abs(m_all).max()))
+        assert_allclose(v_few, v_all[:k], rtol=0, atol=1e-11 * kd)
 
 
 @pytest.mark.parametrize("kind,d,ns,N,grid", [("RBF", 2, [1], 700, False), ("Matern52", 2, [20], 40000, False),
