@@ -665,9 +665,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
       // and xor-8 exchanges each lane holds the quad of its OWN column
       // (lane & 15) = 4 ((lane >> 2) & 3) + (lane & 3).
       const bool a0 = (lane & 4) != 0, a1 = (lane & 8) != 0;
-      const double v0 = (a0 ? sq[1] : sq[0]) + __shfl_xor(a0 ? sq[0] : sq[1], 4, 64);
-      const double v1 = (a0 ? sq[3] : sq[2]) + __shfl_xor(a0 ? sq[2] : sq[3], 4, 64);
-      double t = (a1 ? v1 : v0) + __shfl_xor(a1 ? v0 : v1, 8, 64);
+      // (exchanges by DPP row rotations, the lane-group sums below by permlane swaps --
+      // sweep_shared.h: same values in the same order as the ds_bpermute forms, without
+      // their LDS round trips on the tile's critical path)
+      const double v0 = (a0 ? sq[1] : sq[0]) + take_xor4(a0 ? sq[0] : sq[1], a0);
+      const double v1 = (a0 ? sq[3] : sq[2]) + take_xor4(a0 ? sq[2] : sq[3], a0);
+      double t = (a1 ? v1 : v0) + take_xor8(a1 ? v0 : v1);
       // (the narrow groups: rows l >> 4 of the group, point l & 15 already)
 #pragma unroll
       for (int g = 0; g < kMaxNg; ++g) {
@@ -679,8 +682,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
 
     if ((wcur & SW_GP_END) && !SGP_ABL(32)) {
       // ... then the 4 k-rows
-      const double sumsq = sum_lane_groups(ssq_run);
-      const double mu = sum_lane_groups(mean);
+      const double sumsq = sum_lane_groups_valu(ssq_run);
+      const double mu = sum_lane_groups_valu(mean);
       ssq_run = 0.0;
       mean = 0.0;
 
@@ -723,7 +726,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep(SweepParams p) {
 #pragma unroll
           for (int f = 0; f < R; ++f) {
             if (f < nr_cur) {
-              const double mu_f = sum_lane_groups(mean_r[f]);
+              const double mu_f = sum_lane_groups_valu(mean_r[f]);
               mean_r[f] = 0.0;
               emit(g + 1 + f, mu_f, gpc[g + 1 + f].kern.kdiag);
             }
