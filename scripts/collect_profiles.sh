@@ -88,6 +88,9 @@ python scripts/dev/small_n.py 4 8 16 20 32 48 64 > $OUT/small_n_few.txt 2>&1
 python scripts/dev/high_d.py > $OUT/high_d.txt 2>&1
 # the reference's own problem sizes: the one-launch step against the large-grid path
 python scripts/dev/small_step_time.py > $OUT/small_step.txt 2>&1
+# 49 .. 128 observations: the resident-factor kernel against the 4-wave kernel and the oracle,
+# its counters at n = 64 and 128 (separate PMC passes, kernel trace only)
+{ python scripts/dev/mid_check.py; bash scripts/dev/mid_pmc.sh 2>&1 | grep dispatches; } > $OUT/mid_kernel.txt 2>&1
 if [ -n "$QUICK" ]; then
   { python scripts/bench_bo_loop.py --config 2; python scripts/bench_bo_loop.py --config 3; } > $OUT/bo_loop.json 2>$OUT/bo_loop.err
   python scripts/profiles_digest.py $OUT > $OUT/SUMMARY.txt 2>&1; cat $OUT/SUMMARY.txt; exit 0

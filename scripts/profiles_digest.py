@@ -168,7 +168,8 @@ def main(argv):
         for name in ("ab_kernels.txt", "ablation.txt", "ablation_cfg2.txt", "stamps.txt",
                      "stamps_cfg2.txt", "reconcile.txt", "probes.txt", "bo_loop.json",
                      "swarm_small.txt", "product_kernels.txt", "multirank_path_cost.txt",
-                     "bench_default.json", "small_n.txt", "small_n_few.txt", "high_d.txt", "ab_tables.txt"):
+                     "bench_default.json", "small_n.txt", "small_n_few.txt", "high_d.txt", "ab_tables.txt",
+                     "small_step.txt", "mid_kernel.txt"):
             if os.path.exists(os.path.join(d, name)):
                 shutil.copy(os.path.join(d, name), os.path.join(dst, name))
         tj = os.path.join(ROOT, "profiles", "traffic.json")
