@@ -384,8 +384,11 @@ int64_t sgp_ctx_alloc_count(sgp_ctx* ctx);
 
 /* Which kernel runs gp.predict_noiseless over a grid / a swarm
  * (safeopt/gp_opt.py:469, 929, 973).  0 = automatic (the paired-wave kernel once
- * a GP has more than 256 training rows, csrc/sweep_pair.hip), 1 = always the
- * 4-wave kernel (csrc/sweep.hip), 2 = always the paired-wave kernel; + 4: the
+ * a GP has more than 256 training rows, csrc/sweep_pair.hip; the VALU kernel up to
+ * 48, csrc/sweep_tiny.hip; the resident-factor kernel for 49 .. 128 observations of
+ * single-part kernels up to d = 4, csrc/sweep_mid.hip; the 4-wave kernel otherwise),
+ * 1 = always the 4-wave kernel (csrc/sweep.hip), 2 = always the paired-wave kernel,
+ * 3 = automatic without the VALU kernel and the one-launch step; + 4: the
  * paired-wave kernel does not cut remainder tiles into runs of chunks (same bits
  * either way, tests/test_gpu_parity.py); + 8: no factor tables on tensor grids
  * (sgp_grid_set_axes); + 16: the 4-wave kernel streams small factors through its
@@ -398,7 +401,9 @@ int sgp_ctx_set_sweep(sgp_ctx* ctx, int which);
  * A/B scripts): 0 = none yet, 1 = the 4-wave kernel (n <= 256, csrc/sweep.hip),
  * 2 = the paired-wave kernel (csrc/sweep_pair.hip), 3 = the VALU kernel for GPs with
  * at most 48 observations (csrc/sweep_tiny.hip -- the regime of the reference's own
- * examples), 4 = the few-points path (csrc/factor.hip).                            */
+ * examples), 4 = the few-points path (csrc/factor.hip), 5 = the one-launch step of a
+ * small grid (csrc/step_small.hip), 6 = the resident-factor kernel for 49 .. 128
+ * observations (csrc/sweep_mid.hip).                                                */
 int sgp_ctx_last_sweep(sgp_ctx* ctx);
 
 /* Multi-output case: consecutive GPs of a launch with bit-identical training
