@@ -840,6 +840,13 @@ def main():
     ctx.sync()
     prof_ms, launches, flops = ctx.profile_read()
     ctx.profile_enable(False)
+    sweep_kernel = {"pair": "k_sweep_pair (posterior sweep, paired waves: n > 256)",
+                    "classic": "k_sweep (posterior sweep, 4 waves)",
+                    "mid": "k_sweep_mid (posterior sweep with the factor resident in LDS: 49 .. 128 "
+                           "observations; on tensor grids with factor tables up to 256, in passes "
+                           "of row blocks -- one timed launch = all passes of all GPs)",
+                    "tiny": "k_sweep_tiny (one thread per row, fp64 VALU: up to 48 observations)",
+                    }.get(ctx.last_sweep(), str(ctx.last_sweep()))
 
     # ---- the product's default: consecutive GPs with identical (X, kernel, noise)
     # share the variance contraction -- own timing, own flop count
@@ -942,8 +949,7 @@ def main():
         "scalar_allreduce_us": coll_us if world > 1 else None,
         "roofline": {
             "bound": "mfma",
-            "kernel": ("k_sweep_pair (posterior sweep, paired waves: n > 256)"
-                       if cfg["n"] > 256 else "k_sweep (posterior sweep, 4 waves)"),
+            "kernel": sweep_kernel,
             "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
             "traffic": None,

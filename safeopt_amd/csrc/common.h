@@ -363,6 +363,9 @@ bool tiny_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff, int64_t ro
 
 // sweep_mid.hip: 49 .. 128 observations, single-part kernels, d <= 4, all GPs resident in LDS
 bool mid_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff, int d);
+// ... 129 .. 256 observations with factor tables (a tensor grid, RBF parts): in passes of row blocks
+bool mid_passes_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff, const SepLaunch* sep,
+                       const ConfOut& conf);
 
 // sweep_pair.hip: does the launch take the paired-wave kernel (a GP with more than 256 rows)?
 bool pair_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff);

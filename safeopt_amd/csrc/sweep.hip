@@ -1394,7 +1394,7 @@ int launch_posterior(sgp_ctx* ctx, const SweepParams& p, const GpDev* gh, int d,
     SweepArgs a{p.gps, p.G, p.mode, p.pts, p.conf, p.fit};
     return launch_sweep_tiny(ctx, a, gh, d, Geff, flops);    // (sets ctx->sweep_partials)
   }
-  if (mid_sweep_wanted(ctx, gh, Geff, d)) {
+  if (mid_sweep_wanted(ctx, gh, Geff, d) || mid_passes_wanted(ctx, gh, Geff, sep, p.conf)) {
     ctx->last_sweep = 6;
     SweepArgs a{p.gps, p.G, p.mode, p.pts, p.conf, p.fit};
     return launch_sweep_mid(ctx, a, gh, d, Geff, flops, sep);   // (sets ctx->sweep_partials)

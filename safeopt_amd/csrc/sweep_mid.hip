@@ -57,7 +57,9 @@ constexpr int kMidLds = 160 * 1024;
 
 struct MidParams {
   const GpDev* gps;
-  int G;
+  int G;                      // GPs of this launch: g0 .. g0 + G - 1
+  int g0;
+  int Gtot;                   // GPs of the sweep (row pitch of Q)
   SweepPoints pts;
   ConfOut conf;
   // LDS (doubles): exp table | [waves] transpose buffers | per GP: A blocks, Xs, alpha
@@ -75,17 +77,25 @@ typedef const __attribute__((address_space(4))) GpDev* mid_gpdev_t;
 // is the product of SEP per-axis table entries (SepLaunch, api.hip:sep_launch) instead of an
 // evaluation: at n = 64 the evaluation is as many cycles of the shared fp64 pipe as the
 // matrix instructions (profiles/r05/mid_kernel.txt).  D is not used then (instances: D = 1).
-template <int D, int NB, int WAVES, int SEP>
+// Factors beyond 128 rows (tensor grids with factor tables, launch_sweep_mid below) go
+// through in PASSES of row blocks [B0, B1): a pass keeps its blocks (b, jb <= b) resident,
+// forms the covariances of j-blocks 0 .. B1 - 1 and this pass's share of |L^-1 k|^2; the share
+// of the passes in front comes in through ConfOut::var, and only the FINAL pass of a GP
+// (B1 = all its row blocks) forms alpha . k and runs the row epilogue.
+template <int D, int B0, int B1, int WAVES, int SEP, bool FINAL>
 __global__ __launch_bounds__(64 * WAVES) void k_sweep_mid(MidParams p) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int T = 64 * WAVES;
-  constexpr int kTri = NB * (NB + 1) / 2;
+  constexpr int NB = B1;                                   // j-blocks whose covariances are needed
+  constexpr int NR = B1 - B0;                              // row blocks (accumulators) of the pass
+  constexpr int kTri0 = B0 * (B0 + 1) / 2;
+  constexpr int kTri = B1 * (B1 + 1) / 2 - kTri0;          // resident blocks
   const mid_gpdev_t gpc = (mid_gpdev_t)(p.gps);
   exp_tab_init(lds);
   // ---- the factors, inputs and weights of every GP -> LDS, once.  Block (b, jb <= b),
   // k-step q, lane (k, row): L^-1[16 b + row][16 jb + 4 q + k], zero outside the n x n
   // lower triangle (rows from n on hold whatever a pop or an append buffer left there).
-  for (int g = 0; g < p.G; ++g) {
+  for (int g = p.g0; g < p.g0 + p.G; ++g) {
     const int n = gpc[g].n;
     if (p.lead[g] < 0) {
       const double* Li = gpc[g].Linv;
@@ -93,9 +103,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_sweep_mid(MidParams p) {
       double* A = lds + p.a_off[g];
       for (int e = threadIdx.x; e < kTri * 256; e += T) {
         const int blk = e >> 8, q = (e >> 6) & 3, l = e & 63;
-        int b = 0;
-        while ((b + 1) * (b + 2) / 2 <= blk) ++b;
-        const int jb = blk - b * (b + 1) / 2;
+        int b = B0;
+        while ((b + 1) * (b + 2) / 2 - kTri0 <= blk) ++b;
+        const int jb = blk - (b * (b + 1) / 2 - kTri0);
         const int i = 16 * b + (l & 15), j = 16 * jb + 4 * q + (l >> 4);
         A[e] = (i < n && j <= i) ? Li[int64_t(i) * ld + j] : 0.0;
       }
@@ -105,9 +115,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_sweep_mid(MidParams p) {
       double* Xl = lds + p.x_off[g];
       for (int e = threadIdx.x; e < NB * 16 * D; e += T) Xl[e] = (e / D < n) ? Xs[e] : 0.0;
     }
-    const double* al = gpc[g].alpha;
-    double* all = lds + p.al_off[g];
-    for (int e = threadIdx.x; e < NB * 16; e += T) all[e] = (e < n) ? al[e] : 0.0;
+    if constexpr (FINAL) {
+      const double* al = gpc[g].alpha;
+      double* all = lds + p.al_off[g];
+      for (int e = threadIdx.x; e < NB * 16; e += T) all[e] = (e < n) ? al[e] : 0.0;
+    }
   }
   __syncthreads();
 
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_sweep_mid(MidParams p) {
     bool safe = true;
     double l0 = 0.0, ssq_lead = 0.0;
 #pragma unroll 1
-    for (int g = 0; g < p.G; ++g) {
+    for (int g = p.g0; g < p.g0 + p.G; ++g) {
       KernFast<D> kf;
       double xs[D];
       const double* Xg = lds + p.x_off[g] + k4 * D;
@@ -204,9 +216,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_sweep_mid(MidParams p) {
       if constexpr (SEP > 0) factors(0, fcur);
       if (p.lead[g] < 0) {
         const double* A = lds + p.a_off[g] + lane;
-        double acc[NB][4];
+        double acc[NR][4];
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NR; ++b)
 #pragma unroll
           for (int m = 0; m < 4; ++m) acc[b][m] = 0.0;
 #pragma unroll
@@ -217,33 +229,37 @@ __global__ __launch_bounds__(64 * WAVES) void k_sweep_mid(MidParams p) {
             // the next j-block's factors: their latency passes under this block's slots
             if (jb + 1 < NB) factors(jb + 1, fnxt);
           }
+          if constexpr (FINAL) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) mean = fma(alg[jb * 16 + 4 * q], kv[q], mean);
-          // (pinned here: left alone, the compiler sinks the whole chain to the end of the
-          // tile and keeps every j-block's covariances and weights alive until then)
-          asm volatile("" : "+v"(mean));
+            for (int q = 0; q < 4; ++q) mean = fma(alg[jb * 16 + 4 * q], kv[q], mean);
+            // (pinned here: left alone, the compiler sinks the whole chain to the end of the
+            // tile and keeps every j-block's covariances and weights alive until then)
+            asm volatile("" : "+v"(mean));
+          }
           double kb[4][4];
           broadcast_quads<kMidKbRow>(kv, kbw, lane, kb);
           // the row blocks below (and on) the diagonal: the A operands of block b + 1 are
           // read while block b multiplies; the barriers keep the scheduler from hoisting
           // every read of the tile to its top (400 bytes of scratch per lane without them)
+          const int bfirst = jb > B0 ? jb : B0;
           double a[2][4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) a[0][q] = A[((jb * (jb + 1) / 2 + jb) * 4 + q) * 64];
+          for (int q = 0; q < 4; ++q)
+            a[0][q] = A[((bfirst * (bfirst + 1) / 2 - kTri0 + jb) * 4 + q) * 64];
 #pragma unroll
-          for (int b = jb; b < NB; ++b) {
-            const int cur = (b - jb) & 1;
-            if (b + 1 < NB) {
+          for (int b = (jb > B0 ? jb : B0); b < B1; ++b) {
+            const int cur = (b - (jb > B0 ? jb : B0)) & 1;
+            if (b + 1 < B1) {
 #pragma unroll
               for (int q = 0; q < 4; ++q)
-                a[cur ^ 1][q] = A[(((b + 1) * (b + 2) / 2 + jb) * 4 + q) * 64];
+                a[cur ^ 1][q] = A[(((b + 1) * (b + 2) / 2 - kTri0 + jb) * 4 + q) * 64];
             }
             MID_BARRIER;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
               for (int m = 0; m < 4; ++m)
-                acc[b][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[cur][q], kb[m][q], acc[b][m], 0, 0, 0);
+                acc[b - B0][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[cur][q], kb[m][q], acc[b - B0][m], 0, 0, 0);
             MID_BARRIER;
           }
           if constexpr (SEP > 0) {
@@ -256,7 +272,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_sweep_mid(MidParams p) {
         // over the four 16-lane groups: every lane ends with |L^-1 k|^2 of point l & 15
         double sq[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NR; ++b)
 #pragma unroll
           for (int m = 0; m < 4; ++m) sq[m] = fma(acc[b][m], acc[b][m], sq[m]);
         // (exchanges by DPP / permlane swaps, not through the LDS: sweep_shared.h)
@@ -265,6 +281,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_sweep_mid(MidParams p) {
         const double v1 = (a0 ? sq[3] : sq[2]) + take_xor4(a0 ? sq[2] : sq[3], a0);
         const double t = (a1 ? v1 : v0) + take_xor8(a1 ? v0 : v1);
         ssq = sum_lane_groups_valu(t);
+        if constexpr (B0 > 0) {
+          // the share of the passes in front (rows beyond N: the last row's, unused)
+          const int64_t rr = row < N ? row : N - 1;
+          ssq = p.conf.var[int64_t(g) * N + rr] + ssq;
+        }
         ssq_lead = ssq;
       } else {
         // the factor of the GP in front (GpDev::share): its |L^-1 k|^2, only alpha . k
@@ -277,6 +298,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_sweep_mid(MidParams p) {
           for (int q = 0; q < 4; ++q) mean = fma(alg[jb * 16 + 4 * q], kv[q], mean);
         }
         ssq = ssq_lead;
+      }
+      if constexpr (!FINAL) {
+        if (writer) p.conf.var[int64_t(g) * N + row] = ssq;
+        continue;
       }
       const double mu = sum_lane_groups_valu(mean);
       {
@@ -293,7 +318,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_sweep_mid(MidParams p) {
           __builtin_nontemporal_store(mu, p.conf.mean + int64_t(g) * N + row);
           __builtin_nontemporal_store(var, p.conf.var + int64_t(g) * N + row);
           if (p.conf.Q)
-            *reinterpret_cast<double2_t*>(p.conf.Q + (row * p.G + g) * 2) = double2_t{lo, up};
+            *reinterpret_cast<double2_t*>(p.conf.Q + (row * p.Gtot + g) * 2) = double2_t{lo, up};
         }
       }
     }
@@ -310,6 +335,31 @@ __global__ __launch_bounds__(64 * WAVES) void k_sweep_mid(MidParams p) {
     lmax = wave_max(lmax);
     if (lane == 0) p.conf.partial[int(blockIdx.x) * WAVES + wave] = lmax;
   }
+}
+
+// One launch per GP (the passes below): the safe set and max l0[S] of several GPs from the
+// intervals the launches left in Q (compute_safe_set, gp_opt.py:478-481).
+struct MidFmin {
+  double v[SGP_MAX_GPS];
+};
+__global__ __launch_bounds__(256) void k_mid_safe(const double* Q, uint8_t* S, double* partial,
+                                                  MidFmin fmin, int G, int64_t N) {
+  __shared__ double sh[4];
+  const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  double l0 = -INFINITY;
+  if (row < N) {
+    bool safe = true;
+#pragma unroll
+    for (int g = 0; g < SGP_MAX_GPS; ++g)
+      if (g < G) safe = safe && (Q[(row * G + g) * 2] > fmin.v[g]);
+    S[row] = safe ? 1 : 0;
+    if (safe) l0 = Q[row * G * 2];
+  }
+  l0 = wave_max(l0);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = l0;
+  __syncthreads();
+  if (threadIdx.x == 0 && partial)
+    partial[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
 }
 
 struct MidLayout {
@@ -353,30 +403,62 @@ MidLayout mid_layout(const GpDev* gh, int Geff, int d) {
   return L;
 }
 
-template <int D, int NB, int SEP>
+template <int D, int B0, int B1, int SEP, bool FINAL>
 int launch_mid_v(sgp_ctx* ctx, const MidParams& p, size_t lds_bytes, unsigned nblocks) {
-  constexpr int kW = mid_waves(NB, D, SEP);
+  constexpr int kW = B1 > kMidMaxNB ? 8 : mid_waves(B1, D, SEP);      // (passes: 8 waves)
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(&k_sweep_mid<D, NB, kW, SEP>),
+                     reinterpret_cast<const void*>(&k_sweep_mid<D, B0, B1, kW, SEP, FINAL>),
                      hipFuncAttributeMaxDynamicSharedMemorySize, kMidLds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_sweep_mid<D, NB, kW, SEP>), dim3(nblocks), dim3(64 * kW), lds_bytes,
-                     ctx->stream, p);
+  hipLaunchKernelGGL((k_sweep_mid<D, B0, B1, kW, SEP, FINAL>), dim3(nblocks), dim3(64 * kW),
+                     lds_bytes, ctx->stream, p);
   return 0;
 }
 
 template <int D, int SEP>
 int launch_mid_d(sgp_ctx* ctx, const MidParams& p, int nb, size_t lds_bytes, unsigned nblocks) {
   switch (nb) {
-    case 4: return launch_mid_v<D, 4, SEP>(ctx, p, lds_bytes, nblocks);
-    case 5: return launch_mid_v<D, 5, SEP>(ctx, p, lds_bytes, nblocks);
-    case 6: return launch_mid_v<D, 6, SEP>(ctx, p, lds_bytes, nblocks);
-    case 7: return launch_mid_v<D, 7, SEP>(ctx, p, lds_bytes, nblocks);
-    case 8: return launch_mid_v<D, 8, SEP>(ctx, p, lds_bytes, nblocks);
+    case 4: return launch_mid_v<D, 0, 4, SEP, true>(ctx, p, lds_bytes, nblocks);
+    case 5: return launch_mid_v<D, 0, 5, SEP, true>(ctx, p, lds_bytes, nblocks);
+    case 6: return launch_mid_v<D, 0, 6, SEP, true>(ctx, p, lds_bytes, nblocks);
+    case 7: return launch_mid_v<D, 0, 7, SEP, true>(ctx, p, lds_bytes, nblocks);
+    case 8: return launch_mid_v<D, 0, 8, SEP, true>(ctx, p, lds_bytes, nblocks);
   }
+  return -2;
+}
+
+// ---- factors of 129 .. 256 rows on tensor grids with factor tables: passes --------------
+// Row blocks [0, 9), [9, 13), [13, 16) -- at most 46 resident blocks (92 KB) each; a pass
+// re-forms the covariances of every j-block up to its last row block, which costs next to
+// nothing from tables (and is why evaluated kernels stay with the 4-wave kernel here).
+struct MidPass {
+  int b0, b1;
+};
+int mid_passes(int nb, MidPass (&ps)[3]) {
+  int n = 0;
+  ps[n++] = MidPass{0, nb < 9 ? nb : 9};
+  if (nb > 9) ps[n++] = MidPass{9, nb < 13 ? nb : 13};
+  if (nb > 13) ps[n++] = MidPass{13, nb};
+  return n;
+}
+
+template <int SEP>
+int launch_mid_pass(sgp_ctx* ctx, const MidParams& p, MidPass ps, bool final, size_t lds_bytes,
+                    unsigned nblocks) {
+#define MID_PASS(B0, B1, F) \
+  if (ps.b0 == B0 && ps.b1 == B1 && final == F)  \
+    return launch_mid_v<1, B0, B1, SEP, F>(ctx, p, lds_bytes, nblocks);
+  // (a smaller GP next to one with more than 128 observations: one pass, at least 4 blocks)
+  MID_PASS(0, 4, true) MID_PASS(0, 5, true) MID_PASS(0, 6, true) MID_PASS(0, 7, true)
+  MID_PASS(0, 8, true)
+  MID_PASS(0, 9, true) MID_PASS(0, 9, false)
+  MID_PASS(9, 10, true) MID_PASS(9, 11, true) MID_PASS(9, 12, true) MID_PASS(9, 13, true)
+  MID_PASS(9, 13, false)
+  MID_PASS(13, 14, true) MID_PASS(13, 15, true) MID_PASS(13, 16, true)
+#undef MID_PASS
   return -2;
 }
 
@@ -384,7 +466,7 @@ int launch_mid_d(sgp_ctx* ctx, const MidParams& p, int nb, size_t lds_bytes, uns
 
 // 49 .. 128 observations in the largest GP of the launch, single-part kernels, d <= 4,
 // everything resident in LDS.  By the GPs alone (never by the rows).  SGP_NO_MID=1 /
-// sgp_ctx_set_sweep(1 or 2) keep the general kernels (A/B runs, tests); 3 asks for this one.
+// sgp_ctx_set_sweep(1 or 2) keep the general kernels (A/B runs, tests).
 bool mid_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff, int d) {
   static const bool off = getenv("SGP_NO_MID") != nullptr;
   const int choice = ctx->sweep_choice & 3;
@@ -399,16 +481,95 @@ bool mid_sweep_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff, int d) {
   return mid_layout(gh, Geff, d).nb > 0;
 }
 
+// ... and 129 .. 256 observations when the launch has factor tables (a tensor grid, RBF
+// parts): one launch per GP and pass.  Not with shared factors (a follower would need its
+// leader's |L^-1 k|^2 across launches: the 4-wave kernel's riders do that better), and S
+// only together with Q (the last launch reads the other GPs' intervals back from there).
+bool mid_passes_wanted(const sgp_ctx* ctx, const GpDev* gh, int Geff, const SepLaunch* sep,
+                       const ConfOut& conf) {
+  static const bool off = getenv("SGP_NO_MID") != nullptr || getenv("SGP_NO_MID_PASSES") != nullptr;
+  const int choice = ctx->sweep_choice & 3;
+  if (off || choice == 1 || choice == 2 || !sep || sep->naxes < 1 || sep->naxes > 3) return false;
+  int nmax = 0;
+  for (int g = 0; g < Geff; ++g) {
+    if (gh[g].share >= 0) return false;
+    nmax = std::max(nmax, gh[g].n);
+  }
+  if (nmax <= 16 * kMidMaxNB || nmax > 256) return false;
+  return !(conf.S && !conf.Q && Geff > 1);
+}
+
 int launch_sweep_mid(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d, int Geff,
                      double flops, const SepLaunch* sep) {
+  const int64_t ntiles = (a.pts.N + 15) / 16;
+  if (mid_passes_wanted(ctx, gh, Geff, sep, a.conf)) {
+    const int waves = 8;
+    const unsigned nblocks = unsigned(std::max<int64_t>(
+        1, std::min<int64_t>(ctx->num_cu, (ntiles + waves - 1) / waves)));
+    ctx->sweep_partials = int(nblocks) * waves;
+    SweepTimer timer;
+    SGP_TRY(timer.begin(ctx, flops));
+    for (int g = 0; g < Geff; ++g) {
+      MidPass ps[3];
+      const int nb = std::max(gh[g].nblk, 4);
+      const int np = mid_passes(nb, ps);
+      for (int i = 0; i < np; ++i) {
+        const bool final = i == np - 1, last = final && g == Geff - 1 && Geff == 1;
+        MidParams p{};
+        p.gps = a.gps;
+        p.G = 1;
+        p.g0 = g;
+        p.Gtot = Geff;
+        p.pts = a.pts;
+        p.conf = a.conf;
+        if (!last) {
+          p.conf.S = nullptr;
+          p.conf.partial = nullptr;
+        }
+        p.sep = *sep;
+        for (int h = 0; h < SGP_MAX_GPS; ++h) p.lead[h] = -1;
+        size_t off = kExpTabSize;
+        p.kb_off = int(off);
+        off += size_t(kMidWavesMax) * kMidKbBuf;
+        p.a_off[g] = int(off);
+        off += size_t(ps[i].b1 * (ps[i].b1 + 1) / 2 - ps[i].b0 * (ps[i].b0 + 1) / 2) * 256;
+        p.x_off[g] = int(off);
+        p.al_off[g] = int(off);
+        off += size_t(ps[i].b1) * 16;
+        SGP_CHECK(ctx, off * 8 <= size_t(kMidLds), "launch_sweep_mid: pass of %zu bytes", off * 8);
+        int rc = -2;
+        switch (sep->naxes) {
+          case 1: rc = launch_mid_pass<1>(ctx, p, ps[i], final, off * 8, nblocks); break;
+          case 2: rc = launch_mid_pass<2>(ctx, p, ps[i], final, off * 8, nblocks); break;
+          case 3: rc = launch_mid_pass<3>(ctx, p, ps[i], final, off * 8, nblocks); break;
+        }
+        if (rc != 0) {
+          sgp_set_error(ctx, "launch_sweep_mid: no instance for row blocks %d .. %d", ps[i].b0,
+                        ps[i].b1);
+          return rc;
+        }
+      }
+    }
+    if (Geff > 1 && a.conf.S) {
+      MidFmin fm;
+      for (int h = 0; h < SGP_MAX_GPS; ++h) fm.v[h] = a.conf.fmin[h];
+      const unsigned nb = unsigned((a.pts.N + 255) / 256);
+      hipLaunchKernelGGL(k_mid_safe, dim3(nb), dim3(256), 0, ctx->stream, a.conf.Q, a.conf.S,
+                         a.conf.partial, fm, Geff, a.pts.N);
+      ctx->sweep_partials = int(nb);
+    }
+    SGP_HIP(ctx, hipGetLastError());
+    return timer.end(ctx);
+  }
   MidLayout L = mid_layout(gh, Geff, d);
   SGP_CHECK(ctx, L.nb > 0, "launch_sweep_mid: the GPs do not fit (mid_sweep_wanted)");
   MidParams p = L.p;
   p.gps = a.gps;
   p.G = Geff;
+  p.g0 = 0;
+  p.Gtot = Geff;
   p.pts = a.pts;
   p.conf = a.conf;
-  const int64_t ntiles = (a.pts.N + 15) / 16;
   const int waves = mid_waves(L.nb, d, sep ? sep->naxes : 0);
   if (sep) p.sep = *sep;
   const unsigned nblocks = unsigned(std::max<int64_t>(

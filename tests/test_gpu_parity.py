@@ -565,7 +565,11 @@ def test_few_observations_valu_kernel(mods, kind, d, ns, N):
     ("Matern32", 3, [80, 64, 50], 9000, "abc", False), ("RBF", 1, [100], 3000, "a", True),
     ("RBF", 4, [128], 4000, "a", False), ("Matern52", 2, [96], 20001, "aa", False),
     ("RBF", 2, [72], 5, "aab", False), ("RBF", 3, [112], 17 * 19 * 23, "a", True),
-    ("Matern52", 1, [128], 777, "a", False), ("RBF", 2, [60], 16 * 12 * 256 + 16, "aaa", True)])
+    ("Matern52", 1, [128], 777, "a", False), ("RBF", 2, [60], 16 * 12 * 256 + 16, "aaa", True),
+    # 129 .. 256 observations: in passes of row blocks, with factor tables only
+    ("RBF", 2, [200], 40000, "a", True), ("RBF", 3, [144, 130], 17 * 19 * 23, "ab", True),
+    ("RBF", 2, [256], 20000, "aa", True), ("RBF", 1, [230, 160, 129], 5000, "abc", True),
+    ("Matern52", 2, [150], 9000, "a", True)])
 def test_resident_factor_kernel_49_to_128(mods, kind, d, ns, N, layout, grid):
     """49 .. 128 observations, single-part kernels, d <= 4: the resident-factor kernel
     (csrc/sweep_mid.hip; the whole L^-1 of every GP in LDS, straight-line j-block / row-block
@@ -598,26 +602,42 @@ def test_resident_factor_kernel_49_to_128(mods, kind, d, ns, N, layout, grid):
     out = {}
     old = ctx.set_sweep("auto")
     old_share = ctx.set_share(True)
+    nmax = max(int(c.shape[0]) for c in groups.values())
+    followers = len(set(layout)) < len(layout)
+
+    def expected(which, share, tables):
+        # up to 128 observations everything resident; beyond, passes -- with factor tables
+        # (tensor grid, RBF) and without followers of a shared factor only
+        if which == "classic":
+            return "classic"
+        if nmax <= 128:
+            return "mid"
+        return "mid" if (tables and kind == "RBF" and not (share and followers)) else "classic"
+    variants = [("auto", True, grid), ("auto", False, False), ("classic", False, False)]
+    if grid:
+        variants.append(("auto", False, True))
     try:
-        for which, share, tables in (("auto", True, grid), ("auto", False, False), ("classic", False, False)):
+        for which, share, tables in variants:
             ctx.set_sweep(which)
             ctx.set_share(share)
             g = _hip.DeviceGrid(ctx, pts, G)
             if tables:
                 assert g.set_axes(_hip.tensor_grid_axes(pts))
             ml = g.confidence([gp._fitted() for gp in gps], 2.0, fmin)
-            assert ctx.last_sweep() == ("mid" if which == "auto" else "classic")
-            out[(which, share)] = (ml, g.download(_hip.Q), g.download(_hip.S),
-                                   g.download(_hip.MEAN), g.download(_hip.VAR))
+            assert ctx.last_sweep() == expected(which, share, tables)
+            out[(which, share, tables)] = (ml, g.download(_hip.Q), g.download(_hip.S),
+                                           g.download(_hip.MEAN), g.download(_hip.VAR))
     finally:
         ctx.set_sweep(old)
         ctx.set_share(old_share)
-    (max_l, any_safe), Q, S, mean, var = out[("auto", True)]
-    own = out[("auto", False)]
-    if not (grid and kind == "RBF"):
+    first = ("auto", False, True) if grid else ("auto", True, False)
+    (max_l, any_safe), Q, S, mean, var = out[first]
+    own = out[("auto", False, False)]
+    others = [out[k] for k in out if k != first]
+    if not grid and nmax <= 128:
         # the shared factor: same bits as every GP swept on its own (factor tables: their
         # covariances are products of table entries, another rounding -- 1e-12 below)
-        for x, y in zip(out[("auto", True)][1:], own[1:]):
+        for x, y in zip(out[("auto", True, False)][1:], own[1:]):
             assert_array_equal(x, y)
     sel = rng.choice(pts.shape[0], size=min(400, pts.shape[0]), replace=False)
     for i, go in enumerate(gos):
@@ -627,7 +647,7 @@ def test_resident_factor_kernel_49_to_128(mods, kind, d, ns, N, layout, grid):
         sd = np.sqrt(var[i])
         assert_array_equal(Q[:, 2 * i], mean[i] - 2.0 * sd)
         assert_array_equal(Q[:, 2 * i + 1], mean[i] + 2.0 * sd)
-        for other in (own, out[("classic", False)]):
+        for other in others:
             assert_allclose(mean[i], other[3][i], rtol=0, atol=1e-11 * max(1.0, np.abs(mo).max()))
             assert_allclose(var[i], other[4][i], rtol=0, atol=1e-11 * kd)
     assert_array_equal(S, np.all(Q[:, ::2] > fmin, axis=1))
@@ -647,11 +667,13 @@ def test_resident_factor_kernel_49_to_128(mods, kind, d, ns, N, layout, grid):
     # (point sets of a few thousand rows against 100+ observations go chip-wide, factor.hip
     # "few-points": by the GP and the row count of the CALL -- test_predict_of_a_prefix_of_
     # the_points pins that path; here the sweep kernel)
-    assert k_few in ("mid", "few-points") and k_all in ("mid", "few-points")
+    ok = ("mid", "few-points") if nmax <= 128 else ("classic", "few-points")   # (points: no tables)
+    assert k_few in ok and k_all in ok
     if k_all == k_few == "mid":
         assert_array_equal(m_few, m_all[:k])
         assert_array_equal(v_few, v_all[:k])
-        assert_array_equal(m_all[:, 0], own[3][0])
+        if not grid:
+            assert_array_equal(m_all[:, 0], own[3][0])
     else:
         kd = float(gps[0].kern.Kdiag(np.zeros((1, d)))[0])
         assert_allclose(m_few, m_all[:k], rtol=0, atol=1e-11 * max(1.0, np.abs(m_all).max()))
