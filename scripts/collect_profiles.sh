@@ -55,7 +55,8 @@ python scripts/dev/ab_sweep.py 3 2 4 5 > $OUT/ab_kernels.txt 2>&1
 # factor tables (tensor grids, RBF) against evaluated covariances: config 2 (4-wave kernel:
 # tables by default) and config 4 (paired kernel: tables only while they fit half an L2 --
 # the default evaluates; SGP_SEP_PAIR=1 forces them)
-{ AB_ONLY=classic AB_TAG="  [config 2, factor tables (default)]" python scripts/dev/ab_sweep.py 2 2>&1 | tail -1
+{ AB_ONLY=auto AB_TAG="  [config 2, automatic choice since round 5: k_sweep_mid in passes of row blocks, factor tables]" python scripts/dev/ab_sweep.py 2 2>&1 | tail -1
+  AB_ONLY=classic AB_TAG="  [config 2, 4-wave kernel, factor tables (the choice until round 5)]" python scripts/dev/ab_sweep.py 2 2>&1 | tail -1
   AB_ONLY=classic AB_SEP=0 AB_TAG="  [config 2, evaluated]" python scripts/dev/ab_sweep.py 2 2>&1 | tail -1
   AB_ONLY=pair AB_TAG="  [config 4, default: evaluated (tables 4.8 MB > half an L2)]" python scripts/dev/ab_sweep.py 4 2>&1 | tail -1
   SGP_SEP_PAIR=1 AB_ONLY=pair AB_TAG="  [config 4, factor tables forced (SGP_SEP_PAIR=1)]" python scripts/dev/ab_sweep.py 4 2>&1 | tail -1
