@@ -403,15 +403,26 @@ MidLayout mid_layout(const GpDev* gh, int Geff, int d) {
   return L;
 }
 
+// waves of a pass instance (129 .. 256 observations): the passes behind the first one hold at
+// most 4 x 4 accumulators (101-159 VGPRs: three waves per SIMD), the first holds 9 x 4
+constexpr int mid_pass_waves(int b0) { return b0 > 0 ? 12 : 8; }
+
+// `nblocks` = 0: as many workgroups as the instance's waves ask for (the passes); the launch
+// that leaves the partials of max l0[S] also says how many there are
 template <int D, int B0, int B1, int SEP, bool FINAL>
 int launch_mid_v(sgp_ctx* ctx, const MidParams& p, size_t lds_bytes, unsigned nblocks) {
-  constexpr int kW = B1 > kMidMaxNB ? 8 : mid_waves(B1, D, SEP);      // (passes: 8 waves)
+  constexpr int kW = B1 > kMidMaxNB ? mid_pass_waves(B0) : mid_waves(B1, D, SEP);
   static bool attr_set = false;
   if (!attr_set) {
     SGP_HIP(ctx, hipFuncSetAttribute(
                      reinterpret_cast<const void*>(&k_sweep_mid<D, B0, B1, kW, SEP, FINAL>),
                      hipFuncAttributeMaxDynamicSharedMemorySize, kMidLds));
     attr_set = true;
+  }
+  if (nblocks == 0) {
+    const int64_t ntiles = (p.pts.N + 15) / 16;
+    nblocks = unsigned(std::max<int64_t>(1, std::min<int64_t>(ctx->num_cu, (ntiles + kW - 1) / kW)));
+    if (p.conf.S && p.conf.partial) ctx->sweep_partials = int(nblocks) * kW;
   }
   hipLaunchKernelGGL((k_sweep_mid<D, B0, B1, kW, SEP, FINAL>), dim3(nblocks), dim3(64 * kW),
                      lds_bytes, ctx->stream, p);
@@ -503,10 +514,8 @@ int launch_sweep_mid(sgp_ctx* ctx, const SweepArgs& a, const GpDev* gh, int d, i
                      double flops, const SepLaunch* sep) {
   const int64_t ntiles = (a.pts.N + 15) / 16;
   if (mid_passes_wanted(ctx, gh, Geff, sep, a.conf)) {
-    const int waves = 8;
-    const unsigned nblocks = unsigned(std::max<int64_t>(
-        1, std::min<int64_t>(ctx->num_cu, (ntiles + waves - 1) / waves)));
-    ctx->sweep_partials = int(nblocks) * waves;
+    const unsigned nblocks = 0;        // (per pass: launch_mid_v)
+    ctx->sweep_partials = 0;
     SweepTimer timer;
     SGP_TRY(timer.begin(ctx, flops));
     for (int g = 0; g < Geff; ++g) {
