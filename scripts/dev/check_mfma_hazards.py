@@ -9,7 +9,8 @@ go unpadded (wait states as in LLVM's GCNHazardRecognizer for gfx90a+ DGEMM 4x4)
   R3  MFMA write of a VGPR -> VMEM / LDS / FLAT reads it needs 9  (e.g. a SPILL of
       an accumulator right behind the slot sequence)
   R4  MFMA write -> MFMA reads it as SrcC                needs 4
-  A2  a scratch access (spill) in an instance of either sweep kernel
+  A2  a scratch access (spill) in an instance of a sweep kernel (sweep.hip, sweep_pair.hip,
+      sweep_mid.hip)
   A1  (k_sweep only) an AccVGPR named by an instruction outside the inline asm
       blocks: the accumulators live in hand-assigned AccVGPRs (csrc/sweep_slots.h)
 
@@ -117,7 +118,8 @@ def scan(asm, verbose=True):
         # A2: ... and no instance of either sweep may spill: a scratch access between the
         # asm statements is a register copy the hazard rules below would have to know
         # about (round 3, finding (b)), and costs 5 x in the stage loop besides
-        if op.startswith("scratch_") and ("k_sweepI" in func or "k_sweep_pairI" in func):
+        if op.startswith("scratch_") and ("k_sweepI" in func or "k_sweep_pairI" in func or
+                                          "k_sweep_midI" in func):
             bad.append((func, "A2", 0, "(spill)", t))
         is_mfma = op.startswith("v_mfma") and in_asm
         is_valu = op.startswith("v_") and not op.startswith("v_mfma")
@@ -179,6 +181,11 @@ def main(flags):
         if n < 1000:
             print("too few matrix instructions in the ISA of %s: scan is void" % f)
             total += 1
+    # sweep_mid.hip issues its matrix instructions through the builtin (the compiler pads
+    # them itself): only rule A2 -- no instance may spill
+    COUNT.clear()
+    total += len(scan(isa(os.path.join(CSRC, "sweep_mid.hip"), flags)))
+    print("sweep_mid.hip: scanned for spills")
     print("hazards found: %d" % total)
     return total
 
