@@ -393,8 +393,10 @@ int64_t sgp_ctx_alloc_count(sgp_ctx* ctx);
  * either way, tests/test_gpu_parity.py); + 8: no factor tables on tensor grids
  * (sgp_grid_set_axes); + 16: the 4-wave kernel streams small factors through its
  * double buffer instead of keeping them in LDS for the launch (same bits either
- * way).  Same results within rounding between
- * the two kernels; the switch exists for A/B measurements and tests.  Returns
+ * way); + 32: the paired-wave kernel runs one 16-point block of training points per
+ * stage instead of merging the thin stages of a triangular chunk (the schedule until
+ * round 5: another summation order, same results within rounding).  Same results
+ * within rounding between the two kernels; the switch exists for A/B measurements and tests.  Returns
  * the previous setting.                                                        */
 int sgp_ctx_set_sweep(sgp_ctx* ctx, int which);
 /* Which kernel ran the LAST posterior sweep of this context (tests of the selection,

@@ -303,12 +303,15 @@ class Context(object):
         'classic' and 'pair' switch off), '-nosplit' appended: remainder tiles are not cut into runs of
         chunks, '-notables': no factor tables on tensor grids (set_axes), '-streamed':
         small factors go through the 4-wave kernel's double buffer instead of staying
-        in LDS for the launch; or the integer of sgp_ctx_set_sweep.  Returns the
+        in LDS for the launch, '-unmerged': the paired kernel runs one j-block per stage
+        (the schedule until round 5; merged stages: csrc/sweep_pair.hip); or the integer
+        of sgp_ctx_set_sweep.  Returns the
         previous setting (a name)."""
         names = ("auto", "classic", "pair", "mid", "auto-nosplit", "classic-nosplit",
                  "pair-nosplit", None)
         names = names + tuple(n + "-notables" if n else None for n in names)
         names = names + tuple(n + "-streamed" if n else None for n in names)
+        names = names + tuple(n + "-unmerged" if n else None for n in names)
 
         def code(w):          # a name, or the integer of sgp_ctx_set_sweep
             return int(w) if isinstance(w, (int, np.integer)) else names.index(w)

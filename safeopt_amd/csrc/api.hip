@@ -2014,7 +2014,7 @@ int sgp_ctx_last_sweep(sgp_ctx* ctx) { return ctx ? ctx->last_sweep : 0; }
 int sgp_ctx_set_sweep(sgp_ctx* ctx, int which) {
   if (!ctx) return -1;
   const int old = ctx->sweep_choice;
-  if (which >= 0 && which < 32) ctx->sweep_choice = which;
+  if (which >= 0 && which < 64) ctx->sweep_choice = which;
   return old;
 }
 

@@ -54,7 +54,16 @@ constexpr int kPairSlots = 32;         // row blocks of L^-1 per accumulator chu
 constexpr int kWaveSlots = 16;         // ... per wave (128 accumulator VGPRs)
 constexpr int kPairs = 4;              // pairs per workgroup (64 rows per tile)
 constexpr int kTileRows = 16 * kPairs;
-constexpr int kKbRow = 80;             // doubles between the k-rows of a B buffer
+#ifdef PGP_E3
+constexpr int kKbRow = 80;
+#define PGP_SW(x) 0
+#else
+#define PGP_SW(x) (x)
+constexpr int kKbRow = 64;             // doubles per k-row of a B buffer (odd k-rows are stored with
+                                       // the two halves of a q pair's 32 doubles swapped: no padding)
+#endif
+constexpr int kDuoUnits = 28;          // 2 KB units of L^-1 in a stage of TWO j-blocks: the last four
+                                       // units of its chunk buffer hold the B buffers of the second one
 
 // The structure below is what survived the round-3 experiments (phase orders, pairs
 // on adjacent waves, where and by whom the LDS-DMA is issued, priorities, a second
@@ -62,17 +71,27 @@ constexpr int kKbRow = 80;             // doubles between the k-rows of a B buff
 // in the history of this file up to commit d1566ec).  Debug builds: -DSGP_INSTRUMENT
 // (ablation mask, PGP_ABL) and -DPGP_STAMPS (cycle stamps per phase).
 
-// One stage (GP, chunk, j-block) of a tile.  Global slot t of the staged chunk
-// holds row block bend-1-t, k-steps 4 jb .. 4 jb + 3; its source is
-// a_src - t * rs_bytes.
+// One stage of a tile: ONE j-block of a (GP, chunk) -- or TWO (round 6, "merged stages").
+// The stages of a triangular chunk shrink from 32 active row blocks to one; a thin stage
+// pays the same barrier, table entry, operand fetch and exchange as a full one.  So j-block
+// jb (32 - jb active slots) is put together with a j-block from the other end of the
+// chunk while both fit kDuoUnits: 19 stages of 28 .. 32 units instead of 32 stages of
+// 32 .. 1 at n = 500 (pair_stage_table).  The two j-blocks are the SEGMENTS A and B of the
+// stage: each is a prefix of the accumulator slots (global slot t = row block bend-1-t,
+// k-steps 4 jb .. 4 jb + 3); in the chunk buffer segment A's slots are the units
+// 0 .. nA-1 and segment B's the units nA .. nA+nB-1.
 struct PStage {
-  uint64_t a_src;      // device address of slot 0's 2 KB
+  uint64_t a_src;      // unit u < nA comes from a_src - u * rs_bytes
   uint64_t xa_next;    // device address of the [16 d | 16] block of the NEXT stage
-                       // of the (cyclic) sequence
+                       // of the (cyclic) sequence (its first j-block)
+  uint32_t xb_next;    // ... bytes from there to the block of its second j-block (0: none)
+  uint32_t b_off;      // unit u >= nA comes from a_src + b_off - u * rs_bytes (the host folds
+                       // nA in: b_off = 2 KB * 4 (jb2 - jb) ... + nA * rs_bytes)
   uint32_t rs_bytes;   // bytes between consecutive row blocks in Apack
   uint32_t word;       // PW_*
   uint32_t g_next;     // GP of the NEXT stage (whose riders' alpha blocks go with xa_next)
-  uint32_t jb;         // j-block of THIS stage (factor tables: row [jb] of every axis)
+  uint32_t jb;         // j-block of segment A (factor tables: row [jb] of every axis)
+  uint32_t jb2;        // j-block of segment B
 };
 enum : uint32_t {
   PW_NACT_MASK = 63u,       // active global slots 0 .. nact-1 (1..32)
@@ -87,18 +106,26 @@ enum : uint32_t {
   PW_SHARED = 1u << 22,     // GP with the factor of the GP in front (GpDev::share): its
                             // stages have no active slots, they only evaluate the
                             // covariances for alpha . k; |L^-1 k|^2 is the leader's
+  PW_DUO = 1u << 23,        // the stage has a second j-block (segment B)
+  PW_NB_SHIFT = 24,         // active global slots of segment B (6 bits)
   PW_G_SHIFT = 12           // GP index (3 bits)
 };
 
-// LDS (doubles):  [2][A chunk 64 KB]  [2][16 D rows | 16 alpha]  exp table
+// LDS (doubles):  [2][A chunk 64 KB]  [2][2 j-blocks][16 D rows | 16 alpha]  exp table
 //                 [4 pairs][2][B operands]  [4 pairs][2][32] pair exchange
 //                 [4 pairs] staged Q rows
+// The B operands of a stage's SECOND j-block live in the last four units of the chunk
+// buffer that holds the stage's L^-1 units (kKb2Off; one 2 KB buffer per pair): they are
+// written and read exactly when that buffer's units are (evaluated a stage ahead, while the
+// chunk copy fills the units in front of them).
 // R > 0 (riders, see kMaxRide): R more alpha blocks behind a training block, R more
 // 16-double rows in a pair's exchange buffer.
 template <int D, int R = 0>
 struct LayP {
   static constexpr int kATile = kPairSlots * kSteps * 64;   // 8192 doubles
-  static constexpr int kXBuf = kJC * D + kJC * (1 + R);
+  static constexpr int kKb2Off = kDuoUnits * kSteps * 64;   // (inside a chunk buffer)
+  static constexpr int kXBlk = kJC * D + kJC * (1 + R);     // one j-block's training block
+  static constexpr int kXBuf = 2 * kXBlk;
   static constexpr int kXOff = 2 * kATile;
   static constexpr int kTabOff = kXOff + 2 * kXBuf;
   static constexpr int kKbOff = kTabOff + kExpTabSize;
@@ -118,8 +145,11 @@ struct LayP {
 // (what the LDS of a d <= 4 instance has room for); further followers keep stages
 // without rows (PW_SHARED).
 constexpr int kMaxRide = 2;
+#ifndef PGP_E3
 static_assert(LayP<8>::bytes() <= 160 * 1024, "LDS budget of one workgroup per CU");
+static_assert(LayP<1>::kKb2Off + kPairs * LayP<1>::kKbBuf <= LayP<1>::kATile, "second B buffers");
 static_assert(LayP<4, kMaxRide>::bytes() <= 160 * 1024, "LDS budget with riders");
+#endif
 
 struct PairParams {
   const GpDev* gps;
@@ -188,14 +218,17 @@ struct PairParams {
 typedef const __attribute__((address_space(4))) PStage* pstage_ptr_t;
 typedef const __attribute__((address_space(4))) GpDev* gpdev_cptr_t;
 
-template <bool RIDE = false>
+template <bool RIDE = false, bool SEP = false>
 __device__ __forceinline__ PStage load_pstage(pstage_ptr_t t, int i) {
-  PStage e;      // member-wise: scalar loads (dwordx4 + dwordx2 [+ dword])
+  PStage e;      // member-wise: scalar loads (only what the instance reads stays live)
   e.a_src = t[i].a_src;
+  e.b_off = t[i].b_off;
   e.xa_next = t[i].xa_next;
+  e.xb_next = t[i].xb_next;
   e.rs_bytes = t[i].rs_bytes;
   e.word = t[i].word;
-  e.jb = t[i].jb;
+  e.jb = SEP ? t[i].jb : 0;
+  e.jb2 = SEP ? t[i].jb2 : 0;
   e.g_next = RIDE ? t[i].g_next : 0;
   return e;
 }
@@ -227,25 +260,27 @@ __device__ __forceinline__ void rider_dma(const int (&nride)[SGP_MAX_GPS],
   }
 }
 
-// The share of one wave of half 0 in the copy of the next A chunk (LDS image
-// [global slot][k-step][lane], 2 KB per slot), issued piecewise between the slots of
-// the running stage: group i is the global slot w + kStride i, wanted when
-// left > kStride i.
+// The share of one wave of half 0 in the copy of the next stage's L^-1 units (LDS image
+// [unit][k-step][lane], 2 KB per unit), issued piecewise between the slots of the running
+// stage: wave w of the half copies the units w, w + 4, ..; every hook of the slot sequence
+// sends the next one.
 struct DmaPlan {
-  uint64_t src0;     // source of the wave's first slot
-  uint64_t step;     // bytes between its consecutive slots (kStride row blocks)
-  uint32_t dst0;     // LDS byte address of the wave's first slot
+  uint64_t src;      // unit u < na: src - u * rs; u >= na: src + b_off - u * rs
+  uint32_t b_off;
+  uint32_t rs;
+  uint32_t dst0;     // LDS byte address of unit 0 of the buffer being filled
   uint32_t voff;
-  int left;          // active slots - first slot of the wave
-  bool on;
+  int u;             // the wave's next unit; >= ntot: nothing left (or the copy is off)
+  int u0;
+  int na, ntot;      // units of segment A, of the stage
   bool no_a;         // (timing experiments: the slots skip their A-operand reads)
 };
-template <int kGroups>
-__device__ __forceinline__ void dma_group(const DmaPlan& d, int i) {
-  constexpr int kStride = 32 / (kGroups > 0 ? kGroups : 1);   // global slots between groups
-  if (d.on && d.left > kStride * i)
-    dma_2k(d.src0 - uint64_t(i) * d.step, d.dst0 + uint32_t(i) * (kStride * 2048u),
-           d.voff);
+__device__ __forceinline__ void dma_next(DmaPlan& d) {
+  if (d.u < d.ntot) {
+    const uint64_t off = uint64_t(uint32_t(d.u)) * d.rs - (d.u < d.na ? 0u : d.b_off);
+    dma_2k(d.src - off, d.dst0 + uint32_t(d.u) * 2048u, d.voff);
+    d.u += 4;
+  }
 }
 
 // ---- matrix part (operand maps: see sweep.hip) ------------------------------------
@@ -269,7 +304,7 @@ __device__ __forceinline__ void pair_slot_body(bool narrow0, double (&acc)[kWave
                                                double& accx, const double* aT,
                                                const double (&kb)[4][4], const double (&kvn)[4],
                                                double (&cur)[4], double (&nxt)[4],
-                                               const DmaPlan& dma) {
+                                               DmaPlan& dma) {
   if (S + 1 < kWaveSlots) {
 #if defined(SGP_INSTRUMENT) || defined(PGP_CT_ABL)
     if (dma.no_a) {
@@ -337,7 +372,17 @@ __device__ __forceinline__ void pair_slot_body(bool narrow0, double (&acc)[kWave
     asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
   if constexpr (kGroups > 0) {
     constexpr int kEvery = kWaveSlots / kGroups;
-    if (S % kEvery == 0 && S / kEvery < kGroups) dma_group<kGroups>(dma, S / kEvery);
+#ifdef PGP_E1
+    if (S % kEvery == 0) {
+      constexpr int i = S / kEvery;
+      if (dma.u0 + 4 * i < dma.ntot)
+        dma_2k(dma.src - uint64_t(uint32_t(dma.u0 + 4 * i)) * dma.rs,
+               dma.dst0 + uint32_t(dma.u0 + 4 * i) * 2048u, dma.voff);
+      dma.u = dma.u0 + 4 * (i + 1);
+    }
+#elif !defined(PGP_DMA_BUNCH)
+    if (S % kEvery == 0) dma_next(dma);
+#endif
   }
 }
 
@@ -345,20 +390,29 @@ __device__ __forceinline__ void pair_slot_body(bool narrow0, double (&acc)[kWave
 // body on different paths -- makes the register allocator duplicate the tied accumulators:
 // 430-560 B of scratch in every instance, as with every other second control-flow shape
 // around them; profiles/r05/experiments.txt, section 8.)
-template <int S, bool NARROW_OK, int kGroups, bool ASM_MFMA>
+template <int S, bool NARROW_OK, int kGroups, bool ASM_MFMA, int kMax = kWaveSlots>
 __device__ __forceinline__ void pair_slots(int nw, bool narrow0,
                                            double (&acc)[kWaveSlots][4], double& accx,
                                            const double* aT,
                                            const double (&kb)[4][4],
                                            const double (&kvn)[4],
                                            double (&cur)[4], double (&nxt)[4],
-                                           const DmaPlan& dma) {
-  if constexpr (S < kWaveSlots) {
+                                           DmaPlan& dma) {
+  if constexpr (S < kMax) {
     if (S < nw) {
       pair_slot_body<S, NARROW_OK, kGroups, ASM_MFMA>(narrow0, acc, accx, aT, kb, kvn, cur, nxt, dma);
-      pair_slots<S + 1, false, kGroups, ASM_MFMA>(nw, false, acc, accx, aT, kb, kvn, nxt, cur, dma);
+      pair_slots<S + 1, false, kGroups, ASM_MFMA, kMax>(nw, false, acc, accx, aT, kb, kvn, nxt, cur, dma);
     }
   }
+}
+
+// The lane number, formed where it is used: addresses of the rare paths (the per-lane sums a
+// run of a remainder tile leaves in HBM) are loop invariants the compiler would otherwise
+// keep in registers -- 64-bit pairs -- across the whole stage loop, next to 128 accumulators.
+__device__ __forceinline__ uint32_t cold_lane() {
+  uint32_t l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
 }
 
 // per-tile state of the row epilogue (only the finishing wave of a pair has it)
@@ -552,7 +606,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       soff[a] = idx * 128u + uint32_t(k4) * 32u + uint32_t(H) * 16u;
     }
   };
-  double2_t efn[kAx];
+  double2_t efn[kAx], efn2[kAx];     // (second j-block of a stage: efn2)
   const char* sep_tab[kAx];
   uint32_t sep_pitch[kAx];
   int sep_g = -1;
@@ -573,6 +627,13 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       const char* src = sep_tab[a] + e.jb * sep_pitch[a];      // (<= 256 MB per GP: sep_launch)
       efn[a] = *(gvec_t)(reinterpret_cast<const double2_t*>(src + soff[a]));
     }
+    if (e.word & PW_DUO) {
+#pragma unroll
+      for (int a = 0; a < kAx; ++a) {
+        const char* src = sep_tab[a] + e.jb2 * sep_pitch[a];
+        efn2[a] = *(gvec_t)(reinterpret_cast<const double2_t*>(src + soff[a]));
+      }
+    }
   };
 
   // covariances of one stage: this wave's half (training points 8 H .. 8 H + 7 of
@@ -589,7 +650,9 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   // behind the operand reads of the matrix phase
   struct Rows {
     double y[2 * D];
+#ifdef PGP_ALPHA_EARLY
     double al[2];
+#endif
   };
   auto load_rows = [&](const double* xa, Rows& r) {
     const double* ys = xa + (8 * H + k4) * D;
@@ -597,14 +660,67 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int i = 0; i < D; ++i) r.y[q * D + i] = ys[q * 4 * D + i];
+#ifdef PGP_ALPHA_EARLY
     const double* al = xa + kJC * D + 8 * H + k4;
     r.al[0] = al[0];
     r.al[1] = al[4];
+#endif
   };
   // (only where the 2 D + 2 registers are there for it; elsewhere the evaluation
   // reads its rows itself)
   constexpr bool kRowsFirst = kOpsEarly != 0 && SINGLE && D <= 2;
-  auto evaluate = [&](uint32_t w1, const Rows& r, const double* xa, double* kbw) {
+  // One j-block of a stage: J = 0 the first (its rows may have been fetched in front of
+  // the evaluation: Rows), J = 1 the second of a merged stage.
+  auto eval_block = [&](uint32_t w1, auto jtag, const Rows& r, const double* xa, double* kbw) {
+    constexpr int J = decltype(jtag)::value;
+    double kv[2];
+    if constexpr (SEP > 0) {
+      const double2_t (&ef)[kAx] = J == 0 ? efn : efn2;
+      kv[0] = ef[0].x;
+      kv[1] = ef[0].y;
+#pragma unroll
+      for (int a = 1; a < kAx; ++a) {
+        kv[0] *= ef[a].x;
+        kv[1] *= ef[a].y;
+      }
+    } else if (!PGP_ABL(4)) {
+      if (kRowsFirst && J == 0)
+        kf.template manyn_t<2, SINGLE>(xs_e, r.y, D, tab, kv);
+      else
+        kf.template manyn_t<2, SINGLE>(xs_e, xa + (8 * H + k4) * D, 4 * D, tab, kv);
+    } else {
+      kv[0] = xs_e[0];
+      kv[1] = xs_e[0] + 1.0;
+    }
+    if (w1 & PW_MEAN) {
+      // (alpha is read here, not with the rows: four registers the merged stages need)
+#ifdef PGP_ALPHA_EARLY
+      if (kRowsFirst && J == 0) {
+        mean = fma(r.al[0], kv[0], mean);
+        mean = fma(r.al[1], kv[1], mean);
+      } else
+#endif
+      {
+      const double* al = xa + kJC * D + 8 * H + k4;
+      mean = fma(al[0], kv[0], mean);
+      mean = fma(al[4], kv[1], mean);
+      }
+    }
+    if (R > 0 && (w1 & PW_MEAN)) {
+#pragma unroll
+      for (int f = 0; f < R; ++f) {
+        if (f < nr_e) {
+          const double* al = xa + kJC * D + kJC * (1 + f) + 8 * H + k4;
+          mean_r[f] = fma(al[0], kv[0], mean_r[f]);
+          mean_r[f] = fma(al[4], kv[1], mean_r[f]);
+        }
+      }
+    }
+    // (odd k-rows: the halves of the q pair's 32 doubles swapped -- fetch_ops)
+    *reinterpret_cast<double2_t*>(kbw + k4 * kKbRow + H * 32 + ((c16 * 2) ^ PGP_SW((k4 & 1) * 16))) =
+        double2_t{kv[0], kv[1]};
+  };
+  auto evaluate = [&](uint32_t w1, const Rows& r, const double* xa, double* kbw, double* kb2w) {
     if (SEP == 0 && __builtin_expect((w1 & PW_GP_FIRST) != 0, 0)) {
       kf.load_const(&p.gps[int(w1 >> PW_G_SHIFT) & 7].kern);
       if (R > 0) nr_e = p.nride[int(w1 >> PW_G_SHIFT) & 7];
@@ -621,46 +737,13 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
         }
       }
     }
-    double kv[2];
-    if constexpr (SEP > 0) {
-      kv[0] = efn[0].x;
-      kv[1] = efn[0].y;
-#pragma unroll
-      for (int a = 1; a < kAx; ++a) {
-        kv[0] *= efn[a].x;
-        kv[1] *= efn[a].y;
-      }
-    } else if (!PGP_ABL(4)) {
-      if (kRowsFirst)
-        kf.template manyn_t<2, SINGLE>(xs_e, r.y, D, tab, kv);
-      else
-        kf.template manyn_t<2, SINGLE>(xs_e, xa + (8 * H + k4) * D, 4 * D, tab, kv);
-    } else {
-      kv[0] = xs_e[0];
-      kv[1] = xs_e[0] + 1.0;
-    }
-    if (w1 & PW_MEAN) {
-      if (kRowsFirst) {
-        mean = fma(r.al[0], kv[0], mean);
-        mean = fma(r.al[1], kv[1], mean);
-      } else {
-        const double* al = xa + kJC * D + 8 * H + k4;
-        mean = fma(al[0], kv[0], mean);
-        mean = fma(al[4], kv[1], mean);
-      }
-    }
-    if (R > 0 && (w1 & PW_MEAN)) {
-#pragma unroll
-      for (int f = 0; f < R; ++f) {
-        if (f < nr_e) {
-          const double* al = xa + kJC * D + kJC * (1 + f) + 8 * H + k4;
-          mean_r[f] = fma(al[0], kv[0], mean_r[f]);
-          mean_r[f] = fma(al[4], kv[1], mean_r[f]);
-        }
-      }
-    }
-    *reinterpret_cast<double2_t*>(kbw + k4 * kKbRow + H * 32 + c16 * 2) =
-        double2_t{kv[0], kv[1]};
+    eval_block(w1, std::integral_constant<int, 0>{}, r, xa, kbw);
+    // (no interleaving of the two blocks: four values in flight cost registers the
+    // kernel does not have)
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef PGP_E5
+    if (w1 & PW_DUO) eval_block(w1, std::integral_constant<int, 1>{}, r, xa + L::kXBlk, kb2w);
+#endif
   };
 
   PStage e1{};
@@ -703,11 +786,18 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
 #pragma unroll
         for (int q = 0; q < 4; ++q) o.kb[m][q] = 1.0 + m;
     } else if (part & 1) {
-      const double2_t* r = reinterpret_cast<const double2_t*>(
-          kbr + k4 * kKbRow + (lane & 3) * 2);
+      // (row quads m = 0, 1 | 2, 3 sit in the two 16-double halves of a q pair's 32; odd
+      // k-rows store them swapped: the k-rows of a 16-lane read group then hit different
+      // banks without padding between them)
+      const int sw = PGP_SW((k4 & 1) * 16);
+      const double2_t* r0 = reinterpret_cast<const double2_t*>(
+          kbr + k4 * kKbRow + (lane & 3) * 2 + sw);
+      const double2_t* r1 = reinterpret_cast<const double2_t*>(
+          kbr + k4 * kKbRow + (lane & 3) * 2 + 16 - sw);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const double2_t a = r[m * 4], b = r[16 + m * 4];
+        const double2_t* r = m < 2 ? r0 + m * 4 : r1 + (m - 2) * 4;
+        const double2_t a = r[0], b = r[16];
         o.kb[m][0] = a.x; o.kb[m][1] = a.y; o.kb[m][2] = b.x; o.kb[m][3] = b.y;
       }
     }
@@ -716,7 +806,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       // (read whether slot 0 is narrow or not: two LDS reads are cheaper than a
       // branch and four register moves next to the matrix instructions)
       const double2_t* rn = reinterpret_cast<const double2_t*>(
-          kbr + k4 * kKbRow + c16 * 2);
+          kbr + k4 * kKbRow + ((c16 * 2) ^ PGP_SW((k4 & 1) * 16)));
       const double2_t a = rn[0], b = rn[16];
       o.kvn[0] = a.x; o.kvn[1] = a.y; o.kvn[2] = b.x; o.kvn[3] = b.y;
     }
@@ -724,21 +814,37 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
 #pragma unroll
     for (int q = 0; q < 4; ++q) o.a0[q] = aT[q * 64];
   };
-  auto multiply = [&](uint32_t w, const double* abuf, Ops& o, const DmaPlan& dma) {
-    const int nw = (int(w & PW_NACT_MASK) - H + 1) >> 1;   // this wave's active slots
-    if (nw > 0 && !PGP_ABL(8)) {
-      const bool narrow0 = H == 0 && (w & PW_NARROW) != 0;
-      const double* aT = abuf + H * (kSteps * 64) + lane;
-      double opsB[4];
-      pair_slots<0, H == 0, kDmaGroups, true>(nw, narrow0, acc, accx, aT, o.kb,
-                                                  o.kvn, o.a0, opsB, dma);
+  auto multiply = [&](uint32_t w, const double* abuf, const double* kb2r, Ops& o,
+                      DmaPlan& dma) {
+    // segment A, then (merged stages) segment B through a second, shorter instance of the
+    // slot sequence (segment B has at most kDuoUnits / 2 - 1 units).  Two sequences one
+    // behind the other keep the tied accumulators where they are (no copies, no scratch:
+    // scripts/resource_usage.py); ONE sequence inside a two-trip loop did too, but cost
+    // 0.3 ms at config 3 (profiles/r06/experiments.txt, section 1).
+    const int na = int(w & PW_NACT_MASK), nb = int(w >> PW_NB_SHIFT) & 63;
+    const bool narrow0 = H == 0 && (w & PW_NARROW) != 0;
+    {
+      const int nw = (na - H + 1) >> 1;
+      if (nw > 0 && !PGP_ABL(8)) {
+        const double* aT = abuf + H * (kSteps * 64) + lane;
+        double opsB[4];
+        pair_slots<0, H == 0, kDmaGroups, true>(nw, narrow0, acc, accx, aT, o.kb,
+                                                    o.kvn, o.a0, opsB, dma);
+      }
+      const int nw2 = (nb - H + 1) >> 1;
+      if (nw2 > 0) {
+        const double* aseg2 = abuf + na * (kSteps * 64);
+        fetch_ops(aseg2, kb2r, o, 3);
+        const double* aT = aseg2 + H * (kSteps * 64) + lane;
+        double opsB[4];
+        pair_slots<0, H == 0, kDmaGroups, true, (kDuoUnits / 2 + 1) / 2>(
+            nw2, narrow0, acc, accx, aT, o.kb, o.kvn, o.a0, opsB, dma);
+      }
     }
     if constexpr (kDmaGroups > 0) {
-      // groups whose slot was not active (the hook sits behind slot kEvery * i)
-      constexpr int kEvery = kWaveSlots / (kDmaGroups > 0 ? kDmaGroups : 1);
-#pragma unroll
-      for (int i = 0; i < kDmaGroups; ++i)
-        if (!(nw > kEvery * i && !PGP_ABL(8))) dma_group<kDmaGroups>(dma, i);
+      // units that found no hook (the running stage has fewer slots than the next one units)
+#pragma unroll 1
+      while (dma.u < dma.ntot) dma_next(dma);
     }
     if (__builtin_expect((w & PW_CHUNK_END) != 0, 0)) {
       // squares of the chunk's accumulators, folded at once to this wave's share of
@@ -765,7 +871,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       }
       if (p.split_parts > 0 && tile >= p.split_tile0)
         p.split_t[(size_t(tile - p.split_tile0) * p.nchunks +
-                   (int(w >> PW_CHUNK_SHIFT) & 63)) * 512 + wave * 64 + lane] = t;
+                   (int(w >> PW_CHUNK_SHIFT) & 63)) * 512 + wave * 64 + cold_lane()] = t;
       else
         ssq_run += t;
     }
@@ -838,13 +944,20 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   // the same bits wherever an item begins).  Only the training block of the first
   // stage has to be in LDS before it.
   par = 0;
-  e1 = load_pstage<(R > 0)>(stages, s_lo);
+  e1 = load_pstage<(R > 0), (SEP > 0)>(stages, s_lo);
   if (wave == 7) {
-    const PStage el = load_pstage<(R > 0)>(stages, (s_lo == 0 ? nstages : s_lo) - 1);
-    xa_dma<D>(el.xa_next, lds_xa + L::kXBuf * 8, lane, voff);   // block of the first stage
+    const PStage el = load_pstage<(R > 0), (SEP > 0)>(stages, (s_lo == 0 ? nstages : s_lo) - 1);
+    // block(s) of the first stage
+    xa_dma<D>(el.xa_next, lds_xa + L::kXBuf * 8, lane, voff);
     if (R > 0)
       rider_dma<D>(p.nride, p.ride_delta, int(el.g_next), el.xa_next, lds_xa + L::kXBuf * 8,
                    lane, voff);
+    if (el.xb_next != 0) {
+      xa_dma<D>(el.xa_next + el.xb_next, lds_xa + (L::kXBuf + L::kXBlk) * 8, lane, voff);
+      if (R > 0)
+        rider_dma<D>(p.nride, p.ride_delta, int(el.g_next), el.xa_next + el.xb_next,
+                     lds_xa + (L::kXBuf + L::kXBlk) * 8, lane, voff);
+    }
   }
   wcur = 0;
   ++left;
@@ -887,25 +1000,33 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     // its first slot (config 3 with the shared factor: 5.77 -> 5.65 ms).
     // (d = 4 with riders: wave 7 again -- the other placement spills there)
     constexpr bool kXaHalf0 = R > 0 && D <= 3;
-    if constexpr (R == 0) {
-      if (more && !PGP_ABL(2) && wave == 7)
-        xa_dma<D>(e1.xa_next, lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
-    } else if constexpr (!kXaHalf0) {
-      if (more && !PGP_ABL(2) && wave == 7) {
-        xa_dma<D>(e1.xa_next, lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
-        rider_dma<D>(p.nride, p.ride_delta, int(e1.g_next), e1.xa_next,
-                     lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
+    // (the training blocks of BOTH j-blocks of a merged stage)
+    auto xa_prefetch = [&](const PStage& e, uint32_t dst) {
+      xa_dma<D>(e.xa_next, dst, lane, voff);
+      if (R > 0) rider_dma<D>(p.nride, p.ride_delta, int(e.g_next), e.xa_next, dst, lane, voff);
+      if (e.xb_next != 0) {
+        xa_dma<D>(e.xa_next + e.xb_next, dst + L::kXBlk * 8, lane, voff);
+        if (R > 0)
+          rider_dma<D>(p.nride, p.ride_delta, int(e.g_next), e.xa_next + e.xb_next,
+                       dst + L::kXBlk * 8, lane, voff);
       }
+    };
+    if constexpr (R == 0 || !kXaHalf0) {
+      if (more && !PGP_ABL(2) && wave == 7)
+        xa_prefetch(e1, lds_xa + uint32_t(par) * (L::kXBuf * 8));
     }
     DmaPlan plan{};
     if constexpr (kDmaGroups > 0) {
-      const int w0 = wave & 3;     // first global slot of this wave in the copy
-      plan.src0 = e1.a_src - uint64_t(uint32_t(w0)) * e1.rs_bytes;
-      plan.step = uint64_t(e1.rs_bytes) * (32 / (kDmaGroups > 0 ? kDmaGroups : 1));
-      plan.dst0 = lds_a + uint32_t(par ^ 1) * (L::kATile * 8) + uint32_t(w0) * 2048u;
+      plan.src = e1.a_src;
+      plan.b_off = e1.b_off;
+      plan.rs = e1.rs_bytes;
+      plan.dst0 = lds_a + uint32_t(par ^ 1) * (L::kATile * 8);
       plan.voff = voff;
-      plan.left = int(wnext & PW_NACT_MASK) - w0;
-      plan.on = more && !PGP_ABL(2);
+      plan.na = int(wnext & PW_NACT_MASK);
+      plan.ntot = plan.na + (int(wnext >> PW_NB_SHIFT) & 63);
+      if (!(more && !PGP_ABL(2))) plan.ntot = 0;
+      plan.u = wave & 3;           // first unit of this wave in the copy
+      plan.u0 = plan.u;
     }
     plan.no_a = PGP_ABL(64);
     PGP_STAMP(1);   // LDS-DMA issue
@@ -916,11 +1037,14 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     // letting it start early, the waves of a SIMD then run their VALU bursts
     // together; experiments.txt section 10)
     PStage e2 = e1;
-    if (left > 2) e2 = load_pstage<(R > 0)>(stages, si2);
+    if (left > 2) e2 = load_pstage<(R > 0), (SEP > 0)>(stages, si2);
 
     const double* abuf = lds + par * L::kATile;
     const double* kbr = kbp + par * L::kKbBuf;
     double* kbw = kbp + (par ^ 1) * L::kKbBuf;
+    // (second j-block: in the tail of the chunk buffer of the stage it belongs to)
+    const double* kb2r = abuf + L::kKb2Off + pr * L::kKbBuf;
+    double* kb2w = lds + (par ^ 1) * L::kATile + L::kKb2Off + pr * L::kKbBuf;
     const double* xa = lds + L::kXOff + (par ^ 1) * L::kXBuf;
 
     Ops ops;
@@ -938,7 +1062,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       if (p.split_parts > 0 && tile >= p.split_tile0) {
         // (a run of a remainder tile: per lane, summed by k_pair_split_finish)
         double* sm = p.split_m + (size_t(tile - p.split_tile0) * p.geff + g_end) * 512 +
-                     wave * 64 + lane;
+                     wave * 64 + cold_lane();
         sm[0] = mean;
         if (R > 0) {
 #pragma unroll
@@ -972,7 +1096,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
         for (int f = 0; f < R; ++f) mean_r[f] = 0.0;
       }
     }
-    if (more) evaluate(wnext, rows, xa, kbw);
+    if (more) evaluate(wnext, rows, xa, kbw, kb2w);
     if constexpr (SEP > 0) {
       // the factors of the stage after the next one (its entry, e2, was requested
       // above: it has arrived under the evaluation); they have the matrix phase to come
@@ -988,13 +1112,10 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     PGP_STAMP(3);     // covariance evaluation
     fetch_ops(abuf, kbr, ops, kOpsEarly ? 2 : 3);
     if constexpr (kXaHalf0 && H == 0) {
-      if (more && !PGP_ABL(2) && wave == 0) {
-        xa_dma<D>(e1.xa_next, lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
-        rider_dma<D>(p.nride, p.ride_delta, int(e1.g_next), e1.xa_next,
-                     lds_xa + uint32_t(par) * (L::kXBuf * 8), lane, voff);
-      }
+      if (more && !PGP_ABL(2) && wave == 0)
+        xa_prefetch(e1, lds_xa + uint32_t(par) * (L::kXBuf * 8));
     }
-    multiply(wcur, abuf, ops, plan);
+    multiply(wcur, abuf, kb2r, ops, plan);
     PGP_STAMP(2);     // matrix phase (operand reads, slots, chunk fold)
 
     if (__builtin_expect((wcur & PW_GP_END) != 0, 0)) {
@@ -1112,10 +1233,24 @@ __global__ __launch_bounds__(512) void k_pair_split_finish(PairParams p) {
 // sized for the pitch of L^-1: one-row appends keep their addresses).
 // sep: the launch reads factor tables -- the training block of a stage is its 16 alpha
 // only (the D = 1 instance copies 256 bytes: the address is that of alpha - 128).
+//
+// Merged stages (round 6): inside a chunk the j-blocks are taken from both ends -- the
+// widest one left with the narrowest one left while their active slots together fit
+// kDuoUnits, alone otherwise.  32 row blocks: j-blocks 0 .. 4 alone (32 .. 28 slots), then
+// (5, 31), (6, 30), .. (17, 19) with 28 slots each, then 18 (14): 19 stages instead of 32.
+// An accumulator still meets only j-blocks at or below its row block, in a different
+// order than 0, 1, 2, .. (the sums differ in the last bits from the unmerged schedule,
+// which sgp_ctx_set_sweep(.. | 32) / SGP_PAIR_MERGE=0 keep for A/B runs).
+bool pair_merge_wanted(const sgp_ctx* ctx) {
+  static const bool off = getenv("SGP_PAIR_MERGE") && atoi(getenv("SGP_PAIR_MERGE")) == 0;
+  return !off && !(ctx->sweep_choice & 32);
+}
+
 int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, bool sep, const bool* rides,
                      const PStage** dev, int* nstages) {
+  const bool merge = pair_merge_wanted(ctx);
   std::vector<uint64_t> sig(1, uint64_t(Geff));
-  sig.push_back(uint64_t(d) | (uint64_t(sep) << 8));
+  sig.push_back(uint64_t(d) | (uint64_t(sep) << 8) | (uint64_t(merge) << 9));
   int last_staged = 0;
   for (int g = 0; g < Geff; ++g)
     if (!rides[g]) last_staged = g;
@@ -1132,7 +1267,7 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, bool sep, c
     return 0;
   }
   std::vector<PStage> tab;
-  std::vector<uint64_t> xa;
+  std::vector<uint64_t> xa, xb;   // training block(s) of every stage (xb: 0 = no second one)
   std::vector<uint32_t> gof;      // GP of every stage
   std::vector<int> chunk_start;
   const uint64_t xa_block = uint64_t(16 * d + 16) * sizeof(double);
@@ -1141,62 +1276,62 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, bool sep, c
     const int nblk = gh[g].nblk, nsteps = gh[g].n_pad / 4;
     const int nchunks = (nblk + kPairSlots - 1) / kPairSlots;
     const uint64_t apack = reinterpret_cast<uint64_t>(gh[g].Apack);
+    const uint64_t xa0 = reinterpret_cast<uint64_t>(gh[g].XA) + xa_skip;
     ctx->pstage_chunk_off[g] = int(chunk_start.size());
     if (rides[g]) continue;       // (its alpha . k is formed in its leader's stages)
-    if (gh[g].share >= 0) {
-      // same factor as the GP in front: one "chunk" without rows -- every j-block
-      // once, for alpha . k
+    const bool rowless = gh[g].share >= 0;
+    // same factor as the GP in front: one "chunk" without rows -- every j-block once,
+    // for alpha . k
+    for (int c = 0; c < (rowless ? 1 : nchunks); ++c) {
       const uint32_t chunk_id = uint32_t(chunk_start.size());
       chunk_start.push_back(int(tab.size()));
-      for (int jb = 0; jb < nblk; ++jb) {
-        PStage e{};
-        e.a_src = apack;
-        e.rs_bytes = uint32_t(nsteps) * 512u;
-        e.word = (uint32_t(g) << PW_G_SHIFT) | ((chunk_id & 63u) << PW_CHUNK_SHIFT) |
-                 PW_MEAN | PW_SHARED;
-        e.jb = uint32_t(jb);
-        if (jb == 0) e.word |= PW_GP_FIRST;
-        if (g == last_staged) e.word |= PW_LAST_GP;
-        if (jb == nblk - 1) {
-          e.word |= PW_CHUNK_END | PW_GP_END;
-          if (g == last_staged) e.word |= PW_TILE_END;
-        }
-        tab.push_back(e);
-        xa.push_back(reinterpret_cast<uint64_t>(gh[g].XA) + uint64_t(jb) * xa_block + xa_skip);
-        gof.push_back(uint32_t(g));
-      }
-      continue;
-    }
-    for (int c = 0; c < nchunks; ++c) {
-      const uint32_t chunk_id = uint32_t(chunk_start.size());
-      chunk_start.push_back(int(tab.size()));
+      const bool last_chunk = rowless || c == nchunks - 1;
       const int b0 = c * kPairSlots, nib = std::min(kPairSlots, nblk - b0),
-                bend = b0 + nib;
-      for (int jb = 0; jb < bend; ++jb) {
+                bend = rowless ? nblk : b0 + nib;
+      auto active = [&](int jb) { return rowless ? 0 : std::min(nib, bend - jb); };
+      auto src_of = [&](int jb) { return apack + (uint64_t(bend - 1) * nsteps + 4 * uint64_t(jb)) * 512; };
+      const size_t first = tab.size();
+      int lo = 0, hi = bend - 1;
+      while (lo <= hi) {
         PStage e{};
-        e.a_src = apack + (uint64_t(bend - 1) * nsteps + 4 * uint64_t(jb)) * 512;
+        const int na = active(lo);
+        e.a_src = rowless ? apack : src_of(lo);
         e.rs_bytes = uint32_t(nsteps) * 512u;
-        e.word = uint32_t(std::min(nib, bend - jb)) | (uint32_t(g) << PW_G_SHIFT) |
-                 ((chunk_id & 63u) << PW_CHUNK_SHIFT);
-        e.jb = uint32_t(jb);
-        if (jb == bend - 1) e.word |= PW_CHUNK_END;
-        if (c == nchunks - 1) e.word |= PW_MEAN;
-        if (c == nchunks - 1 && gh[g].narrow) e.word |= PW_NARROW;
-        if (c == 0 && jb == 0) e.word |= PW_GP_FIRST;
-        if (g == last_staged) e.word |= PW_LAST_GP;
-        if (c == nchunks - 1 && jb == bend - 1) {
-          e.word |= PW_GP_END;
-          if (g == last_staged) e.word |= PW_TILE_END;
+        e.jb = e.jb2 = uint32_t(lo);
+        e.word = uint32_t(na) | (uint32_t(g) << PW_G_SHIFT) | ((chunk_id & 63u) << PW_CHUNK_SHIFT);
+        uint64_t second = 0;
+        if (merge && lo < hi && na + active(hi) <= kDuoUnits) {
+          const int nb = active(hi);
+          e.word |= PW_DUO | (uint32_t(nb) << PW_NB_SHIFT);
+          e.jb2 = uint32_t(hi);
+          // unit u >= na is slot u - na of segment B
+          e.b_off = rowless ? 0u : uint32_t(src_of(hi) - src_of(lo) + uint64_t(na) * e.rs_bytes);
+          second = xa0 + uint64_t(hi) * xa_block;
+          --hi;
         }
+        if (rowless) e.word |= PW_SHARED;
+        if (last_chunk) e.word |= PW_MEAN;
+        if (!rowless && last_chunk && gh[g].narrow) e.word |= PW_NARROW;
+        if (g == last_staged) e.word |= PW_LAST_GP;
         tab.push_back(e);
-        xa.push_back(reinterpret_cast<uint64_t>(gh[g].XA) + uint64_t(jb) * xa_block + xa_skip);
+        xa.push_back(xa0 + uint64_t(lo) * xa_block);
+        xb.push_back(second);
         gof.push_back(uint32_t(g));
+        ++lo;
+      }
+      if (c == 0) tab[first].word |= PW_GP_FIRST;
+      tab.back().word |= PW_CHUNK_END;
+      if (last_chunk) {
+        tab.back().word |= PW_GP_END;
+        if (g == last_staged) tab.back().word |= PW_TILE_END;
       }
     }
   }
   for (size_t i = 0; i < tab.size(); ++i) {
-    tab[i].xa_next = xa[(i + 1) % tab.size()];
-    tab[i].g_next = gof[(i + 1) % tab.size()];
+    const size_t nx = (i + 1) % tab.size();
+    tab[i].xa_next = xa[nx];
+    tab[i].xb_next = xb[nx] ? uint32_t(xb[nx] - xa[nx]) : 0u;
+    tab[i].g_next = gof[nx];
   }
   ctx->pstage_chunk_off[Geff] = int(chunk_start.size());
   chunk_start.push_back(int(tab.size()));
