@@ -62,8 +62,12 @@ constexpr int kKbRow = 80;
 constexpr int kKbRow = 64;             // doubles per k-row of a B buffer (odd k-rows are stored with
                                        // the two halves of a q pair's 32 doubles swapped: no padding)
 #endif
+#ifdef PGP_DUO
+constexpr int kDuoUnits = PGP_DUO;
+#else
 constexpr int kDuoUnits = 28;          // 2 KB units of L^-1 in a stage of TWO j-blocks: the last four
                                        // units of its chunk buffer hold the B buffers of the second one
+#endif
 
 // The structure below is what survived the round-3 experiments (phase orders, pairs
 // on adjacent waves, where and by whom the LDS-DMA is issued, priorities, a second
@@ -85,13 +89,18 @@ struct PStage {
   uint64_t xa_next;    // device address of the [16 d | 16] block of the NEXT stage
                        // of the (cyclic) sequence (its first j-block)
   uint32_t xb_next;    // ... bytes from there to the block of its second j-block (0: none)
-  uint32_t b_off;      // unit u >= nA comes from a_src + b_off - u * rs_bytes (the host folds
-                       // nA in: b_off = 2 KB * 4 (jb2 - jb) ... + nA * rs_bytes)
   uint32_t rs_bytes;   // bytes between consecutive row blocks in Apack
   uint32_t word;       // PW_*
-  uint32_t g_next;     // GP of the NEXT stage (whose riders' alpha blocks go with xa_next)
-  uint32_t jb;         // j-block of segment A (factor tables: row [jb] of every axis)
-  uint32_t jb2;        // j-block of segment B
+  uint32_t info;       // PI_*: j-block of segment A (factor tables: row [jb] of every axis), how
+                       // many j-blocks further segment B's is, GP of the NEXT stage (whose
+                       // riders' alpha blocks go with xa_next)
+  // Unit u >= nA comes from a_src + b_off - u * rs_bytes with b_off = 2 KB * (jb2 - jb) +
+  // nA * rs_bytes (formed on the device: the entry stays ONE aligned 32-byte scalar load --
+  // scalar loads count on lgkmcnt like the LDS reads around them, every further piece
+  // of an entry couples another wait to them).
+  __host__ __device__ uint32_t jb() const { return info & 1023u; }
+  __host__ __device__ uint32_t djb() const { return (info >> 10) & 1023u; }
+  __host__ __device__ uint32_t g_next() const { return (info >> 20) & 7u; }
 };
 enum : uint32_t {
   PW_NACT_MASK = 63u,       // active global slots 0 .. nact-1 (1..32)
@@ -146,6 +155,7 @@ struct LayP {
 // without rows (PW_SHARED).
 constexpr int kMaxRide = 2;
 #ifndef PGP_E3
+static_assert(sizeof(PStage) == 32, "one aligned scalar load per stage");
 static_assert(LayP<8>::bytes() <= 160 * 1024, "LDS budget of one workgroup per CU");
 static_assert(LayP<1>::kKb2Off + kPairs * LayP<1>::kKbBuf <= LayP<1>::kATile, "second B buffers");
 static_assert(LayP<4, kMaxRide>::bytes() <= 160 * 1024, "LDS budget with riders");
@@ -222,14 +232,11 @@ template <bool RIDE = false, bool SEP = false>
 __device__ __forceinline__ PStage load_pstage(pstage_ptr_t t, int i) {
   PStage e;      // member-wise: scalar loads (only what the instance reads stays live)
   e.a_src = t[i].a_src;
-  e.b_off = t[i].b_off;
   e.xa_next = t[i].xa_next;
   e.xb_next = t[i].xb_next;
   e.rs_bytes = t[i].rs_bytes;
   e.word = t[i].word;
-  e.jb = SEP ? t[i].jb : 0;
-  e.jb2 = SEP ? t[i].jb2 : 0;
-  e.g_next = RIDE ? t[i].g_next : 0;
+  e.info = t[i].info;
   return e;
 }
 
@@ -540,8 +547,12 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   constexpr bool conf = MODE == MODE_CONF;
   // (32 more live registers across the evaluation: instances that would spill for
   // it -- d >= 6, product kernels -- do without)
+#ifdef PGP_NOEARLY
+  constexpr int kOpsEarly = 0;
+#else
   constexpr int kOpsEarly =
       (SINGLE && D <= 4 && R == 0) ? 2 : 0;
+#endif
   const int pr = wave & 3;
   const int k4 = lane >> 4, c16 = lane & 15;
   const double* tab = lds + L::kTabOff;
@@ -624,13 +635,13 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     typedef const __attribute__((address_space(1))) double2_t* gvec_t;
 #pragma unroll
     for (int a = 0; a < kAx; ++a) {
-      const char* src = sep_tab[a] + e.jb * sep_pitch[a];      // (<= 256 MB per GP: sep_launch)
+      const char* src = sep_tab[a] + e.jb() * sep_pitch[a];    // (<= 256 MB per GP: sep_launch)
       efn[a] = *(gvec_t)(reinterpret_cast<const double2_t*>(src + soff[a]));
     }
     if (e.word & PW_DUO) {
 #pragma unroll
       for (int a = 0; a < kAx; ++a) {
-        const char* src = sep_tab[a] + e.jb2 * sep_pitch[a];
+        const char* src = sep_tab[a] + (e.jb() + e.djb()) * sep_pitch[a];
         efn2[a] = *(gvec_t)(reinterpret_cast<const double2_t*>(src + soff[a]));
       }
     }
@@ -668,7 +679,11 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   };
   // (only where the 2 D + 2 registers are there for it; elsewhere the evaluation
   // reads its rows itself)
+#ifdef PGP_NOROWS
+  constexpr bool kRowsFirst = false;
+#else
   constexpr bool kRowsFirst = kOpsEarly != 0 && SINGLE && D <= 2;
+#endif
   // One j-block of a stage: J = 0 the first (its rows may have been fetched in front of
   // the evaluation: Rows), J = 1 the second of a merged stage.
   auto eval_block = [&](uint32_t w1, auto jtag, const Rows& r, const double* xa, double* kbw) {
@@ -742,7 +757,12 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     // kernel does not have)
     __builtin_amdgcn_sched_barrier(0);
 #ifndef PGP_E5
-    if (w1 & PW_DUO) eval_block(w1, std::integral_constant<int, 1>{}, r, xa + L::kXBlk, kb2w);
+#ifdef PGP_LIKELY
+    if (__builtin_expect((w1 & PW_DUO) != 0, PGP_LIKELY))
+#else
+    if (w1 & PW_DUO)
+#endif
+      eval_block(w1, std::integral_constant<int, 1>{}, r, xa + L::kXBlk, kb2w);
 #endif
   };
 
@@ -760,7 +780,11 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     for (int m = 0; m < 4; ++m) acc[b][m] = 0.0;
   // the half whose wave finishes a pair's rows (sums the two partial |L^-1 k|^2 and
   // alpha . k, runs the row epilogue one stage later); the other hands its share over
+#ifdef PGP_FIN0
+  constexpr int kFin = 0;
+#else
   constexpr int kFin = 1;
+#endif
   RowState rs;                       // (H == kFin: the finishing wave)
   double keep_ssq = 0.0, keep_mu = 0.0;
   double keep_mu_r[R > 0 ? R : 1];
@@ -832,7 +856,11 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
                                                     o.kvn, o.a0, opsB, dma);
       }
       const int nw2 = (nb - H + 1) >> 1;
+#ifdef PGP_LIKELY
+      if (__builtin_expect(nw2 > 0, PGP_LIKELY)) {
+#else
       if (nw2 > 0) {
+#endif
         const double* aseg2 = abuf + na * (kSteps * 64);
         fetch_ops(aseg2, kb2r, o, 3);
         const double* aT = aseg2 + H * (kSteps * 64) + lane;
@@ -950,12 +978,12 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     // block(s) of the first stage
     xa_dma<D>(el.xa_next, lds_xa + L::kXBuf * 8, lane, voff);
     if (R > 0)
-      rider_dma<D>(p.nride, p.ride_delta, int(el.g_next), el.xa_next, lds_xa + L::kXBuf * 8,
+      rider_dma<D>(p.nride, p.ride_delta, int(el.g_next()), el.xa_next, lds_xa + L::kXBuf * 8,
                    lane, voff);
     if (el.xb_next != 0) {
       xa_dma<D>(el.xa_next + el.xb_next, lds_xa + (L::kXBuf + L::kXBlk) * 8, lane, voff);
       if (R > 0)
-        rider_dma<D>(p.nride, p.ride_delta, int(el.g_next), el.xa_next + el.xb_next,
+        rider_dma<D>(p.nride, p.ride_delta, int(el.g_next()), el.xa_next + el.xb_next,
                      lds_xa + (L::kXBuf + L::kXBlk) * 8, lane, voff);
     }
   }
@@ -1003,11 +1031,11 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     // (the training blocks of BOTH j-blocks of a merged stage)
     auto xa_prefetch = [&](const PStage& e, uint32_t dst) {
       xa_dma<D>(e.xa_next, dst, lane, voff);
-      if (R > 0) rider_dma<D>(p.nride, p.ride_delta, int(e.g_next), e.xa_next, dst, lane, voff);
+      if (R > 0) rider_dma<D>(p.nride, p.ride_delta, int(e.g_next()), e.xa_next, dst, lane, voff);
       if (e.xb_next != 0) {
         xa_dma<D>(e.xa_next + e.xb_next, dst + L::kXBlk * 8, lane, voff);
         if (R > 0)
-          rider_dma<D>(p.nride, p.ride_delta, int(e.g_next), e.xa_next + e.xb_next,
+          rider_dma<D>(p.nride, p.ride_delta, int(e.g_next()), e.xa_next + e.xb_next,
                        dst + L::kXBlk * 8, lane, voff);
       }
     };
@@ -1018,7 +1046,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     DmaPlan plan{};
     if constexpr (kDmaGroups > 0) {
       plan.src = e1.a_src;
-      plan.b_off = e1.b_off;
+      plan.b_off = e1.djb() * 2048u + uint32_t(wnext & PW_NACT_MASK) * e1.rs_bytes;
       plan.rs = e1.rs_bytes;
       plan.dst0 = lds_a + uint32_t(par ^ 1) * (L::kATile * 8);
       plan.voff = voff;
@@ -1297,15 +1325,13 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, bool sep, c
         const int na = active(lo);
         e.a_src = rowless ? apack : src_of(lo);
         e.rs_bytes = uint32_t(nsteps) * 512u;
-        e.jb = e.jb2 = uint32_t(lo);
+        e.info = uint32_t(lo);
         e.word = uint32_t(na) | (uint32_t(g) << PW_G_SHIFT) | ((chunk_id & 63u) << PW_CHUNK_SHIFT);
         uint64_t second = 0;
         if (merge && lo < hi && na + active(hi) <= kDuoUnits) {
           const int nb = active(hi);
           e.word |= PW_DUO | (uint32_t(nb) << PW_NB_SHIFT);
-          e.jb2 = uint32_t(hi);
-          // unit u >= na is slot u - na of segment B
-          e.b_off = rowless ? 0u : uint32_t(src_of(hi) - src_of(lo) + uint64_t(na) * e.rs_bytes);
+          e.info |= uint32_t(hi - lo) << 10;
           second = xa0 + uint64_t(hi) * xa_block;
           --hi;
         }
@@ -1331,7 +1357,7 @@ int pair_stage_table(sgp_ctx* ctx, const GpDev* gh, int Geff, int d, bool sep, c
     const size_t nx = (i + 1) % tab.size();
     tab[i].xa_next = xa[nx];
     tab[i].xb_next = xb[nx] ? uint32_t(xb[nx] - xa[nx]) : 0u;
-    tab[i].g_next = gof[nx];
+    tab[i].info |= gof[nx] << 20;
   }
   ctx->pstage_chunk_off[Geff] = int(chunk_start.size());
   chunk_start.push_back(int(tab.size()));
