@@ -445,6 +445,65 @@ def reference_regime(gpy, safeopt_amd, ctx, n=20, steps=200):
                          "unit": "T lane-ops/s", "frac": ops / (t * 1e-3) / 1e12 / 39.3}}
 
 
+def no_expander_state(gpy, safeopt_amd, ctx):
+    """The expander loop of gp_opt.py:557-612 where it has to visit EVERY candidate: a converged
+    run (tests/_scenarios.py: a safe disk whose rim is observed densely, a coarsely observed
+    plateau inside -- thousands of candidates wider than every maximiser -- and no unsafe row
+    within reach of any of them; 2-D RBF, 637 observations), and full_sets = True (:553-555:
+    every safe row is visited).  ms per SafeOpt.optimize() / compute_sets(full_sets=True) with
+    the big passes of round 6 (sgp_grid_expander_pass: hundreds to thousands of candidates per
+    device pass, two synchronisations each) and, on the 1e5-row grid, with the 16-candidates-
+    per-round-trip loop they replace.  Parity: tests/test_gpu_expander_passes.py."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    import _scenarios as sc
+    out = {"note": no_expander_state.__doc__.split("  ms per")[0].strip().replace("\n   ", ""),
+           "pass_sizes": list(safeopt_amd.SafeOpt.pass_sizes)}
+    for side, with_old in ((320, True), (1000, False)):
+        gp, grid = sc.converged_state(side, 0.05, ns=gpy, r0=2.0, rings=8, ls=0.4, dmid=0.45,
+                                      plateau=0.6)
+        row = {"rows": int(len(grid)), "n_train": int(gp.X.shape[0])}
+        for big in ((True, False) if with_old else (True,)):
+            opt = safeopt_amd.SafeOpt(gp, grid, 0.0, threshold=0.1)
+            opt.big_passes = big
+            passes = []
+            if big:
+                orig = opt._backend.expander_pass
+                opt._backend.expander_pass = lambda *a, _o=orig: (passes.append(a[-1]), _o(*a))[1]
+            else:
+                orig = opt._backend.expander_batch
+                opt._backend.expander_batch = lambda *a, _o=orig: (passes.append(a[-1]), _o(*a))[1]
+            opt.optimize()
+            del passes[:]
+            ctx.sync()
+            t0 = time.perf_counter()
+            opt.optimize()
+            ctx.sync()
+            ms = (time.perf_counter() - t0) * 1e3
+            key = "big_passes" if big else "sixteen_per_round_trip"
+            S = np.asarray(opt.S, dtype=bool)
+            row.setdefault("unsafe_rows", int((~S).sum()))
+            row.setdefault("safe_rows", int(S.sum()))
+            row[key] = {"optimize_ms": ms, "device_passes": len(passes),
+                        "expanders_found": int(np.asarray(opt.G).sum())}
+            if side == 320:
+                ctx.sync()
+                t0 = time.perf_counter()
+                opt.compute_sets(full_sets=True)
+                ctx.sync()
+                row[key]["full_sets_ms"] = (time.perf_counter() - t0) * 1e3
+                row[key]["full_sets_expanders"] = int(np.asarray(opt.G).sum())
+        if side == 320:
+            # candidates of the state: S & ~M & wider than every maximiser & above the threshold
+            Q = np.asarray(opt.Q)
+            w = Q[:, 1] - Q[:, 0]
+            M = np.asarray(opt.M, dtype=bool)
+            row["candidates"] = int((S & ~M & (w > w[M].max()) & (w > 0.1 * 2.0)).sum())
+        out["grid_%dx%d" % (side, side)] = row
+    return out
+
+
 def config1(gpy, safeopt_amd, ctx, steps=2000):
     """BASELINE.json configs[0] -- the reference's own problem size, examples/1d_example.ipynb
     plumbing: 1-D RBF (variance 2, lengthscale 1, noise 0.05^2), 1 GP that is objective and
@@ -904,6 +963,10 @@ def main():
                 extras["config1"] = config1(gpy, safeopt_amd, ctx)
             except Exception as e:      # noqa
                 extras["config1"] = {"error": repr(e)}
+            try:
+                extras["no_expander_state"] = no_expander_state(gpy, safeopt_amd, ctx)
+            except Exception as e:      # noqa
+                extras["no_expander_state"] = {"error": repr(e)}
         if default_run:
             try:
                 extras["config4_strong"] = config4_strong(gpy, safeopt_amd, dist, ctx, comm,

@@ -242,6 +242,25 @@ int sgp_grid_expander_batch(sgp_grid* grid, sgp_gp* const* gps, int G, double be
                             int k, double* w_out, int64_t* gidx_out, int* n_out,
                             int32_t* flags);
 
+/* A pass of the expander loop over MANY candidates (safeopt/gp_opt.py:557-612 where the
+ * loop goes far: no expander among the first candidates -- or none at all, the state of a
+ * converged run -- and full_sets = True, :553-555, which visits every safe row): the next
+ * ~want candidates behind the cut in visiting order (key descending -- the interval width,
+ * or minus the row index with mode = 1 -- then index descending; strictly behind: key <
+ * cut_w, or key == cut_w and row < cut_idx) are chosen by a histogram of the keys over
+ * [key_lo, key_hi] (no sort) and ALL of them tested in ONE scan of the unsafe rows: the
+ * rank-1 test of sgp_grid_expander_check per (row, candidate).  Two stream synchronisations
+ * per pass whatever its size.
+ *   out6 = { candidates tested, expanders among them,
+ *            mode 0: key and global row of the FIRST expander in visiting order (nothing is
+ *                    marked in G: the caller settles exact ties, gp_opt.py:542-552),
+ *            key below which the candidates are still untested (-inf: none left), 0 }
+ *   mode 1 (full_sets): every expander of the pass is marked in G on the device.
+ * One rank (the shard is the grid).                                                   */
+int sgp_grid_expander_pass(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
+                           const double* fmin, int mode, double cut_w, int64_t cut_idx,
+                           double key_lo, double key_hi, int want, double* out6);
+
 /* SMALL grids -- the reference's own regime (safeopt/gp_opt.py:651-675 on the 1000-point
  * grid of examples/1d_example.ipynb with n <= 20 observations; BASELINE.json config 1):
  * one whole SafeOpt.optimize() = update_confidence_intervals (gp_opt.py:453-476) +

@@ -130,6 +130,43 @@ def compute_sets(gps, inputs, Q, fmin, scaling, threshold, beta,
     return done()
 
 
+def expander_hits_rank1(gp, inputs, unsafe, cand, u_cand, beta, fmin_i, chunk=256):
+    """``np.any(l2 >= fmin[i])`` of gp_opt.py:585-606 for MANY candidates of ONE GP without
+    refitting: appending ``(x_c, u)`` to a GP with ``Ky^-1 = woodbury_inv`` changes the
+    posterior at ``x`` by the rank-1 (Schur complement) update
+
+        c(x) = k(x, x_c) - k(X, x)^T Ky^-1 k(X, x_c),     s2 = var(x_c) + noise + 1e-8,
+        mean2 = mean + c (u - mean(x_c)) / s2,             var2 = max(var - c^2 / s2, 1e-15)
+
+    -- algebraically what ``_add_data_point`` -> ``set_XY`` -> ``predict_noiseless`` ->
+    ``_remove_last_data_point`` computes from scratch (``var`` taken BEFORE GPy's 1e-15 clip
+    would matter only at rows the GP already knows exactly).  Test infrastructure for the
+    big-pass expander loop, where the refit form (O(n^3 + N n^2) per candidate) cannot be run
+    for thousands of candidates; pinned against the refit form on small problems in
+    tests/test_oracle_safeopt.py.  Returns a boolean per candidate."""
+    inputs = np.asarray(inputs, dtype=float)
+    U = inputs[np.asarray(unsafe, dtype=bool)]
+    cand = np.asarray(cand, dtype=np.int64)
+    Xc = inputs[cand]
+    Wi, alpha = gp.woodbury_inv, gp.woodbury_vector[:, 0]
+    KUX = gp.kern.K(U, gp.X)                             # (Nu, n)
+    mean = KUX.dot(alpha)
+    var = gp.kern.Kdiag(U) - np.einsum('ij,jk,ik->i', KUX, Wi, KUX)
+    out = np.zeros(cand.size, dtype=bool)
+    for a in range(0, cand.size, chunk):
+        xb = Xc[a:a + chunk]
+        KcX = gp.kern.K(gp.X, xb)                        # (n, m)
+        W = Wi.dot(KcX)
+        var_c = gp.kern.Kdiag(xb) - np.sum(KcX * W, axis=0)
+        mu_c = KcX.T.dot(alpha)
+        s2 = var_c + gp.noise_var + 1e-8
+        C = gp.kern.K(U, xb) - KUX.dot(W)                # (Nu, m)
+        mean2 = mean[:, None] + C * ((np.asarray(u_cand)[a:a + chunk] - mu_c) / s2)[None, :]
+        var2 = np.clip(var[:, None] - C * C / s2[None, :], 1e-15, np.inf)
+        out[a:a + chunk] = np.any(mean2 - beta * np.sqrt(var2) >= fmin_i, axis=0)
+    return out
+
+
 def query_index(Q, S, M, G, scaling, ucb=False):
     """``SafeOpt.get_new_query_point`` -- gp_opt.py:617-649 (global index).
 

@@ -94,6 +94,9 @@ PROTOTYPES = {
     "sgp_grid_expander_batch": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p, C.c_int,
                                           C.c_double, C.c_int64, C.c_int, c_double_p, c_i64_p,
                                           c_int_p, c_i32_p]),
+    "sgp_grid_expander_pass": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p, C.c_int,
+                                         C.c_double, C.c_int64, C.c_double, C.c_double, C.c_int,
+                                         c_double_p]),
     "sgp_grid_step_small": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_double_p, c_double_p,
                                       c_double_p, c_i32_p, c_double_p, c_i64_p, c_double_p]),
@@ -318,7 +321,9 @@ class Context(object):
 
         old = names[int(lib().sgp_ctx_set_sweep(self.h, code(which)))]
         #: a sweep kernel is forced (A/B runs, tests): no one-launch step of small grids
-        self.sweep_forced = (code(which) & 3) in (1, 2)
+        # (3 = 'mid' counts too: step_small_eligible in csrc/step_small.hip refuses every
+        # non-zero choice, the driver must not pick the one-launch step then)
+        self.sweep_forced = (code(which) & 3) != 0
         return old
 
     def last_sweep(self):
@@ -693,6 +698,17 @@ class DeviceGrid(object):
             float(cut_w), int(cut_idx), int(k), dptr(w), idx.ctypes.data_as(c_i64_p),
             C.byref(n), flags.ctypes.data_as(c_i32_p)))
         return w[:n.value], idx[:n.value], flags[:n.value]
+
+    def expander_pass(self, gps, beta, fmin, mode, cut_w, cut_idx, key_lo, key_hi, want):
+        """About ``want`` candidates behind the cut, all tested in one scan of the unsafe rows
+        (``sgp_grid_expander_pass``): ``(tested, hits, key, row of the first expander in
+        visiting order, key below which candidates are left or -inf)``."""
+        fmin = f64(fmin)
+        out = np.zeros(6)
+        self.ctx.check(lib().sgp_grid_expander_pass(
+            self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin), int(mode), float(cut_w),
+            int(cut_idx), float(key_lo), float(key_hi), int(want), dptr(out)))
+        return int(out[0]), int(out[1]), float(out[2]), int(out[3]), float(out[4])
 
     def lipschitz_check(self, fmin, lipschitz, xc, u_c):
         fmin = f64(fmin)

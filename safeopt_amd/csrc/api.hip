@@ -1211,6 +1211,113 @@ int sgp_grid_expander_batch(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   return 0;
 }
 
+// A pass of the expander loop over MANY candidates (gp_opt.py:557-612 where the loop has to
+// go far: no expander among the first candidates -- or none at all, the state of a converged
+// run -- and full_sets, which visits every safe row).  The next ~`want` candidates behind
+// the cut (visiting order: key descending -- the width, or minus the row index in full_sets
+// mode -- then index descending), chosen by a histogram of the keys instead of a sort, are
+// ALL tested in one scan of the unsafe rows (k_expander_many); two stream synchronisations
+// (the size of the pass, its result) whatever the number of candidates.
+//   mode 0: out6 = { candidates tested, expanders among them, key and global row of the
+//           FIRST expander in visiting order (nothing is marked: the caller settles exact
+//           ties and marks), key below which the candidates are still untested (-inf: none
+//           left), 0 }
+//   mode 1: every expander of the pass is marked in G; out6[2..3] unused.
+// key_lo / key_hi: range of the keys still behind the cut (histogram range; mode 0:
+// 0 .. the width of the cut).  One rank.
+int sgp_grid_expander_pass(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
+                           const double* fmin, int mode, double cut_w, int64_t cut_idx,
+                           double key_lo, double key_hi, int want, double* out6) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  SGP_CHECK(ctx, want >= 1, "want = %d", want);
+  SGP_CHECK(ctx, key_hi > key_lo, "empty key range %g .. %g", key_lo, key_hi);
+  SGP_CHECK(ctx, g->N < (int64_t(1) << 31), "%lld rows", (long long)g->N);
+  for (int i = 0; i < 6; ++i) out6[i] = 0.0;
+  // selection
+  char* sb = static_cast<char*>(sgp_scratch(ctx, 8, size_t(g->N) * 4 + 16384 + 256));
+  SGP_CHECK(ctx, sb, "device allocation failed: %s", ctx->err.c_str());
+  int* list = reinterpret_cast<int*>(sb);
+  unsigned* hist = reinterpret_cast<unsigned*>(sb + size_t(g->N) * 4);
+  char* sel = sb + size_t(g->N) * 4 + 16384;
+  SGP_TRY(launch_pass_select(g, mode, cut_w, cut_idx, key_lo, key_hi, want, sel, list, hist));
+  struct { double thr; int count, est; } hs;
+  SGP_TRY(sgp_d2h(ctx, &hs, sel, sizeof(hs)));
+  const int count = hs.count;
+  out6[0] = double(count);
+  out6[4] = hs.thr;
+  if (count == 0) {
+    out6[4] = -INFINITY;
+    return 0;
+  }
+  // operands
+  GpDev host[SGP_MAX_GPS];
+  SGP_TRY(collect_gps(ctx, gps, G, g->d, host));
+  const int d = g->d;
+  int np_max = 0;
+  for (int i = 0; i < G; ++i) np_max = host[i].n_pad > np_max ? host[i].n_pad : np_max;
+  const int64_t wstride = int64_t(np_max / 4) * 64;
+  const size_t ngroups = (size_t(count) + 15) / 16;
+  const size_t nxc = ngroups * 16 * d, nv = ngroups * G * 16;
+  double* ob = static_cast<double*>(sgp_scratch(ctx, 9, (nxc + 6 * nv + 8) * 8));
+  SGP_CHECK(ctx, ob, "device allocation failed: %s", ctx->err.c_str());
+  double* Wp = static_cast<double*>(sgp_scratch(ctx, 10, ngroups * G * size_t(wstride) * 8));
+  SGP_CHECK(ctx, Wp, "device allocation failed: %s", ctx->err.c_str());
+  int32_t* dfl = static_cast<int32_t*>(sgp_scratch(ctx, 11, ngroups * 16 * G * 4 + 64));
+  SGP_CHECK(ctx, dfl, "device allocation failed: %s", ctx->err.c_str());
+  double* res = reinterpret_cast<double*>(reinterpret_cast<char*>(dfl) + ngroups * 16 * G * 4);
+  res = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(res) + 7) & ~uintptr_t(7));
+  double *dxc = ob, *dres = ob + nxc, *ddel = dres + nv, *dis2 = ddel + nv, *dtn2 = dis2 + nv;
+  SGP_HIP(ctx, hipMemsetAsync(ob, 0, (nxc + nv) * 8, ctx->stream));
+  SGP_HIP(ctx, hipMemsetAsync(dfl, 0, ngroups * 16 * G * 4, ctx->stream));
+  SGP_TRY(launch_pass_stage(g, list, count, dxc, dres));
+  SGP_TRY(stage_gpdev(g, host, G));
+  ExpanderOps ops{};
+  ops.xc = dxc;
+  ops.resid = dres;
+  ops.Wpack = Wp;
+  ops.delta = ddel;
+  ops.inv_s2 = dis2;
+  ops.tn2 = dtn2;
+  ops.wstride = wstride;
+  ops.m = count;
+  ops.Gs = G;
+  ExpanderArgs ea{};
+  for (int i = 0; i < SGP_MAX_GPS; ++i) {
+    ea.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
+    ea.active[i] = (i < G) && (fmin[i] != -INFINITY);
+    ops.active[i] = ea.active[i];
+  }
+  SGP_TRY(expander_operands_all(ctx, g->gpdev, host, G, d, ops, nullptr));
+  ea.Wpack = Wp;
+  ea.xc = dxc;
+  ea.delta = ddel;
+  ea.inv_s2 = dis2;
+  ea.tn2 = dtn2;
+  ea.stn = dtn2 + nv;
+  ea.svc = dtn2 + 2 * nv;
+  ea.m = count;
+  ea.beta = beta;
+  ea.S = g->S;
+  ea.mean = g->mean;
+  ea.var = g->var;
+  ea.flags = dfl;
+  ea.wstride = wstride;
+  ea.near_frac = 0.0;
+  SweepPoints sp{g->pts, g->N, 1, g->N};
+  SGP_TRY(launch_expander_many(ctx, g->gpdev, G, d, sp, ea));
+  SGP_TRY(launch_pass_result(g, list, count, dfl, fmin, mode, res));
+  double hr[3];
+  SGP_TRY(sgp_d2h(ctx, hr, res, sizeof(hr)));
+  out6[1] = hr[0];
+  out6[2] = hr[1];
+  int64_t bi;
+  memcpy(&bi, &hr[2], 8);
+  out6[3] = double(bi);
+  return 0;
+}
+
 // Host copy of a front block ([0] max width | [1..2] counts (u64) | [3] w_top | [4]
 // idx_top (i64) | [5] n_found, n_tied (int) | x[d] | mean[G] | q[2G]) -> the caller's
 // arrays; out5[4] = -1 when the shard / grid has no candidate, out5[5] = number of

@@ -133,7 +133,7 @@ struct sgp_ctx {
   void* pinned = nullptr;
   size_t pinned_cap = 0;
   // device scratch (grown on demand)
-  DevBuf scratch[8];
+  DevBuf scratch[12];
   int64_t n_allocs = 0;       // hipMalloc calls so far (sgp_ctx_alloc_count)
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -265,7 +265,8 @@ struct ExpanderOps {      // all arrays on the device; [g] blocks as noted
   double* inv_s2;         // [G][16]
   double* tn2;            // [G][16]
   int64_t wstride;
-  int m;
+  int m;                  // candidates; more than 16: groups of 16, arrays [group][Gs][...]
+  int Gs;                 // GP slots of the [group][Gs] layouts (the launch's G)
   int active[SGP_MAX_GPS];
 };
 struct FrontArgs;   // sets_front.h: the fold of the front half's last step into k_expkt
@@ -326,6 +327,8 @@ struct ExpanderArgs {
   const double* delta;   // [G][16]  (u_c - mu_c) / s2
   const double* inv_s2;  // [G][16]
   const double* tn2;     // [G][16]  |L^-1 k(X, x_c)|^2
+  const double* stn;     // k_expander_many: [group][G][16] |L^-1 k_c| and the posterior
+  const double* svc;     // standard deviation at x_c (written by launch_expander_many)
   int m;
   double beta;
   double fmin[SGP_MAX_GPS];
@@ -342,6 +345,10 @@ struct ExpanderArgs {
 int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
                           const GpDev* gps_host, int G, int d, SweepPoints pts,
                           ExpanderArgs ea);
+// ea.m candidates in groups of 16, every per-candidate array [group][G][...] (flags
+// [candidate][G]): sweep.hip, k_expander_many
+int launch_expander_many(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d, SweepPoints pts,
+                         ExpanderArgs ea);
 struct Rank1Args {
   double* Q;
   double* mean;
@@ -400,6 +407,13 @@ int launch_mark_top_if(sgp_grid* g, const int64_t* gidx_dev, const int* nfound_d
                        const int32_t* flags_dev, const double* fmin);
 int launch_mark_if(sgp_grid* g, int64_t li, const int32_t* flags_dev,
                    const double* fmin);
+// a pass of the expander loop over many candidates (sets.hip): selection by a key
+// histogram (sel_dev: { double thr; int count; int est }), operand staging, hits
+int launch_pass_select(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, double lo,
+                       double hi, int want, void* sel_dev, int* list_dev, unsigned* hist_dev);
+int launch_pass_stage(sgp_grid* g, const int* list_dev, int count, double* xc, double* resid);
+int launch_pass_result(sgp_grid* g, const int* list_dev, int count, const int32_t* flags_dev,
+                       const double* fmin, int mode, double* res_dev);
 int launch_topk(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, int k,
                 double* w_out_dev, int64_t* idx_out_dev, int* n_out_dev);
 int launch_count_ties(sgp_grid* g, const double* w_top_dev, const int* n_found_dev,

@@ -713,13 +713,22 @@ struct ExpGpSel {
   int active[SGP_MAX_GPS];
 };
 
+// Many candidates (sgp_grid_expander_pass): blockIdx.z = group of 16 candidates; every
+// per-candidate array is laid out [group][GP slot][...] (ExpanderOps::Gs slots), the group's
+// candidate count is what is left of `m` behind the groups in front.  One group: z = 0.
 // Kc[g][c][j] = k(x_c, X_j)
 template <int D>
 __global__ __launch_bounds__(256) void k_expk(const GpDev* gps, ExpGpSel sel,
                                               const double* xc, int m, double* Kc,
-                                              int64_t ldk) {
+                                              int64_t ldk, int Gs) {
   const int g = blockIdx.y;
   if (!sel.active[g]) return;
+  {
+    const int z = blockIdx.z;
+    xc += int64_t(z) * kMaxRhs * D;
+    Kc += int64_t(z) * Gs * kMaxRhs * ldk;
+    m = min(kMaxRhs, m - kMaxRhs * z);
+  }
   const GpDev& gp = gps[g];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= gp.n) return;
@@ -733,9 +742,15 @@ __global__ __launch_bounds__(256) void k_expk(const GpDev* gps, ExpGpSel sel,
 // T[g][c][i] = sum_{j <= i} Li[i][j] Kc[g][c][j]: one wave per row (k_tri_mv per GP)
 __global__ __launch_bounds__(256) void k_expt(const GpDev* gps, ExpGpSel sel,
                                               const double* Kc, int m, double* Tt,
-                                              int64_t ldk) {
+                                              int64_t ldk, int Gs) {
   const int g = blockIdx.y;
   if (!sel.active[g]) return;
+  {
+    const int z = blockIdx.z;
+    Kc += int64_t(z) * Gs * kMaxRhs * ldk;
+    Tt += int64_t(z) * Gs * kMaxRhs * ldk;
+    m = min(kMaxRhs, m - kMaxRhs * z);
+  }
   const GpDev& gp = gps[g];
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -868,7 +883,14 @@ __global__ __launch_bounds__(512) void k_expw(const GpDev* gps, ExpGpSel sel,
   const int g = blockIdx.y;
   if (!sel.active[g]) return;
   const GpDev& gp = gps[g];
-  const int n = gp.n, m = ops.m;
+  const int z = blockIdx.z;
+  const int n = gp.n, m = min(kMaxRhs, ops.m - kMaxRhs * z);
+  Tt += int64_t(z) * ops.Gs * kMaxRhs * ldk;
+  ops.Wpack += int64_t(z) * ops.Gs * ops.wstride;
+  ops.inv_s2 += int64_t(z) * ops.Gs * 16;
+  ops.delta += int64_t(z) * ops.Gs * 16;
+  ops.tn2 += int64_t(z) * ops.Gs * 16;
+  ops.resid += int64_t(z) * ops.Gs * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j0 = blockIdx.x * 64, j = j0 + lane;
   if (j0 >= gp.n_pad) return;
@@ -940,11 +962,13 @@ int expander_operands_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_h
   }
   SGP_CHECK(ctx, !fold || ops.m == 1, "the front fold goes with one candidate");
   const int64_t ldk = (np_max + 31) / 32 * 32;
+  const int ngroups = (ops.m + kMaxRhs - 1) / kMaxRhs;
+  SGP_CHECK(ctx, ngroups == 1 || ops.Gs == G, "ExpanderOps::Gs = %d for %d GPs", ops.Gs, G);
   double* buf = static_cast<double*>(
-      sgp_scratch(ctx, 3, size_t(2) * G * kMaxRhs * ldk * sizeof(double)));
+      sgp_scratch(ctx, 3, size_t(2) * ngroups * G * kMaxRhs * ldk * sizeof(double)));
   SGP_CHECK(ctx, buf, "device allocation failed: %s", ctx->err.c_str());
   double* Kc = buf;
-  double* Tt = buf + size_t(G) * kMaxRhs * ldk;
+  double* Tt = buf + size_t(ngroups) * G * kMaxRhs * ldk;
   if (ops.m == 1) {
 #define EXPKT_CASE(DD)                                                        \
   case DD:                                                                    \
@@ -967,8 +991,8 @@ int expander_operands_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_h
   }
 #define EXPK_CASE(DD)                                                         \
   case DD:                                                                    \
-    hipLaunchKernelGGL(k_expk<DD>, dim3((n_max + 255) / 256, G), dim3(256), 0,\
-                       ctx->stream, gps_dev, sel, ops.xc, ops.m, Kc, ldk);    \
+    hipLaunchKernelGGL(k_expk<DD>, dim3((n_max + 255) / 256, G, ngroups), dim3(256), 0,\
+                       ctx->stream, gps_dev, sel, ops.xc, ops.m, Kc, ldk, G); \
     break;
   switch (d) {
     EXPK_CASE(1) EXPK_CASE(2) EXPK_CASE(3) EXPK_CASE(4)
@@ -978,9 +1002,9 @@ int expander_operands_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_h
       return -2;
   }
 #undef EXPK_CASE
-  hipLaunchKernelGGL(k_expt, dim3((n_max + 3) / 4, G), dim3(256), 0, ctx->stream,
-                     gps_dev, sel, Kc, ops.m, Tt, ldk);
-  hipLaunchKernelGGL(k_expw, dim3((np_max + 63) / 64, G), dim3(512), 0,
+  hipLaunchKernelGGL(k_expt, dim3((n_max + 3) / 4, G, ngroups), dim3(256), 0, ctx->stream,
+                     gps_dev, sel, Kc, ops.m, Tt, ldk, G);
+  hipLaunchKernelGGL(k_expw, dim3((np_max + 63) / 64, G, ngroups), dim3(512), 0,
                      ctx->stream, gps_dev, sel, Tt, ldk, ops);
   SGP_HIP(ctx, hipGetLastError());
   return 0;

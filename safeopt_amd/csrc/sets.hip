@@ -878,6 +878,201 @@ int launch_mark_top_if(sgp_grid* g, const int64_t* gidx_dev, const int* nfound_d
   return 0;
 }
 
+// ---- a pass of the expander loop over MANY candidates (sgp_grid_expander_pass) ---------
+// The reference walks the candidates by width, widest first, until one certifies
+// (gp_opt.py:542-557, 611-612) -- every one of them when none does, and in plotting mode
+// (full_sets, :553-555) in any case.  A pass takes the next ~`want` candidates behind the cut
+// WITHOUT sorting them: a histogram of their keys (width; -index in full_sets mode) gives the
+// key `thr` above which about `want` of them lie, those are listed in whatever order the
+// workgroups get to them, all of them are tested (k_expander_many), and the first expander in
+// VISITING order is the listed hit with the largest (key, index) -- everything in front of it
+// was tested in this pass or an earlier one.
+namespace {
+constexpr int kPassBins = 4096;
+
+struct PassSel {
+  double thr;      // the pass = candidates behind the cut with key >= thr
+  int count;       // ... as k_pass_list counted them
+  int est;         // ... as the histogram promised
+};
+
+__device__ __forceinline__ bool pass_key(const uint8_t* cand, const double* w, int64_t e,
+                                         int64_t goff, int index_key, double cut_w,
+                                         int64_t cut_idx, double* key) {
+  if (!cand[e]) return false;
+  const int64_t gi = goff + e;
+  const double k = index_key ? -double(gi) : w[e];
+  *key = k;
+  return k < cut_w || (k == cut_w && gi < cut_idx);      // strictly behind the cut
+}
+
+__global__ __launch_bounds__(T) void k_pass_hist(const uint8_t* cand, const double* w,
+                                                 int64_t N, int64_t goff, int index_key,
+                                                 double cut_w, int64_t cut_idx, double lo,
+                                                 double hi, unsigned* hist) {
+  __shared__ unsigned sh[kPassBins];
+  for (int b = threadIdx.x; b < kPassBins; b += T) sh[b] = 0;
+  __syncthreads();
+  const double scale = double(kPassBins) / (hi - lo);
+  for (int64_t e = int64_t(blockIdx.x) * T + threadIdx.x; e < N; e += int64_t(gridDim.x) * T) {
+    double key;
+    if (!pass_key(cand, w, e, goff, index_key, cut_w, cut_idx, &key)) continue;
+    int b = int((key - lo) * scale);
+    b = b < 0 ? 0 : (b >= kPassBins ? kPassBins - 1 : b);
+    atomicAdd(&sh[b], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kPassBins; b += T)
+    if (sh[b]) atomicAdd(&hist[b], sh[b]);
+}
+
+// thr = lower edge of the highest bin at which the count from the top reaches `want`
+// (-inf: fewer than that are left, the pass takes them all)
+__global__ __launch_bounds__(1024) void k_pass_pick(const unsigned* hist, int want, double lo,
+                                                    double hi, PassSel* sel) {
+  __shared__ unsigned part[1024];
+  constexpr int kPer = kPassBins / 1024;
+  const int t = threadIdx.x;
+  // thread t: the bins kPassBins - kPer (t + 1) .. kPassBins - kPer t - 1 (from the top)
+  unsigned mine = 0;
+  for (int q = 0; q < kPer; ++q) mine += hist[kPassBins - 1 - (kPer * t + q)];
+  part[t] = mine;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {           // inclusive scan
+    const unsigned v = (t >= o) ? part[t - o] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  const unsigned incl = part[t], excl = incl - mine;
+  if (t == 1023 && incl < unsigned(want)) {
+    sel->thr = -INFINITY;
+    sel->est = int(incl);
+    sel->count = 0;
+  }
+  if (incl >= unsigned(want) && excl < unsigned(want)) {
+    unsigned c = excl;
+    for (int q = 0; q < kPer; ++q) {
+      const int b = kPassBins - 1 - (kPer * t + q);
+      c += hist[b];
+      if (c >= unsigned(want)) {
+        sel->thr = b == 0 ? -INFINITY : lo + (hi - lo) * (double(b) / double(kPassBins));
+        sel->est = int(c);
+        sel->count = 0;
+        break;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(T) void k_pass_list(const uint8_t* cand, const double* w,
+                                                 int64_t N, int64_t goff, int index_key,
+                                                 double cut_w, int64_t cut_idx, PassSel* sel,
+                                                 int* list) {
+  const double thr = sel->thr;
+  const int lane = threadIdx.x & 63;
+  for (int64_t e0 = int64_t(blockIdx.x) * T; e0 < N; e0 += int64_t(gridDim.x) * T) {
+    const int64_t e = e0 + threadIdx.x;
+    double key = 0.0;
+    const bool take = e < N && pass_key(cand, w, e, goff, index_key, cut_w, cut_idx, &key) &&
+                      key >= thr;
+    const unsigned long long b = __ballot(take);
+    if (b == 0ull) continue;
+    int at = 0;
+    if (lane == 0) at = atomicAdd(&sel->count, __popcll(b));
+    at = __builtin_amdgcn_readfirstlane(at);
+    if (take) list[at + __popcll(b & ((1ull << lane) - 1ull))] = int(e);
+  }
+}
+
+// operand block of the listed candidates: xc[pos][d] = the row, resid[group][g][c] = u_g -
+// mu_g (groups of 16 in list order; the tail of the last group stays zero)
+__global__ __launch_bounds__(T) void k_pass_stage(const int* list, int count, const double* pts,
+                                                  const double* mean, const double* Q, int64_t N,
+                                                  int d, int G, double* xc, double* resid) {
+  const int pos = blockIdx.x * T + threadIdx.x;
+  if (pos >= count) return;
+  const int64_t li = list[pos];
+  for (int k = 0; k < d; ++k) xc[int64_t(pos) * d + k] = pts[int64_t(k) * N + li];
+  for (int g = 0; g < G; ++g)
+    resid[(int64_t(pos >> 4) * G + g) * 16 + (pos & 15)] =
+        Q[li * 2 * G + 2 * g + 1] - mean[int64_t(g) * N + li];
+}
+
+// hits of the pass: a candidate is an expander when every GP with a constraint flagged it.
+// mode 0: the first one in visiting order (largest key, then largest index); mode 1
+// (full_sets): every one of them is marked in G.  res = { hits, key, index (i64 bits) }.
+__global__ __launch_bounds__(1024) void k_pass_result(const int* list, int count,
+                                                      const int32_t* flags, int G, Vec8 fmin,
+                                                      const double* w, int64_t goff,
+                                                      int index_key, uint8_t* Gm, double* res) {
+  __shared__ Pair sh[1024 / 64];
+  __shared__ unsigned shn[1024 / 64];
+  Pair best{-INFINITY, -1};
+  unsigned hits = 0;
+  for (int pos = threadIdx.x; pos < count; pos += 1024) {
+    bool ok = true;
+    for (int g = 0; g < G; ++g)
+      if (fmin.v[g] != -INFINITY && flags[int64_t(pos) * G + g] == 0) ok = false;
+    if (!ok) continue;
+    ++hits;
+    const int64_t e = list[pos];
+    if (index_key) {
+      Gm[e] = 1;
+    } else {
+      const Pair p{w[e], goff + e};
+      if (best.i < 0 || before_desc(p, best)) best = p;
+    }
+  }
+  const Pair win = block_best<false>(best, sh);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) hits += __shfl_xor(hits, o, 64);
+  if ((threadIdx.x & 63) == 0) shn[threadIdx.x >> 6] = hits;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned tot = 0;
+    for (int wv = 0; wv < 1024 / 64; ++wv) tot += shn[wv];
+    res[0] = double(tot);
+    res[1] = win.v;
+    memcpy(&res[2], &win.i, 8);
+  }
+}
+}  // namespace
+
+// Select the pass: list (device, room for N ints) and *sel (thr, count).
+int launch_pass_select(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, double lo,
+                       double hi, int want, void* sel_dev, int* list_dev, unsigned* hist_dev) {
+  sgp_ctx* ctx = g->ctx;
+  const unsigned nb = std::min<unsigned>(nblk(g->N, T), 2048u);
+  SGP_HIP(ctx, hipMemsetAsync(hist_dev, 0, kPassBins * sizeof(unsigned), ctx->stream));
+  hipLaunchKernelGGL(k_pass_hist, dim3(nb), dim3(T), 0, ctx->stream, g->cand, g->w, g->N,
+                     g->goff, mode, cut_w, cut_idx, lo, hi, hist_dev);
+  hipLaunchKernelGGL(k_pass_pick, dim3(1), dim3(1024), 0, ctx->stream, hist_dev, want, lo, hi,
+                     static_cast<PassSel*>(sel_dev));
+  hipLaunchKernelGGL(k_pass_list, dim3(nb), dim3(T), 0, ctx->stream, g->cand, g->w, g->N,
+                     g->goff, mode, cut_w, cut_idx, static_cast<PassSel*>(sel_dev), list_dev);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_pass_stage(sgp_grid* g, const int* list_dev, int count, double* xc, double* resid) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_pass_stage, dim3((count + T - 1) / T), dim3(T), 0, ctx->stream, list_dev,
+                     count, g->pts, g->mean, g->Q, g->N, g->d, g->G, xc, resid);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_pass_result(sgp_grid* g, const int* list_dev, int count, const int32_t* flags_dev,
+                       const double* fmin, int mode, double* res_dev) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_pass_result, dim3(1), dim3(1024), 0, ctx->stream, list_dev, count,
+                     flags_dev, g->G, vec8(fmin, g->G, -INFINITY), g->w, g->goff, mode, g->Gm,
+                     res_dev);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
 int launch_mark(sgp_grid* g, const int64_t* lidx_dev, int m, int value) {
   sgp_ctx* ctx = g->ctx;
   hipLaunchKernelGGL(k_mark, dim3((m + 63) / 64), dim3(64), 0, ctx->stream,

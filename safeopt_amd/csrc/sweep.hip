@@ -925,6 +925,164 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
   expander_rows<D>(gps, G, pts, ea, rrow, unsafe, tab, lane);
 }
 
+// Many candidates in ONE pass over the unsafe rows (sgp_grid_expander_pass; the expander
+// loop of gp_opt.py:557-612 where it has to visit hundreds or thousands of candidates): the
+// candidates come in groups of 16 -- the operand blocks of k_expander, laid out
+// [group][GP][...] -- and a wave keeps its 16 rows, their posterior and the GP's kernel while
+// it walks the groups: pre-filter (one covariance per row and candidate), and only where a
+// row could be lifted above fmin the n-term contraction on the matrix cores.  Same tests,
+// same arithmetic per (row, candidate) as k_expander.
+template <int D>
+__global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
+                                                       SweepPoints pts, ExpanderArgs ea,
+                                                       int ngroups) {
+  __shared__ double tab[kExpTabSize];
+  exp_tab_init(tab);
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t row = int64_t(blockIdx.x) * 64 + wave * 16 + (lane & 15);
+  const bool valid = row < pts.N;
+  const int64_t rrow = valid ? row : pts.N - 1;
+  const bool unsafe = valid && (ea.S[rrow] == 0);
+  if (__ballot(unsafe) == 0ull) return;          // (wave-uniform)
+  double x[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+    x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
+  const int m_total = ea.m;
+  for (int g = 0; g < G; ++g) {
+    if (!ea.active[g]) continue;
+    const GpDev& gp = gps[g];
+    const KernFast<D> kf(gp.kern);
+    const double mu = ea.mean[int64_t(g) * pts.N + rrow];
+    const double var = ea.var[int64_t(g) * pts.N + rrow];
+    const double kdiag = gp.kern.kdiag;
+    // |L^-1 k_x| and the posterior standard deviation of the row (+ room for the rounding
+    // of a variance that is a difference of O(k(x,x)) terms)
+    const double sqx = sqrt(fmax(kdiag - var, 0.0));
+    const double svx = sqrt(var + 1e-12 * kdiag);
+    const double beta2 = ea.beta * ea.beta;
+    double xs[D];
+    kf.prep(x, xs);
+    const int nsteps = gp.n_pad >> 2;
+    gptr_t Xj = (gptr_t)gp.Xs + (lane >> 4) * D;
+    // (16 rows x 16 candidates) blocks that passed the pre-filter wait here until kQ of them
+    // are there: ONE evaluation of the rows' covariances with the training points then
+    // feeds the matrix products of all kQ blocks (the evaluation, ~25 fp64 instructions per
+    // value, costs three times the four matrix instructions it feeds)
+    constexpr int kQ = 4;
+    int zq[kQ];
+    int nq = 0;
+    auto flush = [&]() {
+      double4_t acc[kQ];
+#pragma unroll
+      for (int j = 0; j < kQ; ++j) acc[j] = double4_t{0.0, 0.0, 0.0, 0.0};
+      double xr[4][D], xn[4][D];
+      auto fetch = [&](int s0, double (&xo)[4][D]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int k = 0; k < D; ++k) xo[q][k] = Xj[(s0 + q) * 4 * D + k];
+      };
+      fetch(0, xr);
+#pragma unroll 1
+      for (int s0 = 0; s0 < nsteps; s0 += 4) {
+        if (s0 + 4 < nsteps) fetch(s0 + 4, xn);
+        double kv[4];
+        kf.template many<4>(xs, &xr[0][0], D, tab, kv);
+#pragma unroll
+        for (int j = 0; j < kQ; ++j) {
+          if (j < nq) {                     // (wave-uniform)
+            gptr_t W = (gptr_t)ea.Wpack + (int64_t(zq[j]) * G + g) * ea.wstride + lane;
+            double a[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = W[(s0 + q) * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], kv[q], acc[j], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int k = 0; k < D; ++k) xr[q][k] = xn[q][k];
+      }
+#pragma unroll
+      for (int j = 0; j < kQ; ++j) {
+        if (j < nq) {
+          const int z = zq[j];
+          const int m = min(16, m_total - 16 * z);
+          const int64_t zo = (int64_t(z) * G + g) * 16;
+          const double* xc = ea.xc + int64_t(z) * 16 * D;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 r
+            const int cand = (lane >> 4) + 4 * r;
+            bool hit = false;
+            if (cand < m && unsafe) {
+              const double cx = kf.raw(x, xc + cand * D, tab) - acc[j][r];
+              const double mu2 = mu + cx * ea.delta[zo + cand];
+              const double var2 = fmax(var - cx * cx * ea.inv_s2[zo + cand], 1e-15);
+              hit = mu2 - ea.beta * sqrt(var2) >= ea.fmin[g];
+            }
+            const unsigned long long b = __ballot(hit);
+            if (lane == 0 && b != 0ull) {
+#pragma unroll
+              for (int grp = 0; grp < 4; ++grp) {
+                if ((b >> (16 * grp)) & 0xffffull)
+                  atomicOr(&ea.flags[(int64_t(z) * 16 + grp + 4 * r) * G + g], 1);
+              }
+            }
+          }
+        }
+      }
+      nq = 0;
+    };
+#pragma unroll 1
+    for (int z = 0; z <= ngroups; ++z) {           // (one trip more: the last blocks leave)
+      const int m = z < ngroups ? min(16, m_total - 16 * z) : 0;
+      const int64_t zo = (int64_t(z) * G + g) * 16;
+      const double* xc = ea.xc + int64_t(z) * 16 * D;
+      // Exact pre-filter: an upper bound of the updated lower bound from ONE covariance
+      // evaluation.  c(x) is the POSTERIOR covariance of the row and the candidate:
+      //   |c| <= |k(x, x_c)| + |L^-1 k_x| |L^-1 k_c|        (k_expander's bound: small far
+      //                                                      from the data and the candidate)
+      //   |c| <= sd(x) sd(x_c)                               (Cauchy-Schwarz on the posterior:
+      //                                                      small NEXT to the data)
+      // -- with the second one the rows an observation has pinned below fmin drop out for
+      // every candidate.  Squares instead of square roots per pair (|L^-1 k_c|, sd(x_c):
+      // k_pass_aux).
+      bool possible = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cand = (lane >> 4) + 4 * r;
+        if (cand < m && unsafe) {
+          const double kxc = kf.raw(x, xc + cand * D, tab);
+          const double cmax = fmin(fma(sqx, ea.stn[zo + cand], fabs(kxc)),
+                                   svx * ea.svc[zo + cand]) * (1.0 + 1e-9);
+          const double mu2 = fma(fabs(ea.delta[zo + cand]), cmax, mu);
+          const double var2 = fmax(var - cmax * cmax * ea.inv_s2[zo + cand], 1e-15);
+          // mu2 - beta sqrt(var2) + slack >= fmin
+          const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - ea.fmin[g];
+          possible = possible || (room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2);
+        }
+      }
+#ifndef EXPM_NO_CONTRACT
+      if (__ballot(possible) != 0ull) {            // wave-uniform
+        // (slot of the queue by a chain of uniform tests: the indices stay in scalar registers)
+#pragma unroll
+        for (int j = 0; j < kQ; ++j)
+          if (j == nq) zq[j] = z;
+        ++nq;
+      }
+      if (nq == kQ || (z == ngroups && nq > 0)) flush();
+#endif
+    }
+  }
+}
+
 // Single candidate (the probe of the first candidate and its exact re-scan):
 // the pre-filter runs with one row per lane over the whole shard and appends
 // the rows that could be lifted above fmin to a list (a few per cent of the
@@ -1491,6 +1649,44 @@ int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,
   return launch_sweep(ctx, p, gps_host, d);
 }
 
+
+// |L^-1 k_c| and sd(x_c) of every candidate of a pass, from tn2 = |L^-1 k_c|^2
+__global__ void k_pass_aux(const GpDev* gps, int G, const double* tn2, double* stn, double* svc,
+                           int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int g = (e >> 4) % G;
+  const double t = tn2[e];
+  stn[e] = sqrt(fmax(t, 0.0)) * (1.0 + 1e-12);
+  svc[e] = sqrt(fmax(gps[g].kern.kdiag - t, 0.0) + 1e-12 * gps[g].kern.kdiag);
+}
+
+int launch_expander_many(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d, SweepPoints pts,
+                         ExpanderArgs ea) {
+  if (pts.N <= 0 || ea.m <= 0) return 0;
+  const int nblocks = int((pts.N + 63) / 64);
+  const int ngroups = (ea.m + 15) / 16;
+  {
+    const int n = ngroups * G * 16;
+    hipLaunchKernelGGL(k_pass_aux, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, gps_dev, G,
+                       ea.tn2, const_cast<double*>(ea.stn), const_cast<double*>(ea.svc), n);
+  }
+#define EXPM_CASE(DD)                                                         \
+  case DD:                                                                    \
+    hipLaunchKernelGGL(k_expander_many<DD>, dim3(nblocks), dim3(256), 0,      \
+                       ctx->stream, gps_dev, G, pts, ea, ngroups);            \
+    break;
+  switch (d) {
+    EXPM_CASE(1) EXPM_CASE(2) EXPM_CASE(3) EXPM_CASE(4)
+    EXPM_CASE(5) EXPM_CASE(6) EXPM_CASE(7) EXPM_CASE(8)
+    default:
+      sgp_set_error(ctx, "input dimension %d not in 1..%d", d, SGP_MAX_D);
+      return -2;
+  }
+#undef EXPM_CASE
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
 
 int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
                           const GpDev* gps_host, int G, int d, SweepPoints pts,

@@ -320,6 +320,10 @@ class _HipGridBackend(object):
     def expander_batch(self, beta, fmin, mode, cut_w, cut_idx, k):
         return self.grid.expander_batch(self._dev(), beta, fmin, mode, cut_w, cut_idx, k)
 
+    def expander_pass(self, beta, fmin, mode, cut_w, cut_idx, key_lo, key_hi, want):
+        return self.grid.expander_pass(self._dev(), beta, fmin, mode, cut_w, cut_idx,
+                                       key_lo, key_hi, want)
+
     def small_grid(self):
         """At most 16384 rows and 48 observations per GP: every candidate can be tested at
         once (``sgp_grid_expanders_small``)."""
@@ -886,6 +890,9 @@ class SafeOpt(GaussianProcessOptimization):
                 and hasattr(be, 'expander_batch')):
             # one rank: a pass of the loop -- the next K candidates, their rows, the exact
             # test -- is ONE device round trip
+            big = hasattr(be, 'expander_pass') and self.big_passes
+            if big and full_sets:
+                return self._visit_in_big_passes(beta, active, True, np.inf, -1)
             while True:
                 w_b, i_b, fl = be.expander_batch(beta, self.fmin, mode, cut_w, cut_idx, K)
                 m = i_b.size
@@ -902,6 +909,10 @@ class SafeOpt(GaussianProcessOptimization):
                 if m < K:
                     break
                 cut_w, cut_idx = float(w_b[-1]), int(i_b[-1])
+                if big and K == _hip.TOPK:
+                    # SGP_TOPK candidates in, no expander: from here on hundreds, then
+                    # thousands of candidates per pass
+                    return self._visit_in_big_passes(beta, active, False, cut_w, cut_idx)
                 K = _hip.TOPK
             return
         while True:
@@ -951,6 +962,40 @@ class SafeOpt(GaussianProcessOptimization):
                 break
             cut_w, cut_idx = float(w_b[-1]), int(i_b[-1])
             K = _hip.TOPK
+
+    #: candidates per pass of ``_visit_in_big_passes`` (the last entry repeats)
+    pass_sizes = (256, 2048, 8192)
+    #: False: the expander loop of a large grid stays at SGP_TOPK candidates per round trip
+    big_passes = True
+
+    def _visit_in_big_passes(self, beta, active, full_sets, cut_w, cut_idx):
+        """The expander loop of gp_opt.py:557-612 behind the cut, one rank, where it goes
+        far -- no expander among the first SGP_TOPK candidates (a converged run has none at
+        all), or ``full_sets`` (:553-555: every safe row is visited).  A pass takes the next
+        few hundred to few thousand candidates in visiting order (``pass_sizes``; chosen on
+        the device by a histogram of the widths, not a sort) and tests ALL of them in one
+        scan of the unsafe rows (``sgp_grid_expander_pass``): the first expander in visiting
+        order is the widest hit of the first pass that has one -- every candidate in front of
+        it has been tested -- and exact ties among equal widths are settled as always."""
+        be = self._backend
+        if full_sets:
+            n_all = float(self.inputs.shape[0])
+            lo, hi, mode = -(n_all + 1.0), 1.0, 1           # keys: minus the row index
+        else:
+            lo, hi, mode = 0.0, float(cut_w), 0             # keys: the interval widths
+        for k in range(1 << 30):
+            want = self.pass_sizes[min(k, len(self.pass_sizes) - 1)]
+            tested, hits, key, row, left = be.expander_pass(beta, self.fmin, mode, cut_w,
+                                                            cut_idx, lo, hi, want)
+            if hits and not full_sets:
+                be.mark_expanders(np.array([row], dtype=np.int64))
+                self._settle_ties(beta, active, key, row)
+                return
+            if tested == 0 or left == -np.inf:
+                return
+            cut_w, cut_idx = left, -1
+            if not full_sets:
+                hi = left
 
     def _visit_all_candidates(self, beta, active, full_sets, cut_idx, chunk=1024):
         """The expander loop of a SMALL grid on one rank: every candidate is tested at once
@@ -1151,6 +1196,10 @@ class SafeOpt(GaussianProcessOptimization):
             self._thr_beta = np.broadcast_to(
                 np.asarray(self.threshold, dtype=float) * beta, (len(self.gps),)).copy()
             self._thr_beta_key = key
+        # element-wise edits of opt.S / M / G since the last pass are dropped, not uploaded:
+        # the launch recomputes all three sets (gp_opt.py:478-481, 505-615), exactly as
+        # _flush_masks(for_sets=True) does in front of compute_sets on the large-grid path
+        self._masks_written = set()
         (out5, x_c, mu_c, q_c, flags, val, idx,
          max_l) = self._backend.step_small(devs, beta, self.fmin, self.scaling, self._thr_beta)
         self._stale.update(Q=True, S=True)

@@ -2215,6 +2215,35 @@ def test_mask_writes_reach_the_device(mods):
     assert_array_equal(opt.get_new_query_point(), x0)
 
 
+def test_mask_edits_are_dropped_by_the_one_launch_step(mods):
+    """``optimize()`` recomputes all three sets (gp_opt.py:651-675 -> 478-481, 505-615): an
+    element-wise edit of ``opt.M / G / S`` made before it must not survive it -- on the small
+    grids of the reference's own examples the whole step is ONE launch (``k_step_small``),
+    whose driver has to drop the pending edits just as ``compute_sets`` does on large grids."""
+    safeopt_amd, gpy, gpn, son = mods
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-3, 3, size=(12, 1))
+    Y = smooth(X, 3) - smooth(X, 3).min() + 0.6
+
+    def make():
+        gp = gpy.models.GPRegression(X, Y, gpy.kern.RBF(1, 2.0, 1.0), noise_var=0.05 ** 2)
+        return safeopt_amd.SafeOpt(gp, safeopt_amd.linearly_spaced_combinations([(-5., 5.)], 1000),
+                                   0.0, threshold=0.2)
+    fresh = make()
+    x_ref = fresh.optimize()
+    assert fresh._backend.ctx.last_sweep() == "step-small"
+    for field in ("M", "G", "S"):
+        opt = make()
+        opt.optimize()
+        getattr(opt, field)[:] = False
+        x = opt.optimize()
+        assert opt._backend.ctx.last_sweep() == "step-small"
+        assert_array_equal(x, x_ref)
+        for f in ("S", "M", "G"):
+            assert_array_equal(getattr(opt, f), getattr(fresh, f))
+        assert_array_equal(opt.get_new_query_point(), x_ref)
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("k", [2, 3])
 def test_whole_grid_of_configs_2_and_3_against_oracle(mods, k):

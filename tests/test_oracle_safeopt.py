@@ -133,3 +133,39 @@ def test_tied_widths_golden(seed):
     wd = z["Q"][:, 1] - z["Q"][:, 0]
     s = S & ~M
     assert int(np.sum(wd[s] == wd[s].max())) == int(z["n_tied_top"]) > 1
+
+
+@pytest.mark.parametrize("kind", ["RBF", "Matern52"])
+def test_rank1_expander_form_equals_the_refit_form(kind):
+    """``son.expander_hits_rank1`` -- the closed form the big-pass GPU tests check thousands of
+    candidates with -- against the literal append / predict / pop of gp_opt.py:585-606 on a
+    problem small enough to refit per candidate: same hit per candidate, and the updated
+    lower bounds agree to 1e-9."""
+    rng = np.random.default_rng(11)
+    X = rng.uniform(-2, 2, size=(25, 2))
+    Y = np.sin(X[:, :1]) + 0.5 * np.cos(2 * X[:, 1:]) + 0.6
+    kern = getattr(gpn, kind)(2, variance=1.5, lengthscale=[0.8, 1.1], ARD=True)
+    gp = gpn.GPRegression(X, Y, kern, noise_var=0.03 ** 2)
+    side = 30
+    g = np.linspace(-3, 3, side)
+    grid = np.array([(a, b) for a in g for b in g])
+    beta, fmin = 2.0, 0.0
+    Q = son.confidence_intervals([gp], grid, beta)
+    S = son.safe_set(Q, [fmin])
+    assert S.any() and (~S).any()
+    cand = np.flatnonzero(S)[::3]
+    fast = son.expander_hits_rank1(gp, grid, ~S, cand, Q[cand, 1], beta, fmin, chunk=17)
+    slow = np.zeros(cand.size, dtype=bool)
+    margin = np.zeros(cand.size)
+    for k, idx in enumerate(cand):
+        son._append_point(gp, grid[[idx]], np.atleast_2d(Q[idx, 1]))
+        m2, v2 = gp.predict_noiseless(grid[~S])
+        son._pop_point(gp)
+        l2 = m2.squeeze() - beta * np.sqrt(v2.squeeze())
+        slow[k] = np.any(l2 >= fmin)
+        margin[k] = np.max(l2) - fmin
+    # (a candidate whose best row sits within rounding of fmin may go either way)
+    clear = np.abs(margin) > 1e-9
+    assert clear.sum() > 0.9 * cand.size
+    assert_array_equal(fast[clear], slow[clear])
+    assert fast.any() and not fast.all()
