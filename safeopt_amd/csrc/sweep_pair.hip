@@ -54,26 +54,18 @@ constexpr int kPairSlots = 32;         // row blocks of L^-1 per accumulator chu
 constexpr int kWaveSlots = 16;         // ... per wave (128 accumulator VGPRs)
 constexpr int kPairs = 4;              // pairs per workgroup (64 rows per tile)
 constexpr int kTileRows = 16 * kPairs;
-#ifdef PGP_E3
-constexpr int kKbRow = 80;
-#define PGP_SW(x) 0
-#else
-#define PGP_SW(x) (x)
 constexpr int kKbRow = 64;             // doubles per k-row of a B buffer (odd k-rows are stored with
                                        // the two halves of a q pair's 32 doubles swapped: no padding)
-#endif
-#ifdef PGP_DUO
-constexpr int kDuoUnits = PGP_DUO;
-#else
 constexpr int kDuoUnits = 28;          // 2 KB units of L^-1 in a stage of TWO j-blocks: the last four
                                        // units of its chunk buffer hold the B buffers of the second one
-#endif
 
 // The structure below is what survived the round-3 experiments (phase orders, pairs
 // on adjacent waves, where and by whom the LDS-DMA is issued, priorities, a second
 // barrier, ...: profiles/r03/experiments.txt; the switches they were built with are
-// in the history of this file up to commit d1566ec).  Debug builds: -DSGP_INSTRUMENT
-// (ablation mask, PGP_ABL) and -DPGP_STAMPS (cycle stamps per phase).
+// in the history of this file up to commit d1566ec; those of the merged stages of round 6:
+// profiles/r06/attic/pair_experiment_switches.diff, results in profiles/r06/experiments.txt).
+// Debug builds: -DSGP_INSTRUMENT (ablation mask, PGP_ABL) and -DPGP_STAMPS (cycle stamps per
+// phase).
 
 // One stage of a tile: ONE j-block of a (GP, chunk) -- or TWO (round 6, "merged stages").
 // The stages of a triangular chunk shrink from 32 active row blocks to one; a thin stage
@@ -154,12 +146,10 @@ struct LayP {
 // (what the LDS of a d <= 4 instance has room for); further followers keep stages
 // without rows (PW_SHARED).
 constexpr int kMaxRide = 2;
-#ifndef PGP_E3
 static_assert(sizeof(PStage) == 32, "one aligned scalar load per stage");
 static_assert(LayP<8>::bytes() <= 160 * 1024, "LDS budget of one workgroup per CU");
 static_assert(LayP<1>::kKb2Off + kPairs * LayP<1>::kKbBuf <= LayP<1>::kATile, "second B buffers");
 static_assert(LayP<4, kMaxRide>::bytes() <= 160 * 1024, "LDS budget with riders");
-#endif
 
 struct PairParams {
   const GpDev* gps;
@@ -278,7 +268,6 @@ struct DmaPlan {
   uint32_t dst0;     // LDS byte address of unit 0 of the buffer being filled
   uint32_t voff;
   int u;             // the wave's next unit; >= ntot: nothing left (or the copy is off)
-  int u0;
   int na, ntot;      // units of segment A, of the stage
   bool no_a;         // (timing experiments: the slots skip their A-operand reads)
 };
@@ -379,17 +368,7 @@ __device__ __forceinline__ void pair_slot_body(bool narrow0, double (&acc)[kWave
     asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
   if constexpr (kGroups > 0) {
     constexpr int kEvery = kWaveSlots / kGroups;
-#ifdef PGP_E1
-    if (S % kEvery == 0) {
-      constexpr int i = S / kEvery;
-      if (dma.u0 + 4 * i < dma.ntot)
-        dma_2k(dma.src - uint64_t(uint32_t(dma.u0 + 4 * i)) * dma.rs,
-               dma.dst0 + uint32_t(dma.u0 + 4 * i) * 2048u, dma.voff);
-      dma.u = dma.u0 + 4 * (i + 1);
-    }
-#elif !defined(PGP_DMA_BUNCH)
     if (S % kEvery == 0) dma_next(dma);
-#endif
   }
 }
 
@@ -547,12 +526,8 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   constexpr bool conf = MODE == MODE_CONF;
   // (32 more live registers across the evaluation: instances that would spill for
   // it -- d >= 6, product kernels -- do without)
-#ifdef PGP_NOEARLY
-  constexpr int kOpsEarly = 0;
-#else
   constexpr int kOpsEarly =
       (SINGLE && D <= 4 && R == 0) ? 2 : 0;
-#endif
   const int pr = wave & 3;
   const int k4 = lane >> 4, c16 = lane & 15;
   const double* tab = lds + L::kTabOff;
@@ -661,9 +636,6 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   // behind the operand reads of the matrix phase
   struct Rows {
     double y[2 * D];
-#ifdef PGP_ALPHA_EARLY
-    double al[2];
-#endif
   };
   auto load_rows = [&](const double* xa, Rows& r) {
     const double* ys = xa + (8 * H + k4) * D;
@@ -671,19 +643,10 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int i = 0; i < D; ++i) r.y[q * D + i] = ys[q * 4 * D + i];
-#ifdef PGP_ALPHA_EARLY
-    const double* al = xa + kJC * D + 8 * H + k4;
-    r.al[0] = al[0];
-    r.al[1] = al[4];
-#endif
   };
   // (only where the 2 D + 2 registers are there for it; elsewhere the evaluation
   // reads its rows itself)
-#ifdef PGP_NOROWS
-  constexpr bool kRowsFirst = false;
-#else
   constexpr bool kRowsFirst = kOpsEarly != 0 && SINGLE && D <= 2;
-#endif
   // One j-block of a stage: J = 0 the first (its rows may have been fetched in front of
   // the evaluation: Rows), J = 1 the second of a merged stage.
   auto eval_block = [&](uint32_t w1, auto jtag, const Rows& r, const double* xa, double* kbw) {
@@ -709,12 +672,6 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     }
     if (w1 & PW_MEAN) {
       // (alpha is read here, not with the rows: four registers the merged stages need)
-#ifdef PGP_ALPHA_EARLY
-      if (kRowsFirst && J == 0) {
-        mean = fma(r.al[0], kv[0], mean);
-        mean = fma(r.al[1], kv[1], mean);
-      } else
-#endif
       {
       const double* al = xa + kJC * D + 8 * H + k4;
       mean = fma(al[0], kv[0], mean);
@@ -732,7 +689,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       }
     }
     // (odd k-rows: the halves of the q pair's 32 doubles swapped -- fetch_ops)
-    *reinterpret_cast<double2_t*>(kbw + k4 * kKbRow + H * 32 + ((c16 * 2) ^ PGP_SW((k4 & 1) * 16))) =
+    *reinterpret_cast<double2_t*>(kbw + k4 * kKbRow + H * 32 + ((c16 * 2) ^ ((k4 & 1) * 16))) =
         double2_t{kv[0], kv[1]};
   };
   auto evaluate = [&](uint32_t w1, const Rows& r, const double* xa, double* kbw, double* kb2w) {
@@ -756,14 +713,8 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     // (no interleaving of the two blocks: four values in flight cost registers the
     // kernel does not have)
     __builtin_amdgcn_sched_barrier(0);
-#ifndef PGP_E5
-#ifdef PGP_LIKELY
-    if (__builtin_expect((w1 & PW_DUO) != 0, PGP_LIKELY))
-#else
     if (w1 & PW_DUO)
-#endif
       eval_block(w1, std::integral_constant<int, 1>{}, r, xa + L::kXBlk, kb2w);
-#endif
   };
 
   PStage e1{};
@@ -780,11 +731,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     for (int m = 0; m < 4; ++m) acc[b][m] = 0.0;
   // the half whose wave finishes a pair's rows (sums the two partial |L^-1 k|^2 and
   // alpha . k, runs the row epilogue one stage later); the other hands its share over
-#ifdef PGP_FIN0
-  constexpr int kFin = 0;
-#else
   constexpr int kFin = 1;
-#endif
   RowState rs;                       // (H == kFin: the finishing wave)
   double keep_ssq = 0.0, keep_mu = 0.0;
   double keep_mu_r[R > 0 ? R : 1];
@@ -813,7 +760,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       // (row quads m = 0, 1 | 2, 3 sit in the two 16-double halves of a q pair's 32; odd
       // k-rows store them swapped: the k-rows of a 16-lane read group then hit different
       // banks without padding between them)
-      const int sw = PGP_SW((k4 & 1) * 16);
+      const int sw = ((k4 & 1) * 16);
       const double2_t* r0 = reinterpret_cast<const double2_t*>(
           kbr + k4 * kKbRow + (lane & 3) * 2 + sw);
       const double2_t* r1 = reinterpret_cast<const double2_t*>(
@@ -830,7 +777,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       // (read whether slot 0 is narrow or not: two LDS reads are cheaper than a
       // branch and four register moves next to the matrix instructions)
       const double2_t* rn = reinterpret_cast<const double2_t*>(
-          kbr + k4 * kKbRow + ((c16 * 2) ^ PGP_SW((k4 & 1) * 16)));
+          kbr + k4 * kKbRow + ((c16 * 2) ^ ((k4 & 1) * 16)));
       const double2_t a = rn[0], b = rn[16];
       o.kvn[0] = a.x; o.kvn[1] = a.y; o.kvn[2] = b.x; o.kvn[3] = b.y;
     }
@@ -856,11 +803,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
                                                     o.kvn, o.a0, opsB, dma);
       }
       const int nw2 = (nb - H + 1) >> 1;
-#ifdef PGP_LIKELY
-      if (__builtin_expect(nw2 > 0, PGP_LIKELY)) {
-#else
       if (nw2 > 0) {
-#endif
         const double* aseg2 = abuf + na * (kSteps * 64);
         fetch_ops(aseg2, kb2r, o, 3);
         const double* aT = aseg2 + H * (kSteps * 64) + lane;
@@ -1054,7 +997,6 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       plan.ntot = plan.na + (int(wnext >> PW_NB_SHIFT) & 63);
       if (!(more && !PGP_ABL(2))) plan.ntot = 0;
       plan.u = wave & 3;           // first unit of this wave in the copy
-      plan.u0 = plan.u;
     }
     plan.no_a = PGP_ABL(64);
     PGP_STAMP(1);   // LDS-DMA issue
