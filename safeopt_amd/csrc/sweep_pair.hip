@@ -280,8 +280,8 @@ __device__ __forceinline__ void dma_next(DmaPlan& d) {
 }
 
 // ---- matrix part (operand maps: see sweep.hip) ------------------------------------
-// Local slot S of wave h is global slot 2 S + h; aT points at the wave's first slot
-// (+ lane), consecutive local slots are 2 * kSteps * 64 doubles apart.
+// Local slot S of half h is unit slot_unit(h, S) of the segment (below); aT points at unit 0
+// (+ lane).
 // kGroups > 0: one group of the wave's LDS-DMA share goes out after every
 // (16 / kGroups)-th slot.
 //
@@ -293,6 +293,12 @@ __device__ __forceinline__ void dma_next(DmaPlan& d) {
 // instead (a few register copies at the joins of the slot sequence); since no
 // instance has scratch any more (d >= 7 without registers for the raw rows, kLeanX)
 // all of them take the asm path, and the scanner runs over every one of them.
+// Which unit of a segment is local slot S of half H: alternating, the halves have the same
+// number of slots per stage (+-1).  (Half 0 -- which enters its matrix phase first -- with
+// one slot more per stage, units 0, 1, 3, 5, ..: +0.7 % at config 3, profiles/r06/experiments.txt.)
+__host__ __device__ constexpr int slot_unit(int H, int S) { return 2 * S + H; }
+__device__ __forceinline__ int slots_of(int H, int n) { return (n - H + 1) >> 1; }
+
 // One accumulator slot: the A operands of the NEXT slot are requested first, then the 16
 // (narrow: 4) matrix instructions, then -- half 0 -- a group of the chunk copy.
 template <int S, bool NARROW_OK, int kGroups, bool ASM_MFMA>
@@ -310,7 +316,8 @@ __device__ __forceinline__ void pair_slot_body(bool narrow0, double (&acc)[kWave
 #endif
     {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) nxt[q] = aT[((S + 1) * 2 * kSteps + q) * 64];
+      for (int q = 0; q < 4; ++q)
+        nxt[q] = aT[(slot_unit(kGroups > 0 ? 0 : 1, S + 1) * kSteps + q) * 64];
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -781,7 +788,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
       const double2_t a = rn[0], b = rn[16];
       o.kvn[0] = a.x; o.kvn[1] = a.y; o.kvn[2] = b.x; o.kvn[3] = b.y;
     }
-    const double* aT = abuf + H * (kSteps * 64) + lane;
+    const double* aT = abuf + slot_unit(H, 0) * (kSteps * 64) + lane;
 #pragma unroll
     for (int q = 0; q < 4; ++q) o.a0[q] = aT[q * 64];
   };
@@ -795,18 +802,18 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
     const int na = int(w & PW_NACT_MASK), nb = int(w >> PW_NB_SHIFT) & 63;
     const bool narrow0 = H == 0 && (w & PW_NARROW) != 0;
     {
-      const int nw = (na - H + 1) >> 1;
+      const int nw = slots_of(H, na);
       if (nw > 0 && !PGP_ABL(8)) {
-        const double* aT = abuf + H * (kSteps * 64) + lane;
+        const double* aT = abuf + lane;
         double opsB[4];
         pair_slots<0, H == 0, kDmaGroups, true>(nw, narrow0, acc, accx, aT, o.kb,
                                                     o.kvn, o.a0, opsB, dma);
       }
-      const int nw2 = (nb - H + 1) >> 1;
+      const int nw2 = slots_of(H, nb);
       if (nw2 > 0) {
         const double* aseg2 = abuf + na * (kSteps * 64);
         fetch_ops(aseg2, kb2r, o, 3);
-        const double* aT = aseg2 + H * (kSteps * 64) + lane;
+        const double* aT = aseg2 + lane;
         double opsB[4];
         pair_slots<0, H == 0, kDmaGroups, true, (kDuoUnits / 2 + 1) / 2>(
             nw2, narrow0, acc, accx, aT, o.kb, o.kvn, o.a0, opsB, dma);
