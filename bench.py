@@ -803,6 +803,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     transport = choose_transport(rank, world) if world > 1 else None
+    if (world > 1 and os.environ.get("SAFEOPT_REQUIRE_RCCL") == "1"
+            and not transport["chosen"].startswith(("rccl-in-stream", "rccl (not probed"))):
+        # the operator asked for the product path or nothing: no silent TCP number
+        if rank == 0:
+            print(json.dumps({"metric": "candidate-points/s (posterior+safe-set sweep)",
+                              "value": None, "n_gpus": world,
+                              "error": "SAFEOPT_REQUIRE_RCCL=1: RCCL with the step in stream did "
+                                       "not come up on every rank",
+                              "transport": transport}), flush=True)
+        sys.exit(3)
     ctx, comm = dist.init_from_env()
 
     # configs 2/3: weak scaling (1e6 rows per rank); config 4: the fixed 200^3
@@ -1003,6 +1013,9 @@ def main():
                                    "strong: BASELINE.json's fixed 200^3 grid, 8e6 / ranks rows each",
                    "share_factors": False},
         "rccl_ranks": int(rccl_ranks),
+        # at a glance (N > 1): anything but "rccl-in-stream" here means the RCCL path FAILED
+        # its probe and the number below was measured over a fallback transport
+        "transport_chosen": None if transport is None else transport["chosen"],
         "transport": transport, "nrank_selfcheck": selfcheck,
         "nrank_step": (None if world == 1 else
                        "in stream (sgp_grid_sets_fused_comm: one round trip, merges on the device)"
@@ -1047,7 +1060,7 @@ def main():
             "note": "the product default (sgp_ctx_set_share): the GPs of this config have "
                     "identical inputs, kernel and noise, so |L^-1 k|^2 is formed once and "
                     "alpha . k per GP -- the followers ride in their leader's stages; same "
-                    "bits (tests/test_gpu_parity.py)",
+                    "bits (tests/test_gpu_posterior.py)",
             "value": units / (dts / args.steps), "unit": "candidates/s",
             "ms_per_step": dts * 1e3 / args.steps,
             "kernel_ms_avg": s_ms / max(s_launches, 1),

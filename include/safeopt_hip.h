@@ -409,7 +409,7 @@ int64_t sgp_ctx_alloc_count(sgp_ctx* ctx);
  * 1 = always the 4-wave kernel (csrc/sweep.hip), 2 = always the paired-wave kernel,
  * 3 = automatic without the VALU kernel and the one-launch step; + 4: the
  * paired-wave kernel does not cut remainder tiles into runs of chunks (same bits
- * either way, tests/test_gpu_parity.py); + 8: no factor tables on tensor grids
+ * either way, tests/test_gpu_posterior.py); + 8: no factor tables on tensor grids
  * (sgp_grid_set_axes); + 16: the 4-wave kernel streams small factors through its
  * double buffer instead of keeping them in LDS for the launch (same bits either
  * way); + 32: the paired-wave kernel runs one 16-point block of training points per
@@ -434,7 +434,7 @@ int sgp_ctx_last_sweep(sgp_ctx* ctx);
  * followers per leader take their alpha . k from the covariances the leader's
  * sweep evaluates anyway (both sweep kernels; single-part kernels, d <= 4 / 3),
  * further ones keep covariance-only stages in the paired-wave kernel.  Identical
- * results bit for bit (tests/test_gpu_parity.py).  on = 1 (default) / 0; returns
+ * results bit for bit (tests/test_gpu_posterior.py).  on = 1 (default) / 0; returns
  * the previous setting.                                                         */
 int sgp_ctx_set_share(sgp_ctx* ctx, int on);
 

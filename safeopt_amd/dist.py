@@ -87,7 +87,7 @@ class SocketComm(object):
     RCCL wants one GPU per rank; this communicator does not care where the ranks'
     kernels run, so N processes -- each with its own HIP context and its TRUE shard
     of the grid -- can share one GPU (``SAFEOPT_COMM=socket``; how the N-rank product
-    is tested on a one-GPU box, tests/test_gpu_parity.py), or sit on machines without
+    is tested on a one-GPU box, tests/test_gpu_nrank.py), or sit on machines without
     xGMI.  The payloads of the path are a few dozen bytes per collective
     (SURVEY.md section 8e), latency is all that matters.
 

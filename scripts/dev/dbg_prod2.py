@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.in
 import safeopt_amd.gpy as gpy
 from oracle import gp_numpy as gpn
 from safeopt_amd import _hip
-from test_gpu_parity import smooth
+from _gpu_common import smooth
 def kern(ns, d, spec):
     k = None
     for i, (kind, cols) in enumerate(spec):

@@ -1,7 +1,7 @@
 // Test harness (not part of the product): runs the two device-side merges of the
 // N-rank certified step -- k_merge_front and k_merge_argmax, csrc/sets.hip -- on
 // gathered blocks of MORE than one rank, which no single-GPU run of
-// sgp_grid_sets_fused_comm can produce.  tests/test_gpu_parity.py writes the blocks
+// sgp_grid_sets_fused_comm can produce.  tests/test_gpu_nrank_control_flow.py writes the blocks
 // to stdin and compares stdout with the NumPy merges of safeopt_amd/dist.py (the ones
 // the gloo tests pin against unsharded runs).
 //

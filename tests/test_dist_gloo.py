@@ -2,6 +2,7 @@
 SafeOpt host logic (shard ranges, phase driver, top-k / arg-max merges) with the
 NumPy oracle standing in for the per-rank HIP kernels.  Result must equal the
 reference's golden vectors, i.e. the unsharded run."""
+import json
 import os
 import socket
 import subprocess
@@ -428,3 +429,29 @@ def test_bench_transport_chain_under_the_watchdog(probe):
             assert not any(c["ok"] for c in rep["chain"])
             if probe == "hangs":
                 assert all(c["rc_this_rank"] == -9 for c in rep["chain"])
+
+
+@pytest.mark.timeout(120)
+def test_bench_refuses_a_fallback_when_rccl_is_required():
+    """``SAFEOPT_REQUIRE_RCCL=1 bench.py --gpus N``: when RCCL with the step in stream does not
+    come up on every rank, the run ends NON-ZERO with an error line on rank 0 -- no number
+    measured over TCP under the name of the product path."""
+    port = _free_port()
+    bad = "\x1f".join([sys.executable, "-c", "import sys; sys.exit(1)"])
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SAFEOPT_REQUIRE_RCCL="1",
+                   SAFEOPT_BENCH_PROBE_TIMEOUT="5", SAFEOPT_BENCH_PROBE_CMD=bad)
+        for k in ("SAFEOPT_COMM", "SAFEOPT_RCCL_IN_STREAM"):
+            env.pop(k, None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    outs = [p.communicate(timeout=100) for p in procs]
+    assert [p.returncode for p in procs] == [3, 3], [o[1][-400:] for o in outs]
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["value"] is None and "SAFEOPT_REQUIRE_RCCL" in line["error"]
+    assert line["transport"]["chosen"] == "socket (fallback)"
+    assert [c["ok"] for c in line["transport"]["chain"]] == [False, False]
+    assert outs[1][0].strip() == ""
