@@ -533,8 +533,10 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   constexpr bool conf = MODE == MODE_CONF;
   // (32 more live registers across the evaluation: instances that would spill for
   // it -- d >= 6, product kernels -- do without)
+  // (instances with riders: up to d = 3 -- at d = 4 the fetch spills -- and without the row
+  // prefetch below; config 3 with the shared factor 4.93 -> 4.87 ms)
   constexpr int kOpsEarly =
-      (SINGLE && D <= 4 && R == 0) ? 2 : 0;
+      (SINGLE && D <= 4 && (R == 0 || D <= 3)) ? 2 : 0;
   const int pr = wave & 3;
   const int k4 = lane >> 4, c16 = lane & 15;
   const double* tab = lds + L::kTabOff;
@@ -653,7 +655,7 @@ __device__ __forceinline__ void pair_loop(const PairParams& p, double* lds,
   };
   // (only where the 2 D + 2 registers are there for it; elsewhere the evaluation
   // reads its rows itself)
-  constexpr bool kRowsFirst = kOpsEarly != 0 && SINGLE && D <= 2;
+  constexpr bool kRowsFirst = kOpsEarly != 0 && SINGLE && D <= 2 && R == 0;
   // One j-block of a stage: J = 0 the first (its rows may have been fetched in front of
   // the evaluation: Rows), J = 1 the second of a merged stage.
   auto eval_block = [&](uint32_t w1, auto jtag, const Rows& r, const double* xa, double* kbw) {
