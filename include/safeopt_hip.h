@@ -261,6 +261,23 @@ int sgp_grid_expander_pass(sgp_grid* grid, sgp_gp* const* gps, int G, double bet
                            const double* fmin, int mode, double cut_w, int64_t cut_idx,
                            double key_lo, double key_hi, int want, double* out6);
 
+/* The same pass on N ranks (safeopt/gp_opt.py:557-612 on a row-sharded grid), in three calls
+ * with the ranks' agreement in between: (1) this shard's 4096-bin histogram of the keys of its
+ * candidates behind the cut, over [key_lo, key_hi] -- the ranks sum the histograms and pick
+ * ONE threshold thr; (2) this shard's candidates behind the cut with key >= thr (at most cap):
+ * global rows, keys, the rows themselves [count][d] and u_i - mu_i [count][G] -- the ranks
+ * gather them into one list; (3) the rank-1 test of ALL K listed candidates against this
+ * shard's unsafe rows: flags[c * G + i] != 0 when candidate c lifts one of them above fmin_i
+ * -- the ranks OR the flags; the first expander in visiting order is the hit with the
+ * largest (key, row).  mode as in sgp_grid_expander_pass.                               */
+int sgp_grid_pass_hist(sgp_grid* grid, int mode, double cut_w, int64_t cut_idx, double key_lo,
+                       double key_hi, uint32_t* hist4096);
+int sgp_grid_pass_list(sgp_grid* grid, int mode, double cut_w, int64_t cut_idx, double thr,
+                       int cap, int* count, int64_t* gidx, double* key, double* x, double* resid);
+int sgp_grid_pass_test(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
+                       const double* fmin, int K, const double* xc, const double* resid,
+                       int32_t* flags);
+
 /* SMALL grids -- the reference's own regime (safeopt/gp_opt.py:651-675 on the 1000-point
  * grid of examples/1d_example.ipynb with n <= 20 observations; BASELINE.json config 1):
  * one whole SafeOpt.optimize() = update_confidence_intervals (gp_opt.py:453-476) +

@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("SAFEOPT_HIP_LIB") or os.path.join(_HERE, "libsafeopt_
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
 c_i32_p = C.POINTER(C.c_int32)
+c_u32_p = C.POINTER(C.c_uint32)
 c_i64_p = C.POINTER(C.c_int64)
 c_u8_p = C.POINTER(C.c_uint8)
 vp = C.c_void_p
@@ -97,6 +98,12 @@ PROTOTYPES = {
     "sgp_grid_expander_pass": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p, C.c_int,
                                          C.c_double, C.c_int64, C.c_double, C.c_double, C.c_int,
                                          c_double_p]),
+    "sgp_grid_pass_hist": (C.c_int, [vp, C.c_int, C.c_double, C.c_int64, C.c_double, C.c_double,
+                                     c_u32_p]),
+    "sgp_grid_pass_list": (C.c_int, [vp, C.c_int, C.c_double, C.c_int64, C.c_double, C.c_int,
+                                     c_int_p, c_i64_p, c_double_p, c_double_p, c_double_p]),
+    "sgp_grid_pass_test": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p, C.c_int,
+                                     c_double_p, c_double_p, c_i32_p]),
     "sgp_grid_step_small": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_double_p, c_double_p,
                                       c_double_p, c_i32_p, c_double_p, c_i64_p, c_double_p]),
@@ -709,6 +716,44 @@ class DeviceGrid(object):
             self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin), int(mode), float(cut_w),
             int(cut_idx), float(key_lo), float(key_hi), int(want), dptr(out)))
         return int(out[0]), int(out[1]), float(out[2]), int(out[3]), float(out[4])
+
+    def pass_hist(self, mode, cut_w, cut_idx, key_lo, key_hi):
+        """This shard's histogram (4096 bins over [key_lo, key_hi]) of the keys of its
+        candidates behind the cut (``sgp_grid_pass_hist``)."""
+        hist = np.zeros(4096, dtype=np.uint32)
+        self.ctx.check(lib().sgp_grid_pass_hist(
+            self.h, int(mode), float(cut_w), int(cut_idx), float(key_lo), float(key_hi),
+            hist.ctypes.data_as(c_u32_p)))
+        return hist
+
+    def pass_list(self, mode, cut_w, cut_idx, thr, cap):
+        """This shard's candidates behind the cut with key >= thr: ``(global rows, keys, rows
+        (m, d), u - mu (m, G))`` (``sgp_grid_pass_list``)."""
+        cap = max(int(cap), 1)
+        gidx = np.empty(cap, dtype=np.int64)
+        key = np.empty(cap)
+        x = np.empty((cap, self.d))
+        resid = np.empty((cap, self.G))
+        n = C.c_int(0)
+        self.ctx.check(lib().sgp_grid_pass_list(
+            self.h, int(mode), float(cut_w), int(cut_idx), float(thr), cap, C.byref(n),
+            gidx.ctypes.data_as(c_i64_p), dptr(key), dptr(x), dptr(resid)))
+        m = n.value
+        return gidx[:m], key[:m], x[:m], resid[:m]
+
+    def pass_test(self, gps, beta, fmin, xc, resid):
+        """Flags (K, G): candidate c lifts one of this shard's unsafe rows above fmin_i
+        (``sgp_grid_pass_test``)."""
+        fmin = f64(fmin)
+        xc = f64(xc).reshape(-1, self.d)
+        K = xc.shape[0]
+        resid = f64(resid).reshape(K, self.G)
+        flags = np.zeros((K, self.G), dtype=np.int32)
+        if K:
+            self.ctx.check(lib().sgp_grid_pass_test(
+                self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin), K, dptr(xc),
+                dptr(resid), flags.ctypes.data_as(c_i32_p)))
+        return flags
 
     def lipschitz_check(self, fmin, lipschitz, xc, u_c):
         fmin = f64(fmin)

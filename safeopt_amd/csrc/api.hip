@@ -1318,6 +1318,124 @@ int sgp_grid_expander_pass(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   return 0;
 }
 
+// ---- the same pass on N ranks, in three calls with the ranks' agreement in between ----------
+// (SafeOpt._visit_in_big_passes_nrank): every rank's histogram of the keys behind the cut
+// (the ranks sum them and pick ONE threshold), every rank's candidates above it with what the
+// other ranks need of them (the ranks gather them: the same list everywhere), and the test of
+// ALL those candidates against this rank's unsafe rows (the ranks OR the flags).
+int sgp_grid_pass_hist(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, double key_lo,
+                       double key_hi, uint32_t* hist) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, key_hi > key_lo, "empty key range %g .. %g", key_lo, key_hi);
+  char* sb = static_cast<char*>(sgp_scratch(ctx, 8, size_t(g->N) * 4 + 16384 + 256));
+  SGP_CHECK(ctx, sb, "device allocation failed: %s", ctx->err.c_str());
+  unsigned* dh = reinterpret_cast<unsigned*>(sb + size_t(g->N) * 4);
+  SGP_TRY(launch_pass_hist(g, mode, cut_w, cut_idx, key_lo, key_hi, dh));
+  return sgp_d2h(ctx, hist, dh, 4096 * sizeof(uint32_t));
+}
+
+int sgp_grid_pass_list(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, double thr, int cap,
+                       int* count, int64_t* gidx, double* key, double* x, double* resid) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, g->N < (int64_t(1) << 31), "%lld rows", (long long)g->N);
+  char* sb = static_cast<char*>(sgp_scratch(ctx, 8, size_t(g->N) * 4 + 16384 + 256));
+  SGP_CHECK(ctx, sb, "device allocation failed: %s", ctx->err.c_str());
+  int* list = reinterpret_cast<int*>(sb);
+  char* sel = sb + size_t(g->N) * 4 + 16384;
+  struct { double thr; int count, est; } hs = {thr, 0, 0};
+  SGP_TRY(sgp_h2d(ctx, sel, &hs, sizeof(hs)));
+  SGP_TRY(launch_pass_list(g, mode, cut_w, cut_idx, sel, list));
+  SGP_TRY(sgp_d2h(ctx, &hs, sel, sizeof(hs)));
+  *count = hs.count;
+  if (hs.count == 0) return 0;
+  SGP_CHECK(ctx, hs.count <= cap, "%d candidates above the threshold, room for %d", hs.count, cap);
+  const int d = g->d, G = g->G;
+  const size_t per = 2 + size_t(d) + size_t(G);
+  double* ob = static_cast<double*>(sgp_scratch(ctx, 9, size_t(hs.count) * per * 8));
+  SGP_CHECK(ctx, ob, "device allocation failed: %s", ctx->err.c_str());
+  int64_t* dg = reinterpret_cast<int64_t*>(ob);
+  double *dk = ob + hs.count, *dx = dk + hs.count, *dr = dx + size_t(hs.count) * d;
+  SGP_TRY(launch_pass_gather(g, list, hs.count, mode, dg, dk, dx, dr));
+  std::vector<double> host(size_t(hs.count) * per);
+  SGP_TRY(sgp_d2h(ctx, host.data(), ob, host.size() * 8));
+  memcpy(gidx, host.data(), size_t(hs.count) * 8);
+  memcpy(key, host.data() + hs.count, size_t(hs.count) * 8);
+  memcpy(x, host.data() + 2 * size_t(hs.count), size_t(hs.count) * d * 8);
+  memcpy(resid, host.data() + size_t(hs.count) * (2 + d), size_t(hs.count) * G * 8);
+  return 0;
+}
+
+// xc [K][d], resid [K][G] (u_g - mu_g at the candidate): flags[c * G + i] != 0 when candidate c
+// lifts one of THIS shard's unsafe rows above fmin_i.
+int sgp_grid_pass_test(sgp_grid* g, sgp_gp* const* gps, int G, double beta, const double* fmin,
+                       int K, const double* xc, const double* resid, int32_t* flags) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  if (K <= 0) return 0;
+  GpDev host[SGP_MAX_GPS];
+  SGP_TRY(collect_gps(ctx, gps, G, g->d, host));
+  const int d = g->d;
+  int np_max = 0;
+  for (int i = 0; i < G; ++i) np_max = host[i].n_pad > np_max ? host[i].n_pad : np_max;
+  const int64_t wstride = int64_t(np_max / 4) * 64;
+  const size_t ngroups = (size_t(K) + 15) / 16;
+  const size_t nxc = ngroups * 16 * d, nv = ngroups * G * 16;
+  double* ob = static_cast<double*>(sgp_scratch(ctx, 9, (nxc + 6 * nv + 8) * 8));
+  SGP_CHECK(ctx, ob, "device allocation failed: %s", ctx->err.c_str());
+  double* Wp = static_cast<double*>(sgp_scratch(ctx, 10, ngroups * G * size_t(wstride) * 8));
+  SGP_CHECK(ctx, Wp, "device allocation failed: %s", ctx->err.c_str());
+  int32_t* dfl = static_cast<int32_t*>(sgp_scratch(ctx, 11, ngroups * 16 * G * 4 + 64));
+  SGP_CHECK(ctx, dfl, "device allocation failed: %s", ctx->err.c_str());
+  double *dxc = ob, *dres = ob + nxc, *ddel = dres + nv, *dis2 = ddel + nv, *dtn2 = dis2 + nv;
+  // operand block on the host: xc | resid[group][g][16]
+  std::vector<double> st(nxc + nv, 0.0);
+  memcpy(st.data(), xc, size_t(K) * d * 8);
+  for (int c = 0; c < K; ++c)
+    for (int i = 0; i < G; ++i)
+      st[nxc + (size_t(c >> 4) * G + i) * 16 + (c & 15)] = resid[size_t(c) * G + i];
+  SGP_TRY(sgp_h2d(ctx, ob, st.data(), st.size() * 8));
+  SGP_HIP(ctx, hipMemsetAsync(dfl, 0, ngroups * 16 * G * 4, ctx->stream));
+  SGP_TRY(stage_gpdev(g, host, G));
+  ExpanderOps ops{};
+  ops.xc = dxc;
+  ops.resid = dres;
+  ops.Wpack = Wp;
+  ops.delta = ddel;
+  ops.inv_s2 = dis2;
+  ops.tn2 = dtn2;
+  ops.wstride = wstride;
+  ops.m = K;
+  ops.Gs = G;
+  ExpanderArgs ea{};
+  for (int i = 0; i < SGP_MAX_GPS; ++i) {
+    ea.fmin[i] = (i < G) ? fmin[i] : -INFINITY;
+    ea.active[i] = (i < G) && (fmin[i] != -INFINITY);
+    ops.active[i] = ea.active[i];
+  }
+  SGP_TRY(expander_operands_all(ctx, g->gpdev, host, G, d, ops, nullptr));
+  ea.Wpack = Wp;
+  ea.xc = dxc;
+  ea.delta = ddel;
+  ea.inv_s2 = dis2;
+  ea.tn2 = dtn2;
+  ea.stn = dtn2 + nv;
+  ea.svc = dtn2 + 2 * nv;
+  ea.m = K;
+  ea.beta = beta;
+  ea.S = g->S;
+  ea.mean = g->mean;
+  ea.var = g->var;
+  ea.flags = dfl;
+  ea.wstride = wstride;
+  ea.near_frac = 0.0;
+  SweepPoints sp{g->pts, g->N, 1, g->N};
+  SGP_TRY(launch_expander_many(ctx, g->gpdev, G, d, sp, ea));
+  return sgp_d2h(ctx, flags, dfl, size_t(K) * G * 4);
+}
+
 // Host copy of a front block ([0] max width | [1..2] counts (u64) | [3] w_top | [4]
 // idx_top (i64) | [5] n_found, n_tied (int) | x[d] | mean[G] | q[2G]) -> the caller's
 // arrays; out5[4] = -1 when the shard / grid has no candidate, out5[5] = number of

@@ -411,6 +411,12 @@ int launch_mark_if(sgp_grid* g, int64_t li, const int32_t* flags_dev,
 // histogram (sel_dev: { double thr; int count; int est }), operand staging, hits
 int launch_pass_select(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, double lo,
                        double hi, int want, void* sel_dev, int* list_dev, unsigned* hist_dev);
+int launch_pass_hist(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, double lo, double hi,
+                     unsigned* hist_dev);
+int launch_pass_list(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, void* sel_dev,
+                     int* list_dev);
+int launch_pass_gather(sgp_grid* g, const int* list_dev, int count, int mode, int64_t* gidx,
+                       double* key, double* x, double* resid);
 int launch_pass_stage(sgp_grid* g, const int* list_dev, int count, double* xc, double* resid);
 int launch_pass_result(sgp_grid* g, const int* list_dev, int count, const int32_t* flags_dev,
                        const double* fmin, int mode, double* res_dev);

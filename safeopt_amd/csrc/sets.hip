@@ -999,6 +999,23 @@ __global__ __launch_bounds__(T) void k_pass_stage(const int* list, int count, co
         Q[li * 2 * G + 2 * g + 1] - mean[int64_t(g) * N + li];
 }
 
+// N ranks: what the other ranks need of the listed candidates -- global row, key, the row
+// itself, u_g - mu_g -- in list order.
+__global__ __launch_bounds__(T) void k_pass_gather(const int* list, int count, const double* pts,
+                                                   const double* mean, const double* Q,
+                                                   const double* w, int64_t N, int d, int G,
+                                                   int64_t goff, int index_key, int64_t* gidx,
+                                                   double* key, double* x, double* resid) {
+  const int pos = blockIdx.x * T + threadIdx.x;
+  if (pos >= count) return;
+  const int64_t li = list[pos];
+  gidx[pos] = goff + li;
+  key[pos] = index_key ? -double(goff + li) : w[li];
+  for (int k = 0; k < d; ++k) x[int64_t(pos) * d + k] = pts[int64_t(k) * N + li];
+  for (int g = 0; g < G; ++g)
+    resid[int64_t(pos) * G + g] = Q[li * 2 * G + 2 * g + 1] - mean[int64_t(g) * N + li];
+}
+
 // hits of the pass: a candidate is an expander when every GP with a constraint flagged it.
 // mode 0: the first one in visiting order (largest key, then largest index); mode 1
 // (full_sets): every one of them is marked in G.  res = { hits, key, index (i64 bits) }.
@@ -1051,6 +1068,39 @@ int launch_pass_select(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, dou
                      static_cast<PassSel*>(sel_dev));
   hipLaunchKernelGGL(k_pass_list, dim3(nb), dim3(T), 0, ctx->stream, g->cand, g->w, g->N,
                      g->goff, mode, cut_w, cut_idx, static_cast<PassSel*>(sel_dev), list_dev);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// N ranks: the histogram alone (the ranks sum theirs and pick ONE threshold) ...
+int launch_pass_hist(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, double lo, double hi,
+                     unsigned* hist_dev) {
+  sgp_ctx* ctx = g->ctx;
+  const unsigned nb = std::min<unsigned>(nblk(g->N, T), 2048u);
+  SGP_HIP(ctx, hipMemsetAsync(hist_dev, 0, kPassBins * sizeof(unsigned), ctx->stream));
+  hipLaunchKernelGGL(k_pass_hist, dim3(nb), dim3(T), 0, ctx->stream, g->cand, g->w, g->N,
+                     g->goff, mode, cut_w, cut_idx, lo, hi, hist_dev);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// ... and the list behind a threshold the caller has put into *sel_dev ({ thr, 0, 0 })
+int launch_pass_list(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, void* sel_dev,
+                     int* list_dev) {
+  sgp_ctx* ctx = g->ctx;
+  const unsigned nb = std::min<unsigned>(nblk(g->N, T), 2048u);
+  hipLaunchKernelGGL(k_pass_list, dim3(nb), dim3(T), 0, ctx->stream, g->cand, g->w, g->N,
+                     g->goff, mode, cut_w, cut_idx, static_cast<PassSel*>(sel_dev), list_dev);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_pass_gather(sgp_grid* g, const int* list_dev, int count, int mode, int64_t* gidx,
+                       double* key, double* x, double* resid) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_pass_gather, dim3((count + T - 1) / T), dim3(T), 0, ctx->stream, list_dev,
+                     count, g->pts, g->mean, g->Q, g->w, g->N, g->d, g->G, g->goff, mode, gidx,
+                     key, x, resid);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -324,6 +324,15 @@ class _HipGridBackend(object):
         return self.grid.expander_pass(self._dev(), beta, fmin, mode, cut_w, cut_idx,
                                        key_lo, key_hi, want)
 
+    def pass_hist(self, mode, cut_w, cut_idx, key_lo, key_hi):
+        return self.grid.pass_hist(mode, cut_w, cut_idx, key_lo, key_hi)
+
+    def pass_list(self, mode, cut_w, cut_idx, thr, cap):
+        return self.grid.pass_list(mode, cut_w, cut_idx, thr, cap)
+
+    def pass_test(self, beta, fmin, xc, resid):
+        return self.grid.pass_test(self._dev(), beta, fmin, xc, resid)
+
     def small_grid(self):
         """At most 16384 rows and 48 observations per GP: every candidate can be tested at
         once (``sgp_grid_expanders_small``)."""
@@ -915,6 +924,10 @@ class SafeOpt(GaussianProcessOptimization):
                     return self._visit_in_big_passes(beta, active, False, cut_w, cut_idx)
                 K = _hip.TOPK
             return
+        big_n = (self._comm.world > 1 and not self.use_lipschitz and self.big_passes
+                 and hasattr(be, 'pass_test'))
+        if big_n and full_sets:
+            return self._visit_in_big_passes_nrank(beta, active, True, np.inf, -1)
         while True:
             w_loc, i_loc = be.topk(mode, cut_w, cut_idx, K)
             if self._comm.world > 1:
@@ -961,6 +974,8 @@ class SafeOpt(GaussianProcessOptimization):
             if m < K:
                 break
             cut_w, cut_idx = float(w_b[-1]), int(i_b[-1])
+            if big_n and K == _hip.TOPK:
+                return self._visit_in_big_passes_nrank(beta, active, False, cut_w, cut_idx)
             K = _hip.TOPK
 
     #: candidates per pass of ``_visit_in_big_passes`` (the last entry repeats)
@@ -996,6 +1011,67 @@ class SafeOpt(GaussianProcessOptimization):
             cut_w, cut_idx = left, -1
             if not full_sets:
                 hi = left
+
+    def _visit_in_big_passes_nrank(self, beta, active, full_sets, cut_w, cut_idx):
+        """``_visit_in_big_passes`` on a row-sharded grid.  Per pass: the ranks sum their
+        histograms of the keys behind the cut and pick ONE threshold (every rank computes the
+        same one from the same sum); every rank lists its candidates above it and the lists are
+        gathered -- the same candidates in the same order everywhere; every rank tests ALL of
+        them against its own unsafe rows (the operands of the test are recomputed on every rank:
+        a few MFLOP per candidate against the scan) and the flags are or-ed over the ranks
+        (gp_opt.py:602: ``np.any`` over all unsafe rows).  Three small collectives per pass
+        instead of three per 16 candidates."""
+        be, comm = self._backend, self._comm
+        G, d = len(self.gps), self.inputs.shape[1]
+        if full_sets:
+            n_all = float(self.inputs.shape[0])
+            lo, hi, mode = -(n_all + 1.0), 1.0, 1
+        else:
+            lo, hi, mode = 0.0, float(cut_w), 0
+        nbins = 4096
+        for k in range(1 << 30):
+            want = self.pass_sizes[min(k, len(self.pass_sizes) - 1)]
+            hist = comm.allgather(be.pass_hist(mode, cut_w, cut_idx, lo, hi).astype(np.float64))
+            from_top = np.cumsum(hist.sum(axis=0)[::-1])
+            if from_top[-1] == 0:
+                return
+            # the highest bin at which the count from the top reaches `want` (k_pass_pick)
+            b = nbins - 1 - int(np.argmax(from_top >= want)) if from_top[-1] >= want else 0
+            thr = -np.inf if b == 0 else lo + (hi - lo) * (float(b) / nbins)
+            # (rounding at a bin edge can move a few candidates across it: room for the
+            # bin below as well)
+            cap = int(from_top[min(nbins - 1, nbins - b)] if b > 0 else from_top[-1]) + 64
+            gi, key, xc, resid = be.pass_list(mode, cut_w, cut_idx, thr, cap)
+            counts = comm.allgather(np.array([float(gi.size)]))[:, 0].astype(int)
+            pad = int(counts.max())
+            if pad == 0:
+                return
+            buf = np.zeros((pad, 2 + d + G))
+            buf[:gi.size, 0], buf[:gi.size, 1] = gi, key            # (row indices < 2^53)
+            buf[:gi.size, 2:2 + d], buf[:gi.size, 2 + d:] = xc, resid
+            allp = comm.allgather(buf)
+            rows = np.concatenate([allp[r][:c] for r, c in enumerate(counts)])
+            flags = be.pass_test(beta, self.fmin, rows[:, 2:2 + d], rows[:, 2 + d:])
+            flags = comm.allreduce_max(flags.astype(np.float64)) > 0
+            hits = np.all(flags[:, active], axis=1)
+            gidx_all = rows[:, 0].astype(np.int64)
+            if full_sets:
+                mine = [int(i) for i in gidx_all[hits] if be.owns(int(i))]
+                for a in range(0, len(mine), 4096):
+                    be.mark_expanders(np.asarray(mine[a:a + 4096], dtype=np.int64))
+            elif hits.any():
+                hk, hg = rows[hits, 1], gidx_all[hits]
+                first = np.lexsort((hg, hk))[-1]             # widest, then the larger row
+                row, w_star = int(hg[first]), float(hk[first])
+                if be.owns(row):
+                    be.mark_expanders(np.array([row], dtype=np.int64))
+                self._settle_ties(beta, active, w_star, row)
+                return
+            if thr == -np.inf:
+                return
+            cut_w, cut_idx = thr, -1
+            if not full_sets:
+                hi = thr
 
     def _visit_all_candidates(self, beta, active, full_sets, cut_idx, chunk=1024):
         """The expander loop of a SMALL grid on one rank: every candidate is tested at once

@@ -148,6 +148,61 @@ def _loop_cases(sa, gpy, comm, report):
         report.append((name, bool(ok)))
 
 
+def _big_pass_cases(sa, gpy, comm, report):
+    """The expander loop where it goes far (tests/test_gpu_expander_passes.py has the one-rank
+    form against the oracle): a converged run -- every candidate visited, none marked --, a state
+    whose first expander sits far down the visiting order, and ``full_sets``, on true shards
+    against the SAME product on one rank.  The ranks agree on a threshold from their summed
+    histograms, gather the candidates, test all of them against their own unsafe rows and or
+    the flags (``SafeOpt._visit_in_big_passes_nrank``)."""
+    import _scenarios as sc
+    from safeopt_amd import dist, gp_opt
+    calls = {"n": 0}
+    orig = gp_opt._HipGridBackend.pass_test
+
+    def counted(self, *a, **k):
+        calls["n"] += 1
+        return orig(self, *a, **k)
+    gp_opt._HipGridBackend.pass_test = counted
+    try:
+        state = dict(r0=2.0, rings=8, ls=0.4, dmid=0.45, plateau=0.6)
+        for name, kw, margin in (("converged run (no expander)", state, 0.05),
+                                 ("first expander far down the order", dict(state, plateau=0.45), None)):
+            data = sc.rim_data(160, **kw)
+            grid = data["grid"]
+            if margin is not None:
+                gp0 = sc.make_gp(gpy, data)
+                grid = np.ascontiguousarray(grid[sc.converged_rows(gp0, grid, margin)])
+
+            def build(cm):
+                o = sa.SafeOpt(sc.make_gp(gpy, data), grid, 0.0, threshold=0.1, comm=cm)
+                o.pass_sizes = (64, 512)
+                return o
+            a, b = build(comm), build(dist.LocalComm())
+            before = calls["n"]
+            xa, xb = a.optimize(), b.optimize()
+            ok = (np.array_equal(xa, xb) and np.array_equal(a.S, b.S) and np.array_equal(a.M, b.M)
+                  and np.array_equal(a.G, b.G))
+            report.append(("big passes, %s: |G| = %d, %d N-rank passes" % (
+                name, int(np.sum(b.G)), calls["n"] - before), bool(ok) and calls["n"] > before))
+        # full_sets: every safe row is a candidate, every expander is marked
+        data = sc.rim_data(100, **dict(state, plateau=0.45))
+
+        def build(cm):
+            o = sa.SafeOpt(sc.make_gp(gpy, data), data["grid"], 0.0, threshold=0.1, comm=cm)
+            o.pass_sizes = (200, 1000)
+            o.update_confidence_intervals()
+            o.compute_sets(full_sets=True)
+            return o
+        before = calls["n"]
+        a, b = build(comm), build(dist.LocalComm())
+        report.append(("big passes, full_sets: |G| = %d, %d N-rank passes" % (
+            int(np.sum(b.G)), calls["n"] - before),
+            bool(np.array_equal(a.G, b.G)) and int(np.sum(b.G)) > 0 and calls["n"] > before))
+    finally:
+        gp_opt._HipGridBackend.pass_test = orig
+
+
 def _worker(rank, world, port, q, variant):
     try:
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
@@ -172,6 +227,7 @@ def _worker(rank, world, port, q, variant):
         _golden_cases(sa, gpy, comm, report)
         _tie_cases(sa, gpy, comm, report)
         _loop_cases(sa, gpy, comm, report)
+        _big_pass_cases(sa, gpy, comm, report)
         if variant == "fused_comm":
             # the one-round-trip step (k_merge_front, flag all-reduce, k_merge_argmax behind
             # the staged collectives) is what ran, on every certified step
