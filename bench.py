@@ -449,31 +449,31 @@ def no_expander_state(gpy, safeopt_amd, ctx):
     """The expander loop of gp_opt.py:557-612 where it has to visit EVERY candidate: a converged
     run (tests/_scenarios.py: a safe disk whose rim is observed densely, a coarsely observed
     plateau inside -- thousands of candidates wider than every maximiser -- and no unsafe row
-    within reach of any of them; 2-D RBF, 637 observations), and full_sets = True (:553-555:
-    every safe row is visited).  ms per SafeOpt.optimize() / compute_sets(full_sets=True) with
-    the big passes of round 6 (sgp_grid_expander_pass: hundreds to thousands of candidates per
-    device pass, two synchronisations each) and, on the 1e5-row grid, with the 16-candidates-
-    per-round-trip loop they replace.  Parity: tests/test_gpu_expander_passes.py."""
+    within reach of any of them; 2-D RBF), and full_sets = True (:553-555: every safe row is
+    visited).  Two states: config-2 scale (1e6 rows, 217 observations) and a denser problem on
+    a 1e5-row grid (637 observations).  ms per SafeOpt.optimize() / compute_sets(full_sets=True)
+    with the big passes of round 6 (sgp_grid_expander_pass: hundreds to thousands of candidates
+    per device pass, two synchronisations each) and with the 16-candidates-per-round-trip loop
+    they replace.  Parity: tests/test_gpu_expander_passes.py."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
     import _scenarios as sc
     out = {"note": no_expander_state.__doc__.split("  ms per")[0].strip().replace("\n   ", ""),
            "pass_sizes": list(safeopt_amd.SafeOpt.pass_sizes)}
-    for side, with_old in ((320, True), (1000, False)):
-        gp, grid = sc.converged_state(side, 0.05, ns=gpy, r0=2.0, rings=8, ls=0.4, dmid=0.45,
-                                      plateau=0.6)
+    states = (("config2_scale_1e6_rows", 1000,
+               dict(ls=0.7, rings=5, dring=0.3, dmid=0.8, dtop=0.4, r0=2.0, dout=1.4, plateau=0.6)),
+              ("grid_320x320", 320, dict(r0=2.0, rings=8, ls=0.4, dmid=0.45, plateau=0.6)))
+    for name, side, kw in states:
+        gp, grid = sc.converged_state(side, 0.05, ns=gpy, **kw)
         row = {"rows": int(len(grid)), "n_train": int(gp.X.shape[0])}
-        for big in ((True, False) if with_old else (True,)):
+        for big in (True, False):
             opt = safeopt_amd.SafeOpt(gp, grid, 0.0, threshold=0.1)
             opt.big_passes = big
             passes = []
-            if big:
-                orig = opt._backend.expander_pass
-                opt._backend.expander_pass = lambda *a, _o=orig: (passes.append(a[-1]), _o(*a))[1]
-            else:
-                orig = opt._backend.expander_batch
-                opt._backend.expander_batch = lambda *a, _o=orig: (passes.append(a[-1]), _o(*a))[1]
+            attr = "expander_pass" if big else "expander_batch"
+            orig = getattr(opt._backend, attr)
+            setattr(opt._backend, attr, lambda *a, _o=orig: (passes.append(a[-1]), _o(*a))[1])
             opt.optimize()
             del passes[:]
             ctx.sync()
@@ -487,20 +487,21 @@ def no_expander_state(gpy, safeopt_amd, ctx):
             row.setdefault("safe_rows", int(S.sum()))
             row[key] = {"optimize_ms": ms, "device_passes": len(passes),
                         "expanders_found": int(np.asarray(opt.G).sum())}
-            if side == 320:
+            if big or side <= 400:
                 ctx.sync()
                 t0 = time.perf_counter()
                 opt.compute_sets(full_sets=True)
                 ctx.sync()
                 row[key]["full_sets_ms"] = (time.perf_counter() - t0) * 1e3
                 row[key]["full_sets_expanders"] = int(np.asarray(opt.G).sum())
-        if side == 320:
-            # candidates of the state: S & ~M & wider than every maximiser & above the threshold
-            Q = np.asarray(opt.Q)
-            w = Q[:, 1] - Q[:, 0]
-            M = np.asarray(opt.M, dtype=bool)
-            row["candidates"] = int((S & ~M & (w > w[M].max()) & (w > 0.1 * 2.0)).sum())
-        out["grid_%dx%d" % (side, side)] = row
+            if big:
+                # candidates of the state: S & ~M & wider than every maximiser & above the threshold
+                opt.optimize()
+                Q = np.asarray(opt.Q)
+                w = Q[:, 1] - Q[:, 0]
+                M = np.asarray(opt.M, dtype=bool)
+                row["candidates"] = int((S & ~M & (w > w[M].max()) & (w > 0.1 * 2.0)).sum())
+        out[name] = row
     return out
 
 

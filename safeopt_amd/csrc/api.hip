@@ -1236,12 +1236,14 @@ int sgp_grid_expander_pass(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   SGP_CHECK(ctx, g->N < (int64_t(1) << 31), "%lld rows", (long long)g->N);
   for (int i = 0; i < 6; ++i) out6[i] = 0.0;
   // selection
-  char* sb = static_cast<char*>(sgp_scratch(ctx, 8, size_t(g->N) * 4 + 16384 + 256));
+  const size_t nl = (size_t(g->N) * 4 + 63) & ~size_t(63);      // list | histogram | sel | counts
+  char* sb = static_cast<char*>(sgp_scratch(ctx, 8, nl + 16384 + 256 + (size_t(g->N) / 256 + 2) * 4));
   SGP_CHECK(ctx, sb, "device allocation failed: %s", ctx->err.c_str());
   int* list = reinterpret_cast<int*>(sb);
-  unsigned* hist = reinterpret_cast<unsigned*>(sb + size_t(g->N) * 4);
-  char* sel = sb + size_t(g->N) * 4 + 16384;
-  SGP_TRY(launch_pass_select(g, mode, cut_w, cut_idx, key_lo, key_hi, want, sel, list, hist));
+  unsigned* hist = reinterpret_cast<unsigned*>(sb + nl);
+  char* sel = sb + nl + 16384;
+  int* counts = reinterpret_cast<int*>(sb + nl + 16384 + 256);
+  SGP_TRY(launch_pass_select(g, mode, cut_w, cut_idx, key_lo, key_hi, want, sel, list, hist, counts));
   struct { double thr; int count, est; } hs;
   SGP_TRY(sgp_d2h(ctx, &hs, sel, sizeof(hs)));
   const int count = hs.count;
@@ -1260,7 +1262,7 @@ int sgp_grid_expander_pass(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   const int64_t wstride = int64_t(np_max / 4) * 64;
   const size_t ngroups = (size_t(count) + 15) / 16;
   const size_t nxc = ngroups * 16 * d, nv = ngroups * G * 16;
-  double* ob = static_cast<double*>(sgp_scratch(ctx, 9, (nxc + 6 * nv + 8) * 8));
+  double* ob = static_cast<double*>(sgp_scratch(ctx, 9, (nxc + 7 * nv + ngroups * 2 * d + 8) * 8));
   SGP_CHECK(ctx, ob, "device allocation failed: %s", ctx->err.c_str());
   double* Wp = static_cast<double*>(sgp_scratch(ctx, 10, ngroups * G * size_t(wstride) * 8));
   SGP_CHECK(ctx, Wp, "device allocation failed: %s", ctx->err.c_str());
@@ -1297,6 +1299,8 @@ int sgp_grid_expander_pass(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   ea.tn2 = dtn2;
   ea.stn = dtn2 + nv;
   ea.svc = dtn2 + 2 * nv;
+  ea.agg = dtn2 + 3 * nv;          // (ngroups G 4 <= nv)
+  ea.box = dtn2 + 4 * nv;
   ea.m = count;
   ea.beta = beta;
   ea.S = g->S;
@@ -1328,9 +1332,10 @@ int sgp_grid_pass_hist(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, dou
   sgp_ctx* ctx = g->ctx;
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   SGP_CHECK(ctx, key_hi > key_lo, "empty key range %g .. %g", key_lo, key_hi);
-  char* sb = static_cast<char*>(sgp_scratch(ctx, 8, size_t(g->N) * 4 + 16384 + 256));
+  const size_t nl = (size_t(g->N) * 4 + 63) & ~size_t(63);      // list | histogram | sel | counts
+  char* sb = static_cast<char*>(sgp_scratch(ctx, 8, nl + 16384 + 256 + (size_t(g->N) / 256 + 2) * 4));
   SGP_CHECK(ctx, sb, "device allocation failed: %s", ctx->err.c_str());
-  unsigned* dh = reinterpret_cast<unsigned*>(sb + size_t(g->N) * 4);
+  unsigned* dh = reinterpret_cast<unsigned*>(sb + nl);
   SGP_TRY(launch_pass_hist(g, mode, cut_w, cut_idx, key_lo, key_hi, dh));
   return sgp_d2h(ctx, hist, dh, 4096 * sizeof(uint32_t));
 }
@@ -1340,13 +1345,15 @@ int sgp_grid_pass_list(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, dou
   sgp_ctx* ctx = g->ctx;
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   SGP_CHECK(ctx, g->N < (int64_t(1) << 31), "%lld rows", (long long)g->N);
-  char* sb = static_cast<char*>(sgp_scratch(ctx, 8, size_t(g->N) * 4 + 16384 + 256));
+  const size_t nl = (size_t(g->N) * 4 + 63) & ~size_t(63);      // list | histogram | sel | counts
+  char* sb = static_cast<char*>(sgp_scratch(ctx, 8, nl + 16384 + 256 + (size_t(g->N) / 256 + 2) * 4));
   SGP_CHECK(ctx, sb, "device allocation failed: %s", ctx->err.c_str());
   int* list = reinterpret_cast<int*>(sb);
-  char* sel = sb + size_t(g->N) * 4 + 16384;
+  char* sel = sb + nl + 16384;
   struct { double thr; int count, est; } hs = {thr, 0, 0};
   SGP_TRY(sgp_h2d(ctx, sel, &hs, sizeof(hs)));
-  SGP_TRY(launch_pass_list(g, mode, cut_w, cut_idx, sel, list));
+  int* counts = reinterpret_cast<int*>(sb + nl + 16384 + 256);
+  SGP_TRY(launch_pass_list(g, mode, cut_w, cut_idx, sel, list, counts));
   SGP_TRY(sgp_d2h(ctx, &hs, sel, sizeof(hs)));
   *count = hs.count;
   if (hs.count == 0) return 0;
@@ -1383,7 +1390,7 @@ int sgp_grid_pass_test(sgp_grid* g, sgp_gp* const* gps, int G, double beta, cons
   const int64_t wstride = int64_t(np_max / 4) * 64;
   const size_t ngroups = (size_t(K) + 15) / 16;
   const size_t nxc = ngroups * 16 * d, nv = ngroups * G * 16;
-  double* ob = static_cast<double*>(sgp_scratch(ctx, 9, (nxc + 6 * nv + 8) * 8));
+  double* ob = static_cast<double*>(sgp_scratch(ctx, 9, (nxc + 7 * nv + ngroups * 2 * d + 8) * 8));
   SGP_CHECK(ctx, ob, "device allocation failed: %s", ctx->err.c_str());
   double* Wp = static_cast<double*>(sgp_scratch(ctx, 10, ngroups * G * size_t(wstride) * 8));
   SGP_CHECK(ctx, Wp, "device allocation failed: %s", ctx->err.c_str());
@@ -1423,6 +1430,8 @@ int sgp_grid_pass_test(sgp_grid* g, sgp_gp* const* gps, int G, double beta, cons
   ea.tn2 = dtn2;
   ea.stn = dtn2 + nv;
   ea.svc = dtn2 + 2 * nv;
+  ea.agg = dtn2 + 3 * nv;          // (ngroups G 4 <= nv)
+  ea.box = dtn2 + 4 * nv;
   ea.m = K;
   ea.beta = beta;
   ea.S = g->S;

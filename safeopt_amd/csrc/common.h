@@ -329,6 +329,8 @@ struct ExpanderArgs {
   const double* tn2;     // [G][16]  |L^-1 k(X, x_c)|^2
   const double* stn;     // k_expander_many: [group][G][16] |L^-1 k_c| and the posterior
   const double* svc;     // standard deviation at x_c (written by launch_expander_many)
+  const double* agg;     // ... [group][G][4] extremes of a group, box [group][2][d] (k_pass_agg)
+  const double* box;
   int m;
   double beta;
   double fmin[SGP_MAX_GPS];
@@ -410,11 +412,12 @@ int launch_mark_if(sgp_grid* g, int64_t li, const int32_t* flags_dev,
 // a pass of the expander loop over many candidates (sets.hip): selection by a key
 // histogram (sel_dev: { double thr; int count; int est }), operand staging, hits
 int launch_pass_select(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, double lo,
-                       double hi, int want, void* sel_dev, int* list_dev, unsigned* hist_dev);
+                       double hi, int want, void* sel_dev, int* list_dev, unsigned* hist_dev,
+                       int* counts_dev);
 int launch_pass_hist(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, double lo, double hi,
                      unsigned* hist_dev);
 int launch_pass_list(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, void* sel_dev,
-                     int* list_dev);
+                     int* list_dev, int* counts_dev);
 int launch_pass_gather(sgp_grid* g, const int* list_dev, int count, int mode, int64_t* gidx,
                        double* key, double* x, double* resid);
 int launch_pass_stage(sgp_grid* g, const int* list_dev, int count, double* xc, double* resid);

@@ -965,23 +965,82 @@ __global__ __launch_bounds__(1024) void k_pass_pick(const unsigned* hist, int wa
   }
 }
 
+// The list is in ROW ORDER (a count per 256-row chunk, a prefix sum over the chunks, then the
+// rows behind their chunk's offset): a group of 16 consecutive list entries -- the unit of the
+// test, k_expander_many -- is a run of neighbours along a grid line, and its bounding box is
+// what lets whole (rows x group) blocks skip the pre-filter.  Deterministic, too.
+__device__ __forceinline__ bool pass_take(const uint8_t* cand, const double* w, int64_t e,
+                                          int64_t N, int64_t goff, int index_key, double cut_w,
+                                          int64_t cut_idx, double thr) {
+  double key = 0.0;
+  return e < N && pass_key(cand, w, e, goff, index_key, cut_w, cut_idx, &key) && key >= thr;
+}
+
+__global__ __launch_bounds__(T) void k_pass_count(const uint8_t* cand, const double* w,
+                                                  int64_t N, int64_t goff, int index_key,
+                                                  double cut_w, int64_t cut_idx,
+                                                  const PassSel* sel, int* counts) {
+  __shared__ int wc[T / 64];
+  const double thr = sel->thr;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t e0 = int64_t(blockIdx.x) * T; e0 < N; e0 += int64_t(gridDim.x) * T) {
+    const bool take = pass_take(cand, w, e0 + threadIdx.x, N, goff, index_key, cut_w, cut_idx, thr);
+    const unsigned long long b = __ballot(take);
+    if (lane == 0) wc[wave] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int n = 0;
+      for (int q = 0; q < T / 64; ++q) n += wc[q];
+      counts[e0 / T] = n;
+    }
+    __syncthreads();
+  }
+}
+
+// exclusive prefix sum of the chunk counts (in place), the total into sel->count
+__global__ __launch_bounds__(1024) void k_pass_scan(int* counts, int nchunks, PassSel* sel) {
+  __shared__ int part[1024];
+  __shared__ int carry;
+  const int t = threadIdx.x;
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nchunks; base += 1024) {
+    const int i = base + t;
+    const int v = i < nchunks ? counts[i] : 0;
+    part[t] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int u = (t >= o) ? part[t - o] : 0;
+      __syncthreads();
+      part[t] += u;
+      __syncthreads();
+    }
+    if (i < nchunks) counts[i] = carry + part[t] - v;
+    __syncthreads();
+    if (t == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (t == 0) sel->count = carry;
+}
+
 __global__ __launch_bounds__(T) void k_pass_list(const uint8_t* cand, const double* w,
                                                  int64_t N, int64_t goff, int index_key,
-                                                 double cut_w, int64_t cut_idx, PassSel* sel,
+                                                 double cut_w, int64_t cut_idx,
+                                                 const PassSel* sel, const int* offsets,
                                                  int* list) {
+  __shared__ int wc[T / 64];
   const double thr = sel->thr;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t e0 = int64_t(blockIdx.x) * T; e0 < N; e0 += int64_t(gridDim.x) * T) {
     const int64_t e = e0 + threadIdx.x;
-    double key = 0.0;
-    const bool take = e < N && pass_key(cand, w, e, goff, index_key, cut_w, cut_idx, &key) &&
-                      key >= thr;
+    const bool take = pass_take(cand, w, e, N, goff, index_key, cut_w, cut_idx, thr);
     const unsigned long long b = __ballot(take);
-    if (b == 0ull) continue;
-    int at = 0;
-    if (lane == 0) at = atomicAdd(&sel->count, __popcll(b));
-    at = __builtin_amdgcn_readfirstlane(at);
+    if (lane == 0) wc[wave] = __popcll(b);
+    __syncthreads();
+    int at = offsets[e0 / T];
+    for (int q = 0; q < wave; ++q) at += wc[q];
     if (take) list[at + __popcll(b & ((1ull << lane) - 1ull))] = int(e);
+    __syncthreads();
   }
 }
 
@@ -1056,9 +1115,26 @@ __global__ __launch_bounds__(1024) void k_pass_result(const int* list, int count
 }
 }  // namespace
 
+// count, scan, list behind the threshold in *sel (counts_dev: room for N / 256 + 1 ints)
+static int pass_list_ordered(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, PassSel* sel,
+                             int* list_dev, int* counts_dev) {
+  sgp_ctx* ctx = g->ctx;
+  const unsigned nchunks = nblk(g->N, T);
+  const unsigned nb = std::min<unsigned>(nchunks, 2048u);
+  hipLaunchKernelGGL(k_pass_count, dim3(nb), dim3(T), 0, ctx->stream, g->cand, g->w, g->N,
+                     g->goff, mode, cut_w, cut_idx, sel, counts_dev);
+  hipLaunchKernelGGL(k_pass_scan, dim3(1), dim3(1024), 0, ctx->stream, counts_dev, int(nchunks),
+                     sel);
+  hipLaunchKernelGGL(k_pass_list, dim3(nb), dim3(T), 0, ctx->stream, g->cand, g->w, g->N,
+                     g->goff, mode, cut_w, cut_idx, sel, counts_dev, list_dev);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
 // Select the pass: list (device, room for N ints) and *sel (thr, count).
 int launch_pass_select(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, double lo,
-                       double hi, int want, void* sel_dev, int* list_dev, unsigned* hist_dev) {
+                       double hi, int want, void* sel_dev, int* list_dev, unsigned* hist_dev,
+                       int* counts_dev) {
   sgp_ctx* ctx = g->ctx;
   const unsigned nb = std::min<unsigned>(nblk(g->N, T), 2048u);
   SGP_HIP(ctx, hipMemsetAsync(hist_dev, 0, kPassBins * sizeof(unsigned), ctx->stream));
@@ -1066,10 +1142,8 @@ int launch_pass_select(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, dou
                      g->goff, mode, cut_w, cut_idx, lo, hi, hist_dev);
   hipLaunchKernelGGL(k_pass_pick, dim3(1), dim3(1024), 0, ctx->stream, hist_dev, want, lo, hi,
                      static_cast<PassSel*>(sel_dev));
-  hipLaunchKernelGGL(k_pass_list, dim3(nb), dim3(T), 0, ctx->stream, g->cand, g->w, g->N,
-                     g->goff, mode, cut_w, cut_idx, static_cast<PassSel*>(sel_dev), list_dev);
-  SGP_HIP(ctx, hipGetLastError());
-  return 0;
+  return pass_list_ordered(g, mode, cut_w, cut_idx, static_cast<PassSel*>(sel_dev), list_dev,
+                           counts_dev);
 }
 
 // N ranks: the histogram alone (the ranks sum theirs and pick ONE threshold) ...
@@ -1086,13 +1160,9 @@ int launch_pass_hist(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, doubl
 
 // ... and the list behind a threshold the caller has put into *sel_dev ({ thr, 0, 0 })
 int launch_pass_list(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, void* sel_dev,
-                     int* list_dev) {
-  sgp_ctx* ctx = g->ctx;
-  const unsigned nb = std::min<unsigned>(nblk(g->N, T), 2048u);
-  hipLaunchKernelGGL(k_pass_list, dim3(nb), dim3(T), 0, ctx->stream, g->cand, g->w, g->N,
-                     g->goff, mode, cut_w, cut_idx, static_cast<PassSel*>(sel_dev), list_dev);
-  SGP_HIP(ctx, hipGetLastError());
-  return 0;
+                     int* list_dev, int* counts_dev) {
+  return pass_list_ordered(g, mode, cut_w, cut_idx, static_cast<PassSel*>(sel_dev), list_dev,
+                           counts_dev);
 }
 
 int launch_pass_gather(sgp_grid* g, const int* list_dev, int count, int mode, int64_t* gidx,

@@ -951,6 +951,13 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
 #pragma unroll
   for (int k = 0; k < D; ++k)
     x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
+  // bounding box of the wave's unsafe rows (16 consecutive rows of the grid: a short segment)
+  double xlo[D], xhi[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    xlo[k] = -wave_max(unsafe ? -x[k] : -INFINITY);
+    xhi[k] = wave_max(unsafe ? x[k] : -INFINITY);
+  }
   const int m_total = ea.m;
   for (int g = 0; g < G; ++g) {
     if (!ea.active[g]) continue;
@@ -959,6 +966,14 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
     const double mu = ea.mean[int64_t(g) * pts.N + rrow];
     const double var = ea.var[int64_t(g) * pts.N + rrow];
     const double kdiag = gp.kern.kdiag;
+    // ... and the extremes of their posterior: with the group's extremes (k_pass_agg) an upper
+    // bound of what ANY pair of the block can reach -- most blocks are far apart and end here,
+    // for 1/4 of the instructions of the 256 pair tests
+    const double mu_hi = wave_max(unsafe ? mu : -INFINITY);
+    const double var_hi = wave_max(unsafe ? var : -INFINITY);
+    const double var_lo = -wave_max(unsafe ? -var : -INFINITY);
+    const double sqx_hi = sqrt(fmax(kdiag - var_lo, 0.0));
+    const double svx_hi = sqrt(var_hi + 1e-12 * kdiag);
     // |L^-1 k_x| and the posterior standard deviation of the row (+ room for the rounding
     // of a variance that is a difference of O(k(x,x)) terms)
     const double sqx = sqrt(fmax(kdiag - var, 0.0));
@@ -1040,45 +1055,86 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
       }
       nq = 0;
     };
+    // The groups, 64 at a time.  First the BLOCK test, one group per lane: the covariance of
+    // the closest points of the wave's box and the group's box with the extremes of both
+    // sides bounds what any of the block's 256 pairs can reach -- most blocks are far apart
+    // and end here, for a fraction of an instruction per pair.  Then, for the groups that are
+    // left, the PAIR test: an upper bound of the updated lower bound from ONE covariance
+    // evaluation per (row, candidate).  c(x) is the POSTERIOR covariance of the two:
+    //   |c| <= |k(x, x_c)| + |L^-1 k_x| |L^-1 k_c|        (k_expander's bound: small far
+    //                                                      from the data and the candidate)
+    //   |c| <= sd(x) sd(x_c)                               (Cauchy-Schwarz on the posterior:
+    //                                                      small NEXT to the data)
+    // -- with the second one the rows an observation has pinned below fmin drop out for every
+    // candidate.  Squares instead of square roots (|L^-1 k_c|, sd(x_c): k_pass_aux).
+    int z0 = 0;
+    unsigned long long mask = 0ull;
+    bool done = false;
 #pragma unroll 1
-    for (int z = 0; z <= ngroups; ++z) {           // (one trip more: the last blocks leave)
-      const int m = z < ngroups ? min(16, m_total - 16 * z) : 0;
-      const int64_t zo = (int64_t(z) * G + g) * 16;
-      const double* xc = ea.xc + int64_t(z) * 16 * D;
-      // Exact pre-filter: an upper bound of the updated lower bound from ONE covariance
-      // evaluation.  c(x) is the POSTERIOR covariance of the row and the candidate:
-      //   |c| <= |k(x, x_c)| + |L^-1 k_x| |L^-1 k_c|        (k_expander's bound: small far
-      //                                                      from the data and the candidate)
-      //   |c| <= sd(x) sd(x_c)                               (Cauchy-Schwarz on the posterior:
-      //                                                      small NEXT to the data)
-      // -- with the second one the rows an observation has pinned below fmin drop out for
-      // every candidate.  Squares instead of square roots per pair (|L^-1 k_c|, sd(x_c):
-      // k_pass_aux).
-      bool possible = false;
+    while (true) {
+      if (mask == 0ull) {
+        if (z0 >= ngroups) {
+          done = true;
+        } else {
+          const int zz = z0 + lane;
+          bool blk = zz < ngroups;
+          if (blk && kf.single) {
+            const double* bx = ea.box + int64_t(zz) * 2 * D;
+            double r2 = 0.0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int cand = (lane >> 4) + 4 * r;
-        if (cand < m && unsafe) {
-          const double kxc = kf.raw(x, xc + cand * D, tab);
-          const double cmax = fmin(fma(sqx, ea.stn[zo + cand], fabs(kxc)),
-                                   svx * ea.svc[zo + cand]) * (1.0 + 1e-9);
-          const double mu2 = fma(fabs(ea.delta[zo + cand]), cmax, mu);
-          const double var2 = fmax(var - cmax * cmax * ea.inv_s2[zo + cand], 1e-15);
-          // mu2 - beta sqrt(var2) + slack >= fmin
-          const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - ea.fmin[g];
-          possible = possible || (room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2);
+            for (int k = 0; k < D; ++k) {
+              const double gap = fmax(fmax(bx[k] - xhi[k], xlo[k] - bx[D + k]), 0.0) * kf.sc[k];
+              r2 = fma(gap, gap, r2);
+            }
+            const double kmax = kf.of_r2s(r2, tab);
+            const double* ag = ea.agg + (int64_t(zz) * G + g) * 4;
+            const double cmax = fmin(fma(sqx_hi, ag[2], kmax), svx_hi * ag[3]) * (1.0 + 1e-9);
+            const double mu2 = fma(ag[0], cmax, mu_hi);
+            const double var2 = fmax(var_lo - cmax * cmax * ag[1], 1e-15);
+            const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - ea.fmin[g];
+            blk = room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2;
+          }
+          mask = __ballot(blk);
+          z0 += 64;
+          if (mask == 0ull) continue;
         }
       }
-#ifndef EXPM_NO_CONTRACT
-      if (__ballot(possible) != 0ull) {            // wave-uniform
-        // (slot of the queue by a chain of uniform tests: the indices stay in scalar registers)
+      if (!done) {
+        const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
+        mask &= mask - 1ull;
+        const int z = z0 - 64 + j;
+        const int m = min(16, m_total - 16 * z);
+        const int64_t zo = (int64_t(z) * G + g) * 16;
+        const double* xc = ea.xc + int64_t(z) * 16 * D;
+        bool possible = false;
 #pragma unroll
-        for (int j = 0; j < kQ; ++j)
-          if (j == nq) zq[j] = z;
-        ++nq;
-      }
-      if (nq == kQ || (z == ngroups && nq > 0)) flush();
+        for (int r = 0; r < 4; ++r) {
+          const int cand = (lane >> 4) + 4 * r;
+          if (cand < m && unsafe) {
+            const double kxc = kf.raw(x, xc + cand * D, tab);
+            const double cmax = fmin(fma(sqx, ea.stn[zo + cand], fabs(kxc)),
+                                     svx * ea.svc[zo + cand]) * (1.0 + 1e-9);
+            const double mu2 = fma(fabs(ea.delta[zo + cand]), cmax, mu);
+            const double var2 = fmax(var - cmax * cmax * ea.inv_s2[zo + cand], 1e-15);
+            // mu2 - beta sqrt(var2) + slack >= fmin
+            const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - ea.fmin[g];
+            possible = possible || (room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2);
+          }
+        }
+#ifndef EXPM_NO_CONTRACT
+        if (__ballot(possible) != 0ull) {            // wave-uniform
+          // (slot of the queue by a chain of uniform tests: the indices stay in scalar registers)
+#pragma unroll
+          for (int q = 0; q < kQ; ++q)
+            if (q == nq) zq[q] = z;
+          ++nq;
+        }
 #endif
+      }
+#ifndef EXPM_NO_CONTRACT
+      if (nq == kQ || (done && nq > 0)) flush();
+#endif
+      if (done) break;
     }
   }
 }
@@ -1661,6 +1717,42 @@ __global__ void k_pass_aux(const GpDev* gps, int G, const double* tn2, double* s
   svc[e] = sqrt(fmax(gps[g].kern.kdiag - t, 0.0) + 1e-12 * gps[g].kern.kdiag);
 }
 
+// Per group of 16 candidates: the largest |delta|, 1 / s2, |L^-1 k_c|, sd(x_c) of every GP
+// (agg[(z G + g) 4 ..]) and the bounding box of the candidates' rows (box[z][2][d], raw
+// coordinates) -- what lets a wave decide for a whole (16 rows x 16 candidates) block at once.
+__global__ void k_pass_agg(int G, int d, int m_total, const double* xc, const double* delta,
+                           const double* inv_s2, const double* stn, const double* svc,
+                           double* agg, double* box, int ngroups) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < ngroups * G) {
+    const int z = e / G;
+    const int m = min(16, m_total - 16 * z);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int c = 0; c < m; ++c) {
+      a0 = fmax(a0, fabs(delta[int64_t(e) * 16 + c]));
+      a1 = fmax(a1, inv_s2[int64_t(e) * 16 + c]);
+      a2 = fmax(a2, stn[int64_t(e) * 16 + c]);
+      a3 = fmax(a3, svc[int64_t(e) * 16 + c]);
+    }
+    agg[int64_t(e) * 4 + 0] = a0;
+    agg[int64_t(e) * 4 + 1] = a1;
+    agg[int64_t(e) * 4 + 2] = a2;
+    agg[int64_t(e) * 4 + 3] = a3;
+  }
+  if (e < ngroups * d) {
+    const int z = e / d, k = e - z * d;
+    const int m = min(16, m_total - 16 * z);
+    double lo = INFINITY, hi = -INFINITY;
+    for (int c = 0; c < m; ++c) {
+      const double v = xc[(int64_t(z) * 16 + c) * d + k];
+      lo = fmin(lo, v);
+      hi = fmax(hi, v);
+    }
+    box[(int64_t(z) * 2 + 0) * d + k] = lo;
+    box[(int64_t(z) * 2 + 1) * d + k] = hi;
+  }
+}
+
 int launch_expander_many(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d, SweepPoints pts,
                          ExpanderArgs ea) {
   if (pts.N <= 0 || ea.m <= 0) return 0;
@@ -1670,6 +1762,10 @@ int launch_expander_many(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d, Sweep
     const int n = ngroups * G * 16;
     hipLaunchKernelGGL(k_pass_aux, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, gps_dev, G,
                        ea.tn2, const_cast<double*>(ea.stn), const_cast<double*>(ea.svc), n);
+    const int na = ngroups * (G > d ? G : d);
+    hipLaunchKernelGGL(k_pass_agg, dim3((na + 255) / 256), dim3(256), 0, ctx->stream, G, d, ea.m,
+                       ea.xc, ea.delta, ea.inv_s2, ea.stn, ea.svc, const_cast<double*>(ea.agg),
+                       const_cast<double*>(ea.box), ngroups);
   }
 #define EXPM_CASE(DD)                                                         \
   case DD:                                                                    \

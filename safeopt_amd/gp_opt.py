@@ -902,6 +902,11 @@ class SafeOpt(GaussianProcessOptimization):
             big = hasattr(be, 'expander_pass') and self.big_passes
             if big and full_sets:
                 return self._visit_in_big_passes(beta, active, True, np.inf, -1)
+            if big and np.isfinite(cut_w):
+                # behind a first candidate that is no expander: a pass of 256 candidates costs
+                # less than the 16 of sgp_grid_expander_batch (whose scan knows neither the
+                # block test nor the posterior Cauchy-Schwarz bound)
+                return self._visit_in_big_passes(beta, active, False, cut_w, cut_idx)
             while True:
                 w_b, i_b, fl = be.expander_batch(beta, self.fmin, mode, cut_w, cut_idx, K)
                 m = i_b.size

@@ -34,7 +34,13 @@ if __name__ == "__main__":
     for big in (True, False):
         opt = safeopt_amd.SafeOpt(gp, grid, 0.0, threshold=0.1)
         opt.big_passes = big
+        if os.environ.get("PASS_SIZES"):
+            opt.pass_sizes = tuple(int(v) for v in os.environ["PASS_SIZES"].split(","))
         ctx = opt._backend.ctx
+        passes = []
+        if big:
+            orig = opt._backend.expander_pass
+            opt._backend.expander_pass = lambda *a, _o=orig: (lambda r: (passes.append(r[:2]), r)[1])(_o(*a))
         for rep in range(2):
             ctx.sync(); t0 = time.perf_counter()
             x = opt.optimize()
@@ -44,6 +50,8 @@ if __name__ == "__main__":
         w = (Q[:, 1] - Q[:, 0]) / opt.scaling[0]
         max_var = w[M].max() if M.any() else np.inf
         cand = S & ~M & (w > max_var) & (Q[:, 1] - Q[:, 0] > 0.1 * 2.0)
+        if big:
+            print("    passes (tested, hits):", passes[len(passes) // 2:])
         print("big %d side %d %s n %d rows %d: |S| %d |M| %d cand %d unsafe %d |G| %d %s optimize %.3f ms  x %s" % (
             big, side, kw, gp.X.shape[0], len(grid), S.sum(), M.sum(), cand.sum(), (~S).sum(), Gm.sum(),
             np.flatnonzero(Gm)[:3], dt * 1e3, x), flush=True)
