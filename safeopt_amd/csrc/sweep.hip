@@ -835,8 +835,12 @@ __device__ __forceinline__ void expander_rows(const GpDev* gps, int G,
       kxc[r] = 0.0;
       if (cand < ea.m && unsafe) {
         kxc[r] = kf.raw(x, ea.xc + cand * D, tab);
+        // (the smaller of the two bounds on the posterior covariance: k_expander_many)
+        const double tn2c = ea.tn2[g * 16 + cand];
         const double cmax =
-            (fabs(kxc[r]) + sqrt(qx * ea.tn2[g * 16 + cand])) * (1.0 + 1e-9);
+            fmin(fabs(kxc[r]) + sqrt(qx * tn2c),
+                 sqrt((var + 1e-12 * kdiag) * (fmax(kdiag - tn2c, 0.0) + 1e-12 * kdiag))) *
+            (1.0 + 1e-9);
         const double mu2 = mu + fabs(ea.delta[g * 16 + cand]) * cmax;
         const double var2 =
             fmax(var - cmax * cmax * ea.inv_s2[g * 16 + cand], 1e-15);
@@ -1177,8 +1181,14 @@ __global__ __launch_bounds__(256) void k_expander_filter(const GpDev* gps, int G
       const double kdiag = gp.kern.kdiag;
       const double qx = fmax(kdiag - var, 0.0);
       const double kxc = kf.raw(x, ea.xc, tab);
+      // |c(x)| <= |k(x, x_c)| + |L^-1 k_x| |L^-1 k_c| and, Cauchy-Schwarz on the POSTERIOR
+      // covariance, |c(x)| <= sd(x) sd(x_c): the second bound drops the rows an observation
+      // has pinned below fmin, which the first one lists for every candidate
+      const double tn2c = ea.tn2[g * 16];
       const double cmax =
-          (fabs(kxc) + sqrt(qx * ea.tn2[g * 16])) * (1.0 + 1e-9);
+          fmin(fabs(kxc) + sqrt(qx * tn2c),
+               sqrt((var + 1e-12 * kdiag) * (fmax(kdiag - tn2c, 0.0) + 1e-12 * kdiag))) *
+          (1.0 + 1e-9);
       const double mu2 = mu + fabs(ea.delta[g * 16]) * cmax;
       const double var2 = fmax(var - cmax * cmax * ea.inv_s2[g * 16], 1e-15);
       const double l2max = mu2 - ea.beta * sqrt(var2);
