@@ -936,16 +936,21 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
 // it walks the groups: pre-filter (one covariance per row and candidate), and only where a
 // row could be lifted above fmin the n-term contraction on the matrix cores.  Same tests,
 // same arithmetic per (row, candidate) as k_expander.
+constexpr int kManyKbRow = 80;     // doubles between the k-rows of a wave's transpose buffer
 template <int D>
 __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
                                                        SweepPoints pts, ExpanderArgs ea,
                                                        int ngroups) {
   __shared__ double tab[kExpTabSize];
+  __shared__ __attribute__((aligned(16))) double kbuf[4][4 * kManyKbRow];   // B-operand transposes
+  __shared__ double rows_sh[4][16 * (D + 3)];
   exp_tab_init(tab);
   __syncthreads();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  double* kbw = kbuf[wave];
+  double* rowbuf = rows_sh[wave];
   const int64_t row = int64_t(blockIdx.x) * 64 + wave * 16 + (lane & 15);
   const bool valid = row < pts.N;
   const int64_t rrow = valid ? row : pts.N - 1;
@@ -987,6 +992,17 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
     kf.prep(x, xs);
     const int nsteps = gp.n_pad >> 2;
     gptr_t Xj = (gptr_t)gp.Xs + (lane >> 4) * D;
+    // the wave's rows for the final test of a block: [row][x | mean | var | unsafe]
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16) {
+      double* rb = rowbuf + lane * (D + 3);
+#pragma unroll
+      for (int k = 0; k < D; ++k) rb[k] = x[k];
+      rb[D] = mu;
+      rb[D + 1] = var;
+      rb[D + 2] = unsafe ? 1.0 : 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
     // (16 rows x 16 candidates) blocks that passed the pre-filter wait here until kQ of them
     // are there: ONE evaluation of the rows' covariances with the training points then
     // feeds the matrix products of all kQ blocks (the evaluation, ~25 fp64 instructions per
@@ -994,10 +1010,19 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
     constexpr int kQ = 4;
     int zq[kQ];
     int nq = 0;
+    // The matrix products run on v_mfma_f64_4x4x4_4b_f64 -- the fp64 instruction that reaches
+    // the chip's peak; the 16 x 16 x 4 form stops at two thirds of it --: per k-step four
+    // instructions whose B operands are the rows' covariances with row quad m broadcast to
+    // all four quads (the LDS transpose of the sweeps, broadcast_quads), A = the packed
+    // Ky^-1 k_c as it is (lane 16 k + candidate).  D[blk][i][j] -> lane 16 i + 4 blk + j: a lane
+    // ends with ONE candidate, 4 blk + i, at the four rows 4 m + j -- whose x, mean and
+    // variance it reads from the wave's row buffer.
     auto flush = [&]() {
-      double4_t acc[kQ];
+      double acc[kQ][4];
 #pragma unroll
-      for (int j = 0; j < kQ; ++j) acc[j] = double4_t{0.0, 0.0, 0.0, 0.0};
+      for (int j = 0; j < kQ; ++j)
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) acc[j][m4] = 0.0;
       double xr[4][D], xn[4][D];
       auto fetch = [&](int s0, double (&xo)[4][D]) {
 #pragma unroll
@@ -1009,18 +1034,29 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
 #pragma unroll 1
       for (int s0 = 0; s0 < nsteps; s0 += 4) {
         if (s0 + 4 < nsteps) fetch(s0 + 4, xn);
-        double kv[4];
-        kf.template many<4>(xs, &xr[0][0], D, tab, kv);
+        // the A operands of all queued blocks are requested in front of the evaluation: their
+        // latency (L2) passes under it
+        double a[kQ][4];
 #pragma unroll
         for (int j = 0; j < kQ; ++j) {
           if (j < nq) {                     // (wave-uniform)
             gptr_t W = (gptr_t)ea.Wpack + (int64_t(zq[j]) * G + g) * ea.wstride + lane;
-            double a[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = W[(s0 + q) * 64];
+            for (int q = 0; q < 4; ++q) a[j][q] = W[(s0 + q) * 64];
+          }
+        }
+        double kv[4];
+        kf.template many<4>(xs, &xr[0][0], D, tab, kv);
+        double kb[4][4];
+        broadcast_quads<kManyKbRow>(kv, kbw, lane, kb);
+#pragma unroll
+        for (int j = 0; j < kQ; ++j) {
+          if (j < nq) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], kv[q], acc[j], 0, 0, 0);
+#pragma unroll
+              for (int m4 = 0; m4 < 4; ++m4)
+                acc[j][m4] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j][q], kb[m4][q], acc[j][m4], 0, 0, 0);
           }
         }
 #pragma unroll
@@ -1028,6 +1064,7 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
 #pragma unroll
           for (int k = 0; k < D; ++k) xr[q][k] = xn[q][k];
       }
+      const int cand = 4 * ((lane >> 2) & 3) + (lane >> 4);
 #pragma unroll
       for (int j = 0; j < kQ; ++j) {
         if (j < nq) {
@@ -1035,26 +1072,21 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
           const int m = min(16, m_total - 16 * z);
           const int64_t zo = (int64_t(z) * G + g) * 16;
           const double* xc = ea.xc + int64_t(z) * 16 * D;
+          bool hit = false;
+          if (cand < m) {
+            const double dl = ea.delta[zo + cand], is2 = ea.inv_s2[zo + cand];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            // f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 r
-            const int cand = (lane >> 4) + 4 * r;
-            bool hit = false;
-            if (cand < m && unsafe) {
-              const double cx = kf.raw(x, xc + cand * D, tab) - acc[j][r];
-              const double mu2 = mu + cx * ea.delta[zo + cand];
-              const double var2 = fmax(var - cx * cx * ea.inv_s2[zo + cand], 1e-15);
-              hit = mu2 - ea.beta * sqrt(var2) >= ea.fmin[g];
-            }
-            const unsigned long long b = __ballot(hit);
-            if (lane == 0 && b != 0ull) {
-#pragma unroll
-              for (int grp = 0; grp < 4; ++grp) {
-                if ((b >> (16 * grp)) & 0xffffull)
-                  atomicOr(&ea.flags[(int64_t(z) * 16 + grp + 4 * r) * G + g], 1);
+            for (int m4 = 0; m4 < 4; ++m4) {
+              const double* rb = rowbuf + (4 * m4 + (lane & 3)) * (D + 3);
+              if (rb[D + 2] != 0.0) {                       // an unsafe row of the grid
+                const double cx = kf.raw(rb, xc + cand * D, tab) - acc[j][m4];
+                const double mu2 = rb[D] + cx * dl;
+                const double var2 = fmax(rb[D + 1] - cx * cx * is2, 1e-15);
+                hit = hit || (mu2 - ea.beta * sqrt(var2) >= ea.fmin[g]);
               }
             }
           }
+          if (hit) atomicOr(&ea.flags[(int64_t(z) * 16 + cand) * G + g], 1);
         }
       }
       nq = 0;
