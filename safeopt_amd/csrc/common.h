@@ -133,7 +133,7 @@ struct sgp_ctx {
   void* pinned = nullptr;
   size_t pinned_cap = 0;
   // device scratch (grown on demand)
-  DevBuf scratch[12];
+  DevBuf scratch[13];
   int64_t n_allocs = 0;       // hipMalloc calls so far (sgp_ctx_alloc_count)
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -936,62 +936,69 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
 // it walks the groups: pre-filter (one covariance per row and candidate), and only where a
 // row could be lifted above fmin the n-term contraction on the matrix cores.  Same tests,
 // same arithmetic per (row, candidate) as k_expander.
+//
+// Two launches.  The rows that pass the pre-filter for ANY candidate are few and they sit
+// together (the band next to the safe set whose lower bound is just below fmin: 500 of 750000
+// unsafe rows in the converged state of bench.py, in 290 of 47000 waves) -- and such a row
+// passes it for nearly EVERY candidate, so a scan that contracted in place left the matrix
+// products of a whole pass to a few hundred waves, one block after the other (half of the
+// pass).  So MODE 0, the scan of the grid, only tests: it appends the rows that pass for some
+// candidate to a list per GP (ea.list, ea.count) and a wave leaves a GP as soon as all its
+// unsafe rows are listed.  MODE 1 takes the listed rows 16 at a time and the groups kManyChunk
+// at a time -- an item per wave, as many waves as the chip has -- and runs the same tests and
+// the contraction of what is left of them.
 constexpr int kManyKbRow = 80;     // doubles between the k-rows of a wave's transpose buffer
-template <int D>
-__global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
-                                                       SweepPoints pts, ExpanderArgs ea,
-                                                       int ngroups) {
-  __shared__ double tab[kExpTabSize];
-  __shared__ __attribute__((aligned(16))) double kbuf[4][4 * kManyKbRow];   // B-operand transposes
-  __shared__ double rows_sh[4][16 * (D + 3)];
-  exp_tab_init(tab);
-  __syncthreads();
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  double* kbw = kbuf[wave];
-  double* rowbuf = rows_sh[wave];
-  const int64_t row = int64_t(blockIdx.x) * 64 + wave * 16 + (lane & 15);
-  const bool valid = row < pts.N;
-  const int64_t rrow = valid ? row : pts.N - 1;
-  const bool unsafe = valid && (ea.S[rrow] == 0);
-  if (__ballot(unsafe) == 0ull) return;          // (wave-uniform)
-  double x[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k)
-    x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
-  // bounding box of the wave's unsafe rows (16 consecutive rows of the grid: a short segment)
+constexpr int kManyChunk = 8;      // groups of an item of the second launch
+constexpr int kManyListBlocks = 1024;   // workgroups of the second launch (4 items at a time each)
+#ifdef EXPM_STATS
+__device__ unsigned long long g_expm_stats[16];
+extern "C" void sgp_debug_expm_stats(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_expm_stats), sizeof(g_expm_stats));
+  if (reset) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_expm_stats), z, sizeof(z)); }
+}
+#define EXPM_STAT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); \
+    if (lane == 0) atomicAdd(&g_expm_stats[i], v_); } while (0)
+#else
+#define EXPM_STAT(i, v) do {} while (0)
+#endif
+
+// The wave's 16 rows (x, unsafe; lane & 15) of GP g against the groups [zlo, zhi).
+// MODE 0: returns the 16-bit mask of the rows that passed the pair test of some group.
+template <int D, int MODE>
+__device__ __forceinline__ unsigned many_rows(const GpDev& gp, int g, int G, const ExpanderArgs& ea,
+                                              const double (&x)[D], double mu, double var,
+                                              bool unsafe, int zlo, int zhi, const double* tab,
+                                              double* kbw, double* rowbuf, int lane) {
+  const KernFast<D> kf(gp.kern);
+  const double kdiag = gp.kern.kdiag;
+  const int m_total = ea.m;
+  const unsigned long long urows = __ballot(unsafe) & 0xffffull;
+  // bounding box of the wave's unsafe rows (consecutive rows of the grid: a short segment)
   double xlo[D], xhi[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) {
     xlo[k] = -wave_max(unsafe ? -x[k] : -INFINITY);
     xhi[k] = wave_max(unsafe ? x[k] : -INFINITY);
   }
-  const int m_total = ea.m;
-  for (int g = 0; g < G; ++g) {
-    if (!ea.active[g]) continue;
-    const GpDev& gp = gps[g];
-    const KernFast<D> kf(gp.kern);
-    const double mu = ea.mean[int64_t(g) * pts.N + rrow];
-    const double var = ea.var[int64_t(g) * pts.N + rrow];
-    const double kdiag = gp.kern.kdiag;
-    // ... and the extremes of their posterior: with the group's extremes (k_pass_agg) an upper
-    // bound of what ANY pair of the block can reach -- most blocks are far apart and end here,
-    // for 1/4 of the instructions of the 256 pair tests
-    const double mu_hi = wave_max(unsafe ? mu : -INFINITY);
-    const double var_hi = wave_max(unsafe ? var : -INFINITY);
-    const double var_lo = -wave_max(unsafe ? -var : -INFINITY);
-    const double sqx_hi = sqrt(fmax(kdiag - var_lo, 0.0));
-    const double svx_hi = sqrt(var_hi + 1e-12 * kdiag);
-    // |L^-1 k_x| and the posterior standard deviation of the row (+ room for the rounding
-    // of a variance that is a difference of O(k(x,x)) terms)
-    const double sqx = sqrt(fmax(kdiag - var, 0.0));
-    const double svx = sqrt(var + 1e-12 * kdiag);
-    const double beta2 = ea.beta * ea.beta;
-    double xs[D];
-    kf.prep(x, xs);
-    const int nsteps = gp.n_pad >> 2;
-    gptr_t Xj = (gptr_t)gp.Xs + (lane >> 4) * D;
+  // ... and the extremes of their posterior: with the group's extremes (k_pass_agg) an upper
+  // bound of what ANY pair of the block can reach -- most blocks are far apart and end here,
+  // for 1/4 of the instructions of the 256 pair tests
+  const double mu_hi = wave_max(unsafe ? mu : -INFINITY);
+  const double var_hi = wave_max(unsafe ? var : -INFINITY);
+  const double var_lo = -wave_max(unsafe ? -var : -INFINITY);
+  const double sqx_hi = sqrt(fmax(kdiag - var_lo, 0.0));
+  const double svx_hi = sqrt(var_hi + 1e-12 * kdiag);
+  // |L^-1 k_x| and the posterior standard deviation of the row (+ room for the rounding
+  // of a variance that is a difference of O(k(x,x)) terms)
+  const double sqx = sqrt(fmax(kdiag - var, 0.0));
+  const double svx = sqrt(var + 1e-12 * kdiag);
+  const double beta2 = ea.beta * ea.beta;
+  double xs[D];
+  kf.prep(x, xs);
+  const int nsteps = gp.n_pad >> 2;
+  gptr_t Xj = (gptr_t)gp.Xs + (lane >> 4) * D;
+  if (MODE == 1) {
     // the wave's rows for the final test of a block: [row][x | mean | var | unsafe]
     __builtin_amdgcn_wave_barrier();
     if (lane < 16) {
@@ -1003,174 +1010,248 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
       rb[D + 2] = unsafe ? 1.0 : 0.0;
     }
     __builtin_amdgcn_wave_barrier();
-    // (16 rows x 16 candidates) blocks that passed the pre-filter wait here until kQ of them
-    // are there: ONE evaluation of the rows' covariances with the training points then
-    // feeds the matrix products of all kQ blocks (the evaluation, ~25 fp64 instructions per
-    // value, costs three times the four matrix instructions it feeds)
-    constexpr int kQ = 4;
-    int zq[kQ];
-    int nq = 0;
-    // The matrix products run on v_mfma_f64_4x4x4_4b_f64 -- the fp64 instruction that reaches
-    // the chip's peak; the 16 x 16 x 4 form stops at two thirds of it --: per k-step four
-    // instructions whose B operands are the rows' covariances with row quad m broadcast to
-    // all four quads (the LDS transpose of the sweeps, broadcast_quads), A = the packed
-    // Ky^-1 k_c as it is (lane 16 k + candidate).  D[blk][i][j] -> lane 16 i + 4 blk + j: a lane
-    // ends with ONE candidate, 4 blk + i, at the four rows 4 m + j -- whose x, mean and
-    // variance it reads from the wave's row buffer.
-    auto flush = [&]() {
-      double acc[kQ][4];
+  }
+  // (16 rows x 16 candidates) blocks that passed the pre-filter wait here until kQ of them
+  // are there: ONE evaluation of the rows' covariances with the training points then
+  // feeds the matrix products of all kQ blocks (the evaluation, ~25 fp64 instructions per
+  // value, costs three times the four matrix instructions it feeds)
+  constexpr int kQ = 4;
+  int zq[kQ];
+  int nq = 0;
+  // The matrix products run on v_mfma_f64_4x4x4_4b_f64 -- the fp64 instruction that reaches
+  // the chip's peak; the 16 x 16 x 4 form stops at two thirds of it --: per k-step four
+  // instructions whose B operands are the rows' covariances with row quad m broadcast to
+  // all four quads (the LDS transpose of the sweeps, broadcast_quads), A = the packed
+  // Ky^-1 k_c as it is (lane 16 k + candidate).  D[blk][i][j] -> lane 16 i + 4 blk + j: a lane
+  // ends with ONE candidate, 4 blk + i, at the four rows 4 m + j -- whose x, mean and
+  // variance it reads from the wave's row buffer.
+  auto flush = [&]() {
+    double acc[kQ][4];
 #pragma unroll
-      for (int j = 0; j < kQ; ++j)
+    for (int j = 0; j < kQ; ++j)
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) acc[j][m4] = 0.0;
-      double xr[4][D], xn[4][D];
-      auto fetch = [&](int s0, double (&xo)[4][D]) {
+      for (int m4 = 0; m4 < 4; ++m4) acc[j][m4] = 0.0;
+    double xr[4][D], xn[4][D];
+    auto fetch = [&](int s0, double (&xo)[4][D]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int k = 0; k < D; ++k) xo[q][k] = Xj[(s0 + q) * 4 * D + k];
-      };
-      fetch(0, xr);
+        for (int k = 0; k < D; ++k) xo[q][k] = Xj[(s0 + q) * 4 * D + k];
+    };
+    fetch(0, xr);
 #pragma unroll 1
-      for (int s0 = 0; s0 < nsteps; s0 += 4) {
-        if (s0 + 4 < nsteps) fetch(s0 + 4, xn);
-        // the A operands of all queued blocks are requested in front of the evaluation: their
-        // latency (L2) passes under it
-        double a[kQ][4];
+    for (int s0 = 0; s0 < nsteps; s0 += 4) {
+      if (s0 + 4 < nsteps) fetch(s0 + 4, xn);
+      // the A operands of all queued blocks are requested in front of the evaluation: their
+      // latency (L2) passes under it
+      double a[kQ][4];
 #pragma unroll
-        for (int j = 0; j < kQ; ++j) {
-          if (j < nq) {                     // (wave-uniform)
-            gptr_t W = (gptr_t)ea.Wpack + (int64_t(zq[j]) * G + g) * ea.wstride + lane;
+      for (int j = 0; j < kQ; ++j) {
+        if (j < nq) {                     // (wave-uniform)
+          gptr_t W = (gptr_t)ea.Wpack + (int64_t(zq[j]) * G + g) * ea.wstride + lane;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[j][q] = W[(s0 + q) * 64];
-          }
+          for (int q = 0; q < 4; ++q) a[j][q] = W[(s0 + q) * 64];
         }
-        double kv[4];
-        kf.template many<4>(xs, &xr[0][0], D, tab, kv);
-        double kb[4][4];
-        broadcast_quads<kManyKbRow>(kv, kbw, lane, kb);
-#pragma unroll
-        for (int j = 0; j < kQ; ++j) {
-          if (j < nq) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-              for (int m4 = 0; m4 < 4; ++m4)
-                acc[j][m4] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j][q], kb[m4][q], acc[j][m4], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int k = 0; k < D; ++k) xr[q][k] = xn[q][k];
       }
-      const int cand = 4 * ((lane >> 2) & 3) + (lane >> 4);
+      double kv[4];
+      kf.template many<4>(xs, &xr[0][0], D, tab, kv);
+      double kb[4][4];
+      broadcast_quads<kManyKbRow>(kv, kbw, lane, kb);
 #pragma unroll
       for (int j = 0; j < kQ; ++j) {
         if (j < nq) {
-          const int z = zq[j];
-          const int m = min(16, m_total - 16 * z);
-          const int64_t zo = (int64_t(z) * G + g) * 16;
-          const double* xc = ea.xc + int64_t(z) * 16 * D;
-          bool hit = false;
-          if (cand < m) {
-            const double dl = ea.delta[zo + cand], is2 = ea.inv_s2[zo + cand];
 #pragma unroll
-            for (int m4 = 0; m4 < 4; ++m4) {
-              const double* rb = rowbuf + (4 * m4 + (lane & 3)) * (D + 3);
-              if (rb[D + 2] != 0.0) {                       // an unsafe row of the grid
-                const double cx = kf.raw(rb, xc + cand * D, tab) - acc[j][m4];
-                const double mu2 = rb[D] + cx * dl;
-                const double var2 = fmax(rb[D + 1] - cx * cx * is2, 1e-15);
-                hit = hit || (mu2 - ea.beta * sqrt(var2) >= ea.fmin[g]);
-              }
-            }
-          }
-          if (hit) atomicOr(&ea.flags[(int64_t(z) * 16 + cand) * G + g], 1);
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int m4 = 0; m4 < 4; ++m4)
+              acc[j][m4] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j][q], kb[m4][q], acc[j][m4], 0, 0, 0);
         }
       }
-      nq = 0;
-    };
-    // The groups, 64 at a time.  First the BLOCK test, one group per lane: the covariance of
-    // the closest points of the wave's box and the group's box with the extremes of both
-    // sides bounds what any of the block's 256 pairs can reach -- most blocks are far apart
-    // and end here, for a fraction of an instruction per pair.  Then, for the groups that are
-    // left, the PAIR test: an upper bound of the updated lower bound from ONE covariance
-    // evaluation per (row, candidate).  c(x) is the POSTERIOR covariance of the two:
-    //   |c| <= |k(x, x_c)| + |L^-1 k_x| |L^-1 k_c|        (k_expander's bound: small far
-    //                                                      from the data and the candidate)
-    //   |c| <= sd(x) sd(x_c)                               (Cauchy-Schwarz on the posterior:
-    //                                                      small NEXT to the data)
-    // -- with the second one the rows an observation has pinned below fmin drop out for every
-    // candidate.  Squares instead of square roots (|L^-1 k_c|, sd(x_c): k_pass_aux).
-    int z0 = 0;
-    unsigned long long mask = 0ull;
-    bool done = false;
-#pragma unroll 1
-    while (true) {
-      if (mask == 0ull) {
-        if (z0 >= ngroups) {
-          done = true;
-        } else {
-          const int zz = z0 + lane;
-          bool blk = zz < ngroups;
-          if (blk && kf.single) {
-            const double* bx = ea.box + int64_t(zz) * 2 * D;
-            double r2 = 0.0;
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-              const double gap = fmax(fmax(bx[k] - xhi[k], xlo[k] - bx[D + k]), 0.0) * kf.sc[k];
-              r2 = fma(gap, gap, r2);
-            }
-            const double kmax = kf.of_r2s(r2, tab);
-            const double* ag = ea.agg + (int64_t(zz) * G + g) * 4;
-            const double cmax = fmin(fma(sqx_hi, ag[2], kmax), svx_hi * ag[3]) * (1.0 + 1e-9);
-            const double mu2 = fma(ag[0], cmax, mu_hi);
-            const double var2 = fmax(var_lo - cmax * cmax * ag[1], 1e-15);
-            const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - ea.fmin[g];
-            blk = room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2;
-          }
-          mask = __ballot(blk);
-          z0 += 64;
-          if (mask == 0ull) continue;
-        }
-      }
-      if (!done) {
-        const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
-        mask &= mask - 1ull;
-        const int z = z0 - 64 + j;
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < D; ++k) xr[q][k] = xn[q][k];
+    }
+    const int cand = 4 * ((lane >> 2) & 3) + (lane >> 4);
+#pragma unroll
+    for (int j = 0; j < kQ; ++j) {
+      if (j < nq) {
+        const int z = zq[j];
         const int m = min(16, m_total - 16 * z);
         const int64_t zo = (int64_t(z) * G + g) * 16;
         const double* xc = ea.xc + int64_t(z) * 16 * D;
-        bool possible = false;
+        bool hit = false;
+        if (cand < m) {
+          const double dl = ea.delta[zo + cand], is2 = ea.inv_s2[zo + cand];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int cand = (lane >> 4) + 4 * r;
-          if (cand < m && unsafe) {
-            const double kxc = kf.raw(x, xc + cand * D, tab);
-            const double cmax = fmin(fma(sqx, ea.stn[zo + cand], fabs(kxc)),
-                                     svx * ea.svc[zo + cand]) * (1.0 + 1e-9);
-            const double mu2 = fma(fabs(ea.delta[zo + cand]), cmax, mu);
-            const double var2 = fmax(var - cmax * cmax * ea.inv_s2[zo + cand], 1e-15);
-            // mu2 - beta sqrt(var2) + slack >= fmin
-            const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - ea.fmin[g];
-            possible = possible || (room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2);
+          for (int m4 = 0; m4 < 4; ++m4) {
+            const double* rb = rowbuf + (4 * m4 + (lane & 3)) * (D + 3);
+            if (rb[D + 2] != 0.0) {                       // an unsafe row of the grid
+              const double cx = kf.raw(rb, xc + cand * D, tab) - acc[j][m4];
+              const double mu2 = rb[D] + cx * dl;
+              const double var2 = fmax(rb[D + 1] - cx * cx * is2, 1e-15);
+              hit = hit || (mu2 - ea.beta * sqrt(var2) >= ea.fmin[g]);
+            }
           }
         }
-#ifndef EXPM_NO_CONTRACT
-        if (__ballot(possible) != 0ull) {            // wave-uniform
+        if (hit) atomicOr(&ea.flags[(int64_t(z) * 16 + cand) * G + g], 1);
+      }
+    }
+    nq = 0;
+  };
+  // The groups, 64 at a time.  First the BLOCK test, one group per lane: the covariance of
+  // the closest points of the wave's box and the group's box with the extremes of both
+  // sides bounds what any of the block's 256 pairs can reach -- most blocks are far apart
+  // and end here, for a fraction of an instruction per pair.  Then, for the groups that are
+  // left, the PAIR test: an upper bound of the updated lower bound from ONE covariance
+  // evaluation per (row, candidate).  c(x) is the POSTERIOR covariance of the two:
+  //   |c| <= |k(x, x_c)| + |L^-1 k_x| |L^-1 k_c|        (k_expander's bound: small far
+  //                                                      from the data and the candidate)
+  //   |c| <= sd(x) sd(x_c)                               (Cauchy-Schwarz on the posterior:
+  //                                                      small NEXT to the data)
+  // -- with the second one the rows an observation has pinned below fmin drop out for every
+  // candidate.  Squares instead of square roots (|L^-1 k_c|, sd(x_c): k_pass_aux).
+  int z0 = zlo;
+  unsigned long long mask = 0ull;
+  unsigned long long ever = 0ull;
+  bool done = false;
+  EXPM_STAT(0 + 8 * MODE, 1); EXPM_STAT(1 + 8 * MODE, __popcll(urows));
+#pragma unroll 1
+  while (true) {
+    if (mask == 0ull) {
+      if (z0 >= zhi) {
+        done = true;
+      } else {
+        const int zz = z0 + lane;
+        bool blk = zz < zhi;
+        if (blk && kf.single) {
+          const double* bx = ea.box + int64_t(zz) * 2 * D;
+          double r2 = 0.0;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            const double gap = fmax(fmax(bx[k] - xhi[k], xlo[k] - bx[D + k]), 0.0) * kf.sc[k];
+            r2 = fma(gap, gap, r2);
+          }
+          const double kmax = kf.of_r2s(r2, tab);
+          const double* ag = ea.agg + (int64_t(zz) * G + g) * 4;
+          const double cmax = fmin(fma(sqx_hi, ag[2], kmax), svx_hi * ag[3]) * (1.0 + 1e-9);
+          const double mu2 = fma(ag[0], cmax, mu_hi);
+          const double var2 = fmax(var_lo - cmax * cmax * ag[1], 1e-15);
+          const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - ea.fmin[g];
+          blk = room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2;
+        }
+        EXPM_STAT(2 + 8 * MODE, __popcll(__ballot(zz < zhi)));
+        mask = __ballot(blk);
+        EXPM_STAT(3 + 8 * MODE, __popcll(mask));
+        z0 += 64;
+        if (mask == 0ull) continue;
+      }
+    }
+    if (!done) {
+      const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
+      mask &= mask - 1ull;
+      const int z = z0 - 64 + j;
+      const int m = min(16, m_total - 16 * z);
+      const int64_t zo = (int64_t(z) * G + g) * 16;
+      const double* xc = ea.xc + int64_t(z) * 16 * D;
+      bool possible = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cand = (lane >> 4) + 4 * r;
+        if (cand < m && unsafe) {
+          const double kxc = kf.raw(x, xc + cand * D, tab);
+          const double cmax = fmin(fma(sqx, ea.stn[zo + cand], fabs(kxc)),
+                                   svx * ea.svc[zo + cand]) * (1.0 + 1e-9);
+          const double mu2 = fma(fabs(ea.delta[zo + cand]), cmax, mu);
+          const double var2 = fmax(var - cmax * cmax * ea.inv_s2[zo + cand], 1e-15);
+          // mu2 - beta sqrt(var2) + slack >= fmin
+          const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - ea.fmin[g];
+          possible = possible || (room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2);
+        }
+      }
+      const unsigned long long pb = __ballot(possible);
+      if (pb != 0ull) {                              // wave-uniform
+        EXPM_STAT(4 + 8 * MODE, 1);
+        if (MODE == 0) {
+          ever |= (pb | (pb >> 16) | (pb >> 32) | (pb >> 48)) & 0xffffull;
+          if (ever == urows) break;                  // every unsafe row of the wave is listed
+        } else {
           // (slot of the queue by a chain of uniform tests: the indices stay in scalar registers)
 #pragma unroll
           for (int q = 0; q < kQ; ++q)
             if (q == nq) zq[q] = z;
           ++nq;
         }
-#endif
       }
-#ifndef EXPM_NO_CONTRACT
+    }
+    if (MODE == 1) {
       if (nq == kQ || (done && nq > 0)) flush();
-#endif
-      if (done) break;
+    }
+    if (done) break;
+  }
+  EXPM_STAT(5 + 8 * MODE, __popcll(ever));
+  return unsigned(ever);
+}
+
+template <int D, int MODE>
+__global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
+                                                       SweepPoints pts, ExpanderArgs ea,
+                                                       int ngroups) {
+  __shared__ double tab[kExpTabSize];
+  __shared__ __attribute__((aligned(16))) double kbuf[MODE ? 4 : 1][4 * kManyKbRow];   // B-operand transposes
+  __shared__ double rows_sh[MODE ? 4 : 1][16 * (D + 3)];
+  exp_tab_init(tab);
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  double* kbw = kbuf[MODE ? wave : 0];
+  double* rowbuf = rows_sh[MODE ? wave : 0];
+  if (MODE == 0) {
+    const int64_t row = int64_t(blockIdx.x) * 64 + wave * 16 + (lane & 15);
+    const bool valid = row < pts.N;
+    const int64_t rrow = valid ? row : pts.N - 1;
+    const bool unsafe = valid && (ea.S[rrow] == 0);
+    if (__ballot(unsafe) == 0ull) return;          // (wave-uniform)
+    double x[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
+    for (int g = 0; g < G; ++g) {
+      if (!ea.active[g]) continue;
+      const double mu = ea.mean[int64_t(g) * pts.N + rrow];
+      const double var = ea.var[int64_t(g) * pts.N + rrow];
+      const unsigned hot = many_rows<D, 0>(gps[g], g, G, ea, x, mu, var, unsafe, 0, ngroups, tab,
+                                           kbw, rowbuf, lane);
+      if (hot != 0u) {                             // (wave-uniform) append the wave's hot rows
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&ea.count[g], __popc(hot));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < 16 && ((hot >> lane) & 1u))
+          ea.list[int64_t(g) * pts.N + base + __popc(hot & ((1u << lane) - 1u))] = int(rrow);
+      }
+    }
+  } else {
+    const int nch = (ngroups + kManyChunk - 1) / kManyChunk;
+    for (int g = 0; g < G; ++g) {
+      if (!ea.active[g]) continue;
+      const int cnt = ea.count[g];
+      const int64_t total = int64_t((cnt + 15) >> 4) * nch;
+#pragma unroll 1
+      for (int64_t item = int64_t(blockIdx.x) * 4 + wave; item < total; item += int64_t(gridDim.x) * 4) {
+        const int rb = int(item / nch), gc = int(item - int64_t(rb) * nch);
+        const int idx = rb * 16 + (lane & 15);
+        const bool unsafe = idx < cnt;
+        const int64_t rrow = ea.list[int64_t(g) * pts.N + (unsafe ? idx : cnt - 1)];
+        double x[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+          x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
+        const double mu = ea.mean[int64_t(g) * pts.N + rrow];
+        const double var = ea.var[int64_t(g) * pts.N + rrow];
+        many_rows<D, 1>(gps[g], g, G, ea, x, mu, var, unsafe, gc * kManyChunk,
+                        min(ngroups, (gc + 1) * kManyChunk), tab, kbw, rowbuf, lane);
+      }
     }
   }
 }
@@ -1800,6 +1881,14 @@ int launch_expander_many(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d, Sweep
   if (pts.N <= 0 || ea.m <= 0) return 0;
   const int nblocks = int((pts.N + 63) / 64);
   const int ngroups = (ea.m + 15) / 16;
+  // the rows that pass the pre-filter for some candidate, per GP: [G][N] rows behind G counts
+  {
+    int* hot = static_cast<int*>(sgp_scratch(ctx, 12, (size_t(G) * size_t(pts.N) + 64) * sizeof(int)));
+    SGP_CHECK(ctx, hot, "device allocation failed: %s", ctx->err.c_str());
+    ea.count = hot;
+    ea.list = hot + 64;
+    SGP_HIP(ctx, hipMemsetAsync(hot, 0, 64 * sizeof(int), ctx->stream));
+  }
   {
     const int n = ngroups * G * 16;
     hipLaunchKernelGGL(k_pass_aux, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, gps_dev, G,
@@ -1811,8 +1900,11 @@ int launch_expander_many(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d, Sweep
   }
 #define EXPM_CASE(DD)                                                         \
   case DD:                                                                    \
-    hipLaunchKernelGGL(k_expander_many<DD>, dim3(nblocks), dim3(256), 0,      \
+    hipLaunchKernelGGL((k_expander_many<DD, 0>), dim3(nblocks), dim3(256), 0, \
                        ctx->stream, gps_dev, G, pts, ea, ngroups);            \
+    hipLaunchKernelGGL((k_expander_many<DD, 1>), dim3(kManyListBlocks),       \
+                       dim3(256), 0, ctx->stream, gps_dev, G, pts, ea,        \
+                       ngroups);                                              \
     break;
   switch (d) {
     EXPM_CASE(1) EXPM_CASE(2) EXPM_CASE(3) EXPM_CASE(4)
