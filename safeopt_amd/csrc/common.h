@@ -343,6 +343,9 @@ struct ExpanderArgs {
   double near_frac;      // >0: only rows with k(x,x_c) >= near_frac * k(x,x)
   int* count;            // m == 1: number of rows that passed the pre-filter
   int* list;             //         (zeroed by the caller) / their local indices
+  int* wcount;           // k_expander_many: the 16-row segments with a possible pair, per GP
+  int* wlist;            // (count, [G][N / 16] segments, masks of their listed rows); count /
+  unsigned* wmask;       // list: the rows that pass the pair test of some candidate, [G][N]
 };
 int launch_expander_check(sgp_ctx* ctx, const GpDev* gps_dev,
                           const GpDev* gps_host, int G, int d, SweepPoints pts,

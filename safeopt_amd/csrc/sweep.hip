@@ -937,25 +937,31 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
 // row could be lifted above fmin the n-term contraction on the matrix cores.  Same tests,
 // same arithmetic per (row, candidate) as k_expander.
 //
-// Two launches.  The rows that pass the pre-filter for ANY candidate are few and they sit
+// Three launches.  The rows that pass the pre-filter for ANY candidate are few and they sit
 // together (the band next to the safe set whose lower bound is just below fmin: 500 of 750000
 // unsafe rows in the converged state of bench.py, in 290 of 47000 waves) -- and such a row
-// passes it for nearly EVERY candidate, so a scan that contracted in place left the matrix
-// products of a whole pass to a few hundred waves, one block after the other (half of the
-// pass).  So MODE 0, the scan of the grid, only tests: it appends the rows that pass for some
-// candidate to a list per GP (ea.list, ea.count) and a wave leaves a GP as soon as all its
-// unsafe rows are listed.  MODE 1 takes the listed rows 16 at a time and the groups kManyChunk
-// at a time -- an item per wave, as many waves as the chip has -- and runs the same tests and
-// the contraction of what is left of them.
+// passes it for nearly EVERY candidate, so a scan that tested and contracted in place left the
+// pair tests and the matrix products of a whole pass to a few hundred waves, one block after
+// the other (all but 0.1 ms of a pass).  So
+//   MODE 0, the scan of the grid, only looks for the waves with a block that passes the BLOCK
+//           test (one group per lane, out at the first one) -> a list of waves per GP
+//           (ea.wlist, ea.wcount);
+//   MODE 2  takes the listed waves and the groups kManyTestChunk at a time -- an item per wave
+//           of the launch, as many as the chip has -- and finds the ROWS that pass the pair
+//           test (four groups at a time) for some candidate -> a list of rows per GP
+//           (ea.list, ea.count; a row once: ea.wmask);
+//   MODE 1  takes the listed rows 16 at a time and the groups kManyChunk at a time and runs
+//           the same tests and the contraction of what is left of them.
 constexpr int kManyKbRow = 80;     // doubles between the k-rows of a wave's transpose buffer
-constexpr int kManyChunk = 8;      // groups of an item of the second launch
-constexpr int kManyListBlocks = 1024;   // workgroups of the second launch (4 items at a time each)
+constexpr int kManyChunk = 8;      // groups of an item of MODE 1
+constexpr int kManyTestChunk = 32; //                   of MODE 2
+constexpr int kManyListBlocks = 1024;   // workgroups of MODE 1 / 2 (4 items at a time each)
 #ifdef EXPM_STATS
-__device__ unsigned long long g_expm_stats[16];
+__device__ unsigned long long g_expm_stats[32];
 extern "C" void sgp_debug_expm_stats(unsigned long long* out, int reset) {
   hipDeviceSynchronize();
   hipMemcpyFromSymbol(out, HIP_SYMBOL(g_expm_stats), sizeof(g_expm_stats));
-  if (reset) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_expm_stats), z, sizeof(z)); }
+  if (reset) { unsigned long long z[32] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_expm_stats), z, sizeof(z)); }
 }
 #define EXPM_STAT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); \
     if (lane == 0) atomicAdd(&g_expm_stats[i], v_); } while (0)
@@ -963,54 +969,158 @@ extern "C" void sgp_debug_expm_stats(unsigned long long* out, int reset) {
 #define EXPM_STAT(i, v) do {} while (0)
 #endif
 
-// The wave's 16 rows (x, unsafe; lane & 15) of GP g against the groups [zlo, zhi).
-// MODE 0: returns the 16-bit mask of the rows that passed the pair test of some group.
-template <int D, int MODE>
-__device__ __forceinline__ unsigned many_rows(const GpDev& gp, int g, int G, const ExpanderArgs& ea,
-                                              const double (&x)[D], double mu, double var,
-                                              bool unsafe, int zlo, int zhi, const double* tab,
-                                              double* kbw, double* rowbuf, int lane) {
-  const KernFast<D> kf(gp.kern);
-  const double kdiag = gp.kern.kdiag;
-  const int m_total = ea.m;
-  const unsigned long long urows = __ballot(unsafe) & 0xffffull;
-  // bounding box of the wave's unsafe rows (consecutive rows of the grid: a short segment)
-  double xlo[D], xhi[D];
+// A wave's 16 rows (lane & 15) of one GP, what the tests need of them, and the two tests.
+template <int D>
+struct ManyRows {
+  KernFast<D> kf;
+  double x[D], xlo[D], xhi[D];
+  double mu, var, sqx, svx, mu_hi, var_lo, sqx_hi, svx_hi, beta2, fmin;
+  bool unsafe;
+  int g, G, m_total;
+
+  __device__ __forceinline__ ManyRows(const GpDev& gp, int g_, int G_, const ExpanderArgs& ea,
+                                      const double (&x_)[D], double mu_, double var_, bool unsafe_)
+      : kf(gp.kern), mu(mu_), var(var_), unsafe(unsafe_), g(g_), G(G_), m_total(ea.m) {
+    const double kdiag = gp.kern.kdiag;
+    // bounding box of the wave's unsafe rows (consecutive rows of the grid: a short segment)
 #pragma unroll
-  for (int k = 0; k < D; ++k) {
-    xlo[k] = -wave_max(unsafe ? -x[k] : -INFINITY);
-    xhi[k] = wave_max(unsafe ? x[k] : -INFINITY);
+    for (int k = 0; k < D; ++k) {
+      x[k] = x_[k];
+      xlo[k] = -wave_max(unsafe ? -x[k] : -INFINITY);
+      xhi[k] = wave_max(unsafe ? x[k] : -INFINITY);
+    }
+    // ... and the extremes of their posterior: with the group's extremes (k_pass_agg) an upper
+    // bound of what ANY pair of the block can reach
+    mu_hi = wave_max(unsafe ? mu : -INFINITY);
+    const double var_hi = wave_max(unsafe ? var : -INFINITY);
+    var_lo = -wave_max(unsafe ? -var : -INFINITY);
+    sqx_hi = sqrt(fmax(kdiag - var_lo, 0.0));
+    svx_hi = sqrt(var_hi + 1e-12 * kdiag);
+    // |L^-1 k_x| and the posterior standard deviation of the row (+ room for the rounding
+    // of a variance that is a difference of O(k(x,x)) terms)
+    sqx = sqrt(fmax(kdiag - var, 0.0));
+    svx = sqrt(var + 1e-12 * kdiag);
+    beta2 = ea.beta * ea.beta;
+    fmin = ea.fmin[g];
   }
-  // ... and the extremes of their posterior: with the group's extremes (k_pass_agg) an upper
-  // bound of what ANY pair of the block can reach -- most blocks are far apart and end here,
-  // for 1/4 of the instructions of the 256 pair tests
-  const double mu_hi = wave_max(unsafe ? mu : -INFINITY);
-  const double var_hi = wave_max(unsafe ? var : -INFINITY);
-  const double var_lo = -wave_max(unsafe ? -var : -INFINITY);
-  const double sqx_hi = sqrt(fmax(kdiag - var_lo, 0.0));
-  const double svx_hi = sqrt(var_hi + 1e-12 * kdiag);
-  // |L^-1 k_x| and the posterior standard deviation of the row (+ room for the rounding
-  // of a variance that is a difference of O(k(x,x)) terms)
-  const double sqx = sqrt(fmax(kdiag - var, 0.0));
-  const double svx = sqrt(var + 1e-12 * kdiag);
-  const double beta2 = ea.beta * ea.beta;
+
+  // The BLOCK test, one group per lane: the covariance of the closest points of the wave's
+  // box and the group's box with the extremes of both sides bounds what any of the block's 256
+  // pairs can reach -- most blocks are far apart and end here, for a fraction of an
+  // instruction per pair (single-part kernels).
+  __device__ __forceinline__ bool block(const ExpanderArgs& ea, int zz, const double* tab) const {
+    if (!kf.single) return true;
+    const double* bx = ea.box + int64_t(zz) * 2 * D;
+    double r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const double gap = fmax(fmax(bx[k] - xhi[k], xlo[k] - bx[D + k]), 0.0) * kf.sc[k];
+      r2 = fma(gap, gap, r2);
+    }
+    const double kmax = kf.of_r2s(r2, tab);
+    const double* ag = ea.agg + (int64_t(zz) * G + g) * 4;
+    const double cmax = fmin2(fma(sqx_hi, ag[2], kmax), svx_hi * ag[3]) * (1.0 + 1e-9);
+    const double mu2 = fma(ag[0], cmax, mu_hi);
+    const double var2 = fmax(var_lo - cmax * cmax * ag[1], 1e-15);
+    const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - fmin;
+    return room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2;
+  }
+  static __device__ __forceinline__ double fmin2(double a, double b) { return ::fmin(a, b); }
+
+  // The PAIR test of group z, the lane's row against the candidates (lane >> 4) + 4 r: an
+  // upper bound of the updated lower bound from ONE covariance evaluation per (row,
+  // candidate).  c(x) is the POSTERIOR covariance of the two:
+  //   |c| <= |k(x, x_c)| + |L^-1 k_x| |L^-1 k_c|        (k_expander's bound: small far
+  //                                                      from the data and the candidate)
+  //   |c| <= sd(x) sd(x_c)                               (Cauchy-Schwarz on the posterior:
+  //                                                      small NEXT to the data)
+  // -- with the second one the rows an observation has pinned below fmin drop out for every
+  // candidate.  Squares instead of square roots (|L^-1 k_c|, sd(x_c): k_pass_aux).  No branch
+  // around the loads: several groups' tests overlap (many_test).
+  __device__ __forceinline__ bool pair(const ExpanderArgs& ea, int z, int lane, const double* tab) const {
+    const int m = min(16, m_total - 16 * z);
+    const int64_t zo = (int64_t(z) * G + g) * 16;
+    const double* xc = ea.xc + int64_t(z) * 16 * D;
+    bool possible = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cand = (lane >> 4) + 4 * r;
+      const int cc = min(cand, m - 1);
+      const double kxc = kf.raw(x, xc + cc * D, tab);
+      const double cmax = fmin2(fma(sqx, ea.stn[zo + cc], fabs(kxc)),
+                                svx * ea.svc[zo + cc]) * (1.0 + 1e-9);
+      const double mu2 = fma(fabs(ea.delta[zo + cc]), cmax, mu);
+      const double var2 = fmax(var - cmax * cmax * ea.inv_s2[zo + cc], 1e-15);
+      // mu2 - beta sqrt(var2) + slack >= fmin
+      const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - fmin;
+      possible = possible || (cand < m && room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2);
+    }
+    return possible && unsafe;
+  }
+};
+
+// The tests alone over the groups [zlo, zhi): the 16-bit mask of the wave's rows that pass
+// the pair test of some group (`first`: out at the first group with such a row).  The groups
+// that pass the block test go through the pair test four at a time.
+template <int D>
+__device__ __forceinline__ unsigned many_test(const ManyRows<D>& rw, const ExpanderArgs& ea, int zlo,
+                                              int zhi, bool first, const double* tab, int lane,
+                                              int stat) {
+  const unsigned long long urows = __ballot(rw.unsafe) & 0xffffull;
+  unsigned long long ever = 0ull;
+  EXPM_STAT(stat, 1); EXPM_STAT(stat + 1, __popcll(urows));
+#pragma unroll 1
+  for (int z0 = zlo; z0 < zhi; z0 += 64) {
+    const int zz = z0 + lane;
+    unsigned long long mask = __ballot(zz < zhi && rw.block(ea, zz, tab));
+    EXPM_STAT(stat + 2, min(64, zhi - z0)); EXPM_STAT(stat + 3, __popcll(mask));
+#pragma unroll 1
+    while (mask != 0ull) {
+      int zb[4];
+      zb[0] = z0 + __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
+      mask &= mask - 1ull;
+#pragma unroll
+      for (int b4 = 1; b4 < 4; ++b4) {
+        zb[b4] = mask != 0ull ? z0 + __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask)) : zb[0];
+        mask &= mask - (mask != 0ull ? 1ull : 0ull);
+      }
+      bool possible = false;
+#pragma unroll
+      for (int b4 = 0; b4 < 4; ++b4) possible = rw.pair(ea, zb[b4], lane, tab) || possible;
+      const unsigned long long pb = __ballot(possible);
+      EXPM_STAT(stat + 4, 1);
+      if (pb != 0ull) {                              // wave-uniform
+        ever |= (pb | (pb >> 16) | (pb >> 32) | (pb >> 48)) & 0xffffull;
+        if (first || ever == urows) return unsigned(ever);
+      }
+    }
+  }
+  return unsigned(ever);
+}
+
+// MODE 1: the wave's 16 listed rows against the groups [zlo, zhi), tests and contraction.
+template <int D>
+__device__ __forceinline__ void many_rows(const GpDev& gp, const ManyRows<D>& rw, const ExpanderArgs& ea,
+                                          int zlo, int zhi, const double* tab,
+                                          double* kbw, double* rowbuf, int lane) {
+  const KernFast<D>& kf = rw.kf;
+  const int g = rw.g, G = rw.G;
+  const int m_total = ea.m;
   double xs[D];
-  kf.prep(x, xs);
+  kf.prep(rw.x, xs);
   const int nsteps = gp.n_pad >> 2;
   gptr_t Xj = (gptr_t)gp.Xs + (lane >> 4) * D;
-  if (MODE == 1) {
-    // the wave's rows for the final test of a block: [row][x | mean | var | unsafe]
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 16) {
-      double* rb = rowbuf + lane * (D + 3);
+  // the wave's rows for the final test of a block: [row][x | mean | var | unsafe]
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 16) {
+    double* rb = rowbuf + lane * (D + 3);
 #pragma unroll
-      for (int k = 0; k < D; ++k) rb[k] = x[k];
-      rb[D] = mu;
-      rb[D + 1] = var;
-      rb[D + 2] = unsafe ? 1.0 : 0.0;
-    }
-    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < D; ++k) rb[k] = rw.x[k];
+    rb[D] = rw.mu;
+    rb[D + 1] = rw.var;
+    rb[D + 2] = rw.unsafe ? 1.0 : 0.0;
   }
+  __builtin_amdgcn_wave_barrier();
   // (16 rows x 16 candidates) blocks that passed the pre-filter wait here until kQ of them
   // are there: ONE evaluation of the rows' covariances with the training points then
   // feeds the matrix products of all kQ blocks (the evaluation, ~25 fp64 instructions per
@@ -1099,23 +1209,12 @@ __device__ __forceinline__ unsigned many_rows(const GpDev& gp, int g, int G, con
     }
     nq = 0;
   };
-  // The groups, 64 at a time.  First the BLOCK test, one group per lane: the covariance of
-  // the closest points of the wave's box and the group's box with the extremes of both
-  // sides bounds what any of the block's 256 pairs can reach -- most blocks are far apart
-  // and end here, for a fraction of an instruction per pair.  Then, for the groups that are
-  // left, the PAIR test: an upper bound of the updated lower bound from ONE covariance
-  // evaluation per (row, candidate).  c(x) is the POSTERIOR covariance of the two:
-  //   |c| <= |k(x, x_c)| + |L^-1 k_x| |L^-1 k_c|        (k_expander's bound: small far
-  //                                                      from the data and the candidate)
-  //   |c| <= sd(x) sd(x_c)                               (Cauchy-Schwarz on the posterior:
-  //                                                      small NEXT to the data)
-  // -- with the second one the rows an observation has pinned below fmin drop out for every
-  // candidate.  Squares instead of square roots (|L^-1 k_c|, sd(x_c): k_pass_aux).
+  // The groups, 64 at a time: the block test one group per lane, the pair test for the groups
+  // that are left, the blocks with a possible pair into the queue.
   int z0 = zlo;
   unsigned long long mask = 0ull;
-  unsigned long long ever = 0ull;
   bool done = false;
-  EXPM_STAT(0 + 8 * MODE, 1); EXPM_STAT(1 + 8 * MODE, __popcll(urows));
+  EXPM_STAT(8, 1);
 #pragma unroll 1
   while (true) {
     if (mask == 0ull) {
@@ -1123,26 +1222,7 @@ __device__ __forceinline__ unsigned many_rows(const GpDev& gp, int g, int G, con
         done = true;
       } else {
         const int zz = z0 + lane;
-        bool blk = zz < zhi;
-        if (blk && kf.single) {
-          const double* bx = ea.box + int64_t(zz) * 2 * D;
-          double r2 = 0.0;
-#pragma unroll
-          for (int k = 0; k < D; ++k) {
-            const double gap = fmax(fmax(bx[k] - xhi[k], xlo[k] - bx[D + k]), 0.0) * kf.sc[k];
-            r2 = fma(gap, gap, r2);
-          }
-          const double kmax = kf.of_r2s(r2, tab);
-          const double* ag = ea.agg + (int64_t(zz) * G + g) * 4;
-          const double cmax = fmin(fma(sqx_hi, ag[2], kmax), svx_hi * ag[3]) * (1.0 + 1e-9);
-          const double mu2 = fma(ag[0], cmax, mu_hi);
-          const double var2 = fmax(var_lo - cmax * cmax * ag[1], 1e-15);
-          const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - ea.fmin[g];
-          blk = room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2;
-        }
-        EXPM_STAT(2 + 8 * MODE, __popcll(__ballot(zz < zhi)));
-        mask = __ballot(blk);
-        EXPM_STAT(3 + 8 * MODE, __popcll(mask));
+        mask = __ballot(zz < zhi && rw.block(ea, zz, tab));
         z0 += 64;
         if (mask == 0ull) continue;
       }
@@ -1151,46 +1231,18 @@ __device__ __forceinline__ unsigned many_rows(const GpDev& gp, int g, int G, con
       const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
       mask &= mask - 1ull;
       const int z = z0 - 64 + j;
-      const int m = min(16, m_total - 16 * z);
-      const int64_t zo = (int64_t(z) * G + g) * 16;
-      const double* xc = ea.xc + int64_t(z) * 16 * D;
-      bool possible = false;
+      if (__ballot(rw.pair(ea, z, lane, tab)) != 0ull) {       // wave-uniform
+        EXPM_STAT(9, 1);
+        // (slot of the queue by a chain of uniform tests: the indices stay in scalar registers)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int cand = (lane >> 4) + 4 * r;
-        if (cand < m && unsafe) {
-          const double kxc = kf.raw(x, xc + cand * D, tab);
-          const double cmax = fmin(fma(sqx, ea.stn[zo + cand], fabs(kxc)),
-                                   svx * ea.svc[zo + cand]) * (1.0 + 1e-9);
-          const double mu2 = fma(fabs(ea.delta[zo + cand]), cmax, mu);
-          const double var2 = fmax(var - cmax * cmax * ea.inv_s2[zo + cand], 1e-15);
-          // mu2 - beta sqrt(var2) + slack >= fmin
-          const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - ea.fmin[g];
-          possible = possible || (room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2);
-        }
-      }
-      const unsigned long long pb = __ballot(possible);
-      if (pb != 0ull) {                              // wave-uniform
-        EXPM_STAT(4 + 8 * MODE, 1);
-        if (MODE == 0) {
-          ever |= (pb | (pb >> 16) | (pb >> 32) | (pb >> 48)) & 0xffffull;
-          if (ever == urows) break;                  // every unsafe row of the wave is listed
-        } else {
-          // (slot of the queue by a chain of uniform tests: the indices stay in scalar registers)
-#pragma unroll
-          for (int q = 0; q < kQ; ++q)
-            if (q == nq) zq[q] = z;
-          ++nq;
-        }
+        for (int q = 0; q < kQ; ++q)
+          if (q == nq) zq[q] = z;
+        ++nq;
       }
     }
-    if (MODE == 1) {
-      if (nq == kQ || (done && nq > 0)) flush();
-    }
+    if (nq == kQ || (done && nq > 0)) flush();
     if (done) break;
   }
-  EXPM_STAT(5 + 8 * MODE, __popcll(ever));
-  return unsigned(ever);
 }
 
 template <int D, int MODE>
@@ -1198,17 +1250,17 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
                                                        SweepPoints pts, ExpanderArgs ea,
                                                        int ngroups) {
   __shared__ double tab[kExpTabSize];
-  __shared__ __attribute__((aligned(16))) double kbuf[MODE ? 4 : 1][4 * kManyKbRow];   // B-operand transposes
-  __shared__ double rows_sh[MODE ? 4 : 1][16 * (D + 3)];
+  __shared__ __attribute__((aligned(16))) double kbuf[MODE == 1 ? 4 : 1][4 * kManyKbRow];   // B-operand transposes
+  __shared__ double rows_sh[MODE == 1 ? 4 : 1][16 * (D + 3)];
   exp_tab_init(tab);
   __syncthreads();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  double* kbw = kbuf[MODE ? wave : 0];
-  double* rowbuf = rows_sh[MODE ? wave : 0];
+  const int64_t nwaves = (pts.N + 15) >> 4;        // 16-row segments of the shard
   if (MODE == 0) {
-    const int64_t row = int64_t(blockIdx.x) * 64 + wave * 16 + (lane & 15);
+    const int64_t wid = int64_t(blockIdx.x) * 4 + wave;
+    const int64_t row = wid * 16 + (lane & 15);
     const bool valid = row < pts.N;
     const int64_t rrow = valid ? row : pts.N - 1;
     const bool unsafe = valid && (ea.S[rrow] == 0);
@@ -1219,19 +1271,62 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
       x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
     for (int g = 0; g < G; ++g) {
       if (!ea.active[g]) continue;
-      const double mu = ea.mean[int64_t(g) * pts.N + rrow];
-      const double var = ea.var[int64_t(g) * pts.N + rrow];
-      const unsigned hot = many_rows<D, 0>(gps[g], g, G, ea, x, mu, var, unsafe, 0, ngroups, tab,
-                                           kbw, rowbuf, lane);
-      if (hot != 0u) {                             // (wave-uniform) append the wave's hot rows
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&ea.count[g], __popc(hot));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (lane < 16 && ((hot >> lane) & 1u))
-          ea.list[int64_t(g) * pts.N + base + __popc(hot & ((1u << lane) - 1u))] = int(rrow);
+      const ManyRows<D> rw(gps[g], g, G, ea, x, ea.mean[int64_t(g) * pts.N + rrow],
+                           ea.var[int64_t(g) * pts.N + rrow], unsafe);
+      // (the block test alone, 64 groups at a time: no wave of the scan waits for a chain of
+      // pair tests -- the waves next to the band pass the block test for most groups and the
+      // pair test for none)
+      bool some = false;
+      EXPM_STAT(0, 1); EXPM_STAT(1, __popcll(__ballot(unsafe) & 0xffffull));
+#pragma unroll 1
+      for (int z0 = 0; z0 < ngroups && !some; z0 += 64) {
+        const int zz = z0 + lane;
+        some = __ballot(zz < ngroups && rw.block(ea, zz, tab)) != 0ull;
+        EXPM_STAT(2, min(64, ngroups - z0));
+      }
+      EXPM_STAT(3, some);
+      if (some && lane == 0) {
+        const int at = atomicAdd(&ea.wcount[g], 1);
+        ea.wlist[int64_t(g) * nwaves + at] = int(wid);
+        ea.wmask[int64_t(g) * nwaves + at] = 0u;
+      }
+    }
+  } else if (MODE == 2) {
+    const int nch = (ngroups + kManyTestChunk - 1) / kManyTestChunk;
+    for (int g = 0; g < G; ++g) {
+      if (!ea.active[g]) continue;
+      const int64_t total = int64_t(ea.wcount[g]) * nch;
+#pragma unroll 1
+      for (int64_t item = int64_t(blockIdx.x) * 4 + wave; item < total; item += int64_t(gridDim.x) * 4) {
+        const int hw = int(item / nch), gc = int(item - int64_t(hw) * nch);
+        const int64_t row = int64_t(ea.wlist[int64_t(g) * nwaves + hw]) * 16 + (lane & 15);
+        const bool valid = row < pts.N;
+        const int64_t rrow = valid ? row : pts.N - 1;
+        const bool unsafe = valid && (ea.S[rrow] == 0);
+        double x[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+          x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
+        const ManyRows<D> rw(gps[g], g, G, ea, x, ea.mean[int64_t(g) * pts.N + rrow],
+                             ea.var[int64_t(g) * pts.N + rrow], unsafe);
+        unsigned hot = many_test<D>(rw, ea, gc * kManyTestChunk, min(ngroups, (gc + 1) * kManyTestChunk),
+                                    false, tab, lane, 16);
+        if (hot != 0u) {                           // (wave-uniform) the rows no other item listed
+          int base = 0;
+          if (lane == 0) {
+            hot &= ~atomicOr(&ea.wmask[int64_t(g) * nwaves + hw], hot);
+            if (hot != 0u) base = atomicAdd(&ea.count[g], __popc(hot));
+          }
+          hot = __builtin_amdgcn_readfirstlane(hot);
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (lane < 16 && ((hot >> lane) & 1u))
+            ea.list[int64_t(g) * pts.N + base + __popc(hot & ((1u << lane) - 1u))] = int(rrow);
+        }
       }
     }
   } else {
+    double* kbw = kbuf[wave];
+    double* rowbuf = rows_sh[wave];
     const int nch = (ngroups + kManyChunk - 1) / kManyChunk;
     for (int g = 0; g < G; ++g) {
       if (!ea.active[g]) continue;
@@ -1247,10 +1342,10 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
 #pragma unroll
         for (int k = 0; k < D; ++k)
           x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
-        const double mu = ea.mean[int64_t(g) * pts.N + rrow];
-        const double var = ea.var[int64_t(g) * pts.N + rrow];
-        many_rows<D, 1>(gps[g], g, G, ea, x, mu, var, unsafe, gc * kManyChunk,
-                        min(ngroups, (gc + 1) * kManyChunk), tab, kbw, rowbuf, lane);
+        const ManyRows<D> rw(gps[g], g, G, ea, x, ea.mean[int64_t(g) * pts.N + rrow],
+                             ea.var[int64_t(g) * pts.N + rrow], unsafe);
+        many_rows<D>(gps[g], rw, ea, gc * kManyChunk, min(ngroups, (gc + 1) * kManyChunk), tab,
+                     kbw, rowbuf, lane);
       }
     }
   }
@@ -1881,12 +1976,17 @@ int launch_expander_many(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d, Sweep
   if (pts.N <= 0 || ea.m <= 0) return 0;
   const int nblocks = int((pts.N + 63) / 64);
   const int ngroups = (ea.m + 15) / 16;
-  // the rows that pass the pre-filter for some candidate, per GP: [G][N] rows behind G counts
+  // the waves with a possible pair and the rows that pass the pair test for some candidate, per
+  // GP: counts | [G][N / 16] waves | [G][N / 16] masks of their listed rows | [G][N] rows
   {
-    int* hot = static_cast<int*>(sgp_scratch(ctx, 12, (size_t(G) * size_t(pts.N) + 64) * sizeof(int)));
+    const size_t nw = size_t((pts.N + 15) >> 4);
+    int* hot = static_cast<int*>(sgp_scratch(ctx, 12, (64 + size_t(G) * (2 * nw + size_t(pts.N))) * sizeof(int)));
     SGP_CHECK(ctx, hot, "device allocation failed: %s", ctx->err.c_str());
     ea.count = hot;
-    ea.list = hot + 64;
+    ea.wcount = hot + 32;
+    ea.wlist = hot + 64;
+    ea.wmask = reinterpret_cast<unsigned*>(hot + 64 + size_t(G) * nw);
+    ea.list = hot + 64 + 2 * size_t(G) * nw;
     SGP_HIP(ctx, hipMemsetAsync(hot, 0, 64 * sizeof(int), ctx->stream));
   }
   {
@@ -1902,6 +2002,9 @@ int launch_expander_many(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d, Sweep
   case DD:                                                                    \
     hipLaunchKernelGGL((k_expander_many<DD, 0>), dim3(nblocks), dim3(256), 0, \
                        ctx->stream, gps_dev, G, pts, ea, ngroups);            \
+    hipLaunchKernelGGL((k_expander_many<DD, 2>), dim3(kManyListBlocks),       \
+                       dim3(256), 0, ctx->stream, gps_dev, G, pts, ea,        \
+                       ngroups);                                              \
     hipLaunchKernelGGL((k_expander_many<DD, 1>), dim3(kManyListBlocks),       \
                        dim3(256), 0, ctx->stream, gps_dev, G, pts, ea,        \
                        ngroups);                                              \

@@ -31,7 +31,7 @@ if __name__ == "__main__":
     kw = {k: (float(v) if "." in v else int(v)) for k, v in kw.items()}
     margin = kw.pop("margin", None)
     gp, grid = rim_state(side, **kw) if margin is None else converged_state(side, margin, **kw)
-    for big in (True, False):
+    for big in ((True,) if os.environ.get("ONLY_BIG") else (True, False)):
         opt = safeopt_amd.SafeOpt(gp, grid, 0.0, threshold=0.1)
         opt.big_passes = big
         if os.environ.get("PASS_SIZES"):
