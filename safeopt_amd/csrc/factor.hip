@@ -713,66 +713,168 @@ struct ExpGpSel {
   int active[SGP_MAX_GPS];
 };
 
-// Many candidates (sgp_grid_expander_pass): blockIdx.z = group of 16 candidates; every
-// per-candidate array is laid out [group][GP slot][...] (ExpanderOps::Gs slots), the group's
-// candidate count is what is left of `m` behind the groups in front.  One group: z = 0.
-// Kc[g][c][j] = k(x_c, X_j)
+// 2 .. thousands of candidates (sgp_grid_expander_batch, sgp_grid_expander_pass) in groups of
+// 16; every per-candidate array is laid out [group][GP slot][...] (ExpanderOps::Gs slots), the
+// group's candidate count is what is left of `m` behind the groups in front.  The two
+// triangular products are matrix products of 16-candidate panels on v_mfma_f64_16x16x4_f64:
+// per (group, GP) the panels Kc and T are [j][16 candidates] -- 64 consecutive doubles are a
+// B operand (k_expt_mm: lane 16 k + c <- [4 s + k][c]) or an A operand (k_expw_mm) as they lie.
+constexpr int kOpGroups = 2;       // groups of a wave: one operand of L^-1 feeds that many products
+
+// Kc[group][g][j][c] = k(x_c, X_j); zero for j >= n (the padding meets zeros of L^-1) and c >= m
 template <int D>
 __global__ __launch_bounds__(256) void k_expk(const GpDev* gps, ExpGpSel sel,
                                               const double* xc, int m, double* Kc,
                                               int64_t ldk, int Gs) {
   const int g = blockIdx.y;
   if (!sel.active[g]) return;
-  {
-    const int z = blockIdx.z;
-    xc += int64_t(z) * kMaxRhs * D;
-    Kc += int64_t(z) * Gs * kMaxRhs * ldk;
-    m = min(kMaxRhs, m - kMaxRhs * z);
-  }
+  const int z = blockIdx.z;
+  xc += int64_t(z) * kMaxRhs * D;
+  m = min(kMaxRhs, m - kMaxRhs * z);
   const GpDev& gp = gps[g];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= gp.n) return;
+  if (j >= gp.n_pad) return;
+  double* out = Kc + ((int64_t(z) * Gs + g) * ldk + j) * kMaxRhs;
   double xj[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) xj[k] = gp.Xpad[int64_t(j) * D + k];
-  for (int c = 0; c < m; ++c)
-    Kc[(int64_t(g) * kMaxRhs + c) * ldk + j] = kern_eval<D>(gp.kern, xc + c * D, xj);
+  for (int c = 0; c < kMaxRhs; ++c)
+    out[c] = (j < gp.n && c < m) ? kern_eval<D>(gp.kern, xc + c * D, xj) : 0.0;
 }
 
-// T[g][c][i] = sum_{j <= i} Li[i][j] Kc[g][c][j]: one wave per row (k_tri_mv per GP)
-__global__ __launch_bounds__(256) void k_expt(const GpDev* gps, ExpGpSel sel,
-                                              const double* Kc, int m, double* Tt,
-                                              int64_t ldk, int Gs) {
+// T[group][g][i][c] = sum_{j <= i} Li[i][j] Kc[..][j][c]: a wave per (row block of 16, kOpGroups
+// groups); A = the packed L^-1 of the sweeps (GpDev::Apack: zero above the diagonal and in the
+// padding), B = the panel.  D: column (candidate) = lane & 15, rows (lane >> 4) + 4 r.
+__global__ __launch_bounds__(256) void k_expt_mm(const GpDev* gps, ExpGpSel sel,
+                                                 const double* Kc, double* Tt,
+                                                 int64_t ldk, int Gs, int ngroups) {
   const int g = blockIdx.y;
   if (!sel.active[g]) return;
-  {
-    const int z = blockIdx.z;
-    Kc += int64_t(z) * Gs * kMaxRhs * ldk;
-    Tt += int64_t(z) * Gs * kMaxRhs * ldk;
-    m = min(kMaxRhs, m - kMaxRhs * z);
-  }
   const GpDev& gp = gps[g];
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= gp.n) return;
-  double acc[kMaxRhs];
+  const int b = blockIdx.x;
+  if (b >= gp.nblk) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int z0 = (blockIdx.z * 4 + wave) * kOpGroups;
+  if (z0 >= ngroups) return;
+  const int nsteps = gp.n_pad >> 2;
+  const double* A = gp.Apack + int64_t(b) * nsteps * 64 + lane;
+  // narrow packing of the last row block (k_pack): its rows 4..15 repeat rows 0..3
+  const bool dup = b == gp.nblk - 1 && gp.narrow && (lane & 15) >= 4;
+  const double* B[kOpGroups];
 #pragma unroll
-  for (int c = 0; c < kMaxRhs; ++c) acc[c] = 0.0;
-  const double* row = gp.Linv + int64_t(i) * gp.ld;
-  const double* V = Kc + int64_t(g) * kMaxRhs * ldk;
-  for (int j = lane; j <= i; j += 64) {
-    const double l = row[j];
+  for (int q = 0; q < kOpGroups; ++q)
+    B[q] = Kc + (int64_t(min(z0 + q, ngroups - 1)) * Gs + g) * ldk * kMaxRhs + lane;
+  double4_t acc[kOpGroups];
 #pragma unroll
-    for (int c = 0; c < kMaxRhs; ++c)
-      if (c < m) acc[c] = fma(l, V[c * ldk + j], acc[c]);
+  for (int q = 0; q < kOpGroups; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int send = (b + 1) * 4;                 // up to the diagonal block
+  constexpr int kInFlight = 4;
+#pragma unroll 1
+  for (int s = 0; s < send; s += kInFlight) {   // (send is a multiple of 4)
+    double av[kInFlight], bv[kOpGroups][kInFlight];
+#pragma unroll
+    for (int i = 0; i < kInFlight; ++i) {
+      av[i] = A[(s + i) * 64];
+#pragma unroll
+      for (int q = 0; q < kOpGroups; ++q) bv[q][i] = B[q][(s + i) * 64];
+    }
+#pragma unroll
+    for (int i = 0; i < kInFlight; ++i) {
+      const double a = dup ? 0.0 : av[i];
+#pragma unroll
+      for (int q = 0; q < kOpGroups; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[q][i], acc[q], 0, 0, 0);
+    }
   }
 #pragma unroll
-  for (int c = 0; c < kMaxRhs; ++c) {
-    if (c < m) {
-      double v = acc[c];
+  for (int q = 0; q < kOpGroups; ++q) {
+    if (z0 + q < ngroups) {
+      double* T = Tt + (int64_t(z0 + q) * Gs + g) * ldk * kMaxRhs;
 #pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) Tt[(int64_t(g) * kMaxRhs + c) * ldk + i] = v;
+      for (int r = 0; r < 4; ++r)
+        T[(16 * b + (lane >> 4) + 4 * r) * kMaxRhs + (lane & 15)] = acc[q][r];
+    }
+  }
+}
+
+// W[c][j] = sum_{i >= j} Li[i][j] T[..][i][c] straight into the packed operand
+// (Wpack[(j / 4) * 64 + (j % 4) * 16 + c], zero for j >= n and c >= m): a wave per (column block
+// of 16, kOpGroups groups); A = the panel, B = rows of the dense L^-1 (16 consecutive columns).
+// D: column j = lane & 15, rows (candidates) (lane >> 4) + 4 r.  The wave of column block 0 walks
+// over every row: it also leaves s2 / delta / |t|^2 of its candidates.
+__global__ __launch_bounds__(256) void k_expw_mm(const GpDev* gps, ExpGpSel sel,
+                                                 const double* Tt, int64_t ldk, ExpanderOps ops,
+                                                 int ngroups) {
+  const int g = blockIdx.y;
+  if (!sel.active[g]) return;
+  const GpDev& gp = gps[g];
+  const int jb = blockIdx.x;
+  if (jb >= gp.nblk) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int z0 = (blockIdx.z * 4 + wave) * kOpGroups;
+  if (z0 >= ngroups) return;
+  const int n = gp.n;
+  const int j = 16 * jb + (lane & 15);
+  const double* A[kOpGroups];
+#pragma unroll
+  for (int q = 0; q < kOpGroups; ++q)
+    A[q] = Tt + (int64_t(min(z0 + q, ngroups - 1)) * ops.Gs + g) * ldk * kMaxRhs + lane;
+  const double* Bp = gp.Linv + int64_t(lane >> 4) * gp.ld + min(j, n - 1);
+  double4_t acc[kOpGroups];
+  double ss[kOpGroups];
+#pragma unroll
+  for (int q = 0; q < kOpGroups; ++q) {
+    acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+    ss[q] = 0.0;
+  }
+  const int send = (n + 3) >> 2;
+  constexpr int kInFlight = 4;
+#pragma unroll 1
+  for (int s = 4 * jb; s < send; s += kInFlight) {
+    double av[kOpGroups][kInFlight], bv[kInFlight];
+#pragma unroll
+    for (int i = 0; i < kInFlight; ++i) {
+      const int row = 4 * (s + i) + (lane >> 4);
+      bv[i] = Bp[int64_t(min(4 * (s + i), n - 1 - (lane >> 4))) * gp.ld];
+      bv[i] = (row < n && row >= j && j < n) ? bv[i] : 0.0;
+      // (rows >= n of the panel are zero: k_expt_mm, the padding of Apack)
+#pragma unroll
+      for (int q = 0; q < kOpGroups; ++q) av[q][i] = A[q][min(s + i, (gp.n_pad >> 2) - 1) * 64];
+    }
+#pragma unroll
+    for (int i = 0; i < kInFlight; ++i) {
+#pragma unroll
+      for (int q = 0; q < kOpGroups; ++q) {
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][i], bv[i], acc[q], 0, 0, 0);
+        ss[q] = (s + i < send) ? fma(av[q][i], av[q][i], ss[q]) : ss[q];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kOpGroups; ++q) {
+    const int z = z0 + q;
+    if (z >= ngroups) break;
+    const int m = min(kMaxRhs, ops.m - kMaxRhs * z);
+    if (j < gp.n_pad) {
+      double* Wp = ops.Wpack + (int64_t(z) * ops.Gs + g) * ops.wstride;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = (lane >> 4) + 4 * r;
+        Wp[(j >> 2) * 64 + (j & 3) * 16 + c] = (j < n && c < m) ? acc[q][r] : 0.0;
+      }
+    }
+    if (jb == 0) {
+      double t2 = ss[q];
+      t2 += __shfl_xor(t2, 16, 64);
+      t2 += __shfl_xor(t2, 32, 64);
+      const int c = lane;
+      if (c < m) {
+        const int64_t o = (int64_t(z) * ops.Gs + g) * 16 + c;
+        const double s2 = gp.prior - t2;
+        ops.inv_s2[o] = 1.0 / s2;
+        ops.delta[o] = ops.resid[o] / s2;
+        ops.tn2[o] = t2;
+      }
     }
   }
 }
@@ -873,73 +975,6 @@ __global__ __launch_bounds__(1024) void k_expw1(const GpDev* gps, ExpGpSel sel,
   }
 }
 
-// W[c][j] = sum_{i >= j} Li[i][j] T[c][i] straight into the packed operand
-// (Wpack[(j / 4) * 64 + (j % 4) * 16 + c], zero for j >= n and c >= m); the first
-// workgroup of a GP also leaves s2 / delta / |t|^2 of every candidate.
-__global__ __launch_bounds__(512) void k_expw(const GpDev* gps, ExpGpSel sel,
-                                              const double* Tt, int64_t ldk,
-                                              ExpanderOps ops) {
-  __shared__ double sh[8][64];
-  const int g = blockIdx.y;
-  if (!sel.active[g]) return;
-  const GpDev& gp = gps[g];
-  const int z = blockIdx.z;
-  const int n = gp.n, m = min(kMaxRhs, ops.m - kMaxRhs * z);
-  Tt += int64_t(z) * ops.Gs * kMaxRhs * ldk;
-  ops.Wpack += int64_t(z) * ops.Gs * ops.wstride;
-  ops.inv_s2 += int64_t(z) * ops.Gs * 16;
-  ops.delta += int64_t(z) * ops.Gs * 16;
-  ops.tn2 += int64_t(z) * ops.Gs * 16;
-  ops.resid += int64_t(z) * ops.Gs * 16;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j0 = blockIdx.x * 64, j = j0 + lane;
-  if (j0 >= gp.n_pad) return;
-  const double* T = Tt + int64_t(g) * kMaxRhs * ldk;
-  double* Wp = ops.Wpack + int64_t(g) * ops.wstride;
-  double acc[kMaxRhs];
-#pragma unroll
-  for (int c = 0; c < kMaxRhs; ++c) acc[c] = 0.0;
-  if (j < n) {
-    for (int i = j0 + wave; i < n; i += 8) {
-      const double l = (i >= j) ? gp.Linv[int64_t(i) * gp.ld + j] : 0.0;
-#pragma unroll
-      for (int c = 0; c < kMaxRhs; ++c)
-        if (c < m) acc[c] = fma(l, T[c * ldk + i], acc[c]);
-    }
-  }
-  for (int c = 0; c < kMaxRhs; ++c) {      // uniform trip count: barriers are safe
-    double v = 0.0;
-#pragma unroll
-    for (int k = 0; k < kMaxRhs; ++k) v = (k == c) ? acc[k] : v;
-    sh[wave][lane] = v;
-    __syncthreads();
-    if (wave == 0 && j < gp.n_pad) {
-      double tot = 0.0;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) tot += sh[w][lane];
-      Wp[(j >> 2) * 64 + (j & 3) * 16 + c] = (j < n && c < m) ? tot : 0.0;
-    }
-    __syncthreads();
-  }
-  if (blockIdx.x == 0) {
-    for (int c = wave; c < m; c += 8) {     // one wave per candidate
-      double s = 0.0;
-      for (int i = lane; i < n; i += 64) {
-        const double t = T[c * ldk + i];
-        s = fma(t, t, s);
-      }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-      if (lane == 0) {
-        const double s2 = gp.prior - s;
-        ops.inv_s2[g * 16 + c] = 1.0 / s2;
-        ops.delta[g * 16 + c] = ops.resid[g * 16 + c] / s2;
-        ops.tn2[g * 16 + c] = s;
-      }
-    }
-  }
-}
-
 }  // namespace
 
 int expander_operands_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_host,
@@ -991,7 +1026,7 @@ int expander_operands_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_h
   }
 #define EXPK_CASE(DD)                                                         \
   case DD:                                                                    \
-    hipLaunchKernelGGL(k_expk<DD>, dim3((n_max + 255) / 256, G, ngroups), dim3(256), 0,\
+    hipLaunchKernelGGL(k_expk<DD>, dim3((np_max + 255) / 256, G, ngroups), dim3(256), 0,\
                        ctx->stream, gps_dev, sel, ops.xc, ops.m, Kc, ldk, G); \
     break;
   switch (d) {
@@ -1002,10 +1037,11 @@ int expander_operands_all(sgp_ctx* ctx, const GpDev* gps_dev, const GpDev* gps_h
       return -2;
   }
 #undef EXPK_CASE
-  hipLaunchKernelGGL(k_expt, dim3((n_max + 3) / 4, G, ngroups), dim3(256), 0, ctx->stream,
-                     gps_dev, sel, Kc, ops.m, Tt, ldk, G);
-  hipLaunchKernelGGL(k_expw, dim3((np_max + 63) / 64, G, ngroups), dim3(512), 0,
-                     ctx->stream, gps_dev, sel, Tt, ldk, ops);
+  const int zblocks = (ngroups + 4 * kOpGroups - 1) / (4 * kOpGroups);
+  hipLaunchKernelGGL(k_expt_mm, dim3(np_max / 16, G, zblocks), dim3(256), 0, ctx->stream,
+                     gps_dev, sel, Kc, Tt, ldk, G, ngroups);
+  hipLaunchKernelGGL(k_expw_mm, dim3(np_max / 16, G, zblocks), dim3(256), 0, ctx->stream,
+                     gps_dev, sel, Tt, ldk, ops, ngroups);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }
