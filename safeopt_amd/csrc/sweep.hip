@@ -947,15 +947,19 @@ __global__ __launch_bounds__(256) void k_expander(const GpDev* gps, int G,
 //           test (one group per lane, out at the first one) -> a list of waves per GP
 //           (ea.wlist, ea.wcount);
 //   MODE 2  takes the listed waves and the groups kManyTestChunk at a time -- an item per wave
-//           of the launch, as many as the chip has -- and finds the ROWS that pass the pair
-//           test (four groups at a time) for some candidate -> a list of rows per GP
-//           (ea.list, ea.count; a row once: ea.wmask);
-//   MODE 1  takes the listed rows 16 at a time and the groups kManyChunk at a time and runs
-//           the same tests and the contraction of what is left of them.
+//           of the launch, as many as the chip has -- and finds the ROWS that pass the block
+//           test of the row alone for some group (kernels of several parts, which have no
+//           block test: the pair test for some candidate) -> a list of rows per GP (ea.list,
+//           ea.count; a row once: ea.wmask);
+//   MODE 1  takes the listed rows 16 at a time and the groups kManyChunk at a time -- an item
+//           per wave; with few items 4 at a time, an item per workgroup, its four waves a
+//           quarter of the training points each -- and runs the same tests and the contraction
+//           of what is left of them.
 constexpr int kManyKbRow = 80;     // doubles between the k-rows of a wave's transpose buffer
 constexpr int kManyChunk = 8;      // groups of an item of MODE 1
 constexpr int kManyTestChunk = 32; //                   of MODE 2
 constexpr int kManyListBlocks = 1024;   // workgroups of MODE 1 / 2 (4 items at a time each)
+constexpr int kManyCoopItems = 256;     // MODE 1: up to that many items of 4 groups go one per workgroup
 #ifdef EXPM_STATS
 __device__ unsigned long long g_expm_stats[32];
 extern "C" void sgp_debug_expm_stats(unsigned long long* out, int reset) {
@@ -1026,6 +1030,26 @@ struct ManyRows {
     return room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2;
   }
   static __device__ __forceinline__ double fmin2(double a, double b) { return ::fmin(a, b); }
+
+  // The same bound for the lane's OWN row against group zz (its box, its extremes): what the
+  // pair tests of the row with the group's 16 candidates -- neighbours along a grid line -- can
+  // reach, for one covariance evaluation instead of 16.
+  __device__ __forceinline__ bool row_block(const ExpanderArgs& ea, int zz, const double* tab) const {
+    const double* bx = ea.box + int64_t(zz) * 2 * D;
+    double r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const double gap = fmax(fmax(bx[k] - x[k], x[k] - bx[D + k]), 0.0) * kf.sc[k];
+      r2 = fma(gap, gap, r2);
+    }
+    const double kmax = kf.of_r2s(r2, tab);
+    const double* ag = ea.agg + (int64_t(zz) * G + g) * 4;
+    const double cmax = fmin2(fma(sqx, ag[2], kmax), svx * ag[3]) * (1.0 + 1e-9);
+    const double mu2 = fma(ag[0], cmax, mu);
+    const double var2 = fmax(var - cmax * cmax * ag[1], 1e-15);
+    const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - fmin;
+    return unsafe && room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2;
+  }
 
   // The PAIR test of group z, the lane's row against the candidates (lane >> 4) + 4 r: an
   // upper bound of the updated lower bound from ONE covariance evaluation per (row,
@@ -1102,7 +1126,8 @@ __device__ __forceinline__ unsigned many_test(const ManyRows<D>& rw, const Expan
 template <int D>
 __device__ __forceinline__ void many_rows(const GpDev& gp, const ManyRows<D>& rw, const ExpanderArgs& ea,
                                           int zlo, int zhi, const double* tab,
-                                          double* kbw, double* rowbuf, int lane) {
+                                          double* kbw, double* rowbuf, double* red, int lane,
+                                          int wave, bool coop) {
   const KernFast<D>& kf = rw.kf;
   const int g = rw.g, G = rw.G;
   const int m_total = ea.m;
@@ -1135,34 +1160,41 @@ __device__ __forceinline__ void many_rows(const GpDev& gp, const ManyRows<D>& rw
   // Ky^-1 k_c as it is (lane 16 k + candidate).  D[blk][i][j] -> lane 16 i + 4 blk + j: a lane
   // ends with ONE candidate, 4 blk + i, at the four rows 4 m + j -- whose x, mean and
   // variance it reads from the wave's row buffer.
+  // `coop` (few items in the launch: the pass waits for the longest of them): the four waves of
+  // the workgroup hold the SAME rows and queue (same tests on the same data), each takes a
+  // quarter of the training points, the partial products meet in LDS and wave j finishes block
+  // j -- an item is a chain of n / 64 evaluations, not n / 16.  Otherwise a wave has its own
+  // item and all training points.
   auto flush = [&]() {
     double acc[kQ][4];
 #pragma unroll
     for (int j = 0; j < kQ; ++j)
 #pragma unroll
       for (int m4 = 0; m4 < 4; ++m4) acc[j][m4] = 0.0;
+    const int nit = nsteps >> 2;                       // (n_pad is a multiple of 16)
+    const int sbeg = coop ? 4 * ((nit * wave) >> 2) : 0;
+    const int send = coop ? 4 * ((nit * (wave + 1)) >> 2) : nsteps;
     double xr[4][D], xn[4][D];
-    auto fetch = [&](int s0, double (&xo)[4][D]) {
+    double a[kQ][4], an[kQ][4];
+    auto fetch = [&](int s0, double (&xo)[4][D], double (&ao)[kQ][4]) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int k = 0; k < D; ++k) xo[q][k] = Xj[(s0 + q) * 4 * D + k];
-    };
-    fetch(0, xr);
-#pragma unroll 1
-    for (int s0 = 0; s0 < nsteps; s0 += 4) {
-      if (s0 + 4 < nsteps) fetch(s0 + 4, xn);
-      // the A operands of all queued blocks are requested in front of the evaluation: their
-      // latency (L2) passes under it
-      double a[kQ][4];
+      // (the A operands of all queued blocks one evaluation ahead: their latency passes under it)
 #pragma unroll
       for (int j = 0; j < kQ; ++j) {
         if (j < nq) {                     // (wave-uniform)
           gptr_t W = (gptr_t)ea.Wpack + (int64_t(zq[j]) * G + g) * ea.wstride + lane;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) a[j][q] = W[(s0 + q) * 64];
+          for (int q = 0; q < 4; ++q) ao[j][q] = W[(s0 + q) * 64];
         }
       }
+    };
+    if (sbeg < send) fetch(sbeg, xr, a);
+#pragma unroll 1
+    for (int s0 = sbeg; s0 < send; s0 += 4) {
+      if (s0 + 4 < send) fetch(s0 + 4, xn, an);
       double kv[4];
       kf.template many<4>(xs, &xr[0][0], D, tab, kv);
       double kb[4][4];
@@ -1181,11 +1213,21 @@ __device__ __forceinline__ void many_rows(const GpDev& gp, const ManyRows<D>& rw
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int k = 0; k < D; ++k) xr[q][k] = xn[q][k];
+#pragma unroll
+      for (int j = 0; j < kQ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[j][q] = an[j][q];
     }
+#pragma unroll
+    for (int j = 0; j < kQ; ++j)
+      if (j < nq)
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) red[((wave * kQ + j) * 4 + m4) * 64 + lane] = acc[j][m4];
+    if (coop) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     const int cand = 4 * ((lane >> 2) & 3) + (lane >> 4);
 #pragma unroll
     for (int j = 0; j < kQ; ++j) {
-      if (j < nq) {
+      if (j < nq && (!coop || j == wave)) {            // (coop: block j belongs to wave j)
         const int z = zq[j];
         const int m = min(16, m_total - 16 * z);
         const int64_t zo = (int64_t(z) * G + g) * 16;
@@ -1197,7 +1239,12 @@ __device__ __forceinline__ void many_rows(const GpDev& gp, const ManyRows<D>& rw
           for (int m4 = 0; m4 < 4; ++m4) {
             const double* rb = rowbuf + (4 * m4 + (lane & 3)) * (D + 3);
             if (rb[D + 2] != 0.0) {                       // an unsafe row of the grid
-              const double cx = kf.raw(rb, xc + cand * D, tab) - acc[j][m4];
+              double dot = red[(((coop ? 0 : wave) * kQ + j) * 4 + m4) * 64 + lane];
+              if (coop) {                                 // (in the order of the training points)
+#pragma unroll
+                for (int w = 1; w < 4; ++w) dot += red[((w * kQ + j) * 4 + m4) * 64 + lane];
+              }
+              const double cx = kf.raw(rb, xc + cand * D, tab) - dot;
               const double mu2 = rb[D] + cx * dl;
               const double var2 = fmax(rb[D + 1] - cx * cx * is2, 1e-15);
               hit = hit || (mu2 - ea.beta * sqrt(var2) >= ea.fmin[g]);
@@ -1207,6 +1254,7 @@ __device__ __forceinline__ void many_rows(const GpDev& gp, const ManyRows<D>& rw
         if (hit) atomicOr(&ea.flags[(int64_t(z) * 16 + cand) * G + g], 1);
       }
     }
+    if (coop) __syncthreads();
     nq = 0;
   };
   // The groups, 64 at a time: the block test one group per lane, the pair test for the groups
@@ -1252,6 +1300,7 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
   __shared__ double tab[kExpTabSize];
   __shared__ __attribute__((aligned(16))) double kbuf[MODE == 1 ? 4 : 1][4 * kManyKbRow];   // B-operand transposes
   __shared__ double rows_sh[MODE == 1 ? 4 : 1][16 * (D + 3)];
+  __shared__ double red[MODE == 1 ? 4 * 4 * 4 * 64 : 1];     // [wave][block][m4][lane] partial products
   exp_tab_init(tab);
   __syncthreads();
   const int tid = threadIdx.x;
@@ -1309,8 +1358,19 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
           x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
         const ManyRows<D> rw(gps[g], g, G, ea, x, ea.mean[int64_t(g) * pts.N + rrow],
                              ea.var[int64_t(g) * pts.N + rrow], unsafe);
-        unsigned hot = many_test<D>(rw, ea, gc * kManyTestChunk, min(ngroups, (gc + 1) * kManyTestChunk),
-                                    false, tab, lane, 16);
+        const int zlo = gc * kManyTestChunk, zhi = min(ngroups, (gc + 1) * kManyTestChunk);
+        unsigned hot;
+        if (rw.kf.single) {
+          // row against group, four groups at a time (lane = 16 group + row): no pair tests here
+          bool some = false;
+#pragma unroll 4
+          for (int zz = zlo + (lane >> 4); zz < zhi; zz += 4) some = rw.row_block(ea, zz, tab) || some;
+          const unsigned long long pb = __ballot(some);
+          hot = unsigned((pb | (pb >> 16) | (pb >> 32) | (pb >> 48)) & 0xffffull);
+          EXPM_STAT(16, 1); EXPM_STAT(17, __popc(hot));
+        } else {
+          hot = many_test<D>(rw, ea, zlo, zhi, false, tab, lane, 16);
+        }
         if (hot != 0u) {                           // (wave-uniform) the rows no other item listed
           int base = 0;
           if (lane == 0) {
@@ -1325,15 +1385,24 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
       }
     }
   } else {
+    // an item = 16 listed rows x a chunk of groups.  Few items (one round of the chip's
+    // workgroups at 4 groups each): an item per WORKGROUP, its waves split the training points
+    // (many_rows, coop); otherwise an item of kManyChunk groups per wave.
     double* kbw = kbuf[wave];
     double* rowbuf = rows_sh[wave];
-    const int nch = (ngroups + kManyChunk - 1) / kManyChunk;
     for (int g = 0; g < G; ++g) {
       if (!ea.active[g]) continue;
       const int cnt = ea.count[g];
-      const int64_t total = int64_t((cnt + 15) >> 4) * nch;
+      const int nrb = (cnt + 15) >> 4;
+      const bool coop = int64_t(nrb) * ((ngroups + 3) >> 2) <= kManyCoopItems;
+      const int chunk = coop ? 4 : kManyChunk;
+      const int nch = (ngroups + chunk - 1) / chunk;
+      const int64_t total = int64_t(nrb) * nch;
+      // (coop: the item and the trip count are uniform over the workgroup -- barriers inside)
+      const int64_t first = coop ? int64_t(blockIdx.x) : int64_t(blockIdx.x) * 4 + wave;
+      const int64_t step = coop ? int64_t(gridDim.x) : int64_t(gridDim.x) * 4;
 #pragma unroll 1
-      for (int64_t item = int64_t(blockIdx.x) * 4 + wave; item < total; item += int64_t(gridDim.x) * 4) {
+      for (int64_t item = first; item < total; item += step) {
         const int rb = int(item / nch), gc = int(item - int64_t(rb) * nch);
         const int idx = rb * 16 + (lane & 15);
         const bool unsafe = idx < cnt;
@@ -1344,8 +1413,8 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
           x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
         const ManyRows<D> rw(gps[g], g, G, ea, x, ea.mean[int64_t(g) * pts.N + rrow],
                              ea.var[int64_t(g) * pts.N + rrow], unsafe);
-        many_rows<D>(gps[g], rw, ea, gc * kManyChunk, min(ngroups, (gc + 1) * kManyChunk), tab,
-                     kbw, rowbuf, lane);
+        many_rows<D>(gps[g], rw, ea, gc * chunk, min(ngroups, (gc + 1) * chunk), tab,
+                     kbw, rowbuf, red, lane, wave, coop);
       }
     }
   }
