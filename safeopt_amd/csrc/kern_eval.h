@@ -454,6 +454,22 @@ struct KernFast {
     manyn_t<4, SINGLE>(xs, ys, stride, tab, out);
   }
 
+  // ... with the single-part test resolved at compile time
+  template <bool SINGLE>
+  __device__ __forceinline__ double raw_t(const double* x, const double* y,
+                                          const double* tab) const {
+    if (SINGLE) {
+      double r2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const double t = (x[i] - y[i]) * sc[i];
+        r2 = fma(t, t, r2);
+      }
+      return of_r2s(r2, tab);
+    }
+    return kern_eval<D>(*kd, x, y);
+  }
+
   // both arguments raw (unscaled) rows
   __device__ __forceinline__ double raw(const double* x, const double* y,
                                         const double* tab) const {

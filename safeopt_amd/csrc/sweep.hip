@@ -959,7 +959,7 @@ constexpr int kManyKbRow = 80;     // doubles between the k-rows of a wave's tra
 constexpr int kManyChunk = 8;      // groups of an item of MODE 1
 constexpr int kManyTestChunk = 32; //                   of MODE 2
 constexpr int kManyListBlocks = 1024;   // workgroups of MODE 1 / 2 (4 items at a time each)
-constexpr int kManyCoopItems = 256;     // MODE 1: up to that many items of 4 groups go one per workgroup
+constexpr int kManyCoopItems = 1024;    // MODE 1: up to that many items of 4 groups go one per workgroup
 #ifdef EXPM_STATS
 __device__ unsigned long long g_expm_stats[32];
 extern "C" void sgp_debug_expm_stats(unsigned long long* out, int reset) {
@@ -973,8 +973,11 @@ extern "C" void sgp_debug_expm_stats(unsigned long long* out, int reset) {
 #define EXPM_STAT(i, v) do {} while (0)
 #endif
 
-// A wave's 16 rows (lane & 15) of one GP, what the tests need of them, and the two tests.
-template <int D>
+// A wave's 16 rows (lane & 15) of one GP, what the tests need of them, and the tests.  SINGLE:
+// a kernel of one part (resolved per GP at the top of the launch: the code of a pass is tens
+// of KB and a wave at a time per SIMD runs it -- the paths it does not take stay out of the
+// instruction cache, and the loops below are rolled where four independent chains are enough).
+template <int D, bool SINGLE>
 struct ManyRows {
   KernFast<D> kf;
   double x[D], xlo[D], xhi[D];
@@ -1007,13 +1010,22 @@ struct ManyRows {
     beta2 = ea.beta * ea.beta;
     fmin = ea.fmin[g];
   }
+  static __device__ __forceinline__ double fmin2(double a, double b) { return ::fmin(a, b); }
+
+  // mu + |delta| c - beta sqrt(var - c^2 / s2) + slack >= fmin for the largest |c| allowed
+  __device__ __forceinline__ bool reach(double cmax, double mu_, double var_, double dl, double is2) const {
+    const double mu2 = fma(dl, cmax, mu_);
+    const double var2 = fmax(var_ - cmax * cmax * is2, 1e-15);
+    const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - fmin;
+    return room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2;
+  }
 
   // The BLOCK test, one group per lane: the covariance of the closest points of the wave's
   // box and the group's box with the extremes of both sides bounds what any of the block's 256
   // pairs can reach -- most blocks are far apart and end here, for a fraction of an
   // instruction per pair (single-part kernels).
   __device__ __forceinline__ bool block(const ExpanderArgs& ea, int zz, const double* tab) const {
-    if (!kf.single) return true;
+    if (!SINGLE) return true;
     const double* bx = ea.box + int64_t(zz) * 2 * D;
     double r2 = 0.0;
 #pragma unroll
@@ -1024,12 +1036,8 @@ struct ManyRows {
     const double kmax = kf.of_r2s(r2, tab);
     const double* ag = ea.agg + (int64_t(zz) * G + g) * 4;
     const double cmax = fmin2(fma(sqx_hi, ag[2], kmax), svx_hi * ag[3]) * (1.0 + 1e-9);
-    const double mu2 = fma(ag[0], cmax, mu_hi);
-    const double var2 = fmax(var_lo - cmax * cmax * ag[1], 1e-15);
-    const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - fmin;
-    return room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2;
+    return reach(cmax, mu_hi, var_lo, ag[0], ag[1]);
   }
-  static __device__ __forceinline__ double fmin2(double a, double b) { return ::fmin(a, b); }
 
   // The same bound for the lane's OWN row against group zz (its box, its extremes): what the
   // pair tests of the row with the group's 16 candidates -- neighbours along a grid line -- can
@@ -1045,94 +1053,84 @@ struct ManyRows {
     const double kmax = kf.of_r2s(r2, tab);
     const double* ag = ea.agg + (int64_t(zz) * G + g) * 4;
     const double cmax = fmin2(fma(sqx, ag[2], kmax), svx * ag[3]) * (1.0 + 1e-9);
-    const double mu2 = fma(ag[0], cmax, mu);
-    const double var2 = fmax(var - cmax * cmax * ag[1], 1e-15);
-    const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - fmin;
-    return unsafe && room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2;
+    return unsafe && reach(cmax, mu, var, ag[0], ag[1]);
   }
 
-  // The PAIR test of group z, the lane's row against the candidates (lane >> 4) + 4 r: an
-  // upper bound of the updated lower bound from ONE covariance evaluation per (row,
+  // The PAIR tests of four groups, the lane's row against the candidates (lane >> 4) + 4 r of
+  // each: an upper bound of the updated lower bound from ONE covariance evaluation per (row,
   // candidate).  c(x) is the POSTERIOR covariance of the two:
   //   |c| <= |k(x, x_c)| + |L^-1 k_x| |L^-1 k_c|        (k_expander's bound: small far
   //                                                      from the data and the candidate)
   //   |c| <= sd(x) sd(x_c)                               (Cauchy-Schwarz on the posterior:
   //                                                      small NEXT to the data)
   // -- with the second one the rows an observation has pinned below fmin drop out for every
-  // candidate.  Squares instead of square roots (|L^-1 k_c|, sd(x_c): k_pass_aux).  No branch
-  // around the loads: several groups' tests overlap (many_test).
-  __device__ __forceinline__ bool pair(const ExpanderArgs& ea, int z, int lane, const double* tab) const {
-    const int m = min(16, m_total - 16 * z);
-    const int64_t zo = (int64_t(z) * G + g) * 16;
-    const double* xc = ea.xc + int64_t(z) * 16 * D;
-    bool possible = false;
+  // candidate.  Squares instead of square roots (|L^-1 k_c|, sd(x_c): k_pass_aux).  The four
+  // groups' loads and evaluations overlap (no branch around them); p[b]: a pair of group b passes.
+  __device__ __forceinline__ void pair4(const ExpanderArgs& ea, const int (&z)[4], int lane,
+                                        const double* tab, bool (&p)[4]) const {
 #pragma unroll
+    for (int b4 = 0; b4 < 4; ++b4) p[b4] = false;
+#pragma unroll 1
     for (int r = 0; r < 4; ++r) {
       const int cand = (lane >> 4) + 4 * r;
-      const int cc = min(cand, m - 1);
-      const double kxc = kf.raw(x, xc + cc * D, tab);
-      const double cmax = fmin2(fma(sqx, ea.stn[zo + cc], fabs(kxc)),
-                                svx * ea.svc[zo + cc]) * (1.0 + 1e-9);
-      const double mu2 = fma(fabs(ea.delta[zo + cc]), cmax, mu);
-      const double var2 = fmax(var - cmax * cmax * ea.inv_s2[zo + cc], 1e-15);
-      // mu2 - beta sqrt(var2) + slack >= fmin
-      const double room = mu2 + 1e-9 * (fabs(mu2) + 1.0) - fmin;
-      possible = possible || (cand < m && room >= 0.0 && room * room * (1.0 + 1e-9) >= beta2 * var2);
+#pragma unroll
+      for (int b4 = 0; b4 < 4; ++b4) {
+        const int m = min(16, m_total - 16 * z[b4]);
+        const int cc = min(cand, m - 1);
+        const int64_t zo = (int64_t(z[b4]) * G + g) * 16 + cc;
+        const double kxc = kf.template raw_t<SINGLE>(x, ea.xc + (int64_t(z[b4]) * 16 + cc) * D, tab);
+        const double cmax = fmin2(fma(sqx, ea.stn[zo], fabs(kxc)), svx * ea.svc[zo]) * (1.0 + 1e-9);
+        p[b4] = p[b4] || (cand < m && unsafe && reach(cmax, mu, var, fabs(ea.delta[zo]), ea.inv_s2[zo]));
+      }
     }
-    return possible && unsafe;
   }
 };
 
-// The tests alone over the groups [zlo, zhi): the 16-bit mask of the wave's rows that pass
-// the pair test of some group (`first`: out at the first group with such a row).  The groups
-// that pass the block test go through the pair test four at a time.
-template <int D>
-__device__ __forceinline__ unsigned many_test(const ManyRows<D>& rw, const ExpanderArgs& ea, int zlo,
-                                              int zhi, bool first, const double* tab, int lane,
-                                              int stat) {
-  const unsigned long long urows = __ballot(rw.unsafe) & 0xffffull;
-  unsigned long long ever = 0ull;
-  EXPM_STAT(stat, 1); EXPM_STAT(stat + 1, __popcll(urows));
+// The groups of `mask` (bit j: group zlo + j) whose pair test passes for some pair, four groups
+// at a time; rows: the 16-bit mask of the wave's rows with such a pair.
+template <int D, bool SINGLE>
+__device__ __forceinline__ unsigned long long many_pairs(const ManyRows<D, SINGLE>& rw,
+                                                         const ExpanderArgs& ea, int zlo,
+                                                         unsigned long long mask, const double* tab,
+                                                         int lane, unsigned& rows) {
+  unsigned long long todo = 0ull;
 #pragma unroll 1
-  for (int z0 = zlo; z0 < zhi; z0 += 64) {
-    const int zz = z0 + lane;
-    unsigned long long mask = __ballot(zz < zhi && rw.block(ea, zz, tab));
-    EXPM_STAT(stat + 2, min(64, zhi - z0)); EXPM_STAT(stat + 3, __popcll(mask));
-#pragma unroll 1
-    while (mask != 0ull) {
-      int zb[4];
-      zb[0] = z0 + __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
-      mask &= mask - 1ull;
+  while (mask != 0ull) {
+    int jb[4], zb[4];
+    jb[0] = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
+    mask &= mask - 1ull;
 #pragma unroll
-      for (int b4 = 1; b4 < 4; ++b4) {
-        zb[b4] = mask != 0ull ? z0 + __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask)) : zb[0];
-        mask &= mask - (mask != 0ull ? 1ull : 0ull);
-      }
-      bool possible = false;
+    for (int b4 = 1; b4 < 4; ++b4) {
+      jb[b4] = mask != 0ull ? __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask)) : jb[0];
+      mask &= mask - (mask != 0ull ? 1ull : 0ull);
+    }
 #pragma unroll
-      for (int b4 = 0; b4 < 4; ++b4) possible = rw.pair(ea, zb[b4], lane, tab) || possible;
-      const unsigned long long pb = __ballot(possible);
-      EXPM_STAT(stat + 4, 1);
-      if (pb != 0ull) {                              // wave-uniform
-        ever |= (pb | (pb >> 16) | (pb >> 32) | (pb >> 48)) & 0xffffull;
-        if (first || ever == urows) return unsigned(ever);
+    for (int b4 = 0; b4 < 4; ++b4) zb[b4] = zlo + jb[b4];
+    bool p[4];
+    rw.pair4(ea, zb, lane, tab, p);
+#pragma unroll
+    for (int b4 = 0; b4 < 4; ++b4) {
+      const unsigned long long pb = __ballot(p[b4]);
+      if (pb != 0ull) {                                        // wave-uniform
+        todo |= 1ull << jb[b4];
+        rows |= unsigned((pb | (pb >> 16) | (pb >> 32) | (pb >> 48)) & 0xffffull);
       }
     }
   }
-  return unsigned(ever);
+  return todo;
 }
 
 // MODE 1: the wave's 16 listed rows against the groups [zlo, zhi), tests and contraction.
-template <int D>
-__device__ __forceinline__ void many_rows(const GpDev& gp, const ManyRows<D>& rw, const ExpanderArgs& ea,
-                                          int zlo, int zhi, const double* tab,
+template <int D, bool SINGLE>
+__device__ __forceinline__ void many_rows(const GpDev& gp, const ManyRows<D, SINGLE>& rw,
+                                          const ExpanderArgs& ea, int zlo, int zhi, const double* tab,
                                           double* kbw, double* rowbuf, double* red, int lane,
                                           int wave, bool coop) {
   const KernFast<D>& kf = rw.kf;
   const int g = rw.g, G = rw.G;
   const int m_total = ea.m;
   double xs[D];
-  kf.prep(rw.x, xs);
+  kf.template prep_t<SINGLE>(rw.x, xs);
   const int nsteps = gp.n_pad >> 2;
   gptr_t Xj = (gptr_t)gp.Xs + (lane >> 4) * D;
   // the wave's rows for the final test of a block: [row][x | mean | var | unsafe]
@@ -1146,13 +1144,14 @@ __device__ __forceinline__ void many_rows(const GpDev& gp, const ManyRows<D>& rw
     rb[D + 2] = rw.unsafe ? 1.0 : 0.0;
   }
   __builtin_amdgcn_wave_barrier();
-  // (16 rows x 16 candidates) blocks that passed the pre-filter wait here until kQ of them
-  // are there: ONE evaluation of the rows' covariances with the training points then
-  // feeds the matrix products of all kQ blocks (the evaluation, ~25 fp64 instructions per
-  // value, costs three times the four matrix instructions it feeds)
+  // (16 rows x 16 candidates) blocks that passed the tests go kQ at a time: ONE evaluation of
+  // the rows' covariances with the training points feeds the matrix products of all kQ blocks
+  // (the evaluation, ~25 fp64 instructions per value, costs three times the four matrix
+  // instructions it feeds)
   constexpr int kQ = 4;
-  int zq[kQ];
+  unsigned zpack = 0u;            // the queue: group zlo + byte q of zpack (an item has <= 64 groups)
   int nq = 0;
+  auto zq = [&](int q) { return zlo + int((zpack >> (8 * q)) & 0xffu); };
   // The matrix products run on v_mfma_f64_4x4x4_4b_f64 -- the fp64 instruction that reaches
   // the chip's peak; the 16 x 16 x 4 form stops at two thirds of it --: per k-step four
   // instructions whose B operands are the rows' covariances with row quad m broadcast to
@@ -1175,28 +1174,30 @@ __device__ __forceinline__ void many_rows(const GpDev& gp, const ManyRows<D>& rw
     const int sbeg = coop ? 4 * ((nit * wave) >> 2) : 0;
     const int send = coop ? 4 * ((nit * (wave + 1)) >> 2) : nsteps;
     double xr[4][D], xn[4][D];
-    double a[kQ][4], an[kQ][4];
-    auto fetch = [&](int s0, double (&xo)[4][D], double (&ao)[kQ][4]) {
+    auto fetch = [&](int s0, double (&xo)[4][D]) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int k = 0; k < D; ++k) xo[q][k] = Xj[(s0 + q) * 4 * D + k];
-      // (the A operands of all queued blocks one evaluation ahead: their latency passes under it)
+    };
+    if (sbeg < send) fetch(sbeg, xr);
+#pragma unroll 1
+    for (int s0 = sbeg; s0 < send; s0 += 4) {
+      if (s0 + 4 < send) fetch(s0 + 4, xn);
+      // the A operands of all queued blocks are requested in front of the evaluation: their
+      // latency (L2) passes under it and under the other wave of the SIMD (no second set of
+      // them a step ahead: its 32 registers are the second wave)
+      double a[kQ][4];
 #pragma unroll
       for (int j = 0; j < kQ; ++j) {
         if (j < nq) {                     // (wave-uniform)
-          gptr_t W = (gptr_t)ea.Wpack + (int64_t(zq[j]) * G + g) * ea.wstride + lane;
+          gptr_t W = (gptr_t)ea.Wpack + (int64_t(zq(j)) * G + g) * ea.wstride + lane;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) ao[j][q] = W[(s0 + q) * 64];
+          for (int q = 0; q < 4; ++q) a[j][q] = W[(s0 + q) * 64];
         }
       }
-    };
-    if (sbeg < send) fetch(sbeg, xr, a);
-#pragma unroll 1
-    for (int s0 = sbeg; s0 < send; s0 += 4) {
-      if (s0 + 4 < send) fetch(s0 + 4, xn, an);
       double kv[4];
-      kf.template many<4>(xs, &xr[0][0], D, tab, kv);
+      kf.template manyn_t<4, SINGLE>(xs, &xr[0][0], D, tab, kv);
       double kb[4][4];
       broadcast_quads<kManyKbRow>(kv, kbw, lane, kb);
 #pragma unroll
@@ -1213,83 +1214,177 @@ __device__ __forceinline__ void many_rows(const GpDev& gp, const ManyRows<D>& rw
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int k = 0; k < D; ++k) xr[q][k] = xn[q][k];
-#pragma unroll
-      for (int j = 0; j < kQ; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[j][q] = an[j][q];
     }
 #pragma unroll
     for (int j = 0; j < kQ; ++j)
-      if (j < nq)
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) red[((wave * kQ + j) * 4 + m4) * 64 + lane] = acc[j][m4];
+      for (int m4 = 0; m4 < 4; ++m4) red[((wave * kQ + j) * 4 + m4) * 64 + lane] = acc[j][m4];
     if (coop) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    // the final test of the blocks (coop: block j belongs to wave j), the products from LDS
     const int cand = 4 * ((lane >> 2) & 3) + (lane >> 4);
+    const int jlo = coop ? wave : 0, jhi = coop ? min(wave + 1, nq) : nq;
+#pragma unroll 1
+    for (int j = jlo; j < jhi; ++j) {
+      const int z = zq(j);
+      const int m = min(16, m_total - 16 * z);
+      const int64_t zo = (int64_t(z) * G + g) * 16;
+      const double* xc = ea.xc + int64_t(z) * 16 * D;
+      bool hit = false;
+      if (cand < m) {
+        const double dl = ea.delta[zo + cand], is2 = ea.inv_s2[zo + cand];
 #pragma unroll
-    for (int j = 0; j < kQ; ++j) {
-      if (j < nq && (!coop || j == wave)) {            // (coop: block j belongs to wave j)
-        const int z = zq[j];
-        const int m = min(16, m_total - 16 * z);
-        const int64_t zo = (int64_t(z) * G + g) * 16;
-        const double* xc = ea.xc + int64_t(z) * 16 * D;
-        bool hit = false;
-        if (cand < m) {
-          const double dl = ea.delta[zo + cand], is2 = ea.inv_s2[zo + cand];
+        for (int m4 = 0; m4 < 4; ++m4) {
+          const double* rb = rowbuf + (4 * m4 + (lane & 3)) * (D + 3);
+          if (rb[D + 2] != 0.0) {                       // an unsafe row of the grid
+            double dot = red[(((coop ? 0 : wave) * kQ + j) * 4 + m4) * 64 + lane];
+            if (coop) {                                 // (in the order of the training points)
 #pragma unroll
-          for (int m4 = 0; m4 < 4; ++m4) {
-            const double* rb = rowbuf + (4 * m4 + (lane & 3)) * (D + 3);
-            if (rb[D + 2] != 0.0) {                       // an unsafe row of the grid
-              double dot = red[(((coop ? 0 : wave) * kQ + j) * 4 + m4) * 64 + lane];
-              if (coop) {                                 // (in the order of the training points)
-#pragma unroll
-                for (int w = 1; w < 4; ++w) dot += red[((w * kQ + j) * 4 + m4) * 64 + lane];
-              }
-              const double cx = kf.raw(rb, xc + cand * D, tab) - dot;
-              const double mu2 = rb[D] + cx * dl;
-              const double var2 = fmax(rb[D + 1] - cx * cx * is2, 1e-15);
-              hit = hit || (mu2 - ea.beta * sqrt(var2) >= ea.fmin[g]);
+              for (int w = 1; w < 4; ++w) dot += red[((w * kQ + j) * 4 + m4) * 64 + lane];
             }
+            const double cx = kf.template raw_t<SINGLE>(rb, xc + cand * D, tab) - dot;
+            const double mu2 = rb[D] + cx * dl;
+            const double var2 = fmax(rb[D + 1] - cx * cx * is2, 1e-15);
+            hit = hit || (mu2 - ea.beta * sqrt(var2) >= ea.fmin[g]);
           }
         }
-        if (hit) atomicOr(&ea.flags[(int64_t(z) * 16 + cand) * G + g], 1);
       }
+      if (hit) atomicOr(&ea.flags[(int64_t(z) * 16 + cand) * G + g], 1);
     }
     if (coop) __syncthreads();
     nq = 0;
   };
-  // The groups, 64 at a time: the block test one group per lane, the pair test for the groups
-  // that are left, the blocks with a possible pair into the queue.
-  int z0 = zlo;
-  unsigned long long mask = 0ull;
-  bool done = false;
+  // The item's groups (at most 64): the block test one group per lane, the pair test for the
+  // groups that are left four at a time (their loads and evaluations overlap: at one wave per
+  // SIMD nothing else hides them), then the blocks with a possible pair, four per evaluation.
+  static_assert(kManyChunk <= 64, "one block test per item");
   EXPM_STAT(8, 1);
+  const unsigned long long mask = __ballot(zlo + lane < zhi && rw.block(ea, zlo + lane, tab));
+  unsigned rows = 0u;
+  unsigned long long todo = many_pairs<D, SINGLE>(rw, ea, zlo, mask, tab, lane, rows);
 #pragma unroll 1
-  while (true) {
-    if (mask == 0ull) {
-      if (z0 >= zhi) {
-        done = true;
-      } else {
-        const int zz = z0 + lane;
-        mask = __ballot(zz < zhi && rw.block(ea, zz, tab));
-        z0 += 64;
-        if (mask == 0ull) continue;
-      }
-    }
-    if (!done) {
-      const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
-      mask &= mask - 1ull;
-      const int z = z0 - 64 + j;
-      if (__ballot(rw.pair(ea, z, lane, tab)) != 0ull) {       // wave-uniform
-        EXPM_STAT(9, 1);
-        // (slot of the queue by a chain of uniform tests: the indices stay in scalar registers)
+  while (todo != 0ull) {
+    zpack = 0u;
 #pragma unroll
-        for (int q = 0; q < kQ; ++q)
-          if (q == nq) zq[q] = z;
-        ++nq;
+    for (int q = 0; q < kQ; ++q) {
+      if (todo != 0ull) {
+        zpack |= unsigned(__builtin_amdgcn_readfirstlane(__builtin_ctzll(todo))) << (8 * q);
+        todo &= todo - 1ull;
+        nq = q + 1;
+        EXPM_STAT(9, 1);
       }
     }
-    if (nq == kQ || (done && nq > 0)) flush();
-    if (done) break;
+    flush();
+  }
+}
+
+// One GP of a launch (see k_expander_many).
+template <int D, int MODE, bool SINGLE>
+__device__ __forceinline__ void many_gp(const GpDev* gps, int g, int G, const SweepPoints& pts,
+                                        const ExpanderArgs& ea, int ngroups, const double* tab,
+                                        double* kbw, double* rowbuf, double* red, int lane, int wave) {
+  const int64_t nwaves = (pts.N + 15) >> 4;        // 16-row segments of the shard
+  auto rows_of = [&](int64_t rrow, bool unsafe) {
+    double x[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
+    return ManyRows<D, SINGLE>(gps[g], g, G, ea, x, ea.mean[int64_t(g) * pts.N + rrow],
+                               ea.var[int64_t(g) * pts.N + rrow], unsafe);
+  };
+  if (MODE == 0) {
+    const int64_t wid = int64_t(blockIdx.x) * 4 + wave;
+    const int64_t row = wid * 16 + (lane & 15);
+    const bool valid = row < pts.N;
+    const int64_t rrow = valid ? row : pts.N - 1;
+    const bool unsafe = valid && (ea.S[rrow] == 0);
+    if (__ballot(unsafe) == 0ull) return;          // (wave-uniform)
+    const ManyRows<D, SINGLE> rw = rows_of(rrow, unsafe);
+    // (the block test alone, 64 groups at a time: no wave of the scan waits for a chain of
+    // pair tests -- the waves next to the band pass the block test for most groups and the
+    // pair test for none)
+    bool some = false;
+    EXPM_STAT(0, 1); EXPM_STAT(1, __popcll(__ballot(unsafe) & 0xffffull));
+#pragma unroll 1
+    for (int z0 = 0; z0 < ngroups && !some; z0 += 64) {
+      const int zz = z0 + lane;
+      some = __ballot(zz < ngroups && rw.block(ea, zz, tab)) != 0ull;
+      EXPM_STAT(2, min(64, ngroups - z0));
+    }
+    EXPM_STAT(3, some);
+    if (some && lane == 0) {
+      const int at = atomicAdd(&ea.wcount[g], 1);
+      ea.wlist[int64_t(g) * nwaves + at] = int(wid);
+      ea.wmask[int64_t(g) * nwaves + at] = 0u;
+    }
+  } else if (MODE == 2) {
+    const int nch = (ngroups + kManyTestChunk - 1) / kManyTestChunk;
+    const int64_t total = int64_t(ea.wcount[g]) * nch;
+#pragma unroll 1
+    for (int64_t item = int64_t(blockIdx.x) * 4 + wave; item < total; item += int64_t(gridDim.x) * 4) {
+      const int hw = int(item / nch), gc = int(item - int64_t(hw) * nch);
+      const int64_t row = int64_t(ea.wlist[int64_t(g) * nwaves + hw]) * 16 + (lane & 15);
+      const bool valid = row < pts.N;
+      const int64_t rrow = valid ? row : pts.N - 1;
+      const bool unsafe = valid && (ea.S[rrow] == 0);
+      const ManyRows<D, SINGLE> rw = rows_of(rrow, unsafe);
+      const int zlo = gc * kManyTestChunk, zhi = min(ngroups, (gc + 1) * kManyTestChunk);
+      unsigned hot = 0u;
+      if (SINGLE) {
+        // row against group, four groups at a time (lane = 16 group + row): no pair tests here
+        bool some = false;
+#pragma unroll 4
+        for (int zz = zlo + (lane >> 4); zz < zhi; zz += 4) some = rw.row_block(ea, zz, tab) || some;
+        const unsigned long long pb = __ballot(some);
+        hot = unsigned((pb | (pb >> 16) | (pb >> 32) | (pb >> 48)) & 0xffffull);
+      } else {
+        static_assert(kManyTestChunk <= 64, "one mask per item");
+        many_pairs<D, SINGLE>(rw, ea, zlo, (zhi - zlo >= 64) ? ~0ull : ((1ull << (zhi - zlo)) - 1ull),
+                              tab, lane, hot);
+      }
+      EXPM_STAT(16, 1); EXPM_STAT(17, __popc(hot));
+      if (hot != 0u) {                           // (wave-uniform) the rows no other item listed
+        int base = 0;
+        if (lane == 0) {
+          hot &= ~atomicOr(&ea.wmask[int64_t(g) * nwaves + hw], hot);
+          if (hot != 0u) base = atomicAdd(&ea.count[g], __popc(hot));
+        }
+        hot = __builtin_amdgcn_readfirstlane(hot);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < 16 && ((hot >> lane) & 1u))
+          ea.list[int64_t(g) * pts.N + base + __popc(hot & ((1u << lane) - 1u))] = int(rrow);
+      }
+    }
+  } else {
+    // an item = 16 listed rows x a chunk of groups.  Few items (one round of the chip's
+    // workgroups at 4 groups each): an item per WORKGROUP, its waves split the training points
+    // (many_rows, coop); otherwise an item of kManyChunk groups per wave.
+    const int cnt = ea.count[g];
+    const int nrb = (cnt + 15) >> 4;
+    const bool coop = int64_t(nrb) * ((ngroups + 3) >> 2) <= kManyCoopItems;
+    const int chunk = coop ? 4 : kManyChunk;
+    const int nch = (ngroups + chunk - 1) / chunk;
+    const int64_t total = int64_t(nrb) * nch;
+    // (coop: the item and the trip count are uniform over the workgroup -- barriers inside)
+    // Items in chunk-major order, and a contiguous range of them per XCD (workgroup b runs on
+    // XCD b % 8, each with its own L2): the waves in flight at a time then contract the SAME
+    // few chunks against different rows -- the groups' A operands (n x 16 doubles each, 10 MB
+    // a pass of 6000 candidates at n = 217) are fetched into an L2 once instead of once per
+    // 16 rows.
+    const int per = coop ? 1 : 4;                                  // items of a workgroup at a time
+    const int64_t share = (total + 7) >> 3;                        // of an XCD
+    const int64_t xend = min(total, share * ((blockIdx.x & 7) + 1));
+    const int64_t step = int64_t(gridDim.x >> 3) * per;
+#pragma unroll 1
+    for (int64_t item = share * (blockIdx.x & 7) + int64_t(blockIdx.x >> 3) * per + (coop ? 0 : wave);
+         item < xend; item += step) {
+      const int gc = int(item / nrb), rb = int(item - int64_t(gc) * nrb);
+      const int idx = rb * 16 + (lane & 15);
+      const bool unsafe = idx < cnt;
+      const int64_t rrow = ea.list[int64_t(g) * pts.N + (unsafe ? idx : cnt - 1)];
+      const ManyRows<D, SINGLE> rw = rows_of(rrow, unsafe);
+      many_rows<D, SINGLE>(gps[g], rw, ea, gc * chunk, min(ngroups, (gc + 1) * chunk), tab,
+                           kbw, rowbuf, red, lane, wave, coop);
+    }
   }
 }
 
@@ -1306,117 +1401,14 @@ __global__ __launch_bounds__(256) void k_expander_many(const GpDev* gps, int G,
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int64_t nwaves = (pts.N + 15) >> 4;        // 16-row segments of the shard
-  if (MODE == 0) {
-    const int64_t wid = int64_t(blockIdx.x) * 4 + wave;
-    const int64_t row = wid * 16 + (lane & 15);
-    const bool valid = row < pts.N;
-    const int64_t rrow = valid ? row : pts.N - 1;
-    const bool unsafe = valid && (ea.S[rrow] == 0);
-    if (__ballot(unsafe) == 0ull) return;          // (wave-uniform)
-    double x[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k)
-      x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
-    for (int g = 0; g < G; ++g) {
-      if (!ea.active[g]) continue;
-      const ManyRows<D> rw(gps[g], g, G, ea, x, ea.mean[int64_t(g) * pts.N + rrow],
-                           ea.var[int64_t(g) * pts.N + rrow], unsafe);
-      // (the block test alone, 64 groups at a time: no wave of the scan waits for a chain of
-      // pair tests -- the waves next to the band pass the block test for most groups and the
-      // pair test for none)
-      bool some = false;
-      EXPM_STAT(0, 1); EXPM_STAT(1, __popcll(__ballot(unsafe) & 0xffffull));
-#pragma unroll 1
-      for (int z0 = 0; z0 < ngroups && !some; z0 += 64) {
-        const int zz = z0 + lane;
-        some = __ballot(zz < ngroups && rw.block(ea, zz, tab)) != 0ull;
-        EXPM_STAT(2, min(64, ngroups - z0));
-      }
-      EXPM_STAT(3, some);
-      if (some && lane == 0) {
-        const int at = atomicAdd(&ea.wcount[g], 1);
-        ea.wlist[int64_t(g) * nwaves + at] = int(wid);
-        ea.wmask[int64_t(g) * nwaves + at] = 0u;
-      }
-    }
-  } else if (MODE == 2) {
-    const int nch = (ngroups + kManyTestChunk - 1) / kManyTestChunk;
-    for (int g = 0; g < G; ++g) {
-      if (!ea.active[g]) continue;
-      const int64_t total = int64_t(ea.wcount[g]) * nch;
-#pragma unroll 1
-      for (int64_t item = int64_t(blockIdx.x) * 4 + wave; item < total; item += int64_t(gridDim.x) * 4) {
-        const int hw = int(item / nch), gc = int(item - int64_t(hw) * nch);
-        const int64_t row = int64_t(ea.wlist[int64_t(g) * nwaves + hw]) * 16 + (lane & 15);
-        const bool valid = row < pts.N;
-        const int64_t rrow = valid ? row : pts.N - 1;
-        const bool unsafe = valid && (ea.S[rrow] == 0);
-        double x[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-          x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
-        const ManyRows<D> rw(gps[g], g, G, ea, x, ea.mean[int64_t(g) * pts.N + rrow],
-                             ea.var[int64_t(g) * pts.N + rrow], unsafe);
-        const int zlo = gc * kManyTestChunk, zhi = min(ngroups, (gc + 1) * kManyTestChunk);
-        unsigned hot;
-        if (rw.kf.single) {
-          // row against group, four groups at a time (lane = 16 group + row): no pair tests here
-          bool some = false;
-#pragma unroll 4
-          for (int zz = zlo + (lane >> 4); zz < zhi; zz += 4) some = rw.row_block(ea, zz, tab) || some;
-          const unsigned long long pb = __ballot(some);
-          hot = unsigned((pb | (pb >> 16) | (pb >> 32) | (pb >> 48)) & 0xffffull);
-          EXPM_STAT(16, 1); EXPM_STAT(17, __popc(hot));
-        } else {
-          hot = many_test<D>(rw, ea, zlo, zhi, false, tab, lane, 16);
-        }
-        if (hot != 0u) {                           // (wave-uniform) the rows no other item listed
-          int base = 0;
-          if (lane == 0) {
-            hot &= ~atomicOr(&ea.wmask[int64_t(g) * nwaves + hw], hot);
-            if (hot != 0u) base = atomicAdd(&ea.count[g], __popc(hot));
-          }
-          hot = __builtin_amdgcn_readfirstlane(hot);
-          base = __builtin_amdgcn_readfirstlane(base);
-          if (lane < 16 && ((hot >> lane) & 1u))
-            ea.list[int64_t(g) * pts.N + base + __popc(hot & ((1u << lane) - 1u))] = int(rrow);
-        }
-      }
-    }
-  } else {
-    // an item = 16 listed rows x a chunk of groups.  Few items (one round of the chip's
-    // workgroups at 4 groups each): an item per WORKGROUP, its waves split the training points
-    // (many_rows, coop); otherwise an item of kManyChunk groups per wave.
-    double* kbw = kbuf[wave];
-    double* rowbuf = rows_sh[wave];
-    for (int g = 0; g < G; ++g) {
-      if (!ea.active[g]) continue;
-      const int cnt = ea.count[g];
-      const int nrb = (cnt + 15) >> 4;
-      const bool coop = int64_t(nrb) * ((ngroups + 3) >> 2) <= kManyCoopItems;
-      const int chunk = coop ? 4 : kManyChunk;
-      const int nch = (ngroups + chunk - 1) / chunk;
-      const int64_t total = int64_t(nrb) * nch;
-      // (coop: the item and the trip count are uniform over the workgroup -- barriers inside)
-      const int64_t first = coop ? int64_t(blockIdx.x) : int64_t(blockIdx.x) * 4 + wave;
-      const int64_t step = coop ? int64_t(gridDim.x) : int64_t(gridDim.x) * 4;
-#pragma unroll 1
-      for (int64_t item = first; item < total; item += step) {
-        const int rb = int(item / nch), gc = int(item - int64_t(rb) * nch);
-        const int idx = rb * 16 + (lane & 15);
-        const bool unsafe = idx < cnt;
-        const int64_t rrow = ea.list[int64_t(g) * pts.N + (unsafe ? idx : cnt - 1)];
-        double x[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-          x[k] = pts.base[rrow * pts.stride_row + k * pts.stride_col];
-        const ManyRows<D> rw(gps[g], g, G, ea, x, ea.mean[int64_t(g) * pts.N + rrow],
-                             ea.var[int64_t(g) * pts.N + rrow], unsafe);
-        many_rows<D>(gps[g], rw, ea, gc * chunk, min(ngroups, (gc + 1) * chunk), tab,
-                     kbw, rowbuf, red, lane, wave, coop);
-      }
-    }
+  double* kbw = kbuf[MODE == 1 ? wave : 0];
+  double* rowbuf = rows_sh[MODE == 1 ? wave : 0];
+  for (int g = 0; g < G; ++g) {
+    if (!ea.active[g]) continue;
+    if (__builtin_amdgcn_readfirstlane(int(gps[g].kern.n_parts == 1)))
+      many_gp<D, MODE, true>(gps, g, G, pts, ea, ngroups, tab, kbw, rowbuf, red, lane, wave);
+    else
+      many_gp<D, MODE, false>(gps, g, G, pts, ea, ngroups, tab, kbw, rowbuf, red, lane, wave);
   }
 }
 

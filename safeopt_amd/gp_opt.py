@@ -983,10 +983,25 @@ class SafeOpt(GaussianProcessOptimization):
                 return self._visit_in_big_passes_nrank(beta, active, False, cut_w, cut_idx)
             K = _hip.TOPK
 
-    #: candidates per pass of ``_visit_in_big_passes`` (the last entry repeats)
-    pass_sizes = (256, 2048, 8192)
+    #: candidates per pass of ``_visit_in_big_passes`` (the last entry repeats); None: by the
+    #: number of observations (``_pass_size``)
+    pass_sizes = None
     #: False: the expander loop of a large grid stays at SGP_TOPK candidates per round trip
     big_passes = True
+
+    def _pass_size(self, k):
+        """Candidates of pass k.  A pass costs a scan of the unsafe rows whatever its size
+        (0.1-0.2 ms at 1e6 rows) plus the candidates' operands, 4 n^2 flop each: the first pass
+        takes what keeps the operands at about 1e9 flop -- 8192 candidates up to n = 250, 1024
+        at n = 640, 256 from n = 1000 on, so that an expander among the first candidates stays
+        cheap to find --, the following ones 8 times as many each, up to 8192."""
+        if self.pass_sizes is not None:
+            return self.pass_sizes[min(k, len(self.pass_sizes) - 1)]
+        n = max(int(gp.X.shape[0]) for gp in self.gps)
+        first = 256
+        while first < 8192 and 2 * first * n * n <= 5e8:
+            first *= 2
+        return min(8192, first * 8 ** min(k, 2))
 
     def _visit_in_big_passes(self, beta, active, full_sets, cut_w, cut_idx):
         """The expander loop of gp_opt.py:557-612 behind the cut, one rank, where it goes
@@ -1004,7 +1019,7 @@ class SafeOpt(GaussianProcessOptimization):
         else:
             lo, hi, mode = 0.0, float(cut_w), 0             # keys: the interval widths
         for k in range(1 << 30):
-            want = self.pass_sizes[min(k, len(self.pass_sizes) - 1)]
+            want = self._pass_size(k)
             tested, hits, key, row, left = be.expander_pass(beta, self.fmin, mode, cut_w,
                                                             cut_idx, lo, hi, want)
             if hits and not full_sets:
@@ -1035,7 +1050,7 @@ class SafeOpt(GaussianProcessOptimization):
             lo, hi, mode = 0.0, float(cut_w), 0
         nbins = 4096
         for k in range(1 << 30):
-            want = self.pass_sizes[min(k, len(self.pass_sizes) - 1)]
+            want = self._pass_size(k)
             hist = comm.allgather(be.pass_hist(mode, cut_w, cut_idx, lo, hi).astype(np.float64))
             from_top = np.cumsum(hist.sum(axis=0)[::-1])
             if from_top[-1] == 0:

@@ -64,7 +64,17 @@ def test_converged_run_visits_every_candidate_and_marks_none(mods):
     assert_array_equal(opt.M, M)
     assert_array_equal(opt.G, Gm)
     assert_array_equal(x, grid[idx])
-    assert calls == [256, 2048, 8192]        # 16 + 256 + 2048 + the rest of the candidates
+    assert calls == [1024, 8192]             # (n = 637: SafeOpt._pass_size) the first candidate + 1024 + the rest
+    # ... and in three passes
+    opt3 = safeopt_amd.SafeOpt(sc.make_gp(gpy, data), grid, 0.0, threshold=thr)
+    opt3.pass_sizes = (256, 2048, 8192)
+    calls3 = []
+    orig3 = opt3._backend.expander_pass
+    opt3._backend.expander_pass = lambda *a: calls3.append(a[-1]) or orig3(*a)
+    x3 = opt3.optimize()
+    assert calls3 == [256, 2048, 8192]
+    assert_array_equal(opt3.G, Gm)
+    assert_array_equal(x3, grid[idx])
     # the 16-candidates-per-round-trip loop (round 5): same sets, same point
     ref = safeopt_amd.SafeOpt(sc.make_gp(gpy, data), grid, 0.0, threshold=thr)
     ref.big_passes = False
