@@ -260,6 +260,15 @@ int sgp_grid_expander_batch(sgp_grid* grid, sgp_gp* const* gps, int G, double be
 int sgp_grid_expander_pass(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                            const double* fmin, int mode, double cut_w, int64_t cut_idx,
                            double key_lo, double key_hi, int want, double* out6);
+/* The same pass with Lipschitz certificates (safeopt/gp_opt.py:558-576 in place of :577-606):
+ * candidate c is an expander when for every GP i with a constraint some unsafe row x has
+ * u_i(x_c) - L_i |x_c - x|_2 >= fmin_i -- the comparison of sgp_grid_lipschitz_check per
+ * (row, candidate), the pairs pruned by bounding boxes of 16 rows / 16 candidates.
+ * Selection, modes and out6 as sgp_grid_expander_pass.  One rank.                       */
+int sgp_grid_lipschitz_pass(sgp_grid* grid, int G, const double* fmin,
+                            const double* lipschitz, int mode, double cut_w,
+                            int64_t cut_idx, double key_lo, double key_hi, int want,
+                            double* out6);
 
 /* The same pass on N ranks (safeopt/gp_opt.py:557-612 on a row-sharded grid), in three calls
  * with the ranks' agreement in between: (1) this shard's 4096-bin histogram of the keys of its

@@ -98,6 +98,8 @@ PROTOTYPES = {
     "sgp_grid_expander_pass": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p, C.c_int,
                                          C.c_double, C.c_int64, C.c_double, C.c_double, C.c_int,
                                          c_double_p]),
+    "sgp_grid_lipschitz_pass": (C.c_int, [vp, C.c_int, c_double_p, c_double_p, C.c_int, C.c_double,
+                                          C.c_int64, C.c_double, C.c_double, C.c_int, c_double_p]),
     "sgp_grid_pass_hist": (C.c_int, [vp, C.c_int, C.c_double, C.c_int64, C.c_double, C.c_double,
                                      c_u32_p]),
     "sgp_grid_pass_list": (C.c_int, [vp, C.c_int, C.c_double, C.c_int64, C.c_double, C.c_int,
@@ -715,6 +717,16 @@ class DeviceGrid(object):
         self.ctx.check(lib().sgp_grid_expander_pass(
             self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin), int(mode), float(cut_w),
             int(cut_idx), float(key_lo), float(key_hi), int(want), dptr(out)))
+        return int(out[0]), int(out[1]), float(out[2]), int(out[3]), float(out[4])
+
+    def lipschitz_pass(self, fmin, lipschitz, mode, cut_w, cut_idx, key_lo, key_hi, want):
+        """The same pass with Lipschitz certificates (``sgp_grid_lipschitz_pass``); result as
+        ``expander_pass``."""
+        fmin, lipschitz = f64(fmin), f64(lipschitz)
+        out = np.zeros(6)
+        self.ctx.check(lib().sgp_grid_lipschitz_pass(
+            self.h, len(fmin), dptr(fmin), dptr(lipschitz), int(mode), float(cut_w), int(cut_idx),
+            float(key_lo), float(key_hi), int(want), dptr(out)))
         return int(out[0]), int(out[1]), float(out[2]), int(out[3]), float(out[4])
 
     def pass_hist(self, mode, cut_w, cut_idx, key_lo, key_hi):

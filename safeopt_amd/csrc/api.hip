@@ -1322,6 +1322,57 @@ int sgp_grid_expander_pass(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   return 0;
 }
 
+// The same pass with Lipschitz certificates (gp_opt.py:558-576 instead of :577-606): selection
+// as above, then the distance test of ALL listed candidates in one scan (k_lip_*).  out6 as
+// sgp_grid_expander_pass.  One rank.
+int sgp_grid_lipschitz_pass(sgp_grid* g, int G, const double* fmin, const double* lipschitz,
+                            int mode, double cut_w, int64_t cut_idx, double key_lo,
+                            double key_hi, int want, double* out6) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  SGP_CHECK(ctx, want >= 1, "want = %d", want);
+  SGP_CHECK(ctx, key_hi > key_lo, "empty key range %g .. %g", key_lo, key_hi);
+  SGP_CHECK(ctx, g->N < (int64_t(1) << 31), "%lld rows", (long long)g->N);
+  for (int i = 0; i < 6; ++i) out6[i] = 0.0;
+  const size_t nl = (size_t(g->N) * 4 + 63) & ~size_t(63);      // list | histogram | sel | counts
+  char* sb = static_cast<char*>(sgp_scratch(ctx, 8, nl + 16384 + 256 + (size_t(g->N) / 256 + 2) * 4));
+  SGP_CHECK(ctx, sb, "device allocation failed: %s", ctx->err.c_str());
+  int* list = reinterpret_cast<int*>(sb);
+  unsigned* hist = reinterpret_cast<unsigned*>(sb + nl);
+  char* sel = sb + nl + 16384;
+  int* counts = reinterpret_cast<int*>(sb + nl + 16384 + 256);
+  SGP_TRY(launch_pass_select(g, mode, cut_w, cut_idx, key_lo, key_hi, want, sel, list, hist, counts));
+  struct { double thr; int count, est; } hs;
+  SGP_TRY(sgp_d2h(ctx, &hs, sel, sizeof(hs)));
+  const int count = hs.count;
+  out6[0] = double(count);
+  out6[4] = hs.thr;
+  if (count == 0) {
+    out6[4] = -INFINITY;
+    return 0;
+  }
+  const int d = g->d;
+  const size_t ngroups = (size_t(count) + 15) / 16;
+  double* work = static_cast<double*>(
+      sgp_scratch(ctx, 9, (size_t(count) * (d + G) + ngroups * (2 * d + 1) + 8) * 8));
+  SGP_CHECK(ctx, work, "device allocation failed: %s", ctx->err.c_str());
+  int32_t* dfl = static_cast<int32_t*>(sgp_scratch(ctx, 11, size_t(count) * G * 4 + 64));
+  SGP_CHECK(ctx, dfl, "device allocation failed: %s", ctx->err.c_str());
+  double* res = reinterpret_cast<double*>(reinterpret_cast<char*>(dfl) + size_t(count) * G * 4);
+  res = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(res) + 7) & ~uintptr_t(7));
+  SGP_TRY(launch_lipschitz_many(g, G, fmin, lipschitz, list, count, nullptr, nullptr, work, dfl));
+  SGP_TRY(launch_pass_result(g, list, count, dfl, fmin, mode, res));
+  double hr[3];
+  SGP_TRY(sgp_d2h(ctx, hr, res, sizeof(hr)));
+  out6[1] = hr[0];
+  out6[2] = hr[1];
+  int64_t bi;
+  memcpy(&bi, &hr[2], 8);
+  out6[3] = double(bi);
+  return 0;
+}
+
 // ---- the same pass on N ranks, in three calls with the ranks' agreement in between ----------
 // (SafeOpt._visit_in_big_passes_nrank): every rank's histogram of the keys behind the cut
 // (the ranks sum them and pick ONE threshold), every rank's candidates above it with what the

@@ -424,6 +424,12 @@ int launch_pass_list(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, void*
 int launch_pass_gather(sgp_grid* g, const int* list_dev, int count, int mode, int64_t* gidx,
                        double* key, double* x, double* resid);
 int launch_pass_stage(sgp_grid* g, const int* list_dev, int count, double* xc, double* resid);
+// the Lipschitz test of many candidates (sets.hip: k_lip_*): rows and upper bounds staged from
+// list_dev (local rows) or copied from the host arrays; work: (count (d + G) + groups (2 d + 1))
+// doubles on the device
+int launch_lipschitz_many(sgp_grid* g, int G, const double* fmin, const double* lipschitz,
+                          const int* list_dev, int count, const double* xc_in, const double* uc_in,
+                          double* work, int32_t* flags_dev);
 int launch_pass_result(sgp_grid* g, const int* list_dev, int count, const int32_t* flags_dev,
                        const double* fmin, int mode, double* res_dev);
 int launch_topk(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, int k,

@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int T = 256;
+static __device__ __forceinline__ double fmin2(double a, double b) { return ::fmin(a, b); }
 
 // S = all(Q[:, ::2] > fmin); partial[block] = max l0 over safe rows
 __global__ __launch_bounds__(T) void k_safe_set(const double* Q, int64_t N,
@@ -1058,6 +1059,156 @@ __global__ __launch_bounds__(T) void k_pass_stage(const int* list, int count, co
         Q[li * 2 * G + 2 * g + 1] - mean[int64_t(g) * N + li];
 }
 
+// ---- the Lipschitz test of MANY candidates (sgp_grid_lipschitz_pass) ---------------------
+// gp_opt.py:558-576 for every candidate of a pass: candidate c is an expander when for every
+// GP i with a constraint SOME unsafe row x has u_i(x_c) - L_i |x_c - x| >= fmin_i -- the
+// comparison is monotone in the distance, so that is: the unsafe row NEAREST to x_c passes
+// for every such GP, and one flag per candidate is enough.  The pairs are pruned by boxes:
+// per group of 16 listed candidates (neighbours along a grid line) the bounding box and the
+// largest radius rho_c = min_i (u_i - fmin_i) / L_i (+ room for the rounding of the comparison)
+// any of them has; a 16-row segment of the grid whose box is further than that from the
+// group's box has no pair to test.  What is left gets the arithmetic of k_lipschitz.
+__global__ __launch_bounds__(T) void k_lip_stage(const int* list, int count, const double* pts,
+                                                 const double* Q, int64_t N, int d, int G,
+                                                 double* xc, double* uc) {
+  const int pos = blockIdx.x * T + threadIdx.x;
+  if (pos >= count) return;
+  const int64_t li = list[pos];
+  for (int k = 0; k < d; ++k) xc[int64_t(pos) * d + k] = pts[int64_t(k) * N + li];
+  for (int g = 0; g < G; ++g) uc[int64_t(pos) * G + g] = Q[li * 2 * G + 2 * g + 1];
+}
+
+__global__ __launch_bounds__(T) void k_lip_agg(int count, int d, int G, Vec8 fmin, Vec8 lips,
+                                               const double* xc, const double* uc, double* box,
+                                               double* rad, int ngroups) {
+  const int z = blockIdx.x * T + threadIdx.x;
+  if (z >= ngroups) return;
+  const int m = min(16, count - 16 * z);
+  double rmax = -INFINITY;
+  for (int c = 0; c < m; ++c) {
+    double rc = INFINITY;
+    for (int g = 0; g < G; ++g) {
+      if (fmin.v[g] == -INFINITY) continue;
+      const double u = uc[(int64_t(z) * 16 + c) * G + g];
+      const double room = (u - fmin.v[g]) + 1e-9 * (fabs(u) + fabs(fmin.v[g]) + 1.0);
+      const double r = lips.v[g] > 0.0 ? room / lips.v[g] : (room >= 0.0 ? INFINITY : -INFINITY);
+      rc = fmin2(rc, r);
+    }
+    rmax = fmax(rmax, rc);
+  }
+  rad[z] = rmax;
+  for (int k = 0; k < d; ++k) {
+    double lo = INFINITY, hi = -INFINITY;
+    for (int c = 0; c < m; ++c) {
+      const double v = xc[(int64_t(z) * 16 + c) * d + k];
+      lo = fmin2(lo, v);
+      hi = fmax(hi, v);
+    }
+    box[(int64_t(z) * 2 + 0) * d + k] = lo;
+    box[(int64_t(z) * 2 + 1) * d + k] = hi;
+  }
+}
+
+struct LipPass {
+  const double* pts;
+  const uint8_t* S;
+  int64_t N;
+  int d, G, m, ngroups;
+  Vec8 fmin, lips;
+  const double* xc;     // [m][d]
+  const double* uc;     // [m][G]
+  const double* box;    // [group][2][d]
+  const double* rad;    // [group]
+  int32_t* flags;       // [m][G]
+  int* wcount;          // segments with a group in reach: count, list
+  int* wlist;
+};
+
+// the wave's 16 rows (lane & 15), their box, and the block test of group zz
+struct LipRows {
+  double x[SGP_MAX_D], lo[SGP_MAX_D], hi[SGP_MAX_D];
+  bool unsafe;
+  __device__ __forceinline__ LipRows(const LipPass& a, int64_t wid, int lane) {
+    const int64_t i = wid * 16 + (lane & 15);
+    unsafe = (i < a.N) && (a.S[i] == 0);
+    for (int k = 0; k < a.d; ++k) {
+      x[k] = unsafe ? a.pts[int64_t(k) * a.N + i] : 0.0;
+      double l = unsafe ? x[k] : INFINITY, h = unsafe ? x[k] : -INFINITY;
+      for (int o = 8; o >= 1; o >>= 1) {
+        l = fmin2(l, __shfl_xor(l, o, 64));
+        h = fmax(h, __shfl_xor(h, o, 64));
+      }
+      lo[k] = l;
+      hi[k] = h;
+    }
+  }
+  __device__ __forceinline__ bool in_reach(const LipPass& a, int zz) const {
+    const double r = a.rad[zz];
+    if (!(r >= 0.0)) return false;
+    const double* bx = a.box + int64_t(zz) * 2 * a.d;
+    double d2 = 0.0;
+    for (int k = 0; k < a.d; ++k) {
+      const double gap = fmax(fmax(bx[k] - hi[k], lo[k] - bx[a.d + k]), 0.0);
+      d2 += gap * gap;
+    }
+    return d2 <= r * r * (1.0 + 1e-9);        // (r = inf: in reach)
+  }
+};
+
+// the scan of the grid: the segments with a group in reach (one group per lane)
+__global__ __launch_bounds__(T) void k_lip_scan(LipPass a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = int64_t(blockIdx.x) * (T / 64) + (threadIdx.x >> 6);
+  if (wid * 16 >= a.N) return;
+  const LipRows rw(a, wid, lane);
+  if (__ballot(rw.unsafe) == 0ull) return;
+  bool some = false;
+  for (int z0 = 0; z0 < a.ngroups && !some; z0 += 64) {
+    const int zz = z0 + lane;
+    some = __ballot(zz < a.ngroups && rw.in_reach(a, zz)) != 0ull;
+  }
+  if (some && lane == 0) a.wlist[atomicAdd(a.wcount, 1)] = int(wid);
+}
+
+// the listed segments, 64 groups at a time -- an item per wave of a fixed launch --: the pairs
+// of the groups in reach with the arithmetic of k_lipschitz (lane = 16 (candidate % 4) + row,
+// candidates (lane >> 4) + 4 r)
+__global__ __launch_bounds__(T) void k_lip_items(LipPass a) {
+  const int lane = threadIdx.x & 63;
+  const int nch = (a.ngroups + 63) / 64;
+  const int64_t total = int64_t(*a.wcount) * nch;
+  for (int64_t item = int64_t(blockIdx.x) * (T / 64) + (threadIdx.x >> 6); item < total;
+       item += int64_t(gridDim.x) * (T / 64)) {
+    const int hw = int(item / nch), gc = int(item - int64_t(hw) * nch);
+    const LipRows rw(a, a.wlist[hw], lane);
+    const int zz = gc * 64 + lane;
+    unsigned long long mask = __ballot(zz < a.ngroups && rw.in_reach(a, zz));
+    while (mask != 0ull) {
+      const int z = gc * 64 + __builtin_ctzll(mask);
+      mask &= mask - 1ull;
+      const int m = min(16, a.m - 16 * z);
+      for (int r = 0; r < 4; ++r) {
+        const int cand = (lane >> 4) + 4 * r;
+        if (cand >= m || !rw.unsafe) continue;
+        const int64_t c = int64_t(z) * 16 + cand;
+        double s = 0.0;
+        for (int k = 0; k < a.d; ++k) {
+          const double df = a.xc[c * a.d + k] - rw.x[k];
+          s += df * df;
+        }
+        const double dist = sqrt(s);
+        bool hit = true;
+        for (int g = 0; g < a.G; ++g) {
+          if (a.fmin.v[g] == -INFINITY) continue;
+          hit = hit && (a.uc[c * a.G + g] - a.lips.v[g] * dist >= a.fmin.v[g]);
+        }
+        if (hit && a.flags[c * a.G] == 0)
+          for (int g = 0; g < a.G; ++g) atomicOr(&a.flags[c * a.G + g], 1);
+      }
+    }
+  }
+}
+
 // N ranks: what the other ranks need of the listed candidates -- global row, key, the row
 // itself, u_g - mu_g -- in list order.
 __global__ __launch_bounds__(T) void k_pass_gather(const int* list, int count, const double* pts,
@@ -1189,6 +1340,57 @@ int launch_pass_result(sgp_grid* g, const int* list_dev, int count, const int32_
   hipLaunchKernelGGL(k_pass_result, dim3(1), dim3(1024), 0, ctx->stream, list_dev, count,
                      flags_dev, g->G, vec8(fmin, g->G, -INFINITY), g->w, g->goff, mode, g->Gm,
                      res_dev);
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// the Lipschitz test of `count` listed candidates (list_dev: local rows): stage their rows and
+// upper bounds (xc [count][d], uc [count][G]; box / rad per group behind them), test, flags
+// [count][G] (zeroed here)
+int launch_lipschitz_many(sgp_grid* g, int G, const double* fmin, const double* lipschitz,
+                          const int* list_dev, int count, const double* xc_in, const double* uc_in,
+                          double* work, int32_t* flags_dev) {
+  sgp_ctx* ctx = g->ctx;
+  const int d = g->d;
+  const int ngroups = (count + 15) / 16;
+  double* xc = work;
+  double* uc = xc + size_t(count) * d;
+  double* box = uc + size_t(count) * G;
+  double* rad = box + size_t(ngroups) * 2 * d;
+  if (list_dev) {
+    hipLaunchKernelGGL(k_lip_stage, dim3((count + T - 1) / T), dim3(T), 0, ctx->stream, list_dev,
+                       count, g->pts, g->Q, g->N, d, G, xc, uc);
+  } else {
+    SGP_HIP(ctx, hipMemcpyAsync(xc, xc_in, size_t(count) * d * 8, hipMemcpyHostToDevice, ctx->stream));
+    SGP_HIP(ctx, hipMemcpyAsync(uc, uc_in, size_t(count) * G * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  const size_t nw = size_t((g->N + 15) >> 4);
+  int* hot = static_cast<int*>(sgp_scratch(ctx, 12, (64 + nw) * sizeof(int)));
+  SGP_CHECK(ctx, hot, "device allocation failed: %s", ctx->err.c_str());
+  SGP_HIP(ctx, hipMemsetAsync(hot, 0, 64 * sizeof(int), ctx->stream));
+  SGP_HIP(ctx, hipMemsetAsync(flags_dev, 0, size_t(count) * G * 4, ctx->stream));
+  LipPass a{};
+  a.pts = g->pts;
+  a.S = g->S;
+  a.N = g->N;
+  a.d = d;
+  a.G = G;
+  a.m = count;
+  a.ngroups = ngroups;
+  a.fmin = vec8(fmin, G, -INFINITY);
+  a.lips = vec8(lipschitz, G, 0.0);
+  a.xc = xc;
+  a.uc = uc;
+  a.box = box;
+  a.rad = rad;
+  a.flags = flags_dev;
+  a.wcount = hot;
+  a.wlist = hot + 64;
+  hipLaunchKernelGGL(k_lip_agg, dim3((ngroups + T - 1) / T), dim3(T), 0, ctx->stream, count, d, G,
+                     a.fmin, a.lips, xc, uc, box, rad, ngroups);
+  hipLaunchKernelGGL(k_lip_scan, dim3(unsigned((nw + T / 64 - 1) / (T / 64))), dim3(T), 0,
+                     ctx->stream, a);
+  hipLaunchKernelGGL(k_lip_items, dim3(1024), dim3(T), 0, ctx->stream, a);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -324,6 +324,10 @@ class _HipGridBackend(object):
         return self.grid.expander_pass(self._dev(), beta, fmin, mode, cut_w, cut_idx,
                                        key_lo, key_hi, want)
 
+    def lipschitz_pass(self, fmin, lipschitz, mode, cut_w, cut_idx, key_lo, key_hi, want):
+        return self.grid.lipschitz_pass(fmin, lipschitz, mode, cut_w, cut_idx, key_lo, key_hi,
+                                        want)
+
     def pass_hist(self, mode, cut_w, cut_idx, key_lo, key_hi):
         return self.grid.pass_hist(mode, cut_w, cut_idx, key_lo, key_hi)
 
@@ -933,6 +937,13 @@ class SafeOpt(GaussianProcessOptimization):
                  and hasattr(be, 'pass_test'))
         if big_n and full_sets:
             return self._visit_in_big_passes_nrank(beta, active, True, np.inf, -1)
+        # Lipschitz certificates, one rank: the same big passes (sgp_grid_lipschitz_pass)
+        big_l = (self._comm.world == 1 and self.use_lipschitz and self.big_passes
+                 and hasattr(be, 'lipschitz_pass'))
+        if big_l and full_sets:
+            return self._visit_in_big_passes(beta, active, True, np.inf, -1)
+        if big_l and np.isfinite(cut_w):
+            return self._visit_in_big_passes(beta, active, False, cut_w, cut_idx)
         while True:
             w_loc, i_loc = be.topk(mode, cut_w, cut_idx, K)
             if self._comm.world > 1:
@@ -981,6 +992,9 @@ class SafeOpt(GaussianProcessOptimization):
             cut_w, cut_idx = float(w_b[-1]), int(i_b[-1])
             if big_n and K == _hip.TOPK:
                 return self._visit_in_big_passes_nrank(beta, active, False, cut_w, cut_idx)
+            if big_l:
+                # behind a first candidate that is no expander
+                return self._visit_in_big_passes(beta, active, False, cut_w, cut_idx)
             K = _hip.TOPK
 
     #: candidates per pass of ``_visit_in_big_passes`` (the last entry repeats); None: by the
@@ -997,6 +1011,8 @@ class SafeOpt(GaussianProcessOptimization):
         cheap to find --, the following ones 8 times as many each, up to 8192."""
         if self.pass_sizes is not None:
             return self.pass_sizes[min(k, len(self.pass_sizes) - 1)]
+        if self.use_lipschitz:
+            return 8192                 # (no operands: the distance test alone)
         n = max(int(gp.X.shape[0]) for gp in self.gps)
         first = 256
         while first < 8192 and 2 * first * n * n <= 5e8:
@@ -1020,8 +1036,12 @@ class SafeOpt(GaussianProcessOptimization):
             lo, hi, mode = 0.0, float(cut_w), 0             # keys: the interval widths
         for k in range(1 << 30):
             want = self._pass_size(k)
-            tested, hits, key, row, left = be.expander_pass(beta, self.fmin, mode, cut_w,
-                                                            cut_idx, lo, hi, want)
+            if self.use_lipschitz:
+                tested, hits, key, row, left = be.lipschitz_pass(
+                    self.fmin, self.liptschitz, mode, cut_w, cut_idx, lo, hi, want)
+            else:
+                tested, hits, key, row, left = be.expander_pass(beta, self.fmin, mode, cut_w,
+                                                                cut_idx, lo, hi, want)
             if hits and not full_sets:
                 be.mark_expanders(np.array([row], dtype=np.int64))
                 self._settle_ties(beta, active, key, row)

@@ -32,15 +32,17 @@ if __name__ == "__main__":
     margin = kw.pop("margin", None)
     gp, grid = rim_state(side, **kw) if margin is None else converged_state(side, margin, **kw)
     for big in ((True,) if os.environ.get("ONLY_BIG") else (True, False)):
-        opt = safeopt_amd.SafeOpt(gp, grid, 0.0, threshold=0.1)
+        lip = float(os.environ["LIP"]) if os.environ.get("LIP") else None      # Lipschitz certificates
+        opt = safeopt_amd.SafeOpt(gp, grid, 0.0, lipschitz=lip, threshold=0.1)
         opt.big_passes = big
         if os.environ.get("PASS_SIZES"):
             opt.pass_sizes = tuple(int(v) for v in os.environ["PASS_SIZES"].split(","))
         ctx = opt._backend.ctx
         passes = []
         if big:
-            orig = opt._backend.expander_pass
-            opt._backend.expander_pass = lambda *a, _o=orig: (lambda r: (passes.append(r[:2]), r)[1])(_o(*a))
+            attr = "lipschitz_pass" if lip else "expander_pass"
+            orig = getattr(opt._backend, attr)
+            setattr(opt._backend, attr, lambda *a, _o=orig: (lambda r: (passes.append(r[:2]), r)[1])(_o(*a)))
         for rep in range(2):
             ctx.sync(); t0 = time.perf_counter()
             x = opt.optimize()

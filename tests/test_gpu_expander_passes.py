@@ -143,3 +143,86 @@ def test_full_sets_in_big_passes(mods):
         assert_array_equal(got[-1][rows][clear], hits[clear])
         assert not got[-1][~S].any()
     assert_array_equal(got[0], got[1])
+
+
+def lipschitz_hits(grid, S, cand, u_c, L, fmin, chunk=256):
+    """gp_opt.py:558-576 for many candidates: any(u_c - L d >= fmin) over the unsafe rows."""
+    from scipy.spatial.distance import cdist
+    unsafe = grid[~S]
+    out = np.zeros(cand.size, dtype=bool)
+    for a in range(0, cand.size, chunk):
+        d = cdist(grid[cand[a:a + chunk]], unsafe)
+        out[a:a + chunk] = np.any(u_c[a:a + chunk, None] - L * d >= fmin, axis=1)
+    return out
+
+
+@pytest.mark.timeout(1200)
+def test_lipschitz_certificates_in_big_passes(mods):
+    """The same loop with Lipschitz certificates (gp_opt.py:558-576; ``sgp_grid_lipschitz_pass``):
+    a constant so large that no candidate reaches an unsafe row (every candidate is visited,
+    nothing is marked), one with which the first expander is far down the visiting order, and
+    ``full_sets`` -- against the formula of the reference in numpy and against the 16-candidate
+    loop."""
+    safeopt_amd, gpy, gpn, son = mods
+    data = sc.rim_data(320, **STATE)
+    go, grid = sc.make_gp(gpn, data), data["grid"]
+    beta, thr = 2.0, 0.1
+    Q, S, M, order, w = oracle_front(son, go, grid, beta, thr)
+    assert order.size >= 5000
+    # (1) no expander at all: the candidates are rows of the plateau, u / (distance to the nearest
+    # unsafe row) is 0.6 .. 0.75 for them
+    from scipy.spatial.distance import cdist
+    unsafe = grid[~S]
+    dmin = np.concatenate([cdist(grid[order[a:a + 256]], unsafe).min(axis=1)
+                           for a in range(0, order.size, 256)])
+    ratio = Q[order, 1] / dmin
+    L_far = 1.0
+    assert ratio.max() < 0.9
+    assert not lipschitz_hits(grid, S, order, Q[order, 1], L_far, 0.0).any()
+    # (2) the first expander far down the order: a constant just above what the first 64
+    # candidates would need
+    L_mid = float(ratio[:64].max() * 1.02)
+    h = lipschitz_hits(grid, S, order, Q[order, 1], L_mid, 0.0)
+    assert h.any()
+    first, n_before = int(order[np.argmax(h)]), int(np.argmax(h))
+    assert n_before >= 64
+    assert (w[order] == w[first]).sum() == 1
+    for L, want_G in ((L_far, []), (L_mid, [first])):
+        got = []
+        for big in (True, False):
+            opt = safeopt_amd.SafeOpt(sc.make_gp(gpy, data), grid, 0.0, lipschitz=L, threshold=thr)
+            opt.big_passes = big
+            calls = []
+            if big:
+                orig = opt._backend.lipschitz_pass
+                opt._backend.lipschitz_pass = lambda *a, _o=orig: calls.append(a[-1]) or _o(*a)
+            x = opt.optimize()
+            assert_array_equal(opt.S, S)
+            assert_array_equal(opt.M, M)
+            assert_array_equal(np.flatnonzero(opt.G), want_G)
+            assert big == bool(calls)
+            got.append(x)
+        assert_array_equal(got[0], got[1])
+    # (3) full_sets on a smaller grid: every safe row is tested, every expander marked
+    data = sc.rim_data(120, **STATE)
+    go, grid = sc.make_gp(gpn, data), data["grid"]
+    Q = son.confidence_intervals([go], grid, beta)
+    S = son.safe_set(Q, [0.0])
+    rows = np.flatnonzero(S)
+    L = 1.0
+    hits = lipschitz_hits(grid, S, rows, Q[rows, 1], L, 0.0)
+    clear = hits == lipschitz_hits(grid, S, rows, Q[rows, 1], L, 1e-9)
+    clear &= hits == lipschitz_hits(grid, S, rows, Q[rows, 1], L, -1e-9)
+    assert hits.any() and not hits.all() and clear.sum() >= rows.size - 3
+    got = []
+    for big in (True, False):
+        opt = safeopt_amd.SafeOpt(sc.make_gp(gpy, data), grid, 0.0, lipschitz=L, threshold=thr)
+        opt.big_passes = big
+        opt.pass_sizes = (300, 1000)          # (several passes even on this small grid)
+        opt.update_confidence_intervals()
+        opt.compute_sets(full_sets=True)
+        Gd = np.array(opt.G)
+        assert_array_equal(Gd[rows][clear], hits[clear])
+        assert not Gd[~S].any()
+        got.append(Gd)
+    assert_array_equal(got[0], got[1])

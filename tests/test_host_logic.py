@@ -376,11 +376,13 @@ def test_pass_sizes_follow_the_number_of_observations():
     (4 n^2 flop each) at about 1e9 flop, the following ones take 8 times as many, up to 8192;
     an explicit ``pass_sizes`` wins."""
     from types import SimpleNamespace as NS
-    def sizes(n, pass_sizes=None):
-        o = NS(pass_sizes=pass_sizes, gps=[NS(X=np.zeros((3, 2))), NS(X=np.zeros((n, 2)))])
+    def sizes(n, pass_sizes=None, lip=False):
+        o = NS(pass_sizes=pass_sizes, use_lipschitz=lip,
+               gps=[NS(X=np.zeros((3, 2))), NS(X=np.zeros((n, 2)))])
         return [safeopt_amd.SafeOpt._pass_size(o, k) for k in range(4)]
     assert sizes(217) == [8192, 8192, 8192, 8192]
     assert sizes(637) == [1024, 8192, 8192, 8192]
     assert sizes(1000) == [256, 2048, 8192, 8192]
     assert sizes(2000) == [256, 2048, 8192, 8192]
     assert sizes(2000, (300, 1000)) == [300, 1000, 1000, 1000]
+    assert sizes(2000, lip=True) == [8192] * 4         # (Lipschitz certificates: no operands)
