@@ -155,6 +155,16 @@ void sgp_set_error(sgp_ctx* ctx, const char* fmt, ...) {
   g_err = buf;
 }
 
+// SGP_POISON=1 (debugging): every fresh device allocation is filled with 0xFF bytes -- NaN as
+// doubles, -1 as integers -- so that a kernel that reads what nobody wrote shows in the results
+// instead of depending on what an earlier call left at that address.
+int sgp_poison(sgp_ctx* ctx, void* p, size_t bytes) {
+  static const bool on = getenv("SGP_POISON") && atoi(getenv("SGP_POISON")) != 0;
+  if (!on) return 0;
+  SGP_HIP(ctx, hipMemsetAsync(p, 0xFF, bytes, ctx->stream));    // (in stream order: in front of every use)
+  return 0;
+}
+
 int sgp_reserve(sgp_ctx* ctx, DevBuf* b, size_t bytes) {
   if (bytes <= b->cap && b->p) return 0;
   size_t cap = bytes < 256 ? 256 : bytes;
@@ -170,6 +180,7 @@ int sgp_reserve(sgp_ctx* ctx, DevBuf* b, size_t bytes) {
   SGP_HIP(ctx, hipMalloc(&b->p, cap));
   b->cap = cap;
   ++ctx->n_allocs;
+  SGP_TRY(sgp_poison(ctx, b->p, cap));
   return 0;
 }
 
@@ -538,6 +549,7 @@ int sgp_grid_create(sgp_ctx* ctx, const double* base, int64_t N, int d,
       return -1;
     }
     ++ctx->n_allocs;
+    SGP_TRY(sgp_poison(ctx, *a.p, a.bytes));
   }
   SGP_HIP(ctx, hipMemsetAsync(g->S, 0, N, ctx->stream));
   SGP_HIP(ctx, hipMemsetAsync(g->M, 0, N, ctx->stream));

@@ -244,6 +244,7 @@ struct sgp_grid {
 // ---- helpers (api.hip) ------------------------------------------------------
 int sgp_reserve(sgp_ctx* ctx, DevBuf* b, size_t bytes);
 void* sgp_scratch(sgp_ctx* ctx, int slot, size_t bytes);  // nullptr on failure
+int sgp_poison(sgp_ctx* ctx, void* p, size_t bytes);       // SGP_POISON=1: fill a fresh allocation with 0xFF
 int sgp_h2d(sgp_ctx* ctx, void* dst, const void* src, size_t bytes);
 int sgp_d2h(sgp_ctx* ctx, void* dst, const void* src, size_t bytes);  // syncs
 
@@ -313,6 +314,10 @@ int launch_sep_tables(sgp_ctx* ctx, const GpDev& gp, int d, const uint32_t* coun
                       const double* axis_vals, const int* axis_off, int naxes,
                       const int* cols, double* const* out);
 size_t sep_table_doubles(const GpDev& gp, uint32_t count);
+// j-blocks a factor table has at least: the resident-factor kernel walks the j-blocks of the
+// LARGEST factor of its launch (up to kMidMaxNB, sweep_mid.hip; at least 4) for every GP -- the
+// blocks beyond a GP's own meet zeros of its L^-1, but they have to be there, and finite
+constexpr int kSepMinBlocks = 8;
 // rows == the declared tensor grid?  *mismatch (device int) counts the differences
 int launch_verify_axes(sgp_grid* g, int* mismatch_dev);
 int launch_sweep_fitness(sgp_ctx* ctx, const GpDev* gps_dev,

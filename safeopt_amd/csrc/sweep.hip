@@ -2140,12 +2140,16 @@ __global__ __launch_bounds__(256) void k_sep_table(GpDev gp, SepCols sc, int a,
   const int k = sc.cols[a];
   const uint32_t count = sc.count[k];
   const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
-  const int64_t total = int64_t(gp.nblk) * count * 16;
+  const int64_t total = int64_t(gp.nblk > kSepMinBlocks ? gp.nblk : kSepMinBlocks) * count * 16;
   if (e >= total) return;
   const int pos = int(e & 15);
   const uint32_t i = uint32_t((e >> 4) % count);
   const int jb = int((e >> 4) / count);
   const int j = 16 * jb + 4 * (pos & 3) + (pos >> 2);
+  if (jb >= gp.nblk) {            // (beyond the GP's own blocks: see kSepMinBlocks)
+    out[e] = 0.0;
+    return;
+  }
   const double* xj = gp.Xpad + int64_t(j) * sc.d;
   auto weight = [&](int col) {
     double W = 0.0;
@@ -2167,7 +2171,7 @@ __global__ __launch_bounds__(256) void k_sep_table(GpDev gp, SepCols sc, int a,
 }
 
 size_t sep_table_doubles(const GpDev& gp, uint32_t count) {
-  return size_t(gp.nblk) * count * 16;
+  return size_t(std::max(gp.nblk, kSepMinBlocks)) * count * 16;
 }
 
 int launch_sep_tables(sgp_ctx* ctx, const GpDev& gp, int d, const uint32_t* count,

@@ -44,6 +44,7 @@ namespace {
 #endif
 
 constexpr int kMidMaxNB = 8;          // row blocks of L^-1 (128 padded rows)
+static_assert(kMidMaxNB <= kSepMinBlocks, "a launch reads every GP's tables up to its largest factor's blocks");
 // waves per workgroup: three per SIMD up to 80 padded rows, two beyond (the instances for
 // 6 .. 8 row blocks need 180 .. 210 registers)
 constexpr int mid_waves(int nb, int d, int sep = 0) {

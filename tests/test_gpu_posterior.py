@@ -895,3 +895,22 @@ def test_predict_of_a_prefix_of_the_points(mods, n, kind):
         assert_array_equal(m, m2)
         assert_array_equal(v, v2)
     print("n = %d: full set by %s, prefixes by %s" % (n, kf, sorted(seen)))
+
+
+@pytest.mark.timeout(1800)
+def test_no_kernel_reads_what_nobody_wrote():
+    """SGP_POISON=1 fills every fresh device allocation with 0xFF bytes (NaN as doubles): the
+    launches that mix GPs of different sizes, the factor tables, the few-points path and the
+    resident-factor kernel give the same results -- nothing depends on what an earlier call
+    left at an address.  (Found with it: the resident-factor kernel read a small GP's factor
+    tables up to the j-blocks of the largest factor of the launch -- finite garbage times the
+    zeros of its L^-1 on most days.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SGP_POISON="1")
+    sel = ("tables_match_generic or few_points_path or resident_factor_kernel_49_to_128 "
+           "or test_grid_sweep_both_kernels or shared_factor_same_bits")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_posterior.py"),
+                        "-q", "-m", "gpu", "-x", "--tb=line", "-k", sel],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1700)
+    assert r.returncode == 0, r.stdout[-3000:]
