@@ -186,6 +186,14 @@ int sgp_reserve(sgp_ctx* ctx, DevBuf* b, size_t bytes) {
 
 void* sgp_scratch(sgp_ctx* ctx, int slot, size_t bytes) {
   if (sgp_reserve(ctx, &ctx->scratch[slot], bytes) != 0) return nullptr;
+  // SGP_POISON=2: ... and a scratch slot every time it is asked for (what a call finds there
+  // from the call before is as good as unwritten), except the slots that are asked for again
+  // with their contents in place: the candidate staged in front of enqueue_expander (7), the
+  // selection carried from one call of a pass to the next (8), the operand blocks (9-11)
+  static const bool every = getenv("SGP_POISON") && atoi(getenv("SGP_POISON")) == 2;
+  if (every && (slot < 7 || slot > 11) &&
+      hipMemsetAsync(ctx->scratch[slot].p, 0xFF, bytes, ctx->stream) != hipSuccess)
+    return nullptr;
   return ctx->scratch[slot].p;
 }
 
