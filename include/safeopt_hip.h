@@ -286,6 +286,13 @@ int sgp_grid_pass_list(sgp_grid* grid, int mode, double cut_w, int64_t cut_idx, 
 int sgp_grid_pass_test(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                        const double* fmin, int K, const double* xc, const double* resid,
                        int32_t* flags);
+/* The test of (3) with Lipschitz certificates (safeopt/gp_opt.py:558-576): xc [K][d] and the
+ * candidates' upper bounds uc [K][G] -- sgp_grid_pass_list with mode | 2 returns u_i in place of
+ * u_i - mu_i -- against this shard's unsafe rows; flags as above (one value per candidate, set
+ * for every GP: the comparison is monotone in the distance).                            */
+int sgp_grid_pass_lipschitz_test(sgp_grid* grid, int G, const double* fmin,
+                                 const double* lipschitz, int K, const double* xc,
+                                 const double* uc, int32_t* flags);
 
 /* SMALL grids -- the reference's own regime (safeopt/gp_opt.py:651-675 on the 1000-point
  * grid of examples/1d_example.ipynb with n <= 20 observations; BASELINE.json config 1):

@@ -100,6 +100,8 @@ PROTOTYPES = {
                                          c_double_p]),
     "sgp_grid_lipschitz_pass": (C.c_int, [vp, C.c_int, c_double_p, c_double_p, C.c_int, C.c_double,
                                           C.c_int64, C.c_double, C.c_double, C.c_int, c_double_p]),
+    "sgp_grid_pass_lipschitz_test": (C.c_int, [vp, C.c_int, c_double_p, c_double_p, C.c_int,
+                                               c_double_p, c_double_p, c_i32_p]),
     "sgp_grid_pass_hist": (C.c_int, [vp, C.c_int, C.c_double, C.c_int64, C.c_double, C.c_double,
                                      c_u32_p]),
     "sgp_grid_pass_list": (C.c_int, [vp, C.c_int, C.c_double, C.c_int64, C.c_double, C.c_int,
@@ -765,6 +767,20 @@ class DeviceGrid(object):
             self.ctx.check(lib().sgp_grid_pass_test(
                 self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin), K, dptr(xc),
                 dptr(resid), flags.ctypes.data_as(c_i32_p)))
+        return flags
+
+    def pass_lipschitz_test(self, fmin, lipschitz, xc, u_c):
+        """Flags (K, G) of the Lipschitz test of K gathered candidates against this shard's
+        unsafe rows (``sgp_grid_pass_lipschitz_test``)."""
+        fmin, lipschitz = f64(fmin), f64(lipschitz)
+        xc = f64(xc).reshape(-1, self.d)
+        K = xc.shape[0]
+        u_c = f64(u_c).reshape(K, self.G)
+        flags = np.zeros((K, self.G), dtype=np.int32)
+        if K:
+            self.ctx.check(lib().sgp_grid_pass_lipschitz_test(
+                self.h, self.G, dptr(fmin), dptr(lipschitz), K, dptr(xc), dptr(u_c),
+                flags.ctypes.data_as(c_i32_p)))
         return flags
 
     def lipschitz_check(self, fmin, lipschitz, xc, u_c):

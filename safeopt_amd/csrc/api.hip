@@ -1424,6 +1424,8 @@ int sgp_grid_pass_list(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, dou
   struct { double thr; int count, est; } hs = {thr, 0, 0};
   SGP_TRY(sgp_h2d(ctx, sel, &hs, sizeof(hs)));
   int* counts = reinterpret_cast<int*>(sb + nl + 16384 + 256);
+  const int upper = mode & 2;            // resid = u_i (Lipschitz certificates) instead of u_i - mu_i
+  mode &= 1;
   SGP_TRY(launch_pass_list(g, mode, cut_w, cut_idx, sel, list, counts));
   SGP_TRY(sgp_d2h(ctx, &hs, sel, sizeof(hs)));
   *count = hs.count;
@@ -1435,7 +1437,7 @@ int sgp_grid_pass_list(sgp_grid* g, int mode, double cut_w, int64_t cut_idx, dou
   SGP_CHECK(ctx, ob, "device allocation failed: %s", ctx->err.c_str());
   int64_t* dg = reinterpret_cast<int64_t*>(ob);
   double *dk = ob + hs.count, *dx = dk + hs.count, *dr = dx + size_t(hs.count) * d;
-  SGP_TRY(launch_pass_gather(g, list, hs.count, mode, dg, dk, dx, dr));
+  SGP_TRY(launch_pass_gather(g, list, hs.count, mode | upper, dg, dk, dx, dr));
   std::vector<double> host(size_t(hs.count) * per);
   SGP_TRY(sgp_d2h(ctx, host.data(), ob, host.size() * 8));
   memcpy(gidx, host.data(), size_t(hs.count) * 8);
@@ -1513,6 +1515,27 @@ int sgp_grid_pass_test(sgp_grid* g, sgp_gp* const* gps, int G, double beta, cons
   ea.near_frac = 0.0;
   SweepPoints sp{g->pts, g->N, 1, g->N};
   SGP_TRY(launch_expander_many(ctx, g->gpdev, G, d, sp, ea));
+  return sgp_d2h(ctx, flags, dfl, size_t(K) * G * 4);
+}
+
+// ... and with Lipschitz certificates: the distance test of ALL K gathered candidates (rows xc
+// [K][d], upper bounds uc [K][G]: sgp_grid_pass_list with mode | 2) against this shard's unsafe
+// rows; flags[c * G + i] != 0: some unsafe row of the shard is in reach of candidate c for every
+// GP with a constraint (one flag per candidate, see k_lip_items) -- the ranks OR them.
+int sgp_grid_pass_lipschitz_test(sgp_grid* g, int G, const double* fmin, const double* lipschitz,
+                                 int K, const double* xc, const double* uc, int32_t* flags) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  if (K <= 0) return 0;
+  const int d = g->d;
+  const size_t ngroups = (size_t(K) + 15) / 16;
+  double* work = static_cast<double*>(
+      sgp_scratch(ctx, 9, (size_t(K) * (d + G) + ngroups * (2 * d + 1) + 8) * 8));
+  SGP_CHECK(ctx, work, "device allocation failed: %s", ctx->err.c_str());
+  int32_t* dfl = static_cast<int32_t*>(sgp_scratch(ctx, 11, size_t(K) * G * 4 + 64));
+  SGP_CHECK(ctx, dfl, "device allocation failed: %s", ctx->err.c_str());
+  SGP_TRY(launch_lipschitz_many(g, G, fmin, lipschitz, nullptr, K, xc, uc, work, dfl));
   return sgp_d2h(ctx, flags, dfl, size_t(K) * G * 4);
 }
 

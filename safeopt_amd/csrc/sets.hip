@@ -1220,10 +1220,12 @@ __global__ __launch_bounds__(T) void k_pass_gather(const int* list, int count, c
   if (pos >= count) return;
   const int64_t li = list[pos];
   gidx[pos] = goff + li;
-  key[pos] = index_key ? -double(goff + li) : w[li];
+  key[pos] = (index_key & 1) ? -double(goff + li) : w[li];
   for (int k = 0; k < d; ++k) x[int64_t(pos) * d + k] = pts[int64_t(k) * N + li];
   for (int g = 0; g < G; ++g)
-    resid[int64_t(pos) * G + g] = Q[li * 2 * G + 2 * g + 1] - mean[int64_t(g) * N + li];
+    resid[int64_t(pos) * G + g] =
+        (index_key & 2) ? Q[li * 2 * G + 2 * g + 1]                       // (u_g itself)
+                        : Q[li * 2 * G + 2 * g + 1] - mean[int64_t(g) * N + li];
 }
 
 // hits of the pass: a candidate is an expander when every GP with a constraint flagged it.

@@ -328,6 +328,9 @@ class _HipGridBackend(object):
         return self.grid.lipschitz_pass(fmin, lipschitz, mode, cut_w, cut_idx, key_lo, key_hi,
                                         want)
 
+    def pass_lipschitz_test(self, fmin, lipschitz, xc, u_c):
+        return self.grid.pass_lipschitz_test(fmin, lipschitz, xc, u_c)
+
     def pass_hist(self, mode, cut_w, cut_idx, key_lo, key_hi):
         return self.grid.pass_hist(mode, cut_w, cut_idx, key_lo, key_hi)
 
@@ -933,8 +936,8 @@ class SafeOpt(GaussianProcessOptimization):
                     return self._visit_in_big_passes(beta, active, False, cut_w, cut_idx)
                 K = _hip.TOPK
             return
-        big_n = (self._comm.world > 1 and not self.use_lipschitz and self.big_passes
-                 and hasattr(be, 'pass_test'))
+        big_n = (self._comm.world > 1 and self.big_passes and
+                 hasattr(be, 'pass_lipschitz_test' if self.use_lipschitz else 'pass_test'))
         if big_n and full_sets:
             return self._visit_in_big_passes_nrank(beta, active, True, np.inf, -1)
         # Lipschitz certificates, one rank: the same big passes (sgp_grid_lipschitz_pass)
@@ -1081,7 +1084,9 @@ class SafeOpt(GaussianProcessOptimization):
             # (rounding at a bin edge can move a few candidates across it: room for the
             # bin below as well)
             cap = int(from_top[min(nbins - 1, nbins - b)] if b > 0 else from_top[-1]) + 64
-            gi, key, xc, resid = be.pass_list(mode, cut_w, cut_idx, thr, cap)
+            # (Lipschitz certificates: the candidates' upper bounds themselves, mode | 2)
+            gi, key, xc, resid = be.pass_list(mode | (2 if self.use_lipschitz else 0), cut_w,
+                                              cut_idx, thr, cap)
             counts = comm.allgather(np.array([float(gi.size)]))[:, 0].astype(int)
             pad = int(counts.max())
             if pad == 0:
@@ -1091,7 +1096,11 @@ class SafeOpt(GaussianProcessOptimization):
             buf[:gi.size, 2:2 + d], buf[:gi.size, 2 + d:] = xc, resid
             allp = comm.allgather(buf)
             rows = np.concatenate([allp[r][:c] for r, c in enumerate(counts)])
-            flags = be.pass_test(beta, self.fmin, rows[:, 2:2 + d], rows[:, 2 + d:])
+            if self.use_lipschitz:
+                flags = be.pass_lipschitz_test(self.fmin, self.liptschitz, rows[:, 2:2 + d],
+                                               rows[:, 2 + d:])
+            else:
+                flags = be.pass_test(beta, self.fmin, rows[:, 2:2 + d], rows[:, 2 + d:])
             flags = comm.allreduce_max(flags.astype(np.float64)) > 0
             hits = np.all(flags[:, active], axis=1)
             gidx_all = rows[:, 0].astype(np.int64)

@@ -18,6 +18,7 @@ def run(trials=150, dmax=4, Gmax=3, nmax=300, seed0=1000, verbose=True, products
   constant context columns now and then) with RBF kernels -- factor tables -- and the
   kernel that swept each trial is counted."""
   bad = 0
+  ties = 0
   worst = 0.0
   ran = {}
   for t in range(trials):
@@ -60,6 +61,8 @@ def run(trials=150, dmax=4, Gmax=3, nmax=300, seed0=1000, verbose=True, products
     fmin = [float(rng.uniform(-0.5, 1.0)) if (g == 0 or rng.random() < 0.7) else -np.inf for g in range(G)]
     thr = float(rng.uniform(0, 0.5))
     opt = safeopt_amd.SafeOpt(gps if G > 1 else gps[0], grid, fmin if G > 1 else fmin[0], threshold=thr)
+    if os.environ.get("FUZZ_NO_BIG"):
+        opt.big_passes = False           # (the 16-candidates-per-round-trip loop)
     try:
         x = opt.optimize()
         empty = False
@@ -113,9 +116,34 @@ def run(trials=150, dmax=4, Gmax=3, nmax=300, seed0=1000, verbose=True, products
         fm = np.asarray(fmin)
         lo = Q[:, ::2][:, np.isfinite(fm)]
         margin = float(np.min(np.abs(lo - fm[np.isfinite(fm)])))
-        print("trial %d n=%d d=%d G=%d N=%d: dQ=%.2g empty=%s/%s sets equal=%s min|l-fmin|=%.2g  MISMATCH"
-              % (t, n, d, G, N, dq, empty, oempty, sets_ok, margin))
+        which = ""
+        if not empty and not oempty:
+            which = " [S %s M %s G %s (device %s, oracle %s) x %s]" % (
+                np.array_equal(opt.S, S), np.array_equal(opt.M, M), np.array_equal(opt.G, Gm),
+                np.flatnonzero(opt.G)[:4], np.flatnonzero(Gm)[:4], np.array_equal(x, grid[idx]))
+        print("trial %d n=%d d=%d G=%d N=%d: dQ=%.2g empty=%s/%s sets equal=%s min|l-fmin|=%.2g  MISMATCH%s"
+              % (t, n, d, G, N, dq, empty, oempty, sets_ok, margin, which))
+        if not empty and not oempty and np.array_equal(opt.S, S) and np.array_equal(opt.M, M):
+            # a TIE?  Widths (visiting order: max_i width_i; arg-max: max_i width_i / scaling_i)
+            # of the rows the two sides disagree about, on both sides' Q.  Where they agree to
+            # 1e-9 the choice among them is the reference's unstable argsort / first-index rule
+            # on ITS last bits (gp_opt.py:542-552, 631-641): rows far from every observation
+            # all carry the prior width.
+            Qd = np.asarray(opt.Q)
+            rows = sorted(set(np.flatnonzero(np.asarray(opt.G) != Gm)) |
+                          {int(np.flatnonzero((grid == x).all(axis=1))[0]), int(idx)})
+            sc_ = np.asarray(opt.scaling)
+            wd = np.array([(Qd[r, 1::2] - Qd[r, ::2]).max() for r in rows])
+            wo = np.array([(Q[r, 1::2] - Q[r, ::2]).max() for r in rows])
+            for r, a_, b_ in zip(rows[:6], wd, wo):
+                print("    row %d: width device %.17g oracle %.17g" % (r, a_, b_))
+            if np.ptp(wd) <= 1e-9 * wd.max() and np.ptp(wo) <= 1e-9 * wo.max():
+                print("    -> a tie of the widths within 1e-9 on both sides: not counted")
+                bad -= 1
+                ties += 1
         bad += 1
+  if ties:
+    print("  (%d trials decided by ties of the widths within 1e-9, listed above)" % ties)
   if verbose:
     print("%d trials, %d mismatches, max |Q_dev - Q_oracle| = %.3g" % (trials, bad, worst))
     print("sweep kernels of the trials:", ran)

@@ -199,6 +199,40 @@ def _big_pass_cases(sa, gpy, comm, report):
         report.append(("big passes, full_sets: |G| = %d, %d N-rank passes" % (
             int(np.sum(b.G)), calls["n"] - before),
             bool(np.array_equal(a.G, b.G)) and int(np.sum(b.G)) > 0 and calls["n"] > before))
+        # Lipschitz certificates (gp_opt.py:558-576) on true shards: two constants (the candidates
+        # of this state need L <= 0.6 .. 0.75 to reach an unsafe row) and full_sets -- against the
+        # same product on one rank
+        lcalls = {"n": 0}
+        lorig = gp_opt._HipGridBackend.pass_lipschitz_test
+
+        def lcounted(self, *a, **k):
+            lcalls["n"] += 1
+            return lorig(self, *a, **k)
+        gp_opt._HipGridBackend.pass_lipschitz_test = lcounted
+        try:
+            data = sc.rim_data(160, **state)
+            # (L = 0.72: the first expander is behind the first 16 candidates on this grid)
+            for name, L, full in (("L = 1", 1.0, False), ("L = 0.72", 0.72, False),
+                                  ("L = 0.7", 0.7, False), ("L = 1, full_sets", 1.0, True)):
+                def build(cm):
+                    o = sa.SafeOpt(sc.make_gp(gpy, data), data["grid"], 0.0, lipschitz=L,
+                                   threshold=0.1, comm=cm)
+                    o.pass_sizes = (64, 512)
+                    if full:
+                        o.update_confidence_intervals()
+                        o.compute_sets(full_sets=True)
+                    else:
+                        o.optimize()
+                    return o
+                before = lcalls["n"]
+                a, b = build(comm), build(dist.LocalComm())
+                ok = (np.array_equal(a.S, b.S) and np.array_equal(a.M, b.M)
+                      and np.array_equal(a.G, b.G))
+                report.append(("big passes, Lipschitz certificates, %s: |G| = %d, %d N-rank passes" % (
+                    name, int(np.sum(b.G)), lcalls["n"] - before),
+                    bool(ok) and (lcalls["n"] > before or L == 0.7)))
+        finally:
+            gp_opt._HipGridBackend.pass_lipschitz_test = lorig
     finally:
         gp_opt._HipGridBackend.pass_test = orig
 
