@@ -35,6 +35,11 @@ for n in ns:
     cases = [("RBF", True, "auto"), ("RBF", False, "auto"), ("Matern52", False, "auto")]
     if 48 < n <= 128:    # auto = the resident-factor kernel (sweep_mid.hip); the 4-wave kernel next to it
         cases = cases + [("RBF", True, "classic"), ("RBF", False, "classic"), ("Matern52", False, "classic")]
+    if n > 128 and os.environ.get("PAIR_AB"):
+        # evaluated covariances at n = 129 .. 256: the 4-wave kernel (auto) against the paired
+        # kernel forced (auto takes it from n_pad > 256 on)
+        cases = [("RBF", False, "auto"), ("RBF", False, "pair"), ("Matern52", False, "auto"),
+                 ("Matern52", False, "pair")]
     if n <= 48:      # auto = the VALU kernel (sweep_tiny.hip); the matrix-core kernel next to it
         cases = [("RBF", False, "auto"), ("Matern52", False, "auto"), ("RBF", True, "classic"),
                  ("RBF", False, "classic"), ("Matern52", False, "classic")]
