@@ -506,6 +506,24 @@ def no_expander_state(gpy, safeopt_amd, ctx):
                 w = Q[:, 1] - Q[:, 0]
                 M = np.asarray(opt.M, dtype=bool)
                 row["candidates"] = int((S & ~M & (w > w[M].max()) & (w > 0.1 * 2.0)).sum())
+        if side >= 1000:
+            # the same state with Lipschitz certificates (gp_opt.py:558-576; L = 1: no candidate
+            # reaches an unsafe row): sgp_grid_lipschitz_pass against the 16-candidate loop
+            lip = {"L": 1.0}
+            for big in (True, False):
+                opt = safeopt_amd.SafeOpt(gp, grid, 0.0, lipschitz=1.0, threshold=0.1)
+                opt.big_passes = big
+                opt.optimize()
+                times = []
+                for _ in range(5 if big else 1):
+                    ctx.sync()
+                    t0 = time.perf_counter()
+                    opt.optimize()
+                    ctx.sync()
+                    times.append((time.perf_counter() - t0) * 1e3)
+                lip["big_passes_ms" if big else "sixteen_per_round_trip_ms"] = float(np.median(times))
+                lip["expanders_found"] = int(np.asarray(opt.G).sum())
+            row["lipschitz_certificates"] = lip
         out[name] = row
     return out
 

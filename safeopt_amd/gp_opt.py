@@ -862,7 +862,13 @@ class SafeOpt(GaussianProcessOptimization):
             if self._settle_ties(beta, active, w_c, idx_c, n_tied) != idx_c:
                 self._argmax_cache = None
             return
-        # not certified by the probe: exact scan, then the general loop
+        # not certified by the probe.  One rank with big passes: the exact test of this candidate
+        # rides in the first pass (the cut in FRONT of it) -- a candidate that lifts no row close
+        # to it rarely lifts a far one, and a pass costs little more than its scan
+        if (not exact and world == 1 and self.big_passes and not self.use_lipschitz
+                and hasattr(be, 'expander_pass') and np.isfinite(w_c)):
+            return self._visit_in_big_passes(beta, active, False, w_c, idx_c + 1)
+        # ... otherwise: exact scan, then the general loop
         hit = [False] if exact else self._expander_flags(
             beta, x_c[None, :], mu_c[None, :], q_c[None, 1::2], active, probe=False)
         if hit[0]:
