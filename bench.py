@@ -493,6 +493,8 @@ def no_expander_state(gpy, safeopt_amd, ctx):
             row[key] = {"optimize_ms": ms, "device_passes": len(passes),
                         "expanders_found": int(np.asarray(opt.G).sum())}
             if big or side <= 400:
+                if big:
+                    opt.compute_sets(full_sets=True)        # (first call: the scratch buffers grow)
                 ctx.sync()
                 t0 = time.perf_counter()
                 opt.compute_sets(full_sets=True)
