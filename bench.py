@@ -473,7 +473,7 @@ def no_expander_state(gpy, safeopt_amd, ctx):
             passes = []
             attr = "expander_pass" if big else "expander_batch"
             orig = getattr(opt._backend, attr)
-            setattr(opt._backend, attr, lambda *a, _o=orig: (passes.append(a[-1]), _o(*a))[1])
+            setattr(opt._backend, attr, lambda *a, _o=orig, _i=(7 if big else -1): (passes.append(a[_i]), _o(*a))[1])
             opt.optimize()
             times = []
             for _ in range(5 if big else 1):          # (median of five)

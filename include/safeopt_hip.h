@@ -254,12 +254,16 @@ int sgp_grid_expander_batch(sgp_grid* grid, sgp_gp* const* gps, int G, double be
  *   out6 = { candidates tested, expanders among them,
  *            mode 0: key and global row of the FIRST expander in visiting order (nothing is
  *                    marked in G: the caller settles exact ties, gp_opt.py:542-552),
- *            key below which the candidates are still untested (-inf: none left), 0 }
+ *            key below which the candidates are still untested (-inf: none left),
+ *            scaling != NULL and mode 0: the global row of sgp_grid_argmax(SGP_ARGMAX_MG_WIDTH)
+ *            taken behind the test (gp_opt.py:631-641) -- the next query point when the pass
+ *            ends the loop without an expander, for no further round trip; else -1 }
  *   mode 1 (full_sets): every expander of the pass is marked in G on the device.
  * One rank (the shard is the grid).                                                   */
 int sgp_grid_expander_pass(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                            const double* fmin, int mode, double cut_w, int64_t cut_idx,
-                           double key_lo, double key_hi, int want, double* out6);
+                           double key_lo, double key_hi, int want, const double* scaling,
+                           double* out6);
 /* The same pass with Lipschitz certificates (safeopt/gp_opt.py:558-576 in place of :577-606):
  * candidate c is an expander when for every GP i with a constraint some unsafe row x has
  * u_i(x_c) - L_i |x_c - x|_2 >= fmin_i -- the comparison of sgp_grid_lipschitz_check per
@@ -268,7 +272,7 @@ int sgp_grid_expander_pass(sgp_grid* grid, sgp_gp* const* gps, int G, double bet
 int sgp_grid_lipschitz_pass(sgp_grid* grid, int G, const double* fmin,
                             const double* lipschitz, int mode, double cut_w,
                             int64_t cut_idx, double key_lo, double key_hi, int want,
-                            double* out6);
+                            const double* scaling, double* out6);
 
 /* The same pass on N ranks (safeopt/gp_opt.py:557-612 on a row-sharded grid), in three calls
  * with the ranks' agreement in between: (1) this shard's 4096-bin histogram of the keys of its

@@ -97,9 +97,10 @@ PROTOTYPES = {
                                           c_int_p, c_i32_p]),
     "sgp_grid_expander_pass": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p, C.c_int,
                                          C.c_double, C.c_int64, C.c_double, C.c_double, C.c_int,
-                                         c_double_p]),
+                                         c_double_p, c_double_p]),
     "sgp_grid_lipschitz_pass": (C.c_int, [vp, C.c_int, c_double_p, c_double_p, C.c_int, C.c_double,
-                                          C.c_int64, C.c_double, C.c_double, C.c_int, c_double_p]),
+                                          C.c_int64, C.c_double, C.c_double, C.c_int, c_double_p,
+                                          c_double_p]),
     "sgp_grid_pass_lipschitz_test": (C.c_int, [vp, C.c_int, c_double_p, c_double_p, C.c_int,
                                                c_double_p, c_double_p, c_i32_p]),
     "sgp_grid_pass_hist": (C.c_int, [vp, C.c_int, C.c_double, C.c_int64, C.c_double, C.c_double,
@@ -710,26 +711,32 @@ class DeviceGrid(object):
             C.byref(n), flags.ctypes.data_as(c_i32_p)))
         return w[:n.value], idx[:n.value], flags[:n.value]
 
-    def expander_pass(self, gps, beta, fmin, mode, cut_w, cut_idx, key_lo, key_hi, want):
+    def expander_pass(self, gps, beta, fmin, mode, cut_w, cut_idx, key_lo, key_hi, want,
+                      scaling=None):
         """About ``want`` candidates behind the cut, all tested in one scan of the unsafe rows
         (``sgp_grid_expander_pass``): ``(tested, hits, key, row of the first expander in
-        visiting order, key below which candidates are left or -inf)``."""
+        visiting order, key below which candidates are left or -inf, row of the arg-max of the
+        step taken behind the test or -1 -- with ``scaling``, ``mode`` 0)``."""
         fmin = f64(fmin)
+        sc = None if scaling is None else f64(scaling)
         out = np.zeros(6)
         self.ctx.check(lib().sgp_grid_expander_pass(
             self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin), int(mode), float(cut_w),
-            int(cut_idx), float(key_lo), float(key_hi), int(want), dptr(out)))
-        return int(out[0]), int(out[1]), float(out[2]), int(out[3]), float(out[4])
+            int(cut_idx), float(key_lo), float(key_hi), int(want),
+            None if sc is None else dptr(sc), dptr(out)))
+        return (int(out[0]), int(out[1]), float(out[2]), int(out[3]), float(out[4]), int(out[5]))
 
-    def lipschitz_pass(self, fmin, lipschitz, mode, cut_w, cut_idx, key_lo, key_hi, want):
+    def lipschitz_pass(self, fmin, lipschitz, mode, cut_w, cut_idx, key_lo, key_hi, want,
+                       scaling=None):
         """The same pass with Lipschitz certificates (``sgp_grid_lipschitz_pass``); result as
         ``expander_pass``."""
         fmin, lipschitz = f64(fmin), f64(lipschitz)
+        sc = None if scaling is None else f64(scaling)
         out = np.zeros(6)
         self.ctx.check(lib().sgp_grid_lipschitz_pass(
             self.h, len(fmin), dptr(fmin), dptr(lipschitz), int(mode), float(cut_w), int(cut_idx),
-            float(key_lo), float(key_hi), int(want), dptr(out)))
-        return int(out[0]), int(out[1]), float(out[2]), int(out[3]), float(out[4])
+            float(key_lo), float(key_hi), int(want), None if sc is None else dptr(sc), dptr(out)))
+        return (int(out[0]), int(out[1]), float(out[2]), int(out[3]), float(out[4]), int(out[5]))
 
     def pass_hist(self, mode, cut_w, cut_idx, key_lo, key_hi):
         """This shard's histogram (4096 bins over [key_lo, key_hi]) of the keys of its

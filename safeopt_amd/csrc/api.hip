@@ -1245,9 +1245,34 @@ int sgp_grid_expander_batch(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
 //   mode 1: every expander of the pass is marked in G; out6[2..3] unused.
 // key_lo / key_hi: range of the keys still behind the cut (histogram range; mode 0:
 // 0 .. the width of the cut).  One rank.
+// the result of a pass and, behind it in the same read-back, the arg-max of the step
+// (gp_opt.py:631-641 over M | G) for the case that the pass ends the loop without a hit
+static int pass_result_and_argmax(sgp_grid* g, const int* list, int count, const int32_t* dfl,
+                                  const double* fmin, int mode, const double* scaling,
+                                  double* res, double* out6) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_TRY(launch_pass_result(g, list, count, dfl, fmin, mode, res));
+  const bool spec = scaling != nullptr && mode == 0;
+  if (spec)
+    SGP_TRY(launch_argmax(g, SGP_ARGMAX_MG_WIDTH, scaling, res + 3,
+                          reinterpret_cast<int64_t*>(res + 4)));
+  double hr[5];
+  SGP_TRY(sgp_d2h(ctx, hr, res, sizeof(hr)));
+  out6[1] = hr[0];
+  out6[2] = hr[1];
+  int64_t bi;
+  memcpy(&bi, &hr[2], 8);
+  out6[3] = double(bi);
+  int64_t ai = -1;
+  if (spec) memcpy(&ai, &hr[4], 8);
+  out6[5] = double(ai);
+  return 0;
+}
+
 int sgp_grid_expander_pass(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
                            const double* fmin, int mode, double cut_w, int64_t cut_idx,
-                           double key_lo, double key_hi, int want, double* out6) {
+                           double key_lo, double key_hi, int want, const double* scaling,
+                           double* out6) {
   sgp_ctx* ctx = g->ctx;
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
@@ -1331,15 +1356,7 @@ int sgp_grid_expander_pass(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   ea.near_frac = 0.0;
   SweepPoints sp{g->pts, g->N, 1, g->N};
   SGP_TRY(launch_expander_many(ctx, g->gpdev, G, d, sp, ea));
-  SGP_TRY(launch_pass_result(g, list, count, dfl, fmin, mode, res));
-  double hr[3];
-  SGP_TRY(sgp_d2h(ctx, hr, res, sizeof(hr)));
-  out6[1] = hr[0];
-  out6[2] = hr[1];
-  int64_t bi;
-  memcpy(&bi, &hr[2], 8);
-  out6[3] = double(bi);
-  return 0;
+  return pass_result_and_argmax(g, list, count, dfl, fmin, mode, scaling, res, out6);
 }
 
 // The same pass with Lipschitz certificates (gp_opt.py:558-576 instead of :577-606): selection
@@ -1347,7 +1364,7 @@ int sgp_grid_expander_pass(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
 // sgp_grid_expander_pass.  One rank.
 int sgp_grid_lipschitz_pass(sgp_grid* g, int G, const double* fmin, const double* lipschitz,
                             int mode, double cut_w, int64_t cut_idx, double key_lo,
-                            double key_hi, int want, double* out6) {
+                            double key_hi, int want, const double* scaling, double* out6) {
   sgp_ctx* ctx = g->ctx;
   SGP_HIP(ctx, hipSetDevice(ctx->device));
   SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
@@ -1382,15 +1399,7 @@ int sgp_grid_lipschitz_pass(sgp_grid* g, int G, const double* fmin, const double
   double* res = reinterpret_cast<double*>(reinterpret_cast<char*>(dfl) + size_t(count) * G * 4);
   res = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(res) + 7) & ~uintptr_t(7));
   SGP_TRY(launch_lipschitz_many(g, G, fmin, lipschitz, list, count, nullptr, nullptr, work, dfl));
-  SGP_TRY(launch_pass_result(g, list, count, dfl, fmin, mode, res));
-  double hr[3];
-  SGP_TRY(sgp_d2h(ctx, hr, res, sizeof(hr)));
-  out6[1] = hr[0];
-  out6[2] = hr[1];
-  int64_t bi;
-  memcpy(&bi, &hr[2], 8);
-  out6[3] = double(bi);
-  return 0;
+  return pass_result_and_argmax(g, list, count, dfl, fmin, mode, scaling, res, out6);
 }
 
 // ---- the same pass on N ranks, in three calls with the ranks' agreement in between ----------

@@ -320,13 +320,15 @@ class _HipGridBackend(object):
     def expander_batch(self, beta, fmin, mode, cut_w, cut_idx, k):
         return self.grid.expander_batch(self._dev(), beta, fmin, mode, cut_w, cut_idx, k)
 
-    def expander_pass(self, beta, fmin, mode, cut_w, cut_idx, key_lo, key_hi, want):
+    def expander_pass(self, beta, fmin, mode, cut_w, cut_idx, key_lo, key_hi, want,
+                      scaling=None):
         return self.grid.expander_pass(self._dev(), beta, fmin, mode, cut_w, cut_idx,
-                                       key_lo, key_hi, want)
+                                       key_lo, key_hi, want, scaling)
 
-    def lipschitz_pass(self, fmin, lipschitz, mode, cut_w, cut_idx, key_lo, key_hi, want):
+    def lipschitz_pass(self, fmin, lipschitz, mode, cut_w, cut_idx, key_lo, key_hi, want,
+                       scaling=None):
         return self.grid.lipschitz_pass(fmin, lipschitz, mode, cut_w, cut_idx, key_lo, key_hi,
-                                        want)
+                                        want, scaling)
 
     def pass_lipschitz_test(self, fmin, lipschitz, xc, u_c):
         return self.grid.pass_lipschitz_test(fmin, lipschitz, xc, u_c)
@@ -1045,17 +1047,22 @@ class SafeOpt(GaussianProcessOptimization):
             lo, hi, mode = 0.0, float(cut_w), 0             # keys: the interval widths
         for k in range(1 << 30):
             want = self._pass_size(k)
+            # (the arg-max of the step comes back with the result of the pass: when the pass ends
+            # the loop without an expander G is final and the next query point is known)
+            sc = None if full_sets else self.scaling
             if self.use_lipschitz:
-                tested, hits, key, row, left = be.lipschitz_pass(
-                    self.fmin, self.liptschitz, mode, cut_w, cut_idx, lo, hi, want)
+                tested, hits, key, row, left, amax = be.lipschitz_pass(
+                    self.fmin, self.liptschitz, mode, cut_w, cut_idx, lo, hi, want, sc)
             else:
-                tested, hits, key, row, left = be.expander_pass(beta, self.fmin, mode, cut_w,
-                                                                cut_idx, lo, hi, want)
+                tested, hits, key, row, left, amax = be.expander_pass(
+                    beta, self.fmin, mode, cut_w, cut_idx, lo, hi, want, sc)
             if hits and not full_sets:
                 be.mark_expanders(np.array([row], dtype=np.int64))
                 self._settle_ties(beta, active, key, row)
                 return
             if tested == 0 or left == -np.inf:
+                if amax >= 0 and tested > 0:
+                    self._argmax_cache = (None, amax)
                 return
             cut_w, cut_idx = left, -1
             if not full_sets:

@@ -57,7 +57,7 @@ def test_converged_run_visits_every_candidate_and_marks_none(mods):
     opt = safeopt_amd.SafeOpt(sc.make_gp(gpy, data), grid, 0.0, threshold=thr)
     calls = []
     orig = opt._backend.expander_pass
-    opt._backend.expander_pass = lambda *a: calls.append(a[-1]) or orig(*a)
+    opt._backend.expander_pass = lambda *a: calls.append(a[7]) or orig(*a)       # (a[7]: want)
     x = opt.optimize()
     assert_allclose(opt.Q, Q, rtol=0, atol=1e-8)
     assert_array_equal(opt.S, S)
@@ -70,7 +70,7 @@ def test_converged_run_visits_every_candidate_and_marks_none(mods):
     opt3.pass_sizes = (256, 2048, 8192)
     calls3 = []
     orig3 = opt3._backend.expander_pass
-    opt3._backend.expander_pass = lambda *a: calls3.append(a[-1]) or orig3(*a)
+    opt3._backend.expander_pass = lambda *a: calls3.append(a[7]) or orig3(*a)
     x3 = opt3.optimize()
     assert calls3 == [256, 2048, 8192]
     assert_array_equal(opt3.G, Gm)
@@ -195,7 +195,7 @@ def test_lipschitz_certificates_in_big_passes(mods):
             calls = []
             if big:
                 orig = opt._backend.lipschitz_pass
-                opt._backend.lipschitz_pass = lambda *a, _o=orig: calls.append(a[-1]) or _o(*a)
+                opt._backend.lipschitz_pass = lambda *a, _o=orig: calls.append(a[7]) or _o(*a)
             x = opt.optimize()
             assert_array_equal(opt.S, S)
             assert_array_equal(opt.M, M)
