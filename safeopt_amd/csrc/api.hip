@@ -1307,7 +1307,8 @@ int sgp_grid_expander_pass(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   const int64_t wstride = int64_t(np_max / 4) * 64;
   const size_t ngroups = (size_t(count) + 15) / 16;
   const size_t nxc = ngroups * 16 * d, nv = ngroups * G * 16;
-  double* ob = static_cast<double*>(sgp_scratch(ctx, 9, (nxc + 7 * nv + ngroups * 2 * d + 8) * 8));
+  double* ob = static_cast<double*>(sgp_scratch(
+      ctx, 9, (nxc + 7 * nv + ngroups * 2 * d + 8 + (ngroups / 8 + 1) * (4 * G + 2 * d)) * 8));
   SGP_CHECK(ctx, ob, "device allocation failed: %s", ctx->err.c_str());
   double* Wp = static_cast<double*>(sgp_scratch(ctx, 10, ngroups * G * size_t(wstride) * 8));
   SGP_CHECK(ctx, Wp, "device allocation failed: %s", ctx->err.c_str());
@@ -1346,6 +1347,8 @@ int sgp_grid_expander_pass(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
   ea.svc = dtn2 + 2 * nv;
   ea.agg = dtn2 + 3 * nv;          // (ngroups G 4 <= nv)
   ea.box = dtn2 + 4 * nv;
+  ea.sagg = ea.box + ngroups * 2 * d + 8;
+  ea.sbox = ea.sagg + (ngroups / 8 + 1) * 4 * G;
   ea.m = count;
   ea.beta = beta;
   ea.S = g->S;
@@ -1472,7 +1475,8 @@ int sgp_grid_pass_test(sgp_grid* g, sgp_gp* const* gps, int G, double beta, cons
   const int64_t wstride = int64_t(np_max / 4) * 64;
   const size_t ngroups = (size_t(K) + 15) / 16;
   const size_t nxc = ngroups * 16 * d, nv = ngroups * G * 16;
-  double* ob = static_cast<double*>(sgp_scratch(ctx, 9, (nxc + 7 * nv + ngroups * 2 * d + 8) * 8));
+  double* ob = static_cast<double*>(sgp_scratch(
+      ctx, 9, (nxc + 7 * nv + ngroups * 2 * d + 8 + (ngroups / 8 + 1) * (4 * G + 2 * d)) * 8));
   SGP_CHECK(ctx, ob, "device allocation failed: %s", ctx->err.c_str());
   double* Wp = static_cast<double*>(sgp_scratch(ctx, 10, ngroups * G * size_t(wstride) * 8));
   SGP_CHECK(ctx, Wp, "device allocation failed: %s", ctx->err.c_str());
@@ -1514,6 +1518,8 @@ int sgp_grid_pass_test(sgp_grid* g, sgp_gp* const* gps, int G, double beta, cons
   ea.svc = dtn2 + 2 * nv;
   ea.agg = dtn2 + 3 * nv;          // (ngroups G 4 <= nv)
   ea.box = dtn2 + 4 * nv;
+  ea.sagg = ea.box + ngroups * 2 * d + 8;
+  ea.sbox = ea.sagg + (ngroups / 8 + 1) * 4 * G;
   ea.m = K;
   ea.beta = beta;
   ea.S = g->S;

@@ -336,6 +336,8 @@ struct ExpanderArgs {
   const double* svc;     // standard deviation at x_c (written by launch_expander_many)
   const double* agg;     // ... [group][G][4] extremes of a group, box [group][2][d] (k_pass_agg)
   const double* box;
+  const double* sagg;    // the same per SUPERGROUP of 8 consecutive groups (the scan of the grid
+  const double* sbox;    // tests those first): [super][G][4], [super][2][d]
   int m;
   double beta;
   double fmin[SGP_MAX_GPS];

@@ -1025,8 +1025,13 @@ struct ManyRows {
   // pairs can reach -- most blocks are far apart and end here, for a fraction of an
   // instruction per pair (single-part kernels).
   __device__ __forceinline__ bool block(const ExpanderArgs& ea, int zz, const double* tab) const {
+    return block_at(ea.box, ea.agg, zz, tab);
+  }
+  // (boxes / extremes: of the groups, or of the supergroups of 8 groups)
+  __device__ __forceinline__ bool block_at(const double* boxes, const double* aggs, int zz,
+                                           const double* tab) const {
     if (!SINGLE) return true;
-    const double* bx = ea.box + int64_t(zz) * 2 * D;
+    const double* bx = boxes + int64_t(zz) * 2 * D;
     double r2 = 0.0;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
@@ -1034,7 +1039,7 @@ struct ManyRows {
       r2 = fma(gap, gap, r2);
     }
     const double kmax = kf.of_r2s(r2, tab);
-    const double* ag = ea.agg + (int64_t(zz) * G + g) * 4;
+    const double* ag = aggs + (int64_t(zz) * G + g) * 4;
     const double cmax = fmin2(fma(sqx_hi, ag[2], kmax), svx_hi * ag[3]) * (1.0 + 1e-9);
     return reach(cmax, mu_hi, var_lo, ag[0], ag[1]);
   }
@@ -1302,13 +1307,30 @@ __device__ __forceinline__ void many_gp(const GpDev* gps, int g, int G, const Sw
     // (the block test alone, 64 groups at a time: no wave of the scan waits for a chain of
     // pair tests -- the waves next to the band pass the block test for most groups and the
     // pair test for none)
+    // Two levels: the SUPERGROUPS of 8 consecutive groups first, one per lane (a far segment is
+    // done after one test per 64 x 128 candidates), then the groups of the supergroups that
+    // pass, eight supergroups at a time (lane = 8 supergroup + group).
     bool some = false;
     EXPM_STAT(0, 1); EXPM_STAT(1, __popcll(__ballot(unsafe) & 0xffffull));
+    const int nsuper = (ngroups + 7) >> 3;
 #pragma unroll 1
-    for (int z0 = 0; z0 < ngroups && !some; z0 += 64) {
-      const int zz = z0 + lane;
-      some = __ballot(zz < ngroups && rw.block(ea, zz, tab)) != 0ull;
-      EXPM_STAT(2, min(64, ngroups - z0));
+    for (int Z0 = 0; Z0 < nsuper && !some; Z0 += 64) {
+      const int ZZ = Z0 + lane;
+      unsigned long long sm = __ballot(ZZ < nsuper && rw.block_at(ea.sbox, ea.sagg, ZZ, tab));
+      EXPM_STAT(2, min(64, nsuper - Z0));
+#pragma unroll 1
+      while (sm != 0ull && !some) {
+        int mine = -1;
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx) {
+          const int bpos = sm != 0ull ? __builtin_amdgcn_readfirstlane(__builtin_ctzll(sm)) : -1;
+          if ((lane >> 3) == sidx) mine = bpos;
+          sm &= sm - (sm != 0ull ? 1ull : 0ull);
+        }
+        const int zz = 8 * (Z0 + mine) + (lane & 7);
+        some = __ballot(mine >= 0 && zz < ngroups && rw.block(ea, zz, tab)) != 0ull;
+        EXPM_STAT(4, 1);
+      }
     }
     EXPM_STAT(3, some);
     if (some && lane == 0) {
@@ -2032,6 +2054,31 @@ __global__ void k_pass_agg(int G, int d, int m_total, const double* xc, const do
   }
 }
 
+// ... and the same per SUPERGROUP of 8 consecutive groups, from the groups' values (the scan of
+// the grid tests those first: k_expander_many, MODE 0)
+__global__ void k_pass_sagg(int G, int d, const double* agg, const double* box, double* sagg,
+                            double* sbox, int ngroups) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nsuper = (ngroups + 7) >> 3;
+  if (e < nsuper * G) {
+    const int Z = e / G, g = e - Z * G;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int z = 8 * Z; z < min(8 * Z + 8, ngroups); ++z)
+      for (int q = 0; q < 4; ++q) a[q] = fmax(a[q], agg[(int64_t(z) * G + g) * 4 + q]);
+    for (int q = 0; q < 4; ++q) sagg[int64_t(e) * 4 + q] = a[q];
+  }
+  if (e < nsuper * d) {
+    const int Z = e / d, k = e - Z * d;
+    double lo = INFINITY, hi = -INFINITY;
+    for (int z = 8 * Z; z < min(8 * Z + 8, ngroups); ++z) {
+      lo = fmin(lo, box[(int64_t(z) * 2 + 0) * d + k]);
+      hi = fmax(hi, box[(int64_t(z) * 2 + 1) * d + k]);
+    }
+    sbox[(int64_t(Z) * 2 + 0) * d + k] = lo;
+    sbox[(int64_t(Z) * 2 + 1) * d + k] = hi;
+  }
+}
+
 int launch_expander_many(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d, SweepPoints pts,
                          ExpanderArgs ea) {
   if (pts.N <= 0 || ea.m <= 0) return 0;
@@ -2058,6 +2105,9 @@ int launch_expander_many(sgp_ctx* ctx, const GpDev* gps_dev, int G, int d, Sweep
     hipLaunchKernelGGL(k_pass_agg, dim3((na + 255) / 256), dim3(256), 0, ctx->stream, G, d, ea.m,
                        ea.xc, ea.delta, ea.inv_s2, ea.stn, ea.svc, const_cast<double*>(ea.agg),
                        const_cast<double*>(ea.box), ngroups);
+    const int ns = ((ngroups + 7) / 8) * (G > d ? G : d);
+    hipLaunchKernelGGL(k_pass_sagg, dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, G, d, ea.agg,
+                       ea.box, const_cast<double*>(ea.sagg), const_cast<double*>(ea.sbox), ngroups);
   }
 #define EXPM_CASE(DD)                                                         \
   case DD:                                                                    \

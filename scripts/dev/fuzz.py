@@ -12,11 +12,12 @@ KINDS = ["RBF", "Matern32", "Matern52"]
 
 
 def run(trials=150, dmax=4, Gmax=3, nmax=300, seed0=1000, verbose=True, products=False,
-        grids=False):
+        grids=False, lipschitz=0.0):
   """(mismatches, max |Q_dev - Q_oracle|) over `trials` seeded random problems.
   grids: half of the parameter sets are tensor grids (linearly_spaced_combinations, plus
   constant context columns now and then) with RBF kernels -- factor tables -- and the
-  kernel that swept each trial is counted."""
+  kernel that swept each trial is counted.  lipschitz: that fraction of the trials runs with
+  Lipschitz certificates (gp_opt.py:558-576), a random constant per GP."""
   bad = 0
   ties = 0
   worst = 0.0
@@ -60,7 +61,13 @@ def run(trials=150, dmax=4, Gmax=3, nmax=300, seed0=1000, verbose=True, products
         gos.append(gpn.GPRegression(X, y, kern(gpn), noise_var=noise))
     fmin = [float(rng.uniform(-0.5, 1.0)) if (g == 0 or rng.random() < 0.7) else -np.inf for g in range(G)]
     thr = float(rng.uniform(0, 0.5))
-    opt = safeopt_amd.SafeOpt(gps if G > 1 else gps[0], grid, fmin if G > 1 else fmin[0], threshold=thr)
+    lip = None
+    if lipschitz > 0.0:                      # (drawn last: the other draws stay what they were)
+        lrng = np.random.default_rng(seed0 + t + 7919)
+        if lrng.random() < lipschitz:
+            lip = [float(v) for v in lrng.uniform(0.2, 3.0, size=G)]
+    opt = safeopt_amd.SafeOpt(gps if G > 1 else gps[0], grid, fmin if G > 1 else fmin[0],
+                              lipschitz=(lip if lip is None or G > 1 else lip[0]), threshold=thr)
     if os.environ.get("FUZZ_NO_BIG"):
         opt.big_passes = False           # (the 16-candidates-per-round-trip loop)
     try:
@@ -76,7 +83,7 @@ def run(trials=150, dmax=4, Gmax=3, nmax=300, seed0=1000, verbose=True, products
     key = gps[0]._fitted().ctx.last_sweep() + (" + tables" if tables else "")
     ran[key] = ran.get(key, 0) + 1
     try:
-        idx, Q, S, M, Gm = son.optimize_grid(gos, grid, fmin, opt.scaling, thr, 2.)
+        idx, Q, S, M, Gm = son.optimize_grid(gos, grid, fmin, opt.scaling, thr, 2., lipschitz=lip)
         oempty = False
     except EnvironmentError:
         oempty = True

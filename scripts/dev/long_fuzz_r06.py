@@ -12,6 +12,10 @@ print("fuzz.run(trials=1200, dmax=5, Gmax=4, nmax=600, seed0=960000, products=Tr
 print("  (random n, d, G, kernels, products of two parts, tensor grids with factor tables, thresholds, fmin incl. -inf):")
 bad, worst = f.run(trials=1200, dmax=5, Gmax=4, nmax=600, seed0=960000, verbose=False, products=True, grids=True)
 print("  1200 trials, %d mismatches, max |Q_dev - Q_oracle| = %.3g  (%.0f s)" % (bad, worst, time.time() - t0)); t0 = time.time()
+print("fuzz.run(trials=600, dmax=5, Gmax=4, nmax=400, seed0=980000, products=True, grids=True, lipschitz=1.0)  -- the same with")
+print("  Lipschitz certificates in every trial (gp_opt.py:558-576; sgp_grid_lipschitz_pass behind the first candidate):")
+bad, worst = f.run(trials=600, dmax=5, Gmax=4, nmax=400, seed0=980000, verbose=False, products=True, grids=True, lipschitz=1.0)
+print("  600 trials, %d mismatches, max |Q_dev - Q_oracle| = %.3g  (%.0f s)" % (bad, worst, time.time() - t0)); t0 = time.time()
 s = mod("fuzz_swarm")
 print("fuzz_swarm.run(trials=400, nmax=700, pmax=8000, seed0=970000, products=True)  -- _compute_particle_fitness, 4 swarm types:")
 r = s.run(trials=400, nmax=700, pmax=8000, seed0=970000, verbose=False, products=True)
