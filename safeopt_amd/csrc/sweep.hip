@@ -1258,14 +1258,30 @@ __device__ __forceinline__ void many_rows(const GpDev& gp, const ManyRows<D, SIN
     if (coop) __syncthreads();
     nq = 0;
   };
-  // The item's groups (at most 64): the block test one group per lane, the pair test for the
-  // groups that are left four at a time (their loads and evaluations overlap: at one wave per
-  // SIMD nothing else hides them), then the blocks with a possible pair, four per evaluation.
+  // The item's groups (at most 64): the block test one group per lane, a finer test for the
+  // groups that are left, then the blocks that pass it, four per evaluation.
   static_assert(kManyChunk <= 64, "one block test per item");
   EXPM_STAT(8, 1);
   const unsigned long long mask = __ballot(zlo + lane < zhi && rw.block(ea, zlo + lane, tab));
-  unsigned rows = 0u;
-  unsigned long long todo = many_pairs<D, SINGLE>(rw, ea, zlo, mask, tab, lane, rows);
+  unsigned long long todo = 0ull;
+  if (SINGLE) {
+    // ... which for a kernel of one part is the block test of the ROW against the group, four
+    // groups at a time (lane = 16 group + row): one covariance evaluation per (row, group)
+    // instead of 16 -- the candidates of a group are neighbours along a grid line, their box
+    // and extremes bound nearly what the pairs themselves do
+#pragma unroll 1
+    for (int z4 = zlo; z4 < zhi; z4 += 4) {
+      const int zz = z4 + (lane >> 4);
+      const bool p = zz < zhi && ((mask >> (zz - zlo)) & 1ull) != 0ull && rw.row_block(ea, zz, tab);
+      const unsigned long long pb = __ballot(p);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if ((pb >> (16 * q)) & 0xffffull) todo |= 1ull << (z4 + q - zlo);     // wave-uniform
+    }
+  } else {
+    unsigned rows = 0u;
+    todo = many_pairs<D, SINGLE>(rw, ea, zlo, mask, tab, lane, rows);
+  }
 #pragma unroll 1
   while (todo != 0ull) {
     zpack = 0u;
