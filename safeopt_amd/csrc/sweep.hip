@@ -1264,11 +1264,13 @@ __device__ __forceinline__ void many_rows(const GpDev& gp, const ManyRows<D, SIN
   EXPM_STAT(8, 1);
   const unsigned long long mask = __ballot(zlo + lane < zhi && rw.block(ea, zlo + lane, tab));
   unsigned long long todo = 0ull;
-  if (SINGLE) {
-    // ... which for a kernel of one part is the block test of the ROW against the group, four
-    // groups at a time (lane = 16 group + row): one covariance evaluation per (row, group)
-    // instead of 16 -- the candidates of a group are neighbours along a grid line, their box
-    // and extremes bound nearly what the pairs themselves do
+  if (SINGLE && gp.n_pad <= 256) {
+    // ... which for a kernel of one part and a small factor is the block test of the ROW
+    // against the group, four groups at a time (lane = 16 group + row): one covariance
+    // evaluation per (row, group) instead of 16 -- the candidates of a group are neighbours
+    // along a grid line, their box and extremes bound nearly what the pairs themselves do.
+    // (From n = 257 on a block that the pair test would have dropped costs more than the test:
+    // full_sets at n = 637 5.3 ms against 3.6.)
 #pragma unroll 1
     for (int z4 = zlo; z4 < zhi; z4 += 4) {
       const int zz = z4 + (lane >> 4);
