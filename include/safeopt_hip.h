@@ -320,6 +320,13 @@ int sgp_grid_step_small_ok(sgp_grid* grid, sgp_gp* const* gps, int G);
 int sgp_grid_expanders_small(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
                              const double* fmin, const int64_t* gidx, int m,
                              int32_t* flags);
+/* The same for EVERY candidate of the grid (the mask of sgp_grid_candidates / the one-launch
+ * step), listed on the device in row order: global rows, widths (max_i (u_i - l_i), the key of
+ * the visiting order, safeopt/gp_opt.py:542-552) and flags of the first *count candidates in
+ * one read-back -- the caller sorts and walks them.  *count > cap: only *count is valid.  */
+int sgp_grid_expanders_small_all(sgp_grid* grid, sgp_gp* const* gps, int G, double beta,
+                                 const double* fmin, int cap, int* count, int64_t* gidx,
+                                 double* width, int32_t* flags);
 
 /* The same on N ranks (row shards, sgp_comm_init on the grid's context) after a
  * confidence pass without read-back: max l0[S] and the maximiser width are

@@ -103,6 +103,8 @@ PROTOTYPES = {
                                           c_double_p]),
     "sgp_grid_pass_lipschitz_test": (C.c_int, [vp, C.c_int, c_double_p, c_double_p, C.c_int,
                                                c_double_p, c_double_p, c_i32_p]),
+    "sgp_grid_expanders_small_all": (C.c_int, [vp, vpp, C.c_int, C.c_double, c_double_p, C.c_int,
+                                               C.POINTER(C.c_int), c_i64_p, c_double_p, c_i32_p]),
     "sgp_grid_pass_hist": (C.c_int, [vp, C.c_int, C.c_double, C.c_int64, C.c_double, C.c_double,
                                      c_u32_p]),
     "sgp_grid_pass_list": (C.c_int, [vp, C.c_int, C.c_double, C.c_int64, C.c_double, C.c_int,
@@ -710,6 +712,23 @@ class DeviceGrid(object):
             float(cut_w), int(cut_idx), int(k), dptr(w), idx.ctypes.data_as(c_i64_p),
             C.byref(n), flags.ctypes.data_as(c_i32_p)))
         return w[:n.value], idx[:n.value], flags[:n.value]
+
+    def expanders_small_all(self, gps, beta, fmin, cap=4096):
+        """Every candidate of a small grid tested in one round trip
+        (``sgp_grid_expanders_small_all``): ``(global rows in row order, widths, flags (m, G))``,
+        or None when there are more than ``cap`` candidates."""
+        fmin = f64(fmin)
+        cap = int(min(cap, self.N))
+        gidx = np.empty(cap, dtype=np.int64)
+        width = np.empty(cap)
+        flags = np.empty((cap, len(gps)), dtype=np.int32)
+        n = C.c_int(0)
+        self.ctx.check(lib().sgp_grid_expanders_small_all(
+            self.h, _gp_array(gps), len(gps), float(beta), dptr(fmin), cap, C.byref(n),
+            gidx.ctypes.data_as(c_i64_p), dptr(width), flags.ctypes.data_as(c_i32_p)))
+        if n.value > cap:
+            return None
+        return gidx[:n.value], width[:n.value], flags[:n.value]
 
     def expander_pass(self, gps, beta, fmin, mode, cut_w, cut_idx, key_lo, key_hi, want,
                       scaling=None):

@@ -1990,6 +1990,60 @@ int sgp_grid_expanders_small(sgp_grid* g, sgp_gp* const* gps, int G, double beta
   return sgp_d2h(ctx, flags, dfl, size_t(m) * G * 4);
 }
 
+// ... of EVERY candidate of the grid, listed on the device in row order: global rows, widths and
+// flags come back in ONE read-back (the candidate mask and the widths do not travel first).
+// *count > cap: nothing else is valid (the caller takes the two-step path).
+int sgp_grid_expanders_small_all(sgp_grid* g, sgp_gp* const* gps, int G, double beta,
+                                 const double* fmin, int cap, int* count, int64_t* gidx,
+                                 double* width, int32_t* flags) {
+  sgp_ctx* ctx = g->ctx;
+  SGP_HIP(ctx, hipSetDevice(ctx->device));
+  SGP_CHECK(ctx, G == g->G, "grid was created for %d GPs, got %d", g->G, G);
+  SGP_CHECK(ctx, cap >= 1, "cap = %d", cap);
+  *count = 0;
+  GpDev host[SGP_MAX_GPS];
+  SGP_TRY(collect_gps(ctx, gps, G, g->d, host));
+  SGP_CHECK(ctx, step_small_eligible(ctx, host, G, g->N),
+            "sgp_grid_expanders_small_all: %lld rows / a GP with more than 48 observations",
+            (long long)g->N);
+  SGP_TRY(stage_gpdev(g, host, G));
+  if (cap > g->N) cap = int(g->N);
+  // the list: every candidate, row order (the selection of the big passes with no threshold)
+  const size_t nl = (size_t(g->N) * 4 + 63) & ~size_t(63);
+  char* sb = static_cast<char*>(sgp_scratch(ctx, 8, nl + 16384 + 256 + (size_t(g->N) / 256 + 2) * 4));
+  SGP_CHECK(ctx, sb, "device allocation failed: %s", ctx->err.c_str());
+  int* list = reinterpret_cast<int*>(sb);
+  char* sel = sb + nl + 16384;
+  int* counts = reinterpret_cast<int*>(sb + nl + 16384 + 256);
+  struct { double thr; int count, est; } hs = {-INFINITY, 0, 0};
+  SGP_TRY(sgp_h2d(ctx, sel, &hs, sizeof(hs)));
+  SGP_TRY(launch_pass_list(g, 0, INFINITY, -1, sel, list, counts));
+  const int* count_dev = reinterpret_cast<const int*>(sel + 8);
+  // [count | rows | widths | flags] for the read-back, the operands behind them
+  const size_t bh = 8, bc = size_t(cap) * 8, bw = size_t(cap) * 8,
+               bf = (size_t(cap) * G * 4 + 7) & ~size_t(7);
+  const size_t nops = cand_ops_doubles(cap, G);
+  char* buf = static_cast<char*>(sgp_scratch(ctx, 7, bh + bc + bw + bf + nops * 8));
+  SGP_CHECK(ctx, buf, "device allocation failed: %s", ctx->err.c_str());
+  int64_t* hdr = reinterpret_cast<int64_t*>(buf);
+  int64_t* cl = reinterpret_cast<int64_t*>(buf + bh);
+  double* dw = reinterpret_cast<double*>(buf + bh + bc);
+  int32_t* dfl = reinterpret_cast<int32_t*>(buf + bh + bc + bw);
+  double* ops = reinterpret_cast<double*>(buf + bh + bc + bw + bf);
+  SGP_TRY(launch_small_pack(g, list, count_dev, cap, hdr, cl, dw, dfl));
+  SGP_TRY(launch_cand_all(g, g->gpdev, host, G, beta, fmin, cl, cap, ops, dfl, count_dev));
+  std::vector<char> hb(bh + bc + bw + bf);
+  SGP_TRY(sgp_d2h(ctx, hb.data(), buf, hb.size()));
+  int64_t n64;
+  memcpy(&n64, hb.data(), 8);
+  *count = int(n64);
+  if (n64 > cap) return 0;
+  memcpy(gidx, hb.data() + bh, size_t(n64) * 8);
+  memcpy(width, hb.data() + bh + bc, size_t(n64) * 8);
+  memcpy(flags, hb.data() + bh + bc + bw, size_t(n64) * G * 4);
+  return 0;
+}
+
 // 1 when sgp_grid_step_small serves this grid with these GPs (at most 16384 rows, every GP
 // with at most 48 observations, sweep kernel not forced), else 0
 int sgp_grid_step_small_ok(sgp_grid* g, sgp_gp* const* gps, int G) {

@@ -395,9 +395,12 @@ bool step_small_eligible(const sgp_ctx* ctx, const GpDev* gh, int G, int64_t N);
 int launch_step_small(sgp_grid* g, const GpDev* gps_dev, const GpDev* gh, int G, double beta,
                       const double* fmin, const double* scaling, const double* thr_beta,
                       double* res, int nfront, int nfl, uint64_t seq);
+// count_dev != nullptr: the list was formed on the device, m is its room and *count_dev its length
 int launch_cand_all(sgp_grid* g, const GpDev* gps_dev, const GpDev* gh, int G, double beta,
                     const double* fmin, const int64_t* clist_dev, int m, double* ops,
-                    int32_t* flags);
+                    int32_t* flags, const int* count_dev = nullptr);
+int launch_small_pack(sgp_grid* g, const int* list_dev, const int* count_dev, int cap,
+                      int64_t* hdr, int64_t* clist, double* wout, int32_t* flags);
 size_t cand_ops_doubles(int m, int G);
 constexpr int kStepResWords = 64;     // doubles of the result block (6 + d + 3 G + ... <= 50)
 

@@ -512,9 +512,11 @@ constexpr int kCandOps = 64 + 2;        // doubles per (candidate, GP): w[64] | 
 template <int D>
 __global__ __launch_bounds__(64) void k_cand_ops(const GpDev* gps, int G, SweepPoints pts,
                                                  const double* Q, const double* mean, Vec8 fmin,
-                                                 const int64_t* clist, int64_t goff, double* ops) {
+                                                 const int64_t* clist, int64_t goff, double* ops,
+                                                 const int* count_dev) {
   __shared__ double kc[64], tt[64];
   const int lane = threadIdx.x, c = blockIdx.x;
+  if (count_dev && c >= *count_dev) return;      // (the list was formed on the device: launched for its room)
   const gpdev_c_t gpc = (gpdev_c_t)(gps);
   const int64_t li = clist[c] - goff;
   double xc[D];
@@ -562,14 +564,17 @@ __global__ __launch_bounds__(256) void k_cand_scan(const GpDev* gps, int G, Swee
                                                    const uint8_t* S, const double* mean,
                                                    const double* var, double beta, Vec8 fmin,
                                                    const int64_t* clist, int m, int64_t goff,
-                                                   const double* ops, int32_t* flags) {
+                                                   const double* ops, int32_t* flags,
+                                                   const int* count_dev) {
   __shared__ double tab[kExpTabSize];
   __shared__ double sw[kCandChunk][kCandOps];
   __shared__ double sxc[kCandChunk][D];
   __shared__ int shit[kCandChunk];
+  const int c0 = blockIdx.y * kCandChunk;
+  if (count_dev) m = min(m, *count_dev);
+  if (c0 >= m) return;
   exp_tab_init(tab);
   const int tid = threadIdx.x;
-  const int c0 = blockIdx.y * kCandChunk;
   const int mc = min(kCandChunk, m - c0);
   const gpdev_c_t gpc = (gpdev_c_t)(gps);
   const int64_t row = int64_t(blockIdx.x) * 256 + tid;
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(256) void k_cand_scan(const GpDev* gps, int G, Swee
 
 int launch_cand_all(sgp_grid* g, const GpDev* gps_dev, const GpDev* gh, int G, double beta,
                     const double* fmin, const int64_t* clist_dev, int m, double* ops,
-                    int32_t* flags) {
+                    int32_t* flags, const int* count_dev) {
   sgp_ctx* ctx = g->ctx;
   SweepPoints pts{g->pts, g->N, 1, g->N};
   Vec8 fm;
@@ -646,15 +651,15 @@ int launch_cand_all(sgp_grid* g, const GpDev* gps_dev, const GpDev* gh, int G, d
 #define CAND_CASE(DD)                                                                          \
   case DD:                                                                                     \
     hipLaunchKernelGGL(k_cand_ops<DD>, dim3(m), dim3(64), 0, ctx->stream, gps_dev, G, pts,     \
-                       g->Q, g->mean, fm, clist_dev, g->goff, ops);                            \
+                       g->Q, g->mean, fm, clist_dev, g->goff, ops, count_dev);                 \
     if (np <= 24)                                                                              \
       hipLaunchKernelGGL((k_cand_scan<DD, 24>), sg, dim3(256), 0, ctx->stream, gps_dev, G,     \
                          pts, g->S, g->mean, g->var, beta, fm, clist_dev, m, g->goff, ops,     \
-                         flags);                                                               \
+                         flags, count_dev);                                                    \
     else                                                                                       \
       hipLaunchKernelGGL((k_cand_scan<DD, 48>), sg, dim3(256), 0, ctx->stream, gps_dev, G,     \
                          pts, g->S, g->mean, g->var, beta, fm, clist_dev, m, g->goff, ops,     \
-                         flags);                                                               \
+                         flags, count_dev);                                                    \
     break;
   switch (g->d) {
     CAND_CASE(1) CAND_CASE(2) CAND_CASE(3) CAND_CASE(4)
@@ -664,6 +669,32 @@ int launch_cand_all(sgp_grid* g, const GpDev* gps_dev, const GpDev* gh, int G, d
       return -2;
   }
 #undef CAND_CASE
+  SGP_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// The candidates a device-side selection listed (local rows, count in sel[2] as PassSel has it):
+// their global rows and widths next to each other for ONE read-back, flags zeroed.
+__global__ __launch_bounds__(256) void k_small_pack(const int* list, const int* count_dev, int cap,
+                                                    const double* w, int64_t goff, int G,
+                                                    int64_t* hdr, int64_t* clist, double* wout,
+                                                    int32_t* flags) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  const int count = *count_dev;
+  if (pos == 0) hdr[0] = count;
+  if (pos >= cap) return;
+  const bool in = pos < count;
+  const int li = in ? list[pos] : 0;
+  clist[pos] = in ? goff + li : goff;
+  wout[pos] = in ? w[li] : 0.0;
+  for (int g = 0; g < G; ++g) flags[pos * G + g] = 0;
+}
+
+int launch_small_pack(sgp_grid* g, const int* list_dev, const int* count_dev, int cap,
+                      int64_t* hdr, int64_t* clist, double* wout, int32_t* flags) {
+  sgp_ctx* ctx = g->ctx;
+  hipLaunchKernelGGL(k_small_pack, dim3((cap + 255) / 256), dim3(256), 0, ctx->stream, list_dev,
+                     count_dev, cap, g->w, g->goff, g->G, hdr, clist, wout, flags);
   SGP_HIP(ctx, hipGetLastError());
   return 0;
 }

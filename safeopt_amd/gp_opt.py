@@ -351,6 +351,9 @@ class _HipGridBackend(object):
     def expanders_small(self, beta, fmin, gidx):
         return self.grid.expanders_small(self._dev(), beta, fmin, gidx)
 
+    def expanders_small_all(self, beta, fmin, cap=4096):
+        return self.grid.expanders_small_all(self._dev(), beta, fmin, cap)
+
     def mark_expanders(self, gidx):
         self.grid.mark_expanders(gidx)
 
@@ -1143,6 +1146,20 @@ class SafeOpt(GaussianProcessOptimization):
         the first candidate of the device's order when it is already known to be no expander
         (it is skipped wherever the reference's order puts it)."""
         be = self._backend
+        if not full_sets and hasattr(be, 'expanders_small_all'):
+            # one round trip: the device lists the candidates in row order and tests ALL of
+            # them; rows, widths and flags come back together (up to 4096 candidates)
+            got = be.expanders_small_all(beta, self.fmin)
+            if got is not None:
+                rows, w_rows, flags = got
+                order = w_rows.argsort()[::-1]         # (the reference's width[rows].argsort()[::-1])
+                if 0 <= cut_idx < _I64_MAX:
+                    order = order[rows[order] != cut_idx]
+                is_exp = np.all(flags[order][:, active] != 0, axis=1)
+                if is_exp.any():
+                    be.mark_expanders(rows[order[int(np.argmax(is_exp))]][None])
+                    self._argmax_cache = None
+                return
         cand, width = be.candidate_widths()
         rows = np.flatnonzero(np.asarray(cand, dtype=bool))
         if full_sets:
