@@ -120,6 +120,38 @@ class OracleGridBackend(object):
                 flags[:, i] = np.any(u_c[:, [i]] - lipschitz[i] * d >= fmin[i], axis=1)
         return flags
 
+    # -- the big passes of the expander loop on N ranks (SafeOpt._visit_in_big_passes_nrank) --
+    def _behind(self, mode, cut_w, cut_idx):
+        """Global rows and keys (width; mode & 1: minus the row index) of this shard's
+        candidates strictly behind the cut -- pass_key of csrc/sets.hip."""
+        idx = np.flatnonzero(self.cand) + self.lo
+        key = -idx.astype(float) if (mode & 1) else self.w[idx - self.lo]
+        keep = (key < cut_w) | ((key == cut_w) & (idx < cut_idx))
+        return idx[keep], key[keep]
+
+    def pass_hist(self, mode, cut_w, cut_idx, key_lo, key_hi, nbins=4096):
+        _idx, key = self._behind(mode, cut_w, cut_idx)
+        b = ((key - key_lo) * (float(nbins) / (key_hi - key_lo))).astype(np.int64)
+        return np.bincount(np.clip(b, 0, nbins - 1), minlength=nbins).astype(np.uint32)
+
+    def pass_list(self, mode, cut_w, cut_idx, thr, cap):
+        idx, key = self._behind(mode, cut_w, cut_idx)
+        keep = key >= thr
+        idx, key = idx[keep], key[keep]                   # (row order)
+        assert idx.size <= max(int(cap), 1), (idx.size, cap)
+        li = idx - self.lo
+        u = self.Q[li, 1::2]
+        return idx, key, self.x[li], (u if (mode & 2) else u - self.mean[li])
+
+    def pass_test(self, beta, fmin, xc, resid):
+        xc = np.asarray(xc, dtype=float).reshape(-1, self.x.shape[1])
+        mu_c = np.column_stack([gp.predict_noiseless(xc)[0].ravel() for gp in self.gps])
+        return self.expander_check(beta, fmin, xc, mu_c, mu_c + np.asarray(resid))
+
+    def pass_lipschitz_test(self, fmin, lipschitz, xc, u_c):
+        xc = np.asarray(xc, dtype=float).reshape(-1, self.x.shape[1])
+        return self.lipschitz_check(fmin, lipschitz, xc, np.asarray(u_c).reshape(xc.shape[0], -1))
+
     def sets_front(self, max_l, max_var, scaling, thr_beta):
         width = 0.0
         if max_var is None:

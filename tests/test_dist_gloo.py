@@ -120,6 +120,72 @@ def test_two_ranks_reproduce_unsharded_golden():
         assert report and all(ok for _, _, ok in report), report
 
 
+def _pass_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+        import torch.distributed as td
+        td.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                              rank=rank, world_size=world)
+        import safeopt_amd
+        import _scenarios as sc
+        from oracle import gp_numpy as gpn
+        from oracle import safeopt_numpy as son
+        from _oracle_backend import OracleGridBackend, use_oracle_backend
+        use_oracle_backend()
+        calls = {"gp": 0, "lip": 0}
+        for name, key in (("pass_test", "gp"), ("pass_lipschitz_test", "lip")):
+            orig = getattr(OracleGridBackend, name)
+            setattr(OracleGridBackend, name,
+                    lambda self, *a, _o=orig, _k=key: (calls.__setitem__(_k, calls[_k] + 1), _o(self, *a))[1])
+        comm = TorchComm()
+        # a converged state: 48 candidates, no expander (tests/test_gpu_expander_passes.py at CPU size)
+        data = sc.rim_data(40, ls=0.8, rings=4, dring=0.4, dmid=1.0, dtop=0.5, r0=2.0, dout=2.0,
+                           plateau=0.6)
+        grid = data["grid"]
+        report = []
+        for lip in (None, 1.0, 0.7):
+            go = sc.make_gp(gpn, data)
+            opt = safeopt_amd.SafeOpt(sc.make_gp(gpn, data), grid, 0.0, lipschitz=lip, threshold=0.1,
+                                      comm=comm)
+            opt.pass_sizes = (8, 16)
+            before = dict(calls)
+            x = opt.optimize()
+            idx, Q, S, M, G = son.optimize_grid([go], grid, [0.0], opt.scaling, 0.1, 2.0,
+                                                lipschitz=None if lip is None else [lip])
+            ok = (np.array_equal(x, grid[idx]) and np.array_equal(opt.S, S)
+                  and np.array_equal(opt.M, M) and np.array_equal(opt.G, G))
+            ran = calls["gp" if lip is None else "lip"] - before["gp" if lip is None else "lip"]
+            report.append(("lipschitz=%s: |G| = %d, %d N-rank passes" % (lip, int(G.sum()), ran),
+                           bool(ok) and (ran >= 2 or G.any())))
+        td.destroy_process_group()
+        q.put((rank, report, None))
+    except Exception:
+        import traceback
+        q.put((rank, [], traceback.format_exc()))
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_big_passes_of_the_expander_loop():
+    """``SafeOpt._visit_in_big_passes_nrank`` over gloo with the oracle's arithmetic behind the
+    three calls of a pass (histograms summed, candidates gathered, flags or-ed): a converged
+    state -- every candidate visited in passes of 8 and 16, none marked -- with GP and with
+    Lipschitz certificates, equal to the unsharded oracle."""
+    pytest.importorskip("torch")
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pass_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=550) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    for rank, report, err in sorted(results):
+        assert err is None, "rank %d failed:\n%s" % (rank, err)
+        assert report and all(ok for _, ok in report), report
+
+
 def test_three_way_shard_single_process():
     """Same driver, world = 3 emulated in one process (each 'rank' in turn with
     a communicator that replays the other ranks): covers uneven shards."""
